@@ -1,0 +1,173 @@
+/*
+ * odise_hip.h — C ABI of libodise_hip.so, the MI355X (gfx950) device side of the
+ * ODISE panoptic-inference hot path.
+ *
+ * Every entry point takes plain pointers and sizes (no torch types).  Device pointers
+ * are raw HIP device addresses (hipMalloc'ed by odise_hip_malloc or borrowed from a
+ * torch-ROCm tensor's data_ptr()).  All functions return 0 on success and a negative
+ * code on failure; odise_hip_last_error() returns a human readable message.
+ *
+ * Reference interfaces replaced (paths relative to the reference checkout):
+ *   - odise_hip_ms_deform_attn_forward  <->  MSDA.ms_deform_attn_forward
+ *       third_party/Mask2Former/mask2former/modeling/pixel_decoder/ops/src/ms_deform_attn.h:25-44
+ *       third_party/Mask2Former/mask2former/modeling/pixel_decoder/ops/src/cuda/ms_deform_attn_cuda.cu:25-85
+ *   - odise_hip_unet_features           <->  LdmExtractor.unet_forward
+ *       odise/modeling/meta_arch/ldm.py:469-491 (taps = concat-inputs of output blocks 2,5,8,11)
+ *   - odise_hip_mask_pooling            <->  MaskPooling.forward  odise/modeling/meta_arch/odise.py:937-963
+ *   - op-level entry points (gemm / conv / group-norm / layer-norm / attention) are the
+ *     building blocks the stage-level calls are made of; they are exported so every
+ *     stage can be parity-tested in isolation (SURVEY.md §8b last row).
+ */
+#ifndef ODISE_HIP_H
+#define ODISE_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct odise_hip_ctx odise_hip_ctx;
+
+enum { ODISE_F16 = 0, ODISE_F32 = 1 };
+enum { ODISE_ACT_NONE = 0, ODISE_ACT_SILU = 1, ODISE_ACT_RELU = 2, ODISE_ACT_GELU = 3, ODISE_ACT_QUICKGELU = 4 };
+
+/* error codes */
+enum {
+    ODISE_OK = 0,
+    ODISE_ERR_ARG = -1,      /* bad argument (shape/alignment/dtype) */
+    ODISE_ERR_HIP = -2,      /* a HIP runtime call failed           */
+    ODISE_ERR_STATE = -3,    /* missing weights / wrong call order  */
+    ODISE_ERR_NOMEM = -4     /* workspace / arena exhausted         */
+};
+
+/* ---- context / plumbing ------------------------------------------------------------ */
+int odise_hip_create(int device, odise_hip_ctx** out);
+int odise_hip_destroy(odise_hip_ctx* ctx);
+const char* odise_hip_last_error(void);
+int odise_hip_version(void);
+/* adopt an external hipStream_t (e.g. torch.cuda.current_stream().cuda_stream); NULL = own stream */
+int odise_hip_set_stream(odise_hip_ctx* ctx, void* hip_stream);
+int odise_hip_malloc(odise_hip_ctx* ctx, size_t bytes, void** dptr);
+int odise_hip_free(odise_hip_ctx* ctx, void* dptr);
+int odise_hip_memcpy_h2d(odise_hip_ctx* ctx, void* dst_dev, const void* src_host, size_t bytes);
+int odise_hip_memcpy_d2h(odise_hip_ctx* ctx, void* dst_host, const void* src_dev, size_t bytes);
+int odise_hip_memset(odise_hip_ctx* ctx, void* dst_dev, int value, size_t bytes);
+int odise_hip_sync(odise_hip_ctx* ctx);
+/* HIP-event timing on the context's stream (what bench.py uses around the timed region) */
+int odise_hip_timer_start(odise_hip_ctx* ctx);
+int odise_hip_timer_stop(odise_hip_ctx* ctx, float* elapsed_ms);
+int odise_hip_device_info(odise_hip_ctx* ctx, char* name_buf, int buf_len, int* cu_count, size_t* hbm_bytes);
+
+/* ---- MSDeformAttn forward ------------------------------ */
+/* value        [B, S, M, D]      dtype value_dtype (device)
+ * spatial_shapes [L, 2] int64 (HOST)   (H_l, W_l)
+ * level_start_index [L] int64 (HOST)
+ * sampling_loc [B, Lq, M, L, P, 2] f32 (device), normalised to [0,1]
+ * attn_weight  [B, Lq, M, L, P]   f32 (device)
+ * out          [B, Lq, M*D]       dtype value_dtype (device)
+ * im2col_step is accepted for signature parity and validated like the reference
+ * (B % min(B, im2col_step) == 0, ms_deform_attn_cuda.cu:52) but the kernel is one launch. */
+int odise_hip_ms_deform_attn_forward(odise_hip_ctx* ctx, const void* value, const int64_t* spatial_shapes,
+                                     const int64_t* level_start_index, const float* sampling_loc,
+                                     const float* attn_weight, int B, int S, int M, int D, int Lq, int L, int P,
+                                     int im2col_step, int value_dtype, void* out);
+
+/* ---- GEMM: C[M,N] = epilogue(alpha * A[M,K] * W[N,K]^T) ----------------------------- */
+typedef struct {
+    int M, N, K;              /* K % 8 == 0 */
+    const void* A; int64_t lda;   /* f16, row-major, lda % 8 == 0, 16-byte aligned */
+    const void* W; int64_t ldw;   /* f16, row-major [N,K] ("B^T" form) */
+    void* C; int64_t ldc;
+    int c_dtype;              /* ODISE_F16 | ODISE_F32 */
+    const float* bias_n;      /* [N] or NULL */
+    const float* bias_m;      /* [M] or NULL */
+    const float* scale_m;     /* [M] or NULL: per-row multiplier applied to the accumulator first */
+    const void* residual;     /* f16 [M, ldr] or NULL (added after activation) */
+    int64_t ldr;
+    const float* rowgroup_add;/* [ceil(M/rows_per_group), N] f32 or NULL (added before activation) */
+    int rows_per_group;
+    int act;                  /* ODISE_ACT_* */
+    int geglu;                /* 1: columns are interleaved (a,gate) pairs -> out[M,N/2] = a*gelu(gate) */
+    float alpha;
+    int batch;                /* >=1; batched over grid.z with element strides below */
+    int64_t strideA, strideW, strideC, strideR;
+} odise_gemm_desc;
+int odise_hip_gemm(odise_hip_ctx* ctx, const odise_gemm_desc* d);
+
+/* ---- implicit-GEMM convolution, NHWC f16 -------------------------------------------- */
+typedef struct {
+    int N, H, W, Cin;         /* input  X [N,H,W,Cin] f16, Cin % 8 == 0 */
+    int Cout, KH, KW, stride, pad_t, pad_l, OH, OW;
+    int upsample2x;           /* 1: conv runs on nearest-2x upsampled X (fused gather) */
+    const void* X;
+    const void* Wt;           /* [Cout, KH, KW, Cin] f16 */
+    void* Y; int y_dtype;     /* [N,OH,OW,Cout] */
+    const float* bias;        /* [Cout] or NULL */
+    const void* residual;     /* f16 [N,OH,OW,Cout] or NULL */
+    const float* per_image_add;/* [N, Cout] f32 or NULL (time-embedding broadcast) */
+    int act;
+} odise_conv_desc;
+int odise_hip_conv2d(odise_hip_ctx* ctx, const odise_conv_desc* d);
+
+/* ---- normalisation ------------------------------------------------------------------- */
+/* GroupNorm over NHWC f16 x[N,HW,C]; stats in fp32; y = act(gn(x)*gamma+beta) (f16) */
+int odise_hip_group_norm(odise_hip_ctx* ctx, const void* x, void* y, const float* gamma, const float* beta,
+                         int N, int HW, int C, int groups, float eps, int act);
+/* LayerNorm over the last dim of x[rows, C] f16 -> y f16 */
+int odise_hip_layer_norm(odise_hip_ctx* ctx, const void* x, void* y, const float* gamma, const float* beta,
+                         int rows, int C, float eps);
+
+/* ---- fused attention ------------------------------------------------------------------- */
+/* O[b,q,h*D+d] = softmax_k(scale * Q[b,q,h*D+:] . K[b,k,h*D+:] + mask) V
+ * Q  [B, Lq, ldq] f16, K [B, Lk, ldk] f16, Vt [B, H*D, ldvt] f16 (V TRANSPOSED: row h*D+d, col key),
+ * O  [B, Lq, ldo] f16.  mask: optional u8 [B, Lq, ldmask] (1 = key not visible), shared by heads.
+ * D in {32,40,64,80,160}; ldvt % 8 == 0, ldmask % 4 == 0. */
+typedef struct {
+    int B, H, Lq, Lk, D;
+    const void* Q; int64_t ldq, strideQ;
+    const void* K; int64_t ldk, strideK;
+    const void* Vt; int64_t ldvt, strideVt;
+    void* O; int64_t ldo, strideO;
+    const uint8_t* mask; int64_t ldmask, strideMask;
+    float scale;
+} odise_attn_desc;
+int odise_hip_attention(odise_hip_ctx* ctx, const odise_attn_desc* d);
+
+/* ---- layout / elementwise helpers ---------------------------------------------------- */
+int odise_hip_nchw_f32_to_nhwc_f16(odise_hip_ctx* ctx, const float* x, void* y, int N, int C, int H, int W, int Cpad);
+int odise_hip_nhwc_f16_to_nchw_f32(odise_hip_ctx* ctx, const void* x, float* y, int N, int C, int H, int W);
+int odise_hip_cast_f32_to_f16(odise_hip_ctx* ctx, const float* x, void* y, size_t n);
+int odise_hip_cast_f16_to_f32(odise_hip_ctx* ctx, const void* x, float* y, size_t n);
+/* y[n,p,:] = cat(a[n,p,:Ca], b[n,p,:Cb]) (f16, channels-last) */
+int odise_hip_concat_channels(odise_hip_ctx* ctx, const void* a, const void* b, void* y, size_t pixels, int Ca, int Cb);
+
+/* ---- MaskPooling (odise.py:937-963) --------------------------------------------------- */
+/* x [B,C,H,W] f32 NCHW, mask logits [B,Q,H,W] f32 -> pooled [B,Q,C] f32
+ * pooled = einsum(x, sigmoid(mask)>0.5) / (sum(mask>0) + 1e-8) */
+int odise_hip_mask_pooling(odise_hip_ctx* ctx, const float* x, const float* mask, float* pooled,
+                           int B, int C, int Q, int HW);
+
+/* ---- SD v1 UNet single-step feature extraction (ldm.py:469-491) ----------------------- */
+/* Weights are registered by their checkpoint key (model.diffusion_model.* stripped of that prefix),
+ * host fp32, any rank<=4; the library converts to its packed fp16 layouts.  */
+int odise_hip_load_weight(odise_hip_ctx* ctx, const char* name, const float* host_data, const int64_t* shape, int ndim);
+int odise_hip_unet_build(odise_hip_ctx* ctx);     /* after all weights are loaded; packs + uploads */
+/* x_t [B,4,h,w] f32 NCHW (device), context [B,77,768] f32 (device), cond_emb [B,1280] f32 or NULL (device).
+ * taps: u2 [B,2560,h/8,w/8], u5 [B,1920,h/4,w/4], u8 [B,960,h/2,w/2], u11 [B,640,h,w] f32 NCHW (device), any may be NULL.
+ * timestep t (the reference uses t=0).  */
+int odise_hip_unet_features(odise_hip_ctx* ctx, const float* x_t, const float* context, const float* cond_emb,
+                            int B, int h, int w, int t, float* tap_u2, float* tap_u5, float* tap_u8, float* tap_u11);
+/* same, but keeps taps as fp16 NHWC inside the context (bench / fused pipeline path); returns device pointers */
+int odise_hip_unet_features_nhwc(odise_hip_ctx* ctx, const float* x_t, const float* context, const float* cond_emb,
+                                 int B, int h, int w, int t, void** taps4);
+/* analytic MACs of the last unet call (per the layer shapes actually launched) */
+int odise_hip_unet_last_macs(odise_hip_ctx* ctx, double* macs);
+/* capture the unet forward for (B,h,w) into a hipGraph and replay it on subsequent calls (0 disables) */
+int odise_hip_unet_use_graph(odise_hip_ctx* ctx, int enable);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* ODISE_HIP_H */

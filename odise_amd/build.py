@@ -1,0 +1,84 @@
+"""Build libodise_hip.so (hipcc, gfx950) in-tree.
+
+`python -m odise_amd.build` compiles every source under odise_amd/csrc into
+odise_amd/lib/libodise_hip.so.  Objects are cached under odise_amd/lib/obj and rebuilt only when the
+source (or a header) is newer.  hipcc cross-compiles without a GPU, so this also runs in the CPU-only
+build container; the resulting .so travels to the GPU box with the repo snapshot.
+"""
+from __future__ import annotations
+
+import os
+import shutil
+import subprocess
+import sys
+from concurrent.futures import ThreadPoolExecutor
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, "csrc")
+LIBDIR = os.path.join(HERE, "lib")
+OBJDIR = os.path.join(LIBDIR, "obj")
+LIB = os.path.join(LIBDIR, "libodise_hip.so")
+ARCH = "gfx950"
+
+
+def _hipcc() -> str:
+    for cand in (os.environ.get("HIPCC"), "/opt/rocm/bin/hipcc", shutil.which("hipcc")):
+        if cand and os.path.exists(cand):
+            return cand
+    raise RuntimeError("hipcc not found (need ROCm >= 7.0 for gfx950)")
+
+
+def _sources():
+    return sorted(f for f in os.listdir(CSRC) if f.endswith((".hip", ".cpp")))
+
+
+def _headers_mtime() -> float:
+    m = 0.0
+    for root in (CSRC, os.path.join(HERE, "..", "include")):
+        for f in os.listdir(root):
+            if f.endswith(".h"):
+                m = max(m, os.path.getmtime(os.path.join(root, f)))
+    return m
+
+
+def build(verbose: bool = True, force: bool = False) -> str:
+    os.makedirs(OBJDIR, exist_ok=True)
+    hipcc = _hipcc()
+    hm = _headers_mtime()
+    flags = ["-O3", "-std=c++17", "-fPIC", f"--offload-arch={ARCH}", 
+             "-Wno-unused-result", "-x", "hip"]
+    jobs = []
+    objs = []
+    for src in _sources():
+        sp = os.path.join(CSRC, src)
+        op = os.path.join(OBJDIR, src.rsplit(".", 1)[0] + ".o")
+        objs.append(op)
+        if force or not os.path.exists(op) or os.path.getmtime(op) < max(os.path.getmtime(sp), hm):
+            jobs.append((sp, op))
+
+    def _compile(job):
+        sp, op = job
+        cmd = [hipcc, *flags, "-c", sp, "-o", op]
+        if verbose:
+            print("[odise_amd.build]", " ".join(cmd), flush=True)
+        r = subprocess.run(cmd, capture_output=True, text=True)
+        if r.returncode != 0:
+            raise RuntimeError(f"hipcc failed for {sp}:\n{r.stdout}\n{r.stderr}")
+        if verbose and r.stderr.strip():
+            print(r.stderr, file=sys.stderr)
+
+    if jobs:
+        with ThreadPoolExecutor(max_workers=min(len(jobs), os.cpu_count() or 4)) as ex:
+            list(ex.map(_compile, jobs))
+    if jobs or not os.path.exists(LIB):
+        cmd = [hipcc, "-shared", "-fPIC", f"--offload-arch={ARCH}", "-o", LIB, *objs]
+        if verbose:
+            print("[odise_amd.build]", " ".join(cmd), flush=True)
+        r = subprocess.run(cmd, capture_output=True, text=True)
+        if r.returncode != 0:
+            raise RuntimeError(f"link failed:\n{r.stdout}\n{r.stderr}")
+    return LIB
+
+
+if __name__ == "__main__":
+    print(build(force="--force" in sys.argv))

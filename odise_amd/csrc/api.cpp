@@ -1,0 +1,141 @@
+// api.cpp — context, error reporting and memory/stream plumbing of libodise_hip.so.
+#include <stdarg.h>
+#include <string.h>
+
+#include <mutex>
+
+#include "common.h"
+
+namespace odise {
+static thread_local char g_err[1024] = "";
+void set_error(const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+void models_destroy(odise_hip_ctx* ctx);  // unet.cpp
+}  // namespace odise
+
+using namespace odise;
+
+extern "C" const char* odise_hip_last_error(void) { return g_err; }
+extern "C" int odise_hip_version(void) { return 100; }
+
+extern "C" int odise_hip_create(int device, odise_hip_ctx** out) {
+    ODISE_REQUIRE(out != nullptr, "create: null out pointer");
+    int count = 0;
+    hipError_t e = hipGetDeviceCount(&count);
+    if (e != hipSuccess || count == 0) {
+        set_error("create: no HIP device available (%s)", e == hipSuccess ? "count=0" : hipGetErrorString(e));
+        return ODISE_ERR_HIP;
+    }
+    ODISE_REQUIRE(device >= 0 && device < count, "create: device %d out of range [0,%d)", device, count);
+    ODISE_CHECK_HIP(hipSetDevice(device));
+    odise_hip_ctx* c = new odise_hip_ctx();
+    c->device = device;
+    hipDeviceProp_t prop;
+    ODISE_CHECK_HIP(hipGetDeviceProperties(&prop, device));
+    c->cu_count = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    ODISE_CHECK_HIP(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+    c->own_stream = true;
+    c->ws_bytes = (size_t)256 << 20;
+    ODISE_CHECK_HIP(hipMalloc(&c->ws, c->ws_bytes));
+    ODISE_CHECK_HIP(hipEventCreate(&c->ev0));
+    ODISE_CHECK_HIP(hipEventCreate(&c->ev1));
+    *out = c;
+    return ODISE_OK;
+}
+
+extern "C" int odise_hip_destroy(odise_hip_ctx* ctx) {
+    if (!ctx) return ODISE_OK;
+    hipSetDevice(ctx->device);
+    hipStreamSynchronize(ctx->stream);
+    models_destroy(ctx);
+    if (ctx->ws) hipFree(ctx->ws);
+    if (ctx->ev0) hipEventDestroy(ctx->ev0);
+    if (ctx->ev1) hipEventDestroy(ctx->ev1);
+    if (ctx->own_stream && ctx->stream) hipStreamDestroy(ctx->stream);
+    delete ctx;
+    return ODISE_OK;
+}
+
+extern "C" int odise_hip_set_stream(odise_hip_ctx* ctx, void* hip_stream) {
+    ODISE_REQUIRE(ctx, "set_stream: null context");
+    ODISE_CHECK_HIP(hipStreamSynchronize(ctx->stream));
+    if (hip_stream == nullptr) {
+        if (!ctx->own_stream) {
+            ODISE_CHECK_HIP(hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking));
+            ctx->own_stream = true;
+        }
+        return ODISE_OK;
+    }
+    if (ctx->own_stream && ctx->stream) hipStreamDestroy(ctx->stream);
+    ctx->stream = (hipStream_t)hip_stream;
+    ctx->own_stream = false;
+    return ODISE_OK;
+}
+
+extern "C" int odise_hip_malloc(odise_hip_ctx* ctx, size_t bytes, void** dptr) {
+    ODISE_REQUIRE(ctx && dptr, "malloc: null argument");
+    ODISE_CHECK_HIP(hipSetDevice(ctx->device));
+    *dptr = nullptr;
+    if (bytes == 0) bytes = 16;
+    ODISE_CHECK_HIP(hipMalloc(dptr, bytes));
+    return ODISE_OK;
+}
+extern "C" int odise_hip_free(odise_hip_ctx* ctx, void* dptr) {
+    ODISE_REQUIRE(ctx, "free: null context");
+    if (!dptr) return ODISE_OK;
+    ODISE_CHECK_HIP(hipStreamSynchronize(ctx->stream));
+    ODISE_CHECK_HIP(hipFree(dptr));
+    return ODISE_OK;
+}
+extern "C" int odise_hip_memcpy_h2d(odise_hip_ctx* ctx, void* dst, const void* src, size_t bytes) {
+    ODISE_REQUIRE(ctx && (bytes == 0 || (dst && src)), "memcpy_h2d: null argument");
+    if (bytes == 0) return ODISE_OK;
+    ODISE_CHECK_HIP(hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, ctx->stream));
+    ODISE_CHECK_HIP(hipStreamSynchronize(ctx->stream));
+    return ODISE_OK;
+}
+extern "C" int odise_hip_memcpy_d2h(odise_hip_ctx* ctx, void* dst, const void* src, size_t bytes) {
+    ODISE_REQUIRE(ctx && (bytes == 0 || (dst && src)), "memcpy_d2h: null argument");
+    if (bytes == 0) return ODISE_OK;
+    ODISE_CHECK_HIP(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, ctx->stream));
+    ODISE_CHECK_HIP(hipStreamSynchronize(ctx->stream));
+    return ODISE_OK;
+}
+extern "C" int odise_hip_memset(odise_hip_ctx* ctx, void* dst, int value, size_t bytes) {
+    ODISE_REQUIRE(ctx && (bytes == 0 || dst), "memset: null argument");
+    if (bytes == 0) return ODISE_OK;
+    ODISE_CHECK_HIP(hipMemsetAsync(dst, value, bytes, ctx->stream));
+    return ODISE_OK;
+}
+extern "C" int odise_hip_sync(odise_hip_ctx* ctx) {
+    ODISE_REQUIRE(ctx, "sync: null context");
+    ODISE_CHECK_HIP(hipStreamSynchronize(ctx->stream));
+    return ODISE_OK;
+}
+extern "C" int odise_hip_timer_start(odise_hip_ctx* ctx) {
+    ODISE_REQUIRE(ctx, "timer_start: null context");
+    ODISE_CHECK_HIP(hipEventRecord(ctx->ev0, ctx->stream));
+    return ODISE_OK;
+}
+extern "C" int odise_hip_timer_stop(odise_hip_ctx* ctx, float* ms) {
+    ODISE_REQUIRE(ctx && ms, "timer_stop: null argument");
+    ODISE_CHECK_HIP(hipEventRecord(ctx->ev1, ctx->stream));
+    ODISE_CHECK_HIP(hipEventSynchronize(ctx->ev1));
+    ODISE_CHECK_HIP(hipEventElapsedTime(ms, ctx->ev0, ctx->ev1));
+    return ODISE_OK;
+}
+extern "C" int odise_hip_device_info(odise_hip_ctx* ctx, char* name_buf, int buf_len, int* cu_count, size_t* hbm_bytes) {
+    ODISE_REQUIRE(ctx, "device_info: null context");
+    hipDeviceProp_t prop;
+    ODISE_CHECK_HIP(hipGetDeviceProperties(&prop, ctx->device));
+    if (name_buf && buf_len > 0) {
+        snprintf(name_buf, buf_len, "%s (%s)", prop.name, prop.gcnArchName);
+    }
+    if (cu_count) *cu_count = prop.multiProcessorCount;
+    if (hbm_bytes) *hbm_bytes = prop.totalGlobalMem;
+    return ODISE_OK;
+}

@@ -1,0 +1,238 @@
+// attn.hip — fused (flash-style) multi-head attention forward for gfx950, fp16 in / fp32 softmax.
+//
+// Covers the UNet SpatialTransformer self-attention (tokens 4096/1024/256/64, d_head 40/80/160) and
+// cross-attention (77 context keys) — ldm CrossAttention, SURVEY.md Appendix A.1 — the CLIP ViT-L/14
+// blocks (577/677 tokens, d 64, optional per-(query,key) visibility mask, clip.py:252-280) and the
+// Mask2Former decoder's masked cross-attention (100 queries, d 32, odise.py:760-774).
+//
+// CDNA4 mapping (wave64, v_mfma_f32_32x32x16_f16):
+//   * block = 4 wavefronts = 128 queries; each wave owns 32 queries; KV tiles of 64 keys staged in LDS.
+//   * S^T = K·Q^T ("swapped" product): the MFMA result has column = query = lane&31, so one lane holds
+//     16 of the 32 keys of a tile for ONE query -> row max / row sum are in-register reductions plus a
+//     single cross-half exchange (lane ^ 32); no LDS round trip for P.
+//   * O^T = V^T·P^T: the exponentiated S^T registers ARE the B operand (8 keys per lane for its query),
+//     V arrives pre-transposed ([H*D, keys], produced by the swapped projection GEMM) so the A operand is
+//     two ds_read_b64 per MFMA; the accumulator again has column = query, so the online-softmax rescale
+//     is a per-lane scalar multiply.
+//   * K rows are padded by 16 B and V^T rows by 8 B so the ds_read_b128 / ds_read_b64 lane groups are
+//     bank-conflict free (odd multiples of the access width).
+#include "common.h"
+
+namespace odise {
+
+struct AttnArgs {
+    int B, H, Lq, Lk, D;
+    const f16* Q; int64_t ldq, strideQ;
+    const f16* K; int64_t ldk, strideK;
+    const f16* Vt; int64_t ldvt, strideVt;
+    f16* O; int64_t ldo, strideO;
+    const uint8_t* mask; int64_t ldmask, strideMask;
+    float scale_log2e;
+};
+
+template <int DPAD>
+__global__ void __launch_bounds__(256) attn_kernel(AttnArgs a) {
+    constexpr int KS = DPAD / 16;          // MFMA k-steps of QK^T
+    constexpr int DT = (DPAD + 31) / 32;   // 32-row d tiles of O^T
+    constexpr int KROW = DPAD + 8;         // halves per K row in LDS
+    constexpr int VROW = 64 + 4;           // halves per V^T row in LDS
+    constexpr int KSLOTS = DPAD / 8;       // 16-byte slots per K row
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    f16* Ks = reinterpret_cast<f16*>(smem);                       // [64][KROW]
+    f16* Vs = reinterpret_cast<f16*>(smem + 64 * KROW * 2);       // [DT*32][VROW]
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int hi = lane >> 5, l31 = lane & 31;
+    const int b = blockIdx.z, h = blockIdx.y;
+    const int q = blockIdx.x * 128 + wave * 32 + l31;  // this lane's query
+    const bool qok = q < a.Lq;
+    const int D = a.D;
+
+    const f16* Qb = a.Q + (int64_t)b * a.strideQ + (int64_t)h * D;
+    const f16* Kb = a.K + (int64_t)b * a.strideK + (int64_t)h * D;
+    const f16* Vb = a.Vt + (int64_t)b * a.strideVt + (int64_t)h * D * a.ldvt;
+    const uint8_t* Mb = a.mask ? a.mask + (int64_t)b * a.strideMask + (int64_t)(qok ? q : 0) * a.ldmask : nullptr;
+
+    const f16x8 zero8 = {0, 0, 0, 0, 0, 0, 0, 0};
+    // Q fragments (B operand of S^T): Q[q][16s + 8hi .. +7]
+    f16x8 qf[KS];
+#pragma unroll
+    for (int s = 0; s < KS; ++s) {
+        const int d0 = s * 16 + hi * 8;
+        qf[s] = zero8;
+        if (qok && d0 < D) qf[s] = *reinterpret_cast<const f16x8*>(Qb + (int64_t)q * a.ldq + d0);
+    }
+
+    f32x16 ot[DT];
+#pragma unroll
+    for (int t = 0; t < DT; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) ot[t][r] = 0.f;
+    float m_run = -INFINITY, l_run = 0.f;
+
+    const int ntiles = (a.Lk + 63) / 64;
+    for (int kt = 0; kt < ntiles; ++kt) {
+        const int kv0 = kt * 64;
+        __syncthreads();  // previous tile fully consumed
+        // ---- stage K tile: 64 keys x DPAD ----
+        for (int c = tid; c < 64 * KSLOTS; c += 256) {
+            const int key = c / KSLOTS, sl = c - key * KSLOTS;
+            f16x8 v = zero8;
+            if (kv0 + key < a.Lk && sl * 8 < D) v = *reinterpret_cast<const f16x8*>(Kb + (int64_t)(kv0 + key) * a.ldk + sl * 8);
+            *reinterpret_cast<f16x8*>(Ks + key * KROW + sl * 8) = v;
+        }
+        // ---- stage V^T tile: DT*32 rows (d) x 64 keys ----
+        for (int c = tid; c < DT * 32 * 8; c += 256) {
+            const int d = c >> 3, sl = c & 7;
+            f16x8 v = zero8;
+            const int k0 = kv0 + sl * 8;
+            if (d < D && k0 < a.Lk) {
+                v = *reinterpret_cast<const f16x8*>(Vb + (int64_t)d * a.ldvt + k0);
+                if (k0 + 8 > a.Lk) {
+#pragma unroll
+                    for (int i = 0; i < 8; ++i)
+                        if (k0 + i >= a.Lk) v[i] = (f16)0.f;
+                }
+            }
+            // V^T row stride is 136 B: write as two 8-byte halves (8-byte aligned)
+            f16x4 lo4 = {v[0], v[1], v[2], v[3]}, hi4 = {v[4], v[5], v[6], v[7]};
+            *reinterpret_cast<f16x4*>(Vs + d * VROW + sl * 8) = lo4;
+            *reinterpret_cast<f16x4*>(Vs + d * VROW + sl * 8 + 4) = hi4;
+        }
+        __syncthreads();
+
+        // ---- S^T = K Q^T for two 32-key tiles ----
+        f32x16 st[2];
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) st[t][r] = 0.f;
+#pragma unroll
+            for (int s = 0; s < KS; ++s) {
+                const f16x8 kf = *reinterpret_cast<const f16x8*>(Ks + (t * 32 + l31) * KROW + s * 16 + hi * 8);
+                st[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf, qf[s], st[t], 0, 0, 0);
+            }
+        }
+        // ---- scale, mask, online softmax (this lane: one query, 32 of the 64 keys) ----
+        float mx = -INFINITY;
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int kbase = kv0 + t * 32 + 8 * g + 4 * hi;  // keys kbase .. kbase+3  <-> regs 4g..4g+3
+                uint32_t mbits = 0;
+                if (Mb && kbase < a.Lk) mbits = *reinterpret_cast<const uint32_t*>(Mb + kbase);
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    float s = st[t][4 * g + i] * a.scale_log2e;
+                    const bool dead = (kbase + i >= a.Lk) || ((mbits >> (8 * i)) & 0xff);
+                    s = dead ? -INFINITY : s;
+                    st[t][4 * g + i] = s;
+                    mx = fmaxf(mx, s);
+                }
+            }
+        }
+        mx = fmaxf(mx, __shfl_xor(mx, 32));
+        const float m_new = fmaxf(m_run, mx);
+        const float m_safe = (m_new == -INFINITY) ? 0.f : m_new;
+        const float alpha = exp2f(m_run - m_safe);  // m_run = -inf -> 0
+        float psum = 0.f;
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const float p = exp2f(st[t][r] - m_safe);
+                st[t][r] = p;
+                psum += p;
+            }
+        l_run = l_run * alpha + psum;
+        m_run = m_new;
+#pragma unroll
+        for (int t = 0; t < DT; ++t)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) ot[t][r] *= alpha;
+
+        // ---- O^T += V^T P^T : per (key tile t, half-step s2) one MFMA per d tile ----
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+#pragma unroll
+            for (int s2 = 0; s2 < 2; ++s2) {
+                f16x8 pf;
+#pragma unroll
+                for (int i = 0; i < 8; ++i) pf[i] = (f16)st[t][8 * s2 + i];
+                // keys (local to the 64-key tile) held by this lane half for this step
+                const int kA = t * 32 + 16 * s2 + 4 * hi;  // regs 8*s2+0..3
+                const int kB = kA + 8;                      // regs 8*s2+4..7
+#pragma unroll
+                for (int dt = 0; dt < DT; ++dt) {
+                    const f16* vr = Vs + (dt * 32 + l31) * VROW;
+                    const f16x4 va = *reinterpret_cast<const f16x4*>(vr + kA);
+                    const f16x4 vb = *reinterpret_cast<const f16x4*>(vr + kB);
+                    const f16x8 vf = {va[0], va[1], va[2], va[3], vb[0], vb[1], vb[2], vb[3]};
+                    ot[dt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf, pf, ot[dt], 0, 0, 0);
+                }
+            }
+        }
+    }
+
+    // ---- epilogue: normalise and store O[q][h*D + d] ----
+    const float l_tot = l_run + __shfl_xor(l_run, 32);
+    const float inv = l_tot > 0.f ? 1.f / l_tot : 0.f;
+    if (qok) {
+        f16* Ob = a.O + (int64_t)b * a.strideO + (int64_t)q * a.ldo + (int64_t)h * D;
+#pragma unroll
+        for (int dt = 0; dt < DT; ++dt) {
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int d0 = dt * 32 + 8 * g + 4 * hi;
+                if (d0 < D) {
+                    f16x4 o;
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) o[i] = (f16)(ot[dt][4 * g + i] * inv);
+                    *reinterpret_cast<f16x4*>(Ob + d0) = o;
+                }
+            }
+        }
+    }
+}
+
+template <int DPAD>
+static int launch_attn(odise_hip_ctx* ctx, const AttnArgs& a) {
+    constexpr int DT = (DPAD + 31) / 32;
+    const size_t lds = 64 * (DPAD + 8) * 2 + (size_t)DT * 32 * 68 * 2;
+    dim3 grid((unsigned)ceil_div(a.Lq, 128), (unsigned)a.H, (unsigned)a.B);
+    hipLaunchKernelGGL((attn_kernel<DPAD>), grid, dim3(256), lds, ctx->stream, a);
+    ODISE_CHECK_HIP(hipGetLastError());
+    return ODISE_OK;
+}
+
+}  // namespace odise
+
+extern "C" int odise_hip_attention(odise_hip_ctx* ctx, const odise_attn_desc* d) {
+    using namespace odise;
+    ODISE_REQUIRE(ctx && d, "attention: null argument");
+    ODISE_REQUIRE(d->B >= 0 && d->H >= 1 && d->Lq >= 0 && d->Lk >= 1 && d->D >= 8, "attention: bad dims");
+    ODISE_REQUIRE(d->D % 8 == 0 && d->D <= 160, "attention: head dim %d must be a multiple of 8 and <= 160", d->D);
+    if (d->B == 0 || d->Lq == 0) return ODISE_OK;
+    ODISE_REQUIRE(d->Q && d->K && d->Vt && d->O, "attention: null device pointer");
+    ODISE_REQUIRE(d->ldq % 8 == 0 && d->ldk % 8 == 0 && d->ldvt % 8 == 0 && d->ldo % 4 == 0, "attention: leading dims must keep 16-byte rows");
+    ODISE_REQUIRE(d->ldvt >= round_up(d->Lk, 8), "attention: ldvt=%lld must be >= Lk rounded up to 8", (long long)d->ldvt);
+    ODISE_REQUIRE(!d->mask || (d->ldmask % 4 == 0 && d->ldmask >= round_up(d->Lk, 4)), "attention: ldmask must be a multiple of 4 and >= Lk");
+    ODISE_REQUIRE((d->D * d->H) % 4 == 0, "attention: H*D must be a multiple of 4");
+    AttnArgs a;
+    a.B = d->B; a.H = d->H; a.Lq = d->Lq; a.Lk = d->Lk; a.D = d->D;
+    a.Q = (const f16*)d->Q; a.ldq = d->ldq; a.strideQ = d->strideQ;
+    a.K = (const f16*)d->K; a.ldk = d->ldk; a.strideK = d->strideK;
+    a.Vt = (const f16*)d->Vt; a.ldvt = d->ldvt; a.strideVt = d->strideVt;
+    a.O = (f16*)d->O; a.ldo = d->ldo; a.strideO = d->strideO;
+    a.mask = d->mask; a.ldmask = d->ldmask; a.strideMask = d->strideMask;
+    a.scale_log2e = d->scale * 1.4426950408889634f;
+    const int D = d->D;
+    if (D <= 32) return launch_attn<32>(ctx, a);
+    if (D <= 48) return launch_attn<48>(ctx, a);
+    if (D <= 64) return launch_attn<64>(ctx, a);
+    if (D <= 80) return launch_attn<80>(ctx, a);
+    if (D <= 96) return launch_attn<96>(ctx, a);
+    if (D <= 128) return launch_attn<128>(ctx, a);
+    return launch_attn<160>(ctx, a);
+}

@@ -1,0 +1,65 @@
+// common.h — shared host/device helpers for libodise_hip.so (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <hip/hip_fp16.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string>
+
+#include "../../include/odise_hip.h"
+
+namespace odise {
+
+typedef _Float16 f16;
+typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+void set_error(const char* fmt, ...);
+
+#define ODISE_CHECK_HIP(expr)                                                              \
+    do {                                                                                   \
+        hipError_t _e = (expr);                                                            \
+        if (_e != hipSuccess) {                                                            \
+            ::odise::set_error("%s:%d: %s failed: %s", __FILE__, __LINE__, #expr,          \
+                               hipGetErrorString(_e));                                     \
+            return ODISE_ERR_HIP;                                                          \
+        }                                                                                  \
+    } while (0)
+
+#define ODISE_REQUIRE(cond, ...)                                                           \
+    do {                                                                                   \
+        if (!(cond)) {                                                                     \
+            ::odise::set_error(__VA_ARGS__);                                               \
+            return ODISE_ERR_ARG;                                                          \
+        }                                                                                  \
+    } while (0)
+
+static inline int64_t ceil_div(int64_t a, int64_t b) { return (a + b - 1) / b; }
+static inline int64_t round_up(int64_t a, int64_t b) { return ceil_div(a, b) * b; }
+
+__device__ __forceinline__ float act_apply(float v, int act) {
+    switch (act) {
+        case ODISE_ACT_SILU: return v / (1.0f + __expf(-v));
+        case ODISE_ACT_RELU: return v > 0.f ? v : 0.f;
+        case ODISE_ACT_GELU: return 0.5f * v * (1.0f + erff(v * 0.70710678118654752f));
+        case ODISE_ACT_QUICKGELU: return v / (1.0f + __expf(-1.702f * v));
+        default: return v;
+    }
+}
+
+}  // namespace odise
+
+// The context: one device, one stream, a split-K workspace, an activation arena and the weight store.
+struct odise_hip_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    bool own_stream = false;
+    int cu_count = 256;
+    // split-K / scratch workspace
+    void* ws = nullptr;
+    size_t ws_bytes = 0;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    void* models = nullptr;  // odise::ModelStore* (weights + unet), see unet.cpp
+};

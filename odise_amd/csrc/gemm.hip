@@ -1,0 +1,483 @@
+// gemm.hip — fp16 MFMA GEMM / implicit-GEMM convolution for gfx950 (MI355X).
+//
+//   C[M,N] = epilogue(alpha * A[M,K] * W[N,K]^T)          (dense; every Linear / 1x1 conv of the path)
+//   Y[n,oy,ox,co] = epilogue(sum_{ky,kx,ci} X[n,iy,ix,ci] * Wt[co,ky,kx,ci])   (CONV=true; NHWC, A gathered on the fly)
+//
+// These are the dense conv / im2col and Linear GEMMs of the SD-v1 UNet ResBlock / SpatialTransformer
+// (ldm.py:469-491 -> ldm UNetModel), the VAE, CLIP and Mask2Former heads.
+//
+// CDNA4 mapping: 256 threads = 4 wavefronts (2x2), v_mfma_f32_32x32x16_f16, fp32 accumulate.
+//   * block tile BMxBNx64; A and W tiles staged global->VGPR->LDS (register prefetch of tile t+1 is in
+//     flight while tile t is multiplied; one barrier per K-tile; LDS double-buffered).
+//   * LDS rows are 128 B (64 halves); 16-byte slots are XOR-swizzled with (row>>1)&7 so that the
+//     16-lane groups of ds_read_b128 hit 16 distinct slots of the 256-B bank row (conflict-free),
+//     and the 8-lane groups of ds_write_b128 write one full 128-B row.
+//   * epilogue goes through LDS (fp32) so that bias / time-embedding broadcast / activation / GEGLU /
+//     residual run on 8 consecutive output channels per lane and stores are 16-byte coalesced.
+//   * small-M layers (8x8 / 16x16 latents at batch 1) are weight-streaming bound: split-K over grid.z
+//     with an fp32 workspace and a fused reduce+epilogue kernel keeps >=2 blocks per CU in flight.
+#include "common.h"
+
+namespace odise {
+
+struct GemmEpi {
+    void* C;
+    int64_t ldc;
+    int c_dtype;
+    const float* bias_n;
+    const float* bias_m;
+    const float* scale_m;
+    const f16* residual;
+    int64_t ldr;
+    const float* rowgroup_add;
+    int rows_per_group;
+    int act;
+    int geglu;
+    float alpha;
+    int64_t strideC, strideR;
+};
+
+struct ConvGeom {
+    int H, W, Cin, KH, KW, stride, pad_t, pad_l, OH, OW, ups;
+};
+
+struct GemmArgs {
+    int M, N, K;
+    const f16* A;
+    int64_t lda, strideA;
+    const f16* W;
+    int64_t ldw, strideW;
+    GemmEpi epi;
+    ConvGeom cg;
+    int splitk;
+    int ktiles_per_split;
+    float* ws;
+};
+
+__device__ __forceinline__ float gelu_exact(float v) { return 0.5f * v * (1.0f + erff(v * 0.70710678118654752f)); }
+
+// Applies the epilogue to 8 consecutive columns (n..n+7) of row m and stores them.
+__device__ __forceinline__ void epi_store8(const GemmEpi& e, float (&v)[8], int m, int n, int N, int z) {
+    const int nvalid = (N - n) < 8 ? (N - n) : 8;
+    if (nvalid <= 0) return;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        float x = v[i] * e.alpha;
+        if (e.scale_m) x *= e.scale_m[m];
+        if (i < nvalid) {
+            if (e.bias_n) x += e.bias_n[n + i];
+            if (e.bias_m) x += e.bias_m[m];
+            if (e.rowgroup_add) x += e.rowgroup_add[(int64_t)(m / e.rows_per_group) * N + n + i];
+        }
+        v[i] = x;
+    }
+    if (e.geglu) {
+        // columns are (a, gate) pairs; output has N/2 columns
+        float o[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) o[i] = v[2 * i] * gelu_exact(v[2 * i + 1]);
+        const int no = n >> 1;
+        const int nov = nvalid >> 1;
+        if (e.c_dtype == ODISE_F16) {
+            f16* c = (f16*)e.C + (int64_t)z * e.strideC + (int64_t)m * e.ldc + no;
+            if (nov == 4 && ((e.ldc & 3) == 0)) {
+                f16x4 t;
+                t[0] = (f16)o[0]; t[1] = (f16)o[1]; t[2] = (f16)o[2]; t[3] = (f16)o[3];
+                *reinterpret_cast<f16x4*>(c) = t;
+            } else {
+                for (int i = 0; i < nov; ++i) c[i] = (f16)o[i];
+            }
+        } else {
+            float* c = (float*)e.C + (int64_t)z * e.strideC + (int64_t)m * e.ldc + no;
+            for (int i = 0; i < nov; ++i) c[i] = o[i];
+        }
+        return;
+    }
+#pragma unroll
+    for (int i = 0; i < 8; ++i) v[i] = act_apply(v[i], e.act);
+    if (e.residual) {
+        const f16* r = e.residual + (int64_t)z * e.strideR + (int64_t)m * e.ldr + n;
+        if (nvalid == 8 && ((e.ldr & 7) == 0)) {
+            const f16x8 t = *reinterpret_cast<const f16x8*>(r);
+#pragma unroll
+            for (int i = 0; i < 8; ++i) v[i] += (float)t[i];
+        } else {
+            for (int i = 0; i < nvalid; ++i) v[i] += (float)r[i];
+        }
+    }
+    if (e.c_dtype == ODISE_F16) {
+        f16* c = (f16*)e.C + (int64_t)z * e.strideC + (int64_t)m * e.ldc + n;
+        if (nvalid == 8 && ((e.ldc & 7) == 0)) {
+            f16x8 t;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) t[i] = (f16)v[i];
+            *reinterpret_cast<f16x8*>(c) = t;
+        } else {
+            for (int i = 0; i < nvalid; ++i) c[i] = (f16)v[i];
+        }
+    } else {
+        float* c = (float*)e.C + (int64_t)z * e.strideC + (int64_t)m * e.ldc + n;
+        if (nvalid == 8 && ((e.ldc & 3) == 0)) {
+            *reinterpret_cast<float4*>(c) = make_float4(v[0], v[1], v[2], v[3]);
+            *reinterpret_cast<float4*>(c + 4) = make_float4(v[4], v[5], v[6], v[7]);
+        } else {
+            for (int i = 0; i < nvalid; ++i) c[i] = v[i];
+        }
+    }
+}
+
+template <int BM, int BN, bool CONV>
+__global__ void __launch_bounds__(256) gemm_kernel(GemmArgs g) {
+    constexpr int BK = 64;
+    constexpr int TM = BM / 64;  // 32-row MFMA tiles per wave (waves are 2x2)
+    constexpr int TN = BN / 64;
+    constexpr int JA = BM / 32;  // 16-byte loads per thread per K-tile for A
+    constexpr int JB = BN / 32;
+    constexpr int STAGE_BYTES = (BM + BN) * BK * 2;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int hi = lane >> 5, l31 = lane & 31;
+    const int m0 = blockIdx.y * BM;
+    const int n0 = blockIdx.x * BN;
+    const int z = blockIdx.z;
+    const bool split = g.splitk > 1;
+    const int zb = split ? 0 : z;  // batch index
+
+    const int nk_total = (g.K + BK - 1) / BK;
+    int kt_begin = 0, kt_end = nk_total;
+    if (split) {
+        kt_begin = z * g.ktiles_per_split;
+        kt_end = kt_begin + g.ktiles_per_split;
+        if (kt_end > nk_total) kt_end = nk_total;
+    }
+
+    const f16* Ab = g.A + (int64_t)zb * g.strideA;
+    const f16* Wb = g.W + (int64_t)zb * g.strideW;
+
+    const int slot = tid & 7;
+    const int rbase = tid >> 3;  // 0..31
+
+    // per-thread A row descriptors
+    int64_t a_off[JA];
+    int a_iy0[JA], a_ix0[JA];
+    bool a_ok[JA];
+#pragma unroll
+    for (int j = 0; j < JA; ++j) {
+        const int m = m0 + rbase + 32 * j;
+        a_ok[j] = m < g.M;
+        if (CONV) {
+            const int ohw = g.cg.OH * g.cg.OW;
+            const int mm = a_ok[j] ? m : 0;
+            const int img = mm / ohw;
+            const int rem = mm - img * ohw;
+            const int oy = rem / g.cg.OW;
+            const int ox = rem - oy * g.cg.OW;
+            a_iy0[j] = oy * g.cg.stride - g.cg.pad_t;
+            a_ix0[j] = ox * g.cg.stride - g.cg.pad_l;
+            a_off[j] = (int64_t)img * g.cg.H * g.cg.W * g.cg.Cin;
+        } else {
+            a_iy0[j] = a_ix0[j] = 0;
+            a_off[j] = (int64_t)m * g.lda;
+        }
+    }
+    int64_t b_off[JB];
+    bool b_ok[JB];
+#pragma unroll
+    for (int j = 0; j < JB; ++j) {
+        const int n = n0 + rbase + 32 * j;
+        b_ok[j] = n < g.N;
+        b_off[j] = (int64_t)n * g.ldw;
+    }
+
+    f16x8 ra[JA], rb[JB];
+    const f16x8 zero8 = {0, 0, 0, 0, 0, 0, 0, 0};
+
+    auto load_tile = [&](int kt) {
+        const int k = kt * BK + slot * 8;
+        const bool kok = k < g.K;
+        if (CONV) {
+            int ky = 0, kx = 0, c = 0;
+            if (kok) {
+                const int tap = k / g.cg.Cin;
+                c = k - tap * g.cg.Cin;
+                ky = tap / g.cg.KW;
+                kx = tap - ky * g.cg.KW;
+            }
+#pragma unroll
+            for (int j = 0; j < JA; ++j) {
+                int iy = a_iy0[j] + ky, ix = a_ix0[j] + kx;
+                bool ok = a_ok[j] && kok;
+                if (g.cg.ups) {
+                    ok = ok && iy >= 0 && ix >= 0 && iy < 2 * g.cg.H && ix < 2 * g.cg.W;
+                    iy >>= 1;
+                    ix >>= 1;
+                } else {
+                    ok = ok && iy >= 0 && ix >= 0 && iy < g.cg.H && ix < g.cg.W;
+                }
+                ra[j] = zero8;
+                if (ok) ra[j] = *reinterpret_cast<const f16x8*>(Ab + a_off[j] + ((int64_t)iy * g.cg.W + ix) * g.cg.Cin + c);
+            }
+        } else {
+#pragma unroll
+            for (int j = 0; j < JA; ++j) {
+                ra[j] = zero8;
+                if (a_ok[j] && kok) ra[j] = *reinterpret_cast<const f16x8*>(Ab + a_off[j] + k);
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < JB; ++j) {
+            rb[j] = zero8;
+            if (b_ok[j] && kok) rb[j] = *reinterpret_cast<const f16x8*>(Wb + b_off[j] + k);
+        }
+    };
+
+    auto store_tile = [&](int stage) {
+        char* sa = smem + stage * STAGE_BYTES;
+        char* sb = sa + BM * BK * 2;
+#pragma unroll
+        for (int j = 0; j < JA; ++j) {
+            const int r = rbase + 32 * j;
+            *reinterpret_cast<f16x8*>(sa + r * 128 + ((slot ^ ((r >> 1) & 7)) << 4)) = ra[j];
+        }
+#pragma unroll
+        for (int j = 0; j < JB; ++j) {
+            const int r = rbase + 32 * j;
+            *reinterpret_cast<f16x8*>(sb + r * 128 + ((slot ^ ((r >> 1) & 7)) << 4)) = rb[j];
+        }
+    };
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    if (kt_begin < kt_end) {
+        load_tile(kt_begin);
+        store_tile(0);
+    }
+    __syncthreads();
+
+    for (int kt = kt_begin; kt < kt_end; ++kt) {
+        const int cur = (kt - kt_begin) & 1;
+        const bool more = (kt + 1) < kt_end;
+        if (more) load_tile(kt + 1);
+        const char* sa = smem + cur * STAGE_BYTES;
+        const char* sb = sa + BM * BK * 2;
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            f16x8 af[TM], bf[TN];
+#pragma unroll
+            for (int i = 0; i < TM; ++i) {
+                const int r = wm * (BM / 2) + i * 32 + l31;
+                af[i] = *reinterpret_cast<const f16x8*>(sa + r * 128 + (((s * 2 + hi) ^ ((r >> 1) & 7)) << 4));
+            }
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                const int r = wn * (BN / 2) + j * 32 + l31;
+                bf[j] = *reinterpret_cast<const f16x8*>(sb + r * 128 + (((s * 2 + hi) ^ ((r >> 1) & 7)) << 4));
+            }
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[i], bf[j], acc[i][j], 0, 0, 0);
+        }
+        if (more) store_tile(cur ^ 1);
+        __syncthreads();
+    }
+
+    // ---- epilogue through LDS: 64 rows (2 wave-rows x 32) x BN fp32 per pass ----------------
+    constexpr int LDS_LD = BN + 4;
+    float* stg = reinterpret_cast<float*>(smem);
+#pragma unroll
+    for (int p = 0; p < TM; ++p) {
+        if (p > 0) __syncthreads();
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+                const int col = wn * (BN / 2) + j * 32 + l31;
+                stg[row * LDS_LD + col] = acc[p][j][r];
+            }
+        }
+        __syncthreads();
+        constexpr int CH = BN / 8;
+        for (int c = tid; c < 64 * CH; c += 256) {
+            const int row = c / CH;
+            const int c8 = c - row * CH;
+            const int m = m0 + (row >> 5) * (BM / 2) + p * 32 + (row & 31);
+            const int n = n0 + c8 * 8;
+            if (m < g.M && n < g.N) {
+                float v[8];
+                const float4 t0 = *reinterpret_cast<const float4*>(&stg[row * LDS_LD + c8 * 8]);
+                const float4 t1 = *reinterpret_cast<const float4*>(&stg[row * LDS_LD + c8 * 8 + 4]);
+                v[0] = t0.x; v[1] = t0.y; v[2] = t0.z; v[3] = t0.w;
+                v[4] = t1.x; v[5] = t1.y; v[6] = t1.z; v[7] = t1.w;
+                if (split) {
+                    float* w = g.ws + ((int64_t)z * g.M + m) * g.N + n;
+                    const int nv = (g.N - n) < 8 ? (g.N - n) : 8;
+                    for (int i = 0; i < nv; ++i) w[i] = v[i];
+                } else {
+                    epi_store8(g.epi, v, m, n, g.N, zb);
+                }
+            }
+        }
+    }
+}
+
+__global__ void __launch_bounds__(256) splitk_reduce_kernel(const float* __restrict__ ws, int splitk, int M, int N, GemmEpi e) {
+    const int CH = (N + 7) / 8;
+    const int64_t total = (int64_t)M * CH;
+    for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * blockDim.x) {
+        const int m = (int)(idx / CH);
+        const int n = (int)(idx - (int64_t)m * CH) * 8;
+        const int nv = (N - n) < 8 ? (N - n) : 8;
+        float v[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) v[i] = 0.f;
+        for (int s = 0; s < splitk; ++s) {
+            const float* w = ws + ((int64_t)s * M + m) * N + n;
+            for (int i = 0; i < nv; ++i) v[i] += w[i];
+        }
+        epi_store8(e, v, m, n, N, 0);
+    }
+}
+
+template <int BM, int BN, bool CONV>
+static int launch_gemm_t(odise_hip_ctx* ctx, GemmArgs& g, int batch) {
+    constexpr int stage = (BM + BN) * 64 * 2 * 2;
+    constexpr int epi = 64 * (BN + 4) * 4;
+    constexpr int lds = stage > epi ? stage : epi;
+    dim3 grid((unsigned)ceil_div(g.N, BN), (unsigned)ceil_div(g.M, BM), (unsigned)(g.splitk > 1 ? g.splitk : batch));
+    hipLaunchKernelGGL((gemm_kernel<BM, BN, CONV>), grid, dim3(256), lds, ctx->stream, g);
+    ODISE_CHECK_HIP(hipGetLastError());
+    if (g.splitk > 1) {
+        const int64_t total = (int64_t)g.M * ceil_div(g.N, 8);
+        const int blocks = (int)std::min<int64_t>(ceil_div(total, 256), 4096);
+        hipLaunchKernelGGL(splitk_reduce_kernel, dim3(blocks), dim3(256), 0, ctx->stream, g.ws, g.splitk, g.M, g.N, g.epi);
+        ODISE_CHECK_HIP(hipGetLastError());
+    }
+    return ODISE_OK;
+}
+
+// tile / split-K heuristic: keep >= ~1.5 blocks per CU in flight.
+template <bool CONV>
+static int launch_gemm(odise_hip_ctx* ctx, GemmArgs& g, int batch, int force_tile, int force_split) {
+    const int64_t target = (int64_t)ctx->cu_count * 3 / 2;
+    auto blocks = [&](int bm, int bn) { return ceil_div(g.M, bm) * ceil_div(g.N, bn) * (int64_t)batch; };
+    int tile = 0;  // 0:128x128 1:64x128 2:64x64
+    if (g.M > 64 && blocks(128, 128) >= target) tile = 0;
+    else if (blocks(64, 128) >= target) tile = 1;
+    else tile = 2;
+    if (g.N <= 64) tile = 2;
+    if (force_tile >= 0) tile = force_tile;
+    const int bm = tile == 0 ? 128 : 64, bn = tile == 2 ? 64 : 128;
+    const int nk = (int)ceil_div(g.K, 64);
+    g.splitk = 1;
+    g.ktiles_per_split = nk;
+    const int64_t nb = blocks(bm, bn);
+    if (batch == 1 && nb < ctx->cu_count && nk >= 8) {
+        int want = (int)std::min<int64_t>(ceil_div(target, nb), nk / 4);
+        want = std::max(1, std::min(want, 64));
+        // workspace bound
+        while (want > 1 && (size_t)want * g.M * g.N * sizeof(float) > ctx->ws_bytes) --want;
+        if (want > 1) {
+            g.ktiles_per_split = (int)ceil_div(nk, want);
+            g.splitk = (int)ceil_div(nk, g.ktiles_per_split);
+        }
+    }
+    if (force_split > 0 && batch == 1) {
+        int want = std::min(force_split, nk);
+        g.ktiles_per_split = (int)ceil_div(nk, want);
+        g.splitk = (int)ceil_div(nk, g.ktiles_per_split);
+        ODISE_REQUIRE((size_t)g.splitk * g.M * g.N * sizeof(float) <= ctx->ws_bytes, "gemm: split-K workspace too small");
+    }
+    g.ws = (float*)ctx->ws;
+    switch (tile) {
+        case 0: return launch_gemm_t<128, 128, CONV>(ctx, g, batch);
+        case 1: return launch_gemm_t<64, 128, CONV>(ctx, g, batch);
+        default: return launch_gemm_t<64, 64, CONV>(ctx, g, batch);
+    }
+}
+
+int gemm_forced(odise_hip_ctx* ctx, const odise_gemm_desc* d, int force_tile, int force_split);
+int conv_forced(odise_hip_ctx* ctx, const odise_conv_desc* d, int force_tile, int force_split);
+
+int gemm_forced(odise_hip_ctx* ctx, const odise_gemm_desc* d, int force_tile, int force_split) {
+    ODISE_REQUIRE(ctx && d, "gemm: null argument");
+    ODISE_REQUIRE(d->M >= 0 && d->N >= 0 && d->K > 0, "gemm: bad dims M=%d N=%d K=%d", d->M, d->N, d->K);
+    if (d->M == 0 || d->N == 0) return ODISE_OK;
+    ODISE_REQUIRE(d->K % 8 == 0, "gemm: K=%d must be a multiple of 8", d->K);
+    ODISE_REQUIRE(d->lda % 8 == 0 && d->ldw % 8 == 0, "gemm: lda/ldw must be multiples of 8 (16-byte rows)");
+    ODISE_REQUIRE(((uintptr_t)d->A & 15) == 0 && ((uintptr_t)d->W & 15) == 0, "gemm: A/W must be 16-byte aligned");
+    ODISE_REQUIRE(d->A && d->W && d->C, "gemm: null device pointer");
+    ODISE_REQUIRE(d->c_dtype == ODISE_F16 || d->c_dtype == ODISE_F32, "gemm: bad c_dtype");
+    ODISE_REQUIRE(!d->geglu || (d->N % 2 == 0), "gemm: geglu needs even N");
+    ODISE_REQUIRE(!d->rowgroup_add || d->rows_per_group > 0, "gemm: rows_per_group must be > 0");
+    const int batch = d->batch < 1 ? 1 : d->batch;
+    ODISE_REQUIRE(batch == 1 || ((d->strideA % 8 == 0) && (d->strideW % 8 == 0)), "gemm: batch strides must keep 16-byte alignment");
+    GemmArgs g;
+    g.M = d->M; g.N = d->N; g.K = d->K;
+    g.A = (const f16*)d->A; g.lda = d->lda; g.strideA = d->strideA;
+    g.W = (const f16*)d->W; g.ldw = d->ldw; g.strideW = d->strideW;
+    g.epi.C = d->C; g.epi.ldc = d->ldc; g.epi.c_dtype = d->c_dtype;
+    g.epi.bias_n = d->bias_n; g.epi.bias_m = d->bias_m; g.epi.scale_m = d->scale_m;
+    g.epi.residual = (const f16*)d->residual; g.epi.ldr = d->ldr;
+    g.epi.rowgroup_add = d->rowgroup_add; g.epi.rows_per_group = d->rows_per_group > 0 ? d->rows_per_group : 1;
+    g.epi.act = d->act; g.epi.geglu = d->geglu; g.epi.alpha = d->alpha;
+    g.epi.strideC = d->strideC; g.epi.strideR = d->strideR;
+    g.cg = ConvGeom{};
+    return launch_gemm<false>(ctx, g, batch, force_tile, force_split);
+}
+
+int conv_forced(odise_hip_ctx* ctx, const odise_conv_desc* d, int force_tile, int force_split) {
+    ODISE_REQUIRE(ctx && d, "conv2d: null argument");
+    ODISE_REQUIRE(d->N >= 0 && d->H > 0 && d->W > 0 && d->Cin > 0 && d->Cout > 0, "conv2d: bad dims");
+    ODISE_REQUIRE(d->Cin % 8 == 0, "conv2d: Cin=%d must be a multiple of 8 (pad the input channels)", d->Cin);
+    ODISE_REQUIRE(d->KH >= 1 && d->KW >= 1 && d->stride >= 1 && d->OH > 0 && d->OW > 0, "conv2d: bad kernel geometry");
+    ODISE_REQUIRE(d->X && d->Wt && d->Y, "conv2d: null device pointer");
+    ODISE_REQUIRE(((uintptr_t)d->X & 15) == 0 && ((uintptr_t)d->Wt & 15) == 0, "conv2d: X/Wt must be 16-byte aligned");
+    if (d->N == 0) return ODISE_OK;
+    GemmArgs g;
+    g.M = d->N * d->OH * d->OW;
+    g.N = d->Cout;
+    g.K = d->KH * d->KW * d->Cin;
+    g.A = (const f16*)d->X; g.lda = 0; g.strideA = 0;
+    g.W = (const f16*)d->Wt; g.ldw = g.K; g.strideW = 0;
+    g.epi.C = d->Y; g.epi.ldc = d->Cout; g.epi.c_dtype = d->y_dtype;
+    g.epi.bias_n = d->bias; g.epi.bias_m = nullptr; g.epi.scale_m = nullptr;
+    g.epi.residual = (const f16*)d->residual; g.epi.ldr = d->Cout;
+    g.epi.rowgroup_add = d->per_image_add; g.epi.rows_per_group = d->OH * d->OW;
+    g.epi.act = d->act; g.epi.geglu = 0; g.epi.alpha = 1.0f;
+    g.epi.strideC = 0; g.epi.strideR = 0;
+    g.cg.H = d->H; g.cg.W = d->W; g.cg.Cin = d->Cin; g.cg.KH = d->KH; g.cg.KW = d->KW;
+    g.cg.stride = d->stride; g.cg.pad_t = d->pad_t; g.cg.pad_l = d->pad_l; g.cg.OH = d->OH; g.cg.OW = d->OW;
+    g.cg.ups = d->upsample2x;
+    // a 1x1 stride-1 unpadded conv is a plain GEMM over pixels
+    if (d->KH == 1 && d->KW == 1 && d->stride == 1 && d->pad_t == 0 && d->pad_l == 0 && !d->upsample2x && d->OH == d->H &&
+        d->OW == d->W) {
+        g.lda = d->Cin;
+        return launch_gemm<false>(ctx, g, 1, force_tile, force_split);
+    }
+    return launch_gemm<true>(ctx, g, 1, force_tile, force_split);
+}
+
+}  // namespace odise
+
+extern "C" int odise_hip_gemm(odise_hip_ctx* ctx, const odise_gemm_desc* d) { return odise::gemm_forced(ctx, d, -1, 0); }
+extern "C" int odise_hip_conv2d(odise_hip_ctx* ctx, const odise_conv_desc* d) { return odise::conv_forced(ctx, d, -1, 0); }
+// test hooks: force a tile shape (0:128x128, 1:64x128, 2:64x64) and/or a split-K factor
+extern "C" int odise_hip_gemm_forced(odise_hip_ctx* ctx, const odise_gemm_desc* d, int tile, int splitk) {
+    return odise::gemm_forced(ctx, d, tile, splitk);
+}
+extern "C" int odise_hip_conv2d_forced(odise_hip_ctx* ctx, const odise_conv_desc* d, int tile, int splitk) {
+    return odise::conv_forced(ctx, d, tile, splitk);
+}

@@ -1,0 +1,173 @@
+// msda.hip — multi-scale deformable attention forward for gfx950.
+//
+// Replaces MSDA.ms_deform_attn_forward of the reference
+// (third_party/Mask2Former/mask2former/modeling/pixel_decoder/ops/src/cuda/ms_deform_attn_cuda.cu:25-85,
+//  kernel semantics ms_deform_im2col_cuda.cuh:242-303, bilinear helper :38-89):
+//   out[b,q,m,c] = sum_l sum_p w[b,q,m,l,p] * bilinear(value_l[b,:,m,c], loc*(W_l,H_l) - 0.5)
+// with zero padding outside (-1,H)x(-1,W).
+//
+// MI355X design: the op is an L2/HBM gather.  value is [B,S,M,D] so the D channels of a head are
+// contiguous; each lane owns VEC consecutive channels (16 B for f32, 8 B for f16) and D/VEC lanes
+// share one (q,m) pair, so a 64-wide wavefront covers 64*VEC/D (q,m) pairs and every corner fetch is
+// a contiguous D*sizeof(T)-byte segment.  Sampling locations / weights of a (q,m) pair are read once
+// per lane group (same-address broadcast).  One launch for the whole batch: the reference's
+// im2col_step chunking only bounded its temporary; there is no temporary here.
+#include "common.h"
+
+namespace odise {
+
+struct MsdaLevels {
+    int H[8];
+    int W[8];
+    int start[8];
+};
+
+template <typename T, int VEC>
+struct VecIO;
+
+template <>
+struct VecIO<float, 4> {
+    static __device__ __forceinline__ void load(const float* p, float (&v)[4]) {
+        const float4 t = *reinterpret_cast<const float4*>(p);
+        v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w;
+    }
+    static __device__ __forceinline__ void store(float* p, const float (&v)[4]) {
+        *reinterpret_cast<float4*>(p) = make_float4(v[0], v[1], v[2], v[3]);
+    }
+};
+template <>
+struct VecIO<float, 1> {
+    static __device__ __forceinline__ void load(const float* p, float (&v)[1]) { v[0] = *p; }
+    static __device__ __forceinline__ void store(float* p, const float (&v)[1]) { *p = v[0]; }
+};
+template <>
+struct VecIO<f16, 4> {
+    static __device__ __forceinline__ void load(const f16* p, float (&v)[4]) {
+        const f16x4 t = *reinterpret_cast<const f16x4*>(p);
+        v[0] = (float)t[0]; v[1] = (float)t[1]; v[2] = (float)t[2]; v[3] = (float)t[3];
+    }
+    static __device__ __forceinline__ void store(f16* p, const float (&v)[4]) {
+        f16x4 t;
+        t[0] = (f16)v[0]; t[1] = (f16)v[1]; t[2] = (f16)v[2]; t[3] = (f16)v[3];
+        *reinterpret_cast<f16x4*>(p) = t;
+    }
+};
+template <>
+struct VecIO<f16, 1> {
+    static __device__ __forceinline__ void load(const f16* p, float (&v)[1]) { v[0] = (float)*p; }
+    static __device__ __forceinline__ void store(f16* p, const float (&v)[1]) { *p = (f16)v[0]; }
+};
+
+template <typename T, int VEC>
+__global__ void __launch_bounds__(256) msda_forward_kernel(const T* __restrict__ value, const float* __restrict__ loc,
+                                                          const float* __restrict__ attw, T* __restrict__ out,
+                                                          MsdaLevels lv, int64_t total, int S, int M, int D, int Lq,
+                                                          int L, int P) {
+    const int dchunks = D / VEC;
+    for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
+         idx += (int64_t)gridDim.x * blockDim.x) {
+        const int dc = (int)(idx % dchunks);
+        const int64_t qm = idx / dchunks;  // ((b*Lq + q)*M + m)
+        const int m = (int)(qm % M);
+        const int64_t bq = qm / M;
+        const int b = (int)(bq / Lq);
+        const float* lp = loc + qm * (int64_t)(L * P * 2);
+        const float* wp = attw + qm * (int64_t)(L * P);
+        const T* vb = value + ((int64_t)b * S * M + m) * D + dc * VEC;
+        const int64_t pix_stride = (int64_t)M * D;
+
+        float acc[VEC];
+#pragma unroll
+        for (int i = 0; i < VEC; ++i) acc[i] = 0.f;
+
+        for (int l = 0; l < L; ++l) {
+            const int Hl = lv.H[l], Wl = lv.W[l];
+            const T* vl = vb + (int64_t)lv.start[l] * pix_stride;
+            for (int p = 0; p < P; ++p) {
+                const float lx = lp[(l * P + p) * 2 + 0];
+                const float ly = lp[(l * P + p) * 2 + 1];
+                const float w = wp[l * P + p];
+                const float h_im = ly * (float)Hl - 0.5f;
+                const float w_im = lx * (float)Wl - 0.5f;
+                if (h_im > -1.f && w_im > -1.f && h_im < (float)Hl && w_im < (float)Wl) {
+                    const float hf = floorf(h_im), wf = floorf(w_im);
+                    const int h_low = (int)hf, w_low = (int)wf;
+                    const int h_high = h_low + 1, w_high = w_low + 1;
+                    const float lh = h_im - hf, lw = w_im - wf;
+                    const float hh = 1.f - lh, hw = 1.f - lw;
+                    float v1[VEC], v2[VEC], v3[VEC], v4[VEC];
+#pragma unroll
+                    for (int i = 0; i < VEC; ++i) v1[i] = v2[i] = v3[i] = v4[i] = 0.f;
+                    if (h_low >= 0 && w_low >= 0) VecIO<T, VEC>::load(vl + ((int64_t)h_low * Wl + w_low) * pix_stride, v1);
+                    if (h_low >= 0 && w_high <= Wl - 1) VecIO<T, VEC>::load(vl + ((int64_t)h_low * Wl + w_high) * pix_stride, v2);
+                    if (h_high <= Hl - 1 && w_low >= 0) VecIO<T, VEC>::load(vl + ((int64_t)h_high * Wl + w_low) * pix_stride, v3);
+                    if (h_high <= Hl - 1 && w_high <= Wl - 1) VecIO<T, VEC>::load(vl + ((int64_t)h_high * Wl + w_high) * pix_stride, v4);
+                    const float w1 = hh * hw, w2 = hh * lw, w3 = lh * hw, w4 = lh * lw;
+#pragma unroll
+                    for (int i = 0; i < VEC; ++i) {
+                        const float val = w1 * v1[i] + w2 * v2[i] + w3 * v3[i] + w4 * v4[i];
+                        acc[i] += w * val;
+                    }
+                }
+            }
+        }
+        VecIO<T, VEC>::store(out + qm * D + dc * VEC, acc);
+    }
+}
+
+template <typename T>
+static int launch_msda(hipStream_t stream, const void* value, const float* loc, const float* attw, void* out,
+                       const MsdaLevels& lv, int B, int S, int M, int D, int Lq, int L, int P) {
+    const int threads = 256;
+    if (D % 4 == 0) {
+        const int64_t total = (int64_t)B * Lq * M * (D / 4);
+        if (total == 0) return ODISE_OK;
+        const int blocks = (int)std::min<int64_t>(ceil_div(total, threads), 1 << 20);
+        hipLaunchKernelGGL((msda_forward_kernel<T, 4>), dim3(blocks), dim3(threads), 0, stream, (const T*)value, loc, attw,
+                           (T*)out, lv, total, S, M, D, Lq, L, P);
+    } else {
+        const int64_t total = (int64_t)B * Lq * M * D;
+        if (total == 0) return ODISE_OK;
+        const int blocks = (int)std::min<int64_t>(ceil_div(total, threads), 1 << 20);
+        hipLaunchKernelGGL((msda_forward_kernel<T, 1>), dim3(blocks), dim3(threads), 0, stream, (const T*)value, loc, attw,
+                           (T*)out, lv, total, S, M, D, Lq, L, P);
+    }
+    ODISE_CHECK_HIP(hipGetLastError());
+    return ODISE_OK;
+}
+
+}  // namespace odise
+
+extern "C" int odise_hip_ms_deform_attn_forward(odise_hip_ctx* ctx, const void* value, const int64_t* spatial_shapes,
+                                                const int64_t* level_start_index, const float* sampling_loc,
+                                                const float* attn_weight, int B, int S, int M, int D, int Lq, int L, int P,
+                                                int im2col_step, int value_dtype, void* out) {
+    using namespace odise;
+    ODISE_REQUIRE(ctx != nullptr, "ms_deform_attn_forward: null context");
+    ODISE_REQUIRE(L >= 1 && L <= 8, "ms_deform_attn_forward: n_levels=%d not in [1,8]", L);
+    ODISE_REQUIRE(B >= 0 && S >= 0 && M >= 1 && D >= 1 && Lq >= 0 && P >= 1, "ms_deform_attn_forward: bad dims");
+    ODISE_REQUIRE(spatial_shapes && level_start_index, "ms_deform_attn_forward: spatial_shapes/level_start_index must be host arrays");
+    // the reference asserts batch % im2col_step_ == 0 with im2col_step_ = min(batch, im2col_step)
+    if (B > 0) {
+        const int step = std::min(B, im2col_step);
+        ODISE_REQUIRE(step >= 1 && B % step == 0, "batch(%d) must divide im2col_step(%d)", B, step);
+    }
+    ODISE_REQUIRE(value_dtype == ODISE_F32 || value_dtype == ODISE_F16, "ms_deform_attn_forward: dtype must be f32|f16");
+    MsdaLevels lv;
+    int64_t tot = 0;
+    for (int l = 0; l < L; ++l) {
+        lv.H[l] = (int)spatial_shapes[2 * l + 0];
+        lv.W[l] = (int)spatial_shapes[2 * l + 1];
+        lv.start[l] = (int)level_start_index[l];
+        ODISE_REQUIRE(lv.H[l] >= 1 && lv.W[l] >= 1, "ms_deform_attn_forward: empty level %d", l);
+        ODISE_REQUIRE(lv.start[l] >= 0 && (int64_t)lv.start[l] + (int64_t)lv.H[l] * lv.W[l] <= S,
+                      "ms_deform_attn_forward: level %d exceeds S=%d", l, S);
+        tot += (int64_t)lv.H[l] * lv.W[l];
+    }
+    (void)tot;
+    if (B == 0 || Lq == 0) return ODISE_OK;
+    ODISE_REQUIRE(value && sampling_loc && attn_weight && out, "ms_deform_attn_forward: null device pointer");
+    if (value_dtype == ODISE_F32)
+        return launch_msda<float>(ctx->stream, value, sampling_loc, attn_weight, out, lv, B, S, M, D, Lq, L, P);
+    return launch_msda<f16>(ctx->stream, value, sampling_loc, attn_weight, out, lv, B, S, M, D, Lq, L, P);
+}

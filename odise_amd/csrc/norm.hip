@@ -1,0 +1,189 @@
+// norm.hip — GroupNorm(+SiLU/ReLU) and LayerNorm for NHWC / token-major fp16 activations, fp32 statistics.
+//
+// GroupNorm32 of the SD UNet ResBlock / SpatialTransformer (computed in fp32 and cast back — SURVEY.md
+// Appendix A.1), the VAE `Normalize` (eps 1e-6), detectron2 get_norm("GN") of the projection BottleneckBlocks
+// (feature_extractor.py:53-66) and the pixel decoder convs.  HBM-bound: two passes over x:
+//   1. gn_partial_kernel: per (image, pixel-chunk) partial (sum, sumsq) of every group, deterministic
+//      (no atomics; [N, chunks, G, 2] fp32 partials).
+//   2. gn_apply_kernel: every block re-reduces the (tiny) partials of its image into per-channel
+//      scale/shift in LDS, then streams x -> act(x*scale+shift) with 16-byte loads/stores.
+#include "common.h"
+
+namespace odise {
+
+constexpr int GN_MAX_C = 4096;
+
+// grid (chunks, N); block 256.  Thread owns channel pairs p = tid % PW (+k*PW) and pixel lane tid / PW.
+// LDS: [2][PL][C] fp32 (sum, sumsq) per pixel lane and channel, reduced per group in a fixed order.
+__global__ void __launch_bounds__(256) gn_partial_kernel(const f16* __restrict__ x, float* __restrict__ partial, int HW, int C,
+                                                        int G, int pix_per_chunk) {
+    extern __shared__ float sred[];
+    const int n = blockIdx.y, chunk = blockIdx.x, nchunks = gridDim.x;
+    const int tid = threadIdx.x;
+    const int C2 = C >> 1;
+    const int PW = C2 < 256 ? C2 : 256;
+    const int PL = 256 / PW;  // >= 1
+    float* ssum = sred;
+    float* ssq = sred + PL * C;
+    const int p_begin = chunk * pix_per_chunk;
+    const int p_end = min(HW, p_begin + pix_per_chunk);
+    const int cp = tid % PW;
+    const int pl = tid / PW;
+    if (pl < PL) {
+        for (int cp0 = cp; cp0 < C2; cp0 += PW) {
+            float s0 = 0.f, s1 = 0.f, q0 = 0.f, q1 = 0.f;
+            const f16* xb = x + ((int64_t)n * HW) * C + 2 * cp0;
+            for (int p = p_begin + pl; p < p_end; p += PL) {
+                const __half2 v = *reinterpret_cast<const __half2*>(xb + (int64_t)p * C);
+                const float a = __low2float(v), b = __high2float(v);
+                s0 += a; q0 += a * a;
+                s1 += b; q1 += b * b;
+            }
+            ssum[pl * C + 2 * cp0] = s0; ssum[pl * C + 2 * cp0 + 1] = s1;
+            ssq[pl * C + 2 * cp0] = q0;  ssq[pl * C + 2 * cp0 + 1] = q1;
+        }
+    }
+    __syncthreads();
+    const int cpg = C / G;
+    if (tid < G) {
+        float s = 0.f, q = 0.f;
+        for (int t = 0; t < PL; ++t)
+            for (int c = tid * cpg; c < (tid + 1) * cpg; ++c) { s += ssum[t * C + c]; q += ssq[t * C + c]; }
+        float* o = partial + (((int64_t)n * nchunks + chunk) * G + tid) * 2;
+        o[0] = s; o[1] = q;
+    }
+}
+
+// grid (blocks_per_image, N); block 256
+__global__ void __launch_bounds__(256) gn_apply_kernel(const f16* __restrict__ x, f16* __restrict__ y,
+                                                      const float* __restrict__ partial, const float* __restrict__ gamma,
+                                                      const float* __restrict__ beta, int HW, int C, int G, int nchunks,
+                                                      float eps, int act) {
+    extern __shared__ float sss[];  // scale[C], shift[C], mean[G], rstd[G]
+    float* scale = sss;
+    float* shift = sss + C;
+    float* mean = sss + 2 * C;
+    float* rstd = mean + G;
+    const int n = blockIdx.y, tid = threadIdx.x;
+    const int cpg = C / G;
+    if (tid < G) {
+        double s = 0.0, q = 0.0;
+        for (int ch = 0; ch < nchunks; ++ch) {
+            const float* o = partial + (((int64_t)n * nchunks + ch) * G + tid) * 2;
+            s += (double)o[0]; q += (double)o[1];
+        }
+        const double cnt = (double)HW * cpg;
+        const double mu = s / cnt;
+        double var = q / cnt - mu * mu;
+        if (var < 0.0) var = 0.0;
+        mean[tid] = (float)mu;
+        rstd[tid] = (float)(1.0 / sqrt(var + (double)eps));
+    }
+    __syncthreads();
+    for (int c = tid; c < C; c += blockDim.x) {
+        const int gI = c / cpg;
+        const float sc = rstd[gI] * (gamma ? gamma[c] : 1.f);
+        scale[c] = sc;
+        shift[c] = (beta ? beta[c] : 0.f) - mean[gI] * sc;
+    }
+    __syncthreads();
+    const int C8 = C >> 3;
+    const int64_t total = (int64_t)HW * C8;
+    const f16* xb = x + (int64_t)n * HW * C;
+    f16* yb = y + (int64_t)n * HW * C;
+    for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + tid; idx < total; idx += (int64_t)gridDim.x * blockDim.x) {
+        const int c0 = (int)(idx % C8) * 8;
+        const f16x8 v = *reinterpret_cast<const f16x8*>(xb + idx * 8);
+        f16x8 o;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const float t = (float)v[i] * scale[c0 + i] + shift[c0 + i];
+            o[i] = (f16)act_apply(t, act);
+        }
+        *reinterpret_cast<f16x8*>(yb + idx * 8) = o;
+    }
+}
+
+// one wavefront per row; 4 rows per 256-thread block
+__global__ void __launch_bounds__(256) layer_norm_kernel(const f16* __restrict__ x, f16* __restrict__ y,
+                                                        const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                        int rows, int C, float eps) {
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const f16* xr = x + (int64_t)row * C;
+    f16* yr = y + (int64_t)row * C;
+    float s = 0.f;
+    for (int c = lane * 8; c < C; c += 512) {
+        const f16x8 v = *reinterpret_cast<const f16x8*>(xr + c);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) s += (float)v[i];
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+    const float mu = s / (float)C;
+    float q = 0.f;
+    for (int c = lane * 8; c < C; c += 512) {
+        const f16x8 v = *reinterpret_cast<const f16x8*>(xr + c);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) { const float d = (float)v[i] - mu; q += d * d; }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) q += __shfl_xor(q, o);
+    const float rs = rsqrtf(q / (float)C + eps);
+    for (int c = lane * 8; c < C; c += 512) {
+        const f16x8 v = *reinterpret_cast<const f16x8*>(xr + c);
+        f16x8 o;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const float g = gamma ? gamma[c + i] : 1.f;
+            const float b = beta ? beta[c + i] : 0.f;
+            o[i] = (f16)(((float)v[i] - mu) * rs * g + b);
+        }
+        *reinterpret_cast<f16x8*>(yr + c) = o;
+    }
+}
+
+}  // namespace odise
+
+extern "C" int odise_hip_group_norm(odise_hip_ctx* ctx, const void* x, void* y, const float* gamma, const float* beta, int N,
+                                    int HW, int C, int groups, float eps, int act) {
+    using namespace odise;
+    ODISE_REQUIRE(ctx && x && y, "group_norm: null argument");
+    ODISE_REQUIRE(N >= 0 && HW > 0 && C > 0 && groups > 0, "group_norm: bad dims");
+    ODISE_REQUIRE(C % groups == 0 && C % 8 == 0 && C <= GN_MAX_C, "group_norm: C=%d must be a multiple of 8 and of groups=%d, <= %d", C, groups, GN_MAX_C);
+    ODISE_REQUIRE(groups <= 256, "group_norm: groups=%d > 256", groups);
+    if (N == 0) return ODISE_OK;
+    // chunking: aim for >= 2 blocks per CU in the stats pass, at least 64 pixels per chunk
+    int nchunks = (int)std::min<int64_t>(std::max<int64_t>(1, (int64_t)ctx->cu_count * 2 / N), ceil_div(HW, 64));
+    nchunks = std::max(1, std::min(nchunks, 256));
+    const int ppc = (int)ceil_div(HW, nchunks);
+    nchunks = (int)ceil_div(HW, ppc);
+    const size_t pbytes = (size_t)N * nchunks * groups * 2 * sizeof(float);
+    ODISE_REQUIRE(pbytes <= ctx->ws_bytes, "group_norm: workspace too small");
+    float* partial = (float*)ctx->ws;
+    const int C2h = C / 2;
+    const int PLh = C2h < 256 ? 256 / C2h : 1;
+    hipLaunchKernelGGL(gn_partial_kernel, dim3(nchunks, N), dim3(256), 2 * (size_t)PLh * C * sizeof(float), ctx->stream, (const f16*)x, partial,
+                       HW, C, groups, ppc);
+    ODISE_CHECK_HIP(hipGetLastError());
+    const int64_t total = (int64_t)HW * (C / 8);
+    int bpi = (int)std::min<int64_t>(ceil_div(total, 256 * 4), std::max<int64_t>(1, (int64_t)ctx->cu_count * 8 / N));
+    bpi = std::max(1, bpi);
+    hipLaunchKernelGGL(gn_apply_kernel, dim3(bpi, N), dim3(256), (2 * C + 2 * groups) * sizeof(float), ctx->stream,
+                       (const f16*)x, (f16*)y, partial, gamma, beta, HW, C, groups, nchunks, eps, act);
+    ODISE_CHECK_HIP(hipGetLastError());
+    return ODISE_OK;
+}
+
+extern "C" int odise_hip_layer_norm(odise_hip_ctx* ctx, const void* x, void* y, const float* gamma, const float* beta,
+                                    int rows, int C, float eps) {
+    using namespace odise;
+    ODISE_REQUIRE(ctx && x && y, "layer_norm: null argument");
+    ODISE_REQUIRE(rows >= 0 && C > 0 && C % 8 == 0, "layer_norm: C=%d must be a positive multiple of 8", C);
+    if (rows == 0) return ODISE_OK;
+    hipLaunchKernelGGL(layer_norm_kernel, dim3((unsigned)ceil_div(rows, 4)), dim3(256), 0, ctx->stream, (const f16*)x, (f16*)y,
+                       gamma, beta, rows, C, eps);
+    ODISE_CHECK_HIP(hipGetLastError());
+    return ODISE_OK;
+}

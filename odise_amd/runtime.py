@@ -1,0 +1,280 @@
+"""Host-side runtime over the C ABI: one Context per process/GPU, device buffers, op wrappers.
+
+One process per GPU (SURVEY.md §8b "threading / process model"): the Context binds to `cuda:<LOCAL_RANK>`,
+owns one HIP stream, and is not re-entrant.  numpy arrays are the host-side currency (fp16/fp32); torch is
+only used by callers for CPU tensors and `torch.distributed`.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Optional, Sequence
+
+import numpy as np
+
+from . import _lib
+from ._lib import ACT_NONE, F16, F32, AttnDesc, ConvDesc, GemmDesc, check
+
+_NP = {F16: np.float16, F32: np.float32}
+
+
+class DeviceArray:
+    """A hipMalloc'ed buffer with shape/dtype metadata (dtype is a numpy dtype)."""
+
+    def __init__(self, ctx: "Context", shape: Sequence[int], dtype):
+        self.ctx = ctx
+        self.shape = tuple(int(s) for s in shape)
+        self.dtype = np.dtype(dtype)
+        self.nbytes = int(np.prod(self.shape, dtype=np.int64)) * self.dtype.itemsize
+        p = C.c_void_p()
+        check(ctx.lib.odise_hip_malloc(ctx.h, C.c_size_t(max(self.nbytes, 16)), C.byref(p)), "malloc")
+        self.ptr = p.value
+        self._owned = True
+
+    def free(self):
+        if self._owned and self.ptr and self.ctx.h:
+            self.ctx.lib.odise_hip_free(self.ctx.h, C.c_void_p(self.ptr))
+        self.ptr = None
+        self._owned = False
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
+
+    def numpy(self) -> np.ndarray:
+        out = np.empty(self.shape, dtype=self.dtype)
+        check(self.ctx.lib.odise_hip_memcpy_d2h(self.ctx.h, out.ctypes.data_as(C.c_void_p), C.c_void_p(self.ptr),
+                                                C.c_size_t(self.nbytes)), "memcpy_d2h")
+        return out
+
+    def copy_from(self, host: np.ndarray) -> "DeviceArray":
+        host = np.ascontiguousarray(host, dtype=self.dtype)
+        assert host.shape == self.shape, (host.shape, self.shape)
+        check(self.ctx.lib.odise_hip_memcpy_h2d(self.ctx.h, C.c_void_p(self.ptr), host.ctypes.data_as(C.c_void_p),
+                                                C.c_size_t(self.nbytes)), "memcpy_h2d")
+        return self
+
+
+def _p(a: Optional[DeviceArray]):
+    return C.c_void_p(a.ptr) if a is not None else C.c_void_p(None)
+
+
+class Context:
+    def __init__(self, device: int = 0):
+        self.lib = _lib.load()
+        h = C.c_void_p()
+        check(self.lib.odise_hip_create(C.c_int(device), C.byref(h)), "create")
+        self.h = h
+        self.device = device
+
+    def close(self):
+        if self.h:
+            self.lib.odise_hip_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # ---- memory -----------------------------------------------------------------------------
+    def empty(self, shape, dtype=np.float16) -> DeviceArray:
+        return DeviceArray(self, shape, dtype)
+
+    def zeros(self, shape, dtype=np.float16) -> DeviceArray:
+        a = DeviceArray(self, shape, dtype)
+        check(self.lib.odise_hip_memset(self.h, C.c_void_p(a.ptr), 0, C.c_size_t(a.nbytes)), "memset")
+        return a
+
+    def to_device(self, host, dtype=None) -> DeviceArray:
+        if hasattr(host, "detach"):  # torch CPU tensor
+            host = host.detach().cpu().numpy()
+        host = np.ascontiguousarray(host, dtype=dtype if dtype is not None else host.dtype)
+        return DeviceArray(self, host.shape, host.dtype).copy_from(host)
+
+    def sync(self):
+        check(self.lib.odise_hip_sync(self.h), "sync")
+
+    def timer_start(self):
+        check(self.lib.odise_hip_timer_start(self.h), "timer_start")
+
+    def timer_stop(self) -> float:
+        ms = C.c_float()
+        check(self.lib.odise_hip_timer_stop(self.h, C.byref(ms)), "timer_stop")
+        return float(ms.value)
+
+    def device_info(self):
+        buf = C.create_string_buffer(256)
+        cu = C.c_int()
+        mem = C.c_size_t()
+        check(self.lib.odise_hip_device_info(self.h, buf, 256, C.byref(cu), C.byref(mem)), "device_info")
+        return buf.value.decode(), cu.value, mem.value
+
+    # ---- ops --------------------------------------------------------------------------------
+    def ms_deform_attn_forward(self, value: DeviceArray, spatial_shapes, level_start_index, sampling_loc: DeviceArray,
+                               attn_weight: DeviceArray, im2col_step: int = 128) -> DeviceArray:
+        """MSDA.ms_deform_attn_forward (ms_deform_attn.h:25-44): value [B,S,M,D] -> [B,Lq,M*D]."""
+        B, S, M, D = value.shape
+        _, Lq, M2, L, P, two = sampling_loc.shape
+        assert M2 == M and two == 2 and attn_weight.shape == (B, Lq, M, L, P)
+        ss = np.ascontiguousarray(np.asarray(spatial_shapes, dtype=np.int64).reshape(L, 2))
+        ls = np.ascontiguousarray(np.asarray(level_start_index, dtype=np.int64).reshape(L))
+        assert sampling_loc.dtype == np.float32 and attn_weight.dtype == np.float32
+        dt = F32 if value.dtype == np.float32 else F16
+        out = self.empty((B, Lq, M * D), value.dtype)
+        check(self.lib.odise_hip_ms_deform_attn_forward(
+            self.h, _p(value), ss.ctypes.data_as(C.POINTER(C.c_int64)), ls.ctypes.data_as(C.POINTER(C.c_int64)),
+            _p(sampling_loc), _p(attn_weight), B, S, M, D, Lq, L, P, int(im2col_step), dt, _p(out)),
+            "ms_deform_attn_forward")
+        return out
+
+    def gemm(self, A: DeviceArray, W: DeviceArray, *, bias_n=None, bias_m=None, scale_m=None, residual=None,
+             rowgroup_add=None, rows_per_group=0, act=ACT_NONE, geglu=False, alpha=1.0, out_dtype=np.float16,
+             force_tile=-1, force_split=0) -> DeviceArray:
+        """C[M,N] = epi(alpha * A[M,K] @ W[N,K]^T); 3-D inputs are batched over dim 0."""
+        batched = len(A.shape) == 3 or len(W.shape) == 3
+        batch = (A.shape[0] if len(A.shape) == 3 else W.shape[0]) if batched else 1
+        M, K = A.shape[-2:]
+        N, K2 = W.shape[-2:]
+        assert K == K2
+        No = N // 2 if geglu else N
+        oshape = (batch, M, No) if batched else (M, No)
+        out = self.empty(oshape, out_dtype)
+        d = GemmDesc()
+        d.M, d.N, d.K = M, N, K
+        d.A, d.lda = A.ptr, K
+        d.W, d.ldw = W.ptr, K
+        d.C, d.ldc = out.ptr, No
+        d.c_dtype = F32 if np.dtype(out_dtype) == np.float32 else F16
+        d.bias_n = bias_n.ptr if bias_n is not None else None
+        d.bias_m = bias_m.ptr if bias_m is not None else None
+        d.scale_m = scale_m.ptr if scale_m is not None else None
+        d.residual = residual.ptr if residual is not None else None
+        d.ldr = No
+        d.rowgroup_add = rowgroup_add.ptr if rowgroup_add is not None else None
+        d.rows_per_group = rows_per_group
+        d.act, d.geglu, d.alpha = act, int(geglu), float(alpha)
+        d.batch = batch
+        d.strideA = M * K if len(A.shape) == 3 else 0
+        d.strideW = N * K if len(W.shape) == 3 else 0
+        d.strideC = M * No
+        d.strideR = M * No
+        if force_tile >= 0 or force_split > 0:
+            check(self.lib.odise_hip_gemm_forced(self.h, C.byref(d), int(force_tile), int(force_split)), "gemm_forced")
+        else:
+            check(self.lib.odise_hip_gemm(self.h, C.byref(d)), "gemm")
+        return out
+
+    def conv2d(self, X: DeviceArray, Wt: DeviceArray, *, stride=1, pad=None, pad_tl=None, out_hw=None, upsample2x=False,
+               bias=None, residual=None, per_image_add=None, act=ACT_NONE, out_dtype=np.float16, force_tile=-1,
+               force_split=0) -> DeviceArray:
+        """NHWC conv: X [N,H,W,Cin] f16, Wt [Cout,KH,KW,Cin] f16 -> [N,OH,OW,Cout]."""
+        N, H, W, Cin = X.shape
+        Cout, KH, KW, Cin2 = Wt.shape
+        assert Cin == Cin2
+        if pad is None:
+            pad = KH // 2
+        pt, pl = pad_tl if pad_tl is not None else (pad, pad)
+        Hin, Win = (2 * H, 2 * W) if upsample2x else (H, W)
+        if out_hw is None:
+            OH = (Hin + 2 * pad - KH) // stride + 1
+            OW = (Win + 2 * pad - KW) // stride + 1
+        else:
+            OH, OW = out_hw
+        out = self.empty((N, OH, OW, Cout), out_dtype)
+        d = ConvDesc()
+        d.N, d.H, d.W, d.Cin = N, H, W, Cin
+        d.Cout, d.KH, d.KW, d.stride = Cout, KH, KW, stride
+        d.pad_t, d.pad_l, d.OH, d.OW = pt, pl, OH, OW
+        d.upsample2x = int(upsample2x)
+        d.X, d.Wt, d.Y = X.ptr, Wt.ptr, out.ptr
+        d.y_dtype = F32 if np.dtype(out_dtype) == np.float32 else F16
+        d.bias = bias.ptr if bias is not None else None
+        d.residual = residual.ptr if residual is not None else None
+        d.per_image_add = per_image_add.ptr if per_image_add is not None else None
+        d.act = act
+        if force_tile >= 0 or force_split > 0:
+            check(self.lib.odise_hip_conv2d_forced(self.h, C.byref(d), int(force_tile), int(force_split)), "conv2d_forced")
+        else:
+            check(self.lib.odise_hip_conv2d(self.h, C.byref(d)), "conv2d")
+        return out
+
+    def group_norm(self, x: DeviceArray, gamma: Optional[DeviceArray], beta: Optional[DeviceArray], groups=32, eps=1e-5,
+                   act=ACT_NONE) -> DeviceArray:
+        """x [N, ..., C] f16 channels-last."""
+        N, Cc = x.shape[0], x.shape[-1]
+        HW = int(np.prod(x.shape[1:-1]))
+        y = self.empty(x.shape, np.float16)
+        check(self.lib.odise_hip_group_norm(self.h, _p(x), _p(y), _p(gamma), _p(beta), N, HW, Cc, groups, C.c_float(eps), act),
+              "group_norm")
+        return y
+
+    def layer_norm(self, x: DeviceArray, gamma, beta, eps=1e-5) -> DeviceArray:
+        Cc = x.shape[-1]
+        rows = int(np.prod(x.shape[:-1]))
+        y = self.empty(x.shape, np.float16)
+        check(self.lib.odise_hip_layer_norm(self.h, _p(x), _p(y), _p(gamma), _p(beta), rows, Cc, C.c_float(eps)), "layer_norm")
+        return y
+
+    def attention(self, Q: DeviceArray, K: DeviceArray, Vt: DeviceArray, heads: int, scale: float,
+                  mask: Optional[DeviceArray] = None, Lk: Optional[int] = None) -> DeviceArray:
+        """Q [B,Lq,H*D], K [B,Lk,H*D], Vt [B,H*D,ldvt] (transposed V) -> O [B,Lq,H*D] (all f16)."""
+        B, Lq, HD = Q.shape
+        Lk = Lk if Lk is not None else K.shape[1]
+        D = HD // heads
+        O = self.empty((B, Lq, HD), np.float16)
+        d = AttnDesc()
+        d.B, d.H, d.Lq, d.Lk, d.D = B, heads, Lq, Lk, D
+        d.Q, d.ldq, d.strideQ = Q.ptr, HD, Lq * HD
+        d.K, d.ldk, d.strideK = K.ptr, HD, K.shape[1] * HD
+        d.Vt, d.ldvt, d.strideVt = Vt.ptr, Vt.shape[2], Vt.shape[1] * Vt.shape[2]
+        d.O, d.ldo, d.strideO = O.ptr, HD, Lq * HD
+        if mask is not None:
+            assert mask.dtype == np.uint8 and mask.shape[0] == B and mask.shape[1] == Lq
+            d.mask, d.ldmask, d.strideMask = mask.ptr, mask.shape[2], mask.shape[1] * mask.shape[2]
+        d.scale = float(scale)
+        check(self.lib.odise_hip_attention(self.h, C.byref(d)), "attention")
+        return O
+
+    def nchw_to_nhwc_f16(self, x: DeviceArray, cpad: Optional[int] = None) -> DeviceArray:
+        N, Cc, H, W = x.shape
+        cpad = cpad or ((Cc + 7) // 8) * 8
+        y = self.empty((N, H, W, cpad), np.float16)
+        check(self.lib.odise_hip_nchw_f32_to_nhwc_f16(self.h, _p(x), _p(y), N, Cc, H, W, cpad), "nchw_to_nhwc")
+        return y
+
+    def nhwc_to_nchw_f32(self, x: DeviceArray) -> DeviceArray:
+        N, H, W, Cc = x.shape
+        y = self.empty((N, Cc, H, W), np.float32)
+        check(self.lib.odise_hip_nhwc_f16_to_nchw_f32(self.h, _p(x), _p(y), N, Cc, H, W), "nhwc_to_nchw")
+        return y
+
+    def concat_channels(self, a: DeviceArray, b: DeviceArray) -> DeviceArray:
+        assert a.shape[:-1] == b.shape[:-1]
+        pixels = int(np.prod(a.shape[:-1]))
+        y = self.empty(a.shape[:-1] + (a.shape[-1] + b.shape[-1],), np.float16)
+        check(self.lib.odise_hip_concat_channels(self.h, _p(a), _p(b), _p(y), C.c_size_t(pixels), a.shape[-1], b.shape[-1]),
+              "concat_channels")
+        return y
+
+    def mask_pooling(self, x: DeviceArray, mask: DeviceArray) -> DeviceArray:
+        """MaskPooling.forward (odise.py:937-963): x [B,C,H,W] f32, mask [B,Q,H,W] f32 -> [B,Q,C] f32."""
+        B, Cc, H, W = x.shape
+        Q = mask.shape[1]
+        out = self.empty((B, Q, Cc), np.float32)
+        check(self.lib.odise_hip_mask_pooling(self.h, _p(x), _p(mask), _p(out), B, Cc, Q, H * W), "mask_pooling")
+        return out
+
+
+_default: Optional[Context] = None
+
+
+def default_context() -> Context:
+    """Process-wide context on cuda:<LOCAL_RANK> (one process per GPU)."""
+    global _default
+    if _default is None:
+        import os
+        _default = Context(int(os.environ.get("LOCAL_RANK", "0")))
+    return _default

@@ -1,0 +1,24 @@
+import os
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+@pytest.fixture(scope="session")
+def ctx():
+    """One libodise_hip context for the whole GPU test session (fails loudly if the .so is missing)."""
+    from odise_amd.runtime import Context
+    c = Context(0)
+    yield c
+    c.close()
+
+
+GOLDEN = os.path.join(ROOT, "tests", "golden")
