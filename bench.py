@@ -1,0 +1,164 @@
+#!/usr/bin/env python3
+"""bench.py — hot-path benchmark of the MI355X-native ODISE inference path.
+
+Round-1 workload (BASELINE.json configs[1]): SD-v1 UNet single-step feature extraction (LdmExtractor.unet_forward,
+odise/modeling/meta_arch/ldm.py:469-491), bs=1 512x512 crop (64x64 latent) per GPU, fp16 MFMA, synthetic
+SD-v1-shaped weights (859.5 M parameters, seed 1234) and synthetic inputs.  One "step" = one
+pass of the UNet tap extraction over `--crops` crops, inputs already resident in HBM.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--crops C] [--no-graph] [--no-cpu-baseline]
+
+Multi-GPU: one process per GPU (torch.distributed.run), crops are independent units sharded across ranks with no
+data-path collective (weak scaling: fixed crops per GPU); the only collective is the timing barrier / max.
+Prints ONE JSON line on rank 0.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import numpy as np  # noqa: E402
+
+# analytic work per 512x512 crop (SURVEY.md §8d / BASELINE.md §2)
+UNET_FLOPS_LIVE = 0.7401e12      # taps only (output_blocks[11] + out skipped — their results are discarded by the reference)
+UNET_FLOPS_REFERENCE = 0.8033e12  # as the reference executes it
+MFMA_F16_PEAK = 2.5e15           # dense fp16 MFMA, /opt/skills/guides/MI355X_MICROARCH.md
+
+
+def parse():
+    p = argparse.ArgumentParser()
+    p.add_argument("--gpus", type=int, default=1)
+    p.add_argument("--steps", type=int, default=20)
+    p.add_argument("--warmup", type=int, default=5)
+    p.add_argument("--crops", type=int, default=1, help="512x512 crops per step per GPU (configs[1] = 1; a 1024^2 image = 4)")
+    p.add_argument("--no-graph", action="store_true", help="launch kernels eagerly instead of replaying the captured hipGraph")
+    p.add_argument("--no-cpu-baseline", action="store_true")
+    p.add_argument("--cpu-steps", type=int, default=2)
+    return p.parse_args()
+
+
+def cpu_baseline(model, steps):
+    """The oracle restatement (kind='port') timed on the host cores: bounded sample = 1 warm-up + `steps` crops."""
+    import torch
+    from oracle.sd_unet import config2_inputs, unet_forward
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    x, context, cond_emb = config2_inputs(1, 64)
+    t = torch.zeros(1, dtype=torch.long)
+    unet_forward(model, x, t, context, cond_emb)
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        unet_forward(model, x, t, context, cond_emb)
+    dt = (time.perf_counter() - t0) / steps
+    return {"value": 1.0 / dt, "unit": "crops/s", "cores": cores, "kind": "port",
+            "sample": f"{steps} timed UNet single-step forwards (bs=1, 64x64 latent, fp32 torch CPU oracle, live path) after 1 warm-up"}
+
+
+def main():
+    args = parse()
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus and world > 1:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+
+    import torch
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    from odise_amd.runtime import Context
+    from odise_amd.unet import HipUNet
+    from oracle.sd_unet import UNetModel, config2_inputs, init_synthetic_
+
+    ctx = Context(local_rank)
+    # random-init weights of the SD-v1 UNet architecture (no network / checkpoints); identical on every rank
+    model = init_synthetic_(UNetModel(width_div=1), seed=1234).eval()
+    hip = HipUNet(ctx, model.state_dict(), use_graph=not args.no_graph)
+    B = args.crops
+    x, context, cond_emb = config2_inputs(B, 64)
+    dx, dc, de = ctx.to_device(x.numpy()), ctx.to_device(context.numpy()), ctx.to_device(cond_emb.numpy())
+
+    def barrier():
+        ctx.sync()
+        if dist is not None:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        hip.run_nhwc(dx, dc, de, 0)
+    barrier()
+    t0 = time.perf_counter()
+    ctx.timer_start()
+    for _ in range(args.steps):
+        hip.run_nhwc(dx, dc, de, 0)
+    ev_ms = ctx.timer_stop()  # HIP events on the library's stream (synchronises)
+    barrier()
+    wall = time.perf_counter() - t0
+    macs = hip.last_macs()
+
+    if dist is not None:
+        tt = torch.tensor([wall, ev_ms], dtype=torch.float64, device="cuda")
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        wall, ev_ms = float(tt[0]), float(tt[1])
+
+    if rank == 0:
+        ms_per_step = wall * 1e3 / args.steps
+        crops_per_s = world * B * args.steps / wall
+        dev_name, cus, _ = ctx.device_info()
+        step_ms_ev = ev_ms / args.steps
+        achieved = UNET_FLOPS_LIVE * B / (step_ms_ev * 1e-3) / 1e12  # TFLOP/s per GPU, live (non-dead) work only
+        out = {
+            "metric": "SD-UNet single-step feature extraction crops/sec (hot-path stage of panoptic-inference images/sec @1024x1024; UNet MFMA %peak)",
+            "value": crops_per_s,
+            "unit": "crops/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": ms_per_step,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f16",
+            "data": "synthetic",
+            "config": {
+                "workload": f"BASELINE configs[1]: SD-UNet single-step feature extraction, bs={B} x 512x512 crop (64x64 latent) per GPU, "
+                            "t=0, 77x768 context, taps u2/u5/u8/u11; synthetic SD-v1-shaped weights (859.5M params, seed 1234)",
+                "crops_per_step_per_gpu": B,
+                "images_1024_equiv_per_s": crops_per_s / 4.0,
+                "launch": "eager" if args.no_graph else "hipGraph replay",
+                "device": dev_name,
+                "compute_units": cus,
+                "parallelism": f"dp{world} (independent crops, no data-path collective)",
+            },
+            "roofline": {
+                "bound": "mfma",
+                "achieved": achieved,
+                "peak": MFMA_F16_PEAK / 1e12,
+                "unit": "TFLOP/s",
+                "frac": achieved * 1e12 / MFMA_F16_PEAK,
+                "traffic": None,
+                "kernel": "whole UNet step (MFMA implicit-GEMM conv / GEMM / attention kernels; HIP events over the timed region)",
+                "algorithmic_flops_per_crop": UNET_FLOPS_LIVE,
+                "reference_equivalent_flops_per_crop": UNET_FLOPS_REFERENCE,
+                "launched_macs_per_step": macs,
+                "event_ms_per_step": step_ms_ev,
+            },
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(model, args.cpu_steps)
+        print(json.dumps(out), flush=True)
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+    ctx.close()
+
+
+if __name__ == "__main__":
+    main()

@@ -88,6 +88,7 @@ typedef struct {
     int64_t ldr;
     const float* rowgroup_add;/* [ceil(M/rows_per_group), N] f32 or NULL (added before activation) */
     int rows_per_group;
+    int64_t ldg;              /* row stride of rowgroup_add (0 -> N) */
     int act;                  /* ODISE_ACT_* */
     int geglu;                /* 1: columns are interleaved (a,gate) pairs -> out[M,N/2] = a*gelu(gate) */
     float alpha;
@@ -107,6 +108,7 @@ typedef struct {
     const float* bias;        /* [Cout] or NULL */
     const void* residual;     /* f16 [N,OH,OW,Cout] or NULL */
     const float* per_image_add;/* [N, Cout] f32 or NULL (time-embedding broadcast) */
+    int64_t per_image_add_ld; /* row stride of per_image_add (0 -> Cout) */
     int act;
 } odise_conv_desc;
 int odise_hip_conv2d(odise_hip_ctx* ctx, const odise_conv_desc* d);
@@ -154,6 +156,7 @@ int odise_hip_mask_pooling(odise_hip_ctx* ctx, const float* x, const float* mask
  * host fp32, any rank<=4; the library converts to its packed fp16 layouts.  */
 int odise_hip_load_weight(odise_hip_ctx* ctx, const char* name, const float* host_data, const int64_t* shape, int ndim);
 int odise_hip_unet_build(odise_hip_ctx* ctx);     /* after all weights are loaded; packs + uploads */
+int odise_hip_clear_host_weights(odise_hip_ctx* ctx);  /* drop the host fp32 staging copies after build */
 /* x_t [B,4,h,w] f32 NCHW (device), context [B,77,768] f32 (device), cond_emb [B,1280] f32 or NULL (device).
  * taps: u2 [B,2560,h/8,w/8], u5 [B,1920,h/4,w/4], u8 [B,960,h/2,w/2], u11 [B,640,h,w] f32 NCHW (device), any may be NULL.
  * timestep t (the reference uses t=0).  */

@@ -29,7 +29,7 @@ class GemmDesc(C.Structure):
         ("c_dtype", c_int),
         ("bias_n", c_void_p), ("bias_m", c_void_p), ("scale_m", c_void_p),
         ("residual", c_void_p), ("ldr", c_int64),
-        ("rowgroup_add", c_void_p), ("rows_per_group", c_int),
+        ("rowgroup_add", c_void_p), ("rows_per_group", c_int), ("ldg", c_int64),
         ("act", c_int), ("geglu", c_int), ("alpha", c_float),
         ("batch", c_int),
         ("strideA", c_int64), ("strideW", c_int64), ("strideC", c_int64), ("strideR", c_int64),
@@ -43,7 +43,7 @@ class ConvDesc(C.Structure):
         ("pad_t", c_int), ("pad_l", c_int), ("OH", c_int), ("OW", c_int),
         ("upsample2x", c_int),
         ("X", c_void_p), ("Wt", c_void_p), ("Y", c_void_p), ("y_dtype", c_int),
-        ("bias", c_void_p), ("residual", c_void_p), ("per_image_add", c_void_p),
+        ("bias", c_void_p), ("residual", c_void_p), ("per_image_add", c_void_p), ("per_image_add_ld", c_int64),
         ("act", c_int),
     ]
 

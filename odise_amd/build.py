@@ -70,7 +70,7 @@ def build(verbose: bool = True, force: bool = False) -> str:
     if jobs:
         with ThreadPoolExecutor(max_workers=min(len(jobs), os.cpu_count() or 4)) as ex:
             list(ex.map(_compile, jobs))
-    if jobs or not os.path.exists(LIB):
+    if jobs or not os.path.exists(LIB) or any(os.path.getmtime(o) > os.path.getmtime(LIB) for o in objs):
         cmd = [hipcc, "-shared", "-fPIC", f"--offload-arch={ARCH}", "-o", LIB, *objs]
         if verbose:
             print("[odise_amd.build]", " ".join(cmd), flush=True)

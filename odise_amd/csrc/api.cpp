@@ -139,3 +139,7 @@ extern "C" int odise_hip_device_info(odise_hip_ctx* ctx, char* name_buf, int buf
     if (hbm_bytes) *hbm_bytes = prop.totalGlobalMem;
     return ODISE_OK;
 }
+// ABI self-description used by tests/test_lib_abi.py to validate the ctypes mirrors
+extern "C" int odise_hip_sizeof_gemm_desc(void) { return (int)sizeof(odise_gemm_desc); }
+extern "C" int odise_hip_sizeof_conv_desc(void) { return (int)sizeof(odise_conv_desc); }
+extern "C" int odise_hip_sizeof_attn_desc(void) { return (int)sizeof(odise_attn_desc); }

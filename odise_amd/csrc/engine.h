@@ -1,0 +1,118 @@
+// engine.h — host-side graph executor pieces shared by the model stages (UNet, VAE, CLIP, heads):
+// weight store (checkpoint-keyed host tensors -> packed device tensors), activation arena, layer structs and
+// thin launch helpers over the op-level C ABI.  All device work goes through the exported ops, so what the
+// op-level parity tests cover is exactly what the stages run.
+#pragma once
+#include <map>
+#include <string>
+#include <vector>
+
+#include "common.h"
+
+namespace odise {
+
+#define ODISE_TRY(expr)                \
+    do {                               \
+        int _rc = (expr);              \
+        if (_rc != ODISE_OK) return _rc; \
+    } while (0)
+
+struct HostTensor {
+    std::vector<float> data;
+    std::vector<int64_t> shape;
+    int64_t numel() const {
+        int64_t n = 1;
+        for (auto s : shape) n *= s;
+        return n;
+    }
+};
+
+// Bump allocator over one hipMalloc'ed slab; mark()/release() give stack-like reuse inside a forward so the
+// working set of a block stays small (L2 / Infinity-Cache resident) and pointers are identical call to call
+// (required for hipGraph replay).
+struct Arena {
+    char* base = nullptr;
+    size_t cap = 0, off = 0, peak = 0;
+    void* alloc(size_t bytes) {
+        off = (off + 255) & ~(size_t)255;
+        if (off + bytes > cap) return nullptr;
+        void* p = base + off;
+        off += bytes;
+        if (off > peak) peak = off;
+        return p;
+    }
+    size_t mark() const { return off; }
+    void release(size_t m) { off = m; }
+    void reset() { off = 0; }
+};
+
+struct Act {  // NHWC fp16 activation
+    f16* p = nullptr;
+    int n = 0, h = 0, w = 0, c = 0;
+    int64_t pixels() const { return (int64_t)n * h * w; }
+    int64_t elems() const { return pixels() * c; }
+};
+
+struct ConvW {
+    f16* w = nullptr;   // [cout][k][k][cin_pad]
+    float* b = nullptr; // [cout] or null
+    int cin = 0, cin_pad = 0, cout = 0, k = 1;
+};
+struct LinW {
+    f16* w = nullptr;   // [out][in]
+    float* b = nullptr;
+    int in = 0, out = 0;
+};
+struct NormW {
+    float* g = nullptr;
+    float* b = nullptr;
+    int c = 0;
+};
+
+struct UNetModel;
+
+struct ModelStore {
+    std::map<std::string, HostTensor> host;
+    std::vector<void*> dev_allocs;
+    Arena arena;
+    UNetModel* unet = nullptr;
+    double macs = 0.0;  // analytic MACs of the ops launched since the last reset
+};
+
+ModelStore* store_of(odise_hip_ctx* ctx);
+
+// ---- weight packing (host) + upload -------------------------------------------------------------------------
+struct Packer {
+    odise_hip_ctx* ctx;
+    ModelStore* ms;
+    std::string prefix;
+    std::string missing;  // first missing key (error reporting)
+
+    const HostTensor* find(const std::string& key);
+    int upload(const void* host, size_t bytes, void** dev);
+    int conv(const std::string& key, ConvW& out, bool bias = true);     // key.weight [O,I,kh,kw] (+ key.bias)
+    int linear(const std::string& key, LinW& out, bool bias = true);    // key.weight [O,I] or [O,I,1,1]
+    int norm(const std::string& key, NormW& out);                       // key.weight/bias [C]
+    int vec_f32(const std::string& key, float** out, int64_t expect);   // raw fp32 vector
+};
+
+// ---- launch helpers (count MACs, allocate outputs from the arena) ---------------------------------------------
+struct Exec {
+    odise_hip_ctx* ctx;
+    ModelStore* ms;
+    int alloc(Act& a, int n, int h, int w, int c);
+    void* alloc_bytes(size_t bytes);
+
+    int conv(const Act& x, const ConvW& w, Act& y, int stride = 1, int pad = -1, bool upsample = false, const Act* residual = nullptr,
+             const float* per_image_add = nullptr, int64_t pia_ld = 0, int act = ODISE_ACT_NONE, int pad_t = -1, int pad_l = -1,
+             int oh = -1, int ow = -1);
+    // y[M, out] = act(x[M,in] W^T + b) (+ residual)
+    int linear(const f16* x, int64_t M, const LinW& w, f16* y, int act = ODISE_ACT_NONE, const f16* residual = nullptr,
+               bool geglu = false);
+    int group_norm(const Act& x, const NormW& w, Act& y, float eps, int act);
+    int layer_norm(const f16* x, f16* y, int64_t rows, const NormW& w, float eps);
+    int gemm(const odise_gemm_desc& d);
+    int attention(const odise_attn_desc& d);
+};
+
+}  // namespace odise

@@ -31,6 +31,7 @@ struct GemmEpi {
     int64_t ldr;
     const float* rowgroup_add;
     int rows_per_group;
+    int64_t ldg;
     int act;
     int geglu;
     float alpha;
@@ -67,7 +68,7 @@ __device__ __forceinline__ void epi_store8(const GemmEpi& e, float (&v)[8], int 
         if (i < nvalid) {
             if (e.bias_n) x += e.bias_n[n + i];
             if (e.bias_m) x += e.bias_m[m];
-            if (e.rowgroup_add) x += e.rowgroup_add[(int64_t)(m / e.rows_per_group) * N + n + i];
+            if (e.rowgroup_add) x += e.rowgroup_add[(int64_t)(m / e.rows_per_group) * e.ldg + n + i];
         }
         v[i] = x;
     }
@@ -432,6 +433,7 @@ int gemm_forced(odise_hip_ctx* ctx, const odise_gemm_desc* d, int force_tile, in
     g.epi.bias_n = d->bias_n; g.epi.bias_m = d->bias_m; g.epi.scale_m = d->scale_m;
     g.epi.residual = (const f16*)d->residual; g.epi.ldr = d->ldr;
     g.epi.rowgroup_add = d->rowgroup_add; g.epi.rows_per_group = d->rows_per_group > 0 ? d->rows_per_group : 1;
+    g.epi.ldg = d->ldg > 0 ? d->ldg : d->N;
     g.epi.act = d->act; g.epi.geglu = d->geglu; g.epi.alpha = d->alpha;
     g.epi.strideC = d->strideC; g.epi.strideR = d->strideR;
     g.cg = ConvGeom{};
@@ -456,6 +458,7 @@ int conv_forced(odise_hip_ctx* ctx, const odise_conv_desc* d, int force_tile, in
     g.epi.bias_n = d->bias; g.epi.bias_m = nullptr; g.epi.scale_m = nullptr;
     g.epi.residual = (const f16*)d->residual; g.epi.ldr = d->Cout;
     g.epi.rowgroup_add = d->per_image_add; g.epi.rows_per_group = d->OH * d->OW;
+    g.epi.ldg = d->per_image_add_ld > 0 ? d->per_image_add_ld : d->Cout;
     g.epi.act = d->act; g.epi.geglu = 0; g.epi.alpha = 1.0f;
     g.epi.strideC = 0; g.epi.strideR = 0;
     g.cg.H = d->H; g.cg.W = d->W; g.cg.Cin = d->Cin; g.cg.KH = d->KH; g.cg.KW = d->KW;

@@ -1,0 +1,328 @@
+"""GPU parity tests of the op-level C ABI (libodise_hip.so) against the CPU oracle / plain torch fp32.
+
+Tolerances: fp32 ops (MSDeformAttn fp32) 1e-5 relative; fp16-input MFMA ops are compared with an fp32
+computation on the SAME fp16-rounded inputs, so the only differences are accumulation order and the final fp16
+rounding of the output: rtol 2e-3 + atol scaled to the output magnitude (SURVEY.md §8c allows 2e-2/2e-3 per stage).
+"""
+import os
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from odise_amd import _lib
+from oracle.msda import make_inputs, msda_forward_torch
+
+pytestmark = pytest.mark.gpu
+GOLDEN = os.path.join(os.path.dirname(__file__), "golden")
+
+
+def h(x):  # fp16-round a torch tensor, keep fp32
+    return x.half().float()
+
+
+def close(got, ref, rtol=2e-3, atol=None, what=""):
+    got = np.asarray(got, dtype=np.float64)
+    ref = np.asarray(ref, dtype=np.float64)
+    assert got.shape == ref.shape, (what, got.shape, ref.shape)
+    scale = np.abs(ref).max() + 1e-12
+    atol = atol if atol is not None else 2e-3 * scale
+    err = np.abs(got - ref)
+    bad = err > atol + rtol * np.abs(ref)
+    if bad.any() or not np.isfinite(got).all():
+        idx = np.argwhere(bad | ~np.isfinite(got))[:5]
+        raise AssertionError(f"{what}: {bad.sum()}/{bad.size} mismatches, max err {err.max():.4g} (scale {scale:.4g}); first {idx.tolist()} "
+                             f"got {[got[tuple(i)] for i in idx]} ref {[ref[tuple(i)] for i in idx]}")
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# MSDeformAttn
+# ---------------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("name", ["msda_ops_test_f64", "msda_ops_test_f32", "msda_oob", "msda_odd_d", "msda_d32_3lvl"])
+def test_msda_golden(ctx, name):
+    g = np.load(os.path.join(GOLDEN, name + ".npz"))
+    out = ctx.ms_deform_attn_forward(ctx.to_device(g["value"], np.float32), g["shapes"], g["start"], ctx.to_device(g["loc"], np.float32),
+                                     ctx.to_device(g["w"], np.float32), im2col_step=2 if "ops_test" in name else 128).numpy()
+    # the reference's own fp32 tolerance (ops/test.py:57) is rtol 1e-2 / atol 1e-3; we hold fp32 round-off
+    np.testing.assert_allclose(out, g["out"], rtol=1e-4, atol=1e-7)
+
+
+def test_msda_production_shape_fp32_and_fp16(ctx):
+    shapes = [(32, 32), (64, 64), (128, 128)]
+    Lq = sum(a * b for a, b in shapes)  # 21504 queries (1024^2 image)
+    value, shp, start, loc, w = make_inputs(1, 8, 32, Lq, shapes, 4, seed=21, loc_range=(-0.05, 1.05), value_scale=1.0)
+    ref = msda_forward_torch(value.double(), shp, start, loc, w).numpy()
+    out = ctx.ms_deform_attn_forward(ctx.to_device(value), shp.numpy(), start.numpy(), ctx.to_device(loc), ctx.to_device(w)).numpy()
+    np.testing.assert_allclose(out, ref, rtol=1e-4, atol=1e-5)
+    v16 = value.half()
+    ref16 = msda_forward_torch(v16.double(), shp, start, loc, w).numpy()
+    out16 = ctx.ms_deform_attn_forward(ctx.to_device(v16.numpy()), shp.numpy(), start.numpy(), ctx.to_device(loc), ctx.to_device(w)).numpy()
+    close(out16, ref16, rtol=2e-3, what="msda fp16")
+
+
+def test_msda_linearity_and_empty(ctx):
+    value, shp, start, loc, w = make_inputs(2, 8, 32, 300, [(16, 16), (8, 8)], 4, seed=22, value_scale=1.0)
+    v2 = torch.rand_like(value)
+    f = lambda v: ctx.ms_deform_attn_forward(ctx.to_device(v), shp.numpy(), start.numpy(), ctx.to_device(loc), ctx.to_device(w)).numpy()
+    np.testing.assert_allclose(f(value + 3 * v2), f(value) + 3 * f(v2), rtol=1e-4, atol=1e-5)
+    # empty query set
+    e = ctx.ms_deform_attn_forward(ctx.to_device(value), shp.numpy(), start.numpy(), ctx.empty((2, 0, 8, 2, 4, 2), np.float32),
+                                   ctx.empty((2, 0, 8, 2, 4), np.float32))
+    assert e.shape == (2, 0, 256)
+
+
+def test_msda_bad_im2col_step_raises(ctx):
+    value, shp, start, loc, w = make_inputs(3, 2, 4, 5, [(4, 4)], 2, seed=23)
+    with pytest.raises(RuntimeError):
+        ctx.ms_deform_attn_forward(ctx.to_device(value), shp.numpy(), start.numpy(), ctx.to_device(loc), ctx.to_device(w), im2col_step=2)
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# GEMM
+# ---------------------------------------------------------------------------------------------------------------
+GEMM_CASES = [
+    # M, N, K, tile, split
+    (128, 128, 64, 0, 0), (256, 384, 320, 0, 0), (200, 136, 72, 0, 0),
+    (64, 128, 128, 1, 0), (100, 100, 256, 1, 0), (64, 64, 64, 2, 0), (37, 24, 40, 2, 0),
+    (64, 1280, 2304, 2, 6), (77, 320, 768, 1, 3), (4096, 320, 320, -1, 0), (1, 1280, 320, -1, 0),
+    (300, 250, 1000, -1, 0),
+]
+
+
+@pytest.mark.parametrize("M,N,K,tile,split", GEMM_CASES)
+def test_gemm_plain(ctx, M, N, K, tile, split):
+    g = torch.Generator().manual_seed(M * 7 + N * 3 + K)
+    A = h(torch.randn(M, K, generator=g))
+    W = h(torch.randn(N, K, generator=g) / K ** 0.5)
+    ref = A @ W.t()
+    out = ctx.gemm(ctx.to_device(A.half().numpy()), ctx.to_device(W.half().numpy()), force_tile=tile, force_split=split).numpy()
+    close(out, ref.numpy(), what=f"gemm {M}x{N}x{K} tile{tile} split{split}")
+    out32 = ctx.gemm(ctx.to_device(A.half().numpy()), ctx.to_device(W.half().numpy()), out_dtype=np.float32, force_tile=tile,
+                     force_split=split).numpy()
+    close(out32, ref.numpy(), rtol=1e-4, atol=1e-4 * float(ref.abs().max()), what="gemm f32 out")
+
+
+def test_gemm_asymmetric_identity(ctx):
+    # transpose-detecting check (guide rule 16): A = I, W asymmetric -> C = W^T
+    n = 128
+    A = torch.eye(n)
+    W = torch.arange(n * n, dtype=torch.float32).reshape(n, n) % 97 - 48 + torch.arange(n).view(n, 1) * 0.25
+    W = h(W)
+    out = ctx.gemm(ctx.to_device(A.half().numpy()), ctx.to_device(W.half().numpy()), out_dtype=np.float32).numpy()
+    np.testing.assert_allclose(out, W.t().numpy(), rtol=0, atol=1e-3)
+
+
+@pytest.mark.parametrize("tile,split", [(0, 0), (2, 0), (2, 4)])
+def test_gemm_epilogues(ctx, tile, split):
+    g = torch.Generator().manual_seed(5)
+    M, N, K = 192, 160, 320
+    A = h(torch.randn(M, K, generator=g))
+    W = h(torch.randn(N, K, generator=g) / K ** 0.5)
+    bias = torch.randn(N, generator=g)
+    bias_m = torch.randn(M, generator=g)
+    res = h(torch.randn(M, N, generator=g))
+    rga = torch.randn(3, N, generator=g)  # rows_per_group = 64
+    dA, dW = ctx.to_device(A.half().numpy()), ctx.to_device(W.half().numpy())
+    base = A @ W.t()
+    kw = dict(force_tile=tile, force_split=split)
+    # bias + silu + residual
+    out = ctx.gemm(dA, dW, bias_n=ctx.to_device(bias), act=_lib.ACT_SILU, residual=ctx.to_device(res.half().numpy()), **kw).numpy()
+    close(out, (F.silu(base + bias) + res).numpy(), what="bias+silu+res")
+    # time-embedding style broadcast + bias_m, alpha
+    out = ctx.gemm(dA, dW, bias_m=ctx.to_device(bias_m), rowgroup_add=ctx.to_device(rga), rows_per_group=64, alpha=0.5, **kw).numpy()
+    ref = 0.5 * base + bias_m[:, None] + rga.repeat_interleave(64, 0)
+    close(out, ref.numpy(), what="rowgroup+bias_m+alpha")
+    # GEGLU: interleaved (a, gate) columns
+    out = ctx.gemm(dA, dW, bias_n=ctx.to_device(bias), geglu=True, **kw).numpy()
+    t = base + bias
+    close(out, (t[:, 0::2] * F.gelu(t[:, 1::2])).numpy(), what="geglu")
+    # quickgelu / gelu / relu + scale_m
+    sm = torch.rand(M, generator=g) + 0.5
+    for act, fn in ((_lib.ACT_QUICKGELU, lambda x: x * torch.sigmoid(1.702 * x)), (_lib.ACT_GELU, F.gelu), (_lib.ACT_RELU, F.relu)):
+        out = ctx.gemm(dA, dW, act=act, scale_m=ctx.to_device(sm), **kw).numpy()
+        close(out, fn(base * sm[:, None]).numpy(), what=f"act{act}")
+
+
+def test_gemm_batched_and_swapped_vt(ctx):
+    # the V^T production trick: Vt[b] = Wv @ X[b]^T  ==  gemm(A=Wv, W=X[b])
+    g = torch.Generator().manual_seed(9)
+    B, L, Cc = 3, 77, 320
+    X = h(torch.randn(B, L, 768, generator=g))
+    Wv = h(torch.randn(Cc, 768, generator=g) / 768 ** 0.5)
+    out = ctx.gemm(ctx.to_device(Wv.half().numpy()), ctx.to_device(X.half().numpy())).numpy()
+    ref = torch.einsum("ck,blk->bcl", Wv, X)
+    close(out, ref.numpy(), what="batched swapped")
+
+
+def test_gemm_rejects_bad_k(ctx):
+    with pytest.raises(RuntimeError):
+        ctx.gemm(ctx.zeros((8, 12)), ctx.zeros((8, 12)))
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# Convolution (NHWC implicit GEMM)
+# ---------------------------------------------------------------------------------------------------------------
+def _conv_ref(x_nhwc, w_okkc, stride, padding, bias=None):
+    x = x_nhwc.permute(0, 3, 1, 2)
+    w = w_okkc.permute(0, 3, 1, 2)
+    return F.conv2d(x, w, bias, stride=stride, padding=padding).permute(0, 2, 3, 1)
+
+
+@pytest.mark.parametrize("N,H,W,Cin,Cout,k,tile,split", [
+    (2, 16, 16, 32, 64, 3, -1, 0), (1, 64, 64, 320, 320, 3, -1, 0), (1, 8, 8, 1280, 640, 3, -1, 0), (3, 9, 7, 8, 24, 3, 2, 0),
+    (1, 32, 32, 64, 128, 1, -1, 0), (2, 8, 8, 640, 320, 3, 2, 5), (1, 24, 40, 128, 136, 3, 0, 0),
+])
+def test_conv3x3_and_1x1(ctx, N, H, W, Cin, Cout, k, tile, split):
+    g = torch.Generator().manual_seed(N + H + Cin + Cout)
+    x = h(torch.randn(N, H, W, Cin, generator=g))
+    w = h(torch.randn(Cout, k, k, Cin, generator=g) / (k * k * Cin) ** 0.5)
+    b = torch.randn(Cout, generator=g)
+    ref = _conv_ref(x, w, 1, k // 2, b)
+    out = ctx.conv2d(ctx.to_device(x.half().numpy()), ctx.to_device(w.half().numpy()), bias=ctx.to_device(b), force_tile=tile,
+                     force_split=split).numpy()
+    close(out, ref.numpy(), what=f"conv{k}x{k} {N}x{H}x{W}x{Cin}->{Cout}")
+
+
+def test_conv_stride2_variants(ctx):
+    g = torch.Generator().manual_seed(3)
+    x = h(torch.randn(2, 16, 16, 64, generator=g))
+    w = h(torch.randn(96, 3, 3, 64, generator=g) / 24.0)
+    dx, dw = ctx.to_device(x.half().numpy()), ctx.to_device(w.half().numpy())
+    # UNet Downsample: conv3x3 stride 2 pad 1
+    close(ctx.conv2d(dx, dw, stride=2, pad=1).numpy(), _conv_ref(x, w, 2, 1).numpy(), what="stride2 pad1")
+    # VAE encoder Downsample: F.pad (0,1,0,1) then conv3x3 stride 2 pad 0
+    xp = F.pad(x.permute(0, 3, 1, 2), (0, 1, 0, 1)).permute(0, 2, 3, 1)
+    ref = _conv_ref(xp, w, 2, 0)
+    close(ctx.conv2d(dx, dw, stride=2, pad_tl=(0, 0), out_hw=(8, 8)).numpy(), ref.numpy(), what="stride2 asym pad")
+
+
+def test_conv_fused_upsample_residual_timeemb(ctx):
+    g = torch.Generator().manual_seed(4)
+    x = h(torch.randn(2, 8, 8, 64, generator=g))
+    w = h(torch.randn(64, 3, 3, 64, generator=g) / 24.0)
+    b = torch.randn(64, generator=g)
+    dx, dw = ctx.to_device(x.half().numpy()), ctx.to_device(w.half().numpy())
+    up = F.interpolate(x.permute(0, 3, 1, 2), scale_factor=2, mode="nearest").permute(0, 2, 3, 1)
+    close(ctx.conv2d(dx, dw, upsample2x=True, bias=ctx.to_device(b)).numpy(), _conv_ref(up, w, 1, 1, b).numpy(), what="fused upsample")
+    res = h(torch.randn(2, 8, 8, 64, generator=g))
+    temb = torch.randn(2, 64, generator=g)
+    out = ctx.conv2d(dx, dw, bias=ctx.to_device(b), residual=ctx.to_device(res.half().numpy()), per_image_add=ctx.to_device(temb)).numpy()
+    ref = _conv_ref(x, w, 1, 1, b) + temb[:, None, None, :] + res
+    close(out, ref.numpy(), what="conv + temb + residual")
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# Norms
+# ---------------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("N,HW,C,act", [(2, 64, 320, 1), (1, 4096, 320, 0), (3, 256, 128, 1), (1, 64, 2560, 1), (2, 1024, 960, 2),
+                                        (1, 100, 512, 0)])
+def test_group_norm(ctx, N, HW, C, act):
+    g = torch.Generator().manual_seed(C + HW)
+    x = h(torch.randn(N, HW, C, generator=g) * 2 + 0.5)
+    gamma, beta = torch.randn(C, generator=g), torch.randn(C, generator=g)
+    ref = F.group_norm(x.permute(0, 2, 1), 32, gamma, beta, eps=1e-5).permute(0, 2, 1)
+    ref = {0: lambda t: t, 1: F.silu, 2: F.relu}[act](ref)
+    out = ctx.group_norm(ctx.to_device(x.half().numpy()), ctx.to_device(gamma), ctx.to_device(beta), 32, 1e-5, act).numpy()
+    close(out, ref.numpy(), rtol=3e-3, what=f"group_norm C={C}")
+
+
+@pytest.mark.parametrize("rows,C", [(77, 768), (4096, 320), (5, 1280), (577, 1024), (100, 256)])
+def test_layer_norm(ctx, rows, C):
+    g = torch.Generator().manual_seed(rows + C)
+    x = h(torch.randn(rows, C, generator=g) * 3 + 1)
+    gamma, beta = torch.randn(C, generator=g), torch.randn(C, generator=g)
+    ref = F.layer_norm(x, (C,), gamma, beta, 1e-5)
+    out = ctx.layer_norm(ctx.to_device(x.half().numpy()), ctx.to_device(gamma), ctx.to_device(beta), 1e-5).numpy()
+    close(out, ref.numpy(), rtol=3e-3, what=f"layer_norm C={C}")
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# Attention
+# ---------------------------------------------------------------------------------------------------------------
+def _vt(V, ldvt):  # [B,Lk,HD] -> [B,HD,ldvt] with NaN-poisoned padding (the kernel must ignore it)
+    B, Lk, HD = V.shape
+    out = np.full((B, HD, ldvt), np.nan, dtype=np.float16)
+    out[:, :, :Lk] = V.transpose(0, 2, 1)
+    return out
+
+
+@pytest.mark.parametrize("B,H,Lq,Lk,D", [(1, 8, 256, 256, 40), (2, 8, 64, 64, 160), (1, 8, 1024, 1024, 80), (2, 8, 300, 77, 40),
+                                         (1, 16, 577, 577, 64), (2, 8, 100, 1000, 32), (1, 2, 130, 65, 64), (1, 8, 4096, 4096, 40)])
+def test_attention(ctx, B, H, Lq, Lk, D):
+    g = torch.Generator().manual_seed(B + H + Lq + Lk + D)
+    HD = H * D
+    Q, K, V = (h(torch.randn(B, L, HD, generator=g)) for L in (Lq, Lk, Lk))
+    scale = D ** -0.5
+    q = Q.view(B, Lq, H, D).transpose(1, 2)
+    k = K.view(B, Lk, H, D).transpose(1, 2)
+    v = V.view(B, Lk, H, D).transpose(1, 2)
+    ref = (torch.softmax(q @ k.transpose(-1, -2) * scale, -1) @ v).transpose(1, 2).reshape(B, Lq, HD)
+    ldvt = (Lk + 7) // 8 * 8
+    out = ctx.attention(ctx.to_device(Q.half().numpy()), ctx.to_device(K.half().numpy()), ctx.to_device(_vt(V.half().numpy(), ldvt)), H, scale,
+                        Lk=Lk).numpy()
+    close(out, ref.numpy(), rtol=5e-3, atol=3e-3, what=f"attention B{B} H{H} Lq{Lq} Lk{Lk} D{D}")
+
+
+def test_attention_masked_and_spiked(ctx):
+    g = torch.Generator().manual_seed(77)
+    B, H, Lq, Lk, D = 2, 8, 100, 333, 32
+    HD = H * D
+    Q, K, V = (h(torch.randn(B, L, HD, generator=g)) for L in (Lq, Lk, Lk))
+    # force the online-softmax rescale path: one key with a huge score in a late tile
+    K[:, 200] = Q[:, 5] * 4
+    mask = torch.rand(B, Lq, Lk, generator=g) < 0.5
+    mask[:, 3, :] = True      # a fully masked row -> output 0 (the caller un-masks such rows, odise.py:683)
+    mask[:, 7, :] = False
+    mask[:, 7, 64:] = True    # only the first tile visible
+    scale = D ** -0.5
+    q = Q.view(B, Lq, H, D).transpose(1, 2)
+    k = K.view(B, Lk, H, D).transpose(1, 2)
+    v = V.view(B, Lk, H, D).transpose(1, 2)
+    s = (q @ k.transpose(-1, -2) * scale).masked_fill(mask[:, None], float("-inf"))
+    p = torch.softmax(s, -1)
+    p = torch.nan_to_num(p, nan=0.0)
+    ref = (p @ v).transpose(1, 2).reshape(B, Lq, HD)
+    ldm = (Lk + 3) // 4 * 4
+    m8 = np.zeros((B, Lq, ldm), dtype=np.uint8)
+    m8[:, :, :Lk] = mask.numpy()
+    ldvt = (Lk + 7) // 8 * 8
+    out = ctx.attention(ctx.to_device(Q.half().numpy()), ctx.to_device(K.half().numpy()), ctx.to_device(_vt(V.half().numpy(), ldvt)), H, scale,
+                        mask=ctx.to_device(m8), Lk=Lk).numpy()
+    close(out, ref.numpy(), rtol=5e-3, atol=3e-3, what="masked attention")
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# Layout helpers and MaskPooling
+# ---------------------------------------------------------------------------------------------------------------
+def test_layout_roundtrip_and_concat(ctx):
+    g = torch.Generator().manual_seed(1)
+    x = torch.randn(2, 4, 16, 12, generator=g)
+    y = ctx.nchw_to_nhwc_f16(ctx.to_device(x), 8)
+    yn = y.numpy()
+    np.testing.assert_array_equal(yn[..., :4], x.permute(0, 2, 3, 1).half().numpy())
+    assert (yn[..., 4:] == 0).all()
+    back = ctx.nhwc_to_nchw_f32(y).numpy()
+    np.testing.assert_array_equal(back[:, :4], x.half().float().numpy())
+    a = torch.randn(3, 5, 16, generator=g).half()
+    b = torch.randn(3, 5, 24, generator=g).half()
+    c = ctx.concat_channels(ctx.to_device(a.numpy()), ctx.to_device(b.numpy())).numpy()
+    np.testing.assert_array_equal(c, torch.cat([a, b], -1).numpy())
+
+
+@pytest.mark.parametrize("B,C,Q,H,W", [(2, 256, 100, 32, 32), (1, 256, 100, 128, 128), (1, 64, 7, 8, 9)])
+def test_mask_pooling(ctx, B, C, Q, H, W):
+    # MaskPooling.forward, odise/modeling/meta_arch/odise.py:937-963
+    g = torch.Generator().manual_seed(B + C + Q + H)
+    x = torch.randn(B, C, H, W, generator=g)
+    mask = torch.randn(B, Q, H, W, generator=g)
+    mask[:, 0] = -1.0  # empty mask -> zeros (denominator 1e-8)
+    m = (mask.sigmoid() > 0.5).to(mask.dtype)
+    denorm = m.sum(dim=(-1, -2), keepdim=True) + 1e-8
+    ref = torch.einsum("bchw,bqhw->bqc", x, m / denorm)
+    if (H * W) % 8:
+        with pytest.raises(RuntimeError):
+            ctx.mask_pooling(ctx.to_device(x), ctx.to_device(mask))
+        return
+    out = ctx.mask_pooling(ctx.to_device(x), ctx.to_device(mask)).numpy()
+    close(out, ref.numpy(), rtol=2e-3, atol=2e-3, what="mask_pooling")
