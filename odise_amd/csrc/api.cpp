@@ -41,6 +41,8 @@ extern "C" int odise_hip_create(int device, odise_hip_ctx** out) {
     c->own_stream = true;
     c->ws_bytes = (size_t)256 << 20;
     ODISE_CHECK_HIP(hipMalloc(&c->ws, c->ws_bytes));
+    ODISE_CHECK_HIP(hipMalloc(&c->zeros, 256));
+    ODISE_CHECK_HIP(hipMemset(c->zeros, 0, 256));
     ODISE_CHECK_HIP(hipEventCreate(&c->ev0));
     ODISE_CHECK_HIP(hipEventCreate(&c->ev1));
     *out = c;
@@ -53,6 +55,7 @@ extern "C" int odise_hip_destroy(odise_hip_ctx* ctx) {
     hipStreamSynchronize(ctx->stream);
     models_destroy(ctx);
     if (ctx->ws) hipFree(ctx->ws);
+    if (ctx->zeros) hipFree(ctx->zeros);
     if (ctx->ev0) hipEventDestroy(ctx->ev0);
     if (ctx->ev1) hipEventDestroy(ctx->ev1);
     if (ctx->own_stream && ctx->stream) hipStreamDestroy(ctx->stream);

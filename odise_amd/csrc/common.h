@@ -60,6 +60,7 @@ struct odise_hip_ctx {
     // split-K / scratch workspace
     void* ws = nullptr;
     size_t ws_bytes = 0;
+    void* zeros = nullptr;  // 256 zero bytes
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     void* models = nullptr;  // odise::ModelStore* (weights + unet), see unet.cpp
 };

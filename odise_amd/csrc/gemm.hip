@@ -53,7 +53,14 @@ struct GemmArgs {
     int splitk;
     int ktiles_per_split;
     float* ws;
+    const f16* zeros;  // >= 16 zero bytes (source of padded / out-of-range operand slots)
 };
+
+// 16-byte global -> LDS DMA (global_load_lds_dwordx4): LDS address = wave-uniform `lds_base` + lane*16.
+__device__ __forceinline__ void glds16(const void* gsrc, void* lds_base) {
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gsrc,
+                                     (__attribute__((address_space(3))) void*)lds_base, 16, 0, 0);
+}
 
 __device__ __forceinline__ float gelu_exact(float v) { return 0.5f * v * (1.0f + erff(v * 0.70710678118654752f)); }
 
@@ -142,8 +149,21 @@ __global__ void __launch_bounds__(256) gemm_kernel(GemmArgs g) {
     const int wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
     const int hi = lane >> 5, l31 = lane & 31;
-    const int m0 = blockIdx.y * BM;
-    const int n0 = blockIdx.x * BN;
+    // XCD-aware tile order: the dispatcher round-robins workgroups over the 8 XCDs (private 4 MiB L2 each); remap so that
+    // each XCD walks a contiguous run of tiles (n fastest): its co-resident blocks then share A row-panels and W
+    // column-panels in L2 instead of every XCD streaming every panel from HBM.  Bijective for any grid size.
+    int bx, by;
+    {
+        const int nbx = gridDim.x, nb = gridDim.x * gridDim.y;
+        const int bid = blockIdx.y * nbx + blockIdx.x;
+        const int q = nb >> 3, r = nb & 7;
+        const int xcd = bid & 7, idx = bid >> 3;
+        const int logical = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+        by = logical / nbx;
+        bx = logical - by * nbx;
+    }
+    const int m0 = by * BM;
+    const int n0 = bx * BN;
     const int z = blockIdx.z;
     const bool split = g.splitk > 1;
     const int zb = split ? 0 : z;  // batch index
@@ -194,11 +214,16 @@ __global__ void __launch_bounds__(256) gemm_kernel(GemmArgs g) {
         b_off[j] = (int64_t)n * g.ldw;
     }
 
-    f16x8 ra[JA], rb[JB];
-    const f16x8 zero8 = {0, 0, 0, 0, 0, 0, 0, 0};
-
-    auto load_tile = [&](int kt) {
-        const int k = kt * BK + slot * 8;
+    // ---- global -> LDS direct (LDS-DMA, 16 B per lane).  The LDS image of one instruction is lane-linear (wave base +
+    // lane*16 = 8 rows x 128 B), so the bank swizzle is applied to the SOURCE: the lane that fills physical slot p of row r
+    // fetches logical k-slot p ^ ((r>>1)&7); (r>>1)&7 does not depend on j because rows advance by 32.  Rows / k beyond
+    // the problem and conv padding read from a zero line instead of being predicated (every lane must write its slot).
+    const int ls = slot ^ ((rbase >> 1) & 7);
+    const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+    auto issue_tile = [&](int kt, int stage) {
+        char* sa = smem + stage * STAGE_BYTES;
+        char* sb = sa + BM * BK * 2;
+        const int k = kt * BK + ls * 8;
         const bool kok = k < g.K;
         if (CONV) {
             int ky = 0, kx = 0, c = 0;
@@ -219,35 +244,20 @@ __global__ void __launch_bounds__(256) gemm_kernel(GemmArgs g) {
                 } else {
                     ok = ok && iy >= 0 && ix >= 0 && iy < g.cg.H && ix < g.cg.W;
                 }
-                ra[j] = zero8;
-                if (ok) ra[j] = *reinterpret_cast<const f16x8*>(Ab + a_off[j] + ((int64_t)iy * g.cg.W + ix) * g.cg.Cin + c);
+                const f16* src = ok ? Ab + a_off[j] + ((int64_t)iy * g.cg.W + ix) * g.cg.Cin + c : g.zeros;
+                glds16(src, sa + (j * 256 + wave_u * 64) * 16);
             }
         } else {
 #pragma unroll
             for (int j = 0; j < JA; ++j) {
-                ra[j] = zero8;
-                if (a_ok[j] && kok) ra[j] = *reinterpret_cast<const f16x8*>(Ab + a_off[j] + k);
+                const f16* src = (a_ok[j] && kok) ? Ab + a_off[j] + k : g.zeros;
+                glds16(src, sa + (j * 256 + wave_u * 64) * 16);
             }
         }
 #pragma unroll
         for (int j = 0; j < JB; ++j) {
-            rb[j] = zero8;
-            if (b_ok[j] && kok) rb[j] = *reinterpret_cast<const f16x8*>(Wb + b_off[j] + k);
-        }
-    };
-
-    auto store_tile = [&](int stage) {
-        char* sa = smem + stage * STAGE_BYTES;
-        char* sb = sa + BM * BK * 2;
-#pragma unroll
-        for (int j = 0; j < JA; ++j) {
-            const int r = rbase + 32 * j;
-            *reinterpret_cast<f16x8*>(sa + r * 128 + ((slot ^ ((r >> 1) & 7)) << 4)) = ra[j];
-        }
-#pragma unroll
-        for (int j = 0; j < JB; ++j) {
-            const int r = rbase + 32 * j;
-            *reinterpret_cast<f16x8*>(sb + r * 128 + ((slot ^ ((r >> 1) & 7)) << 4)) = rb[j];
+            const f16* src = (b_ok[j] && kok) ? Wb + b_off[j] + k : g.zeros;
+            glds16(src, sb + (j * 256 + wave_u * 64) * 16);
         }
     };
 
@@ -259,16 +269,16 @@ __global__ void __launch_bounds__(256) gemm_kernel(GemmArgs g) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-    if (kt_begin < kt_end) {
-        load_tile(kt_begin);
-        store_tile(0);
-    }
-    __syncthreads();
+    if (kt_begin < kt_end) issue_tile(kt_begin, 0);
 
     for (int kt = kt_begin; kt < kt_end; ++kt) {
         const int cur = (kt - kt_begin) & 1;
         const bool more = (kt + 1) < kt_end;
-        if (more) load_tile(kt + 1);
+        // tile kt has landed (this wave's DMA) and, after the barrier, everybody's; all waves are also done reading
+        // the other buffer (they finished compute(kt-1) before arriving here), so it can be refilled.
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (more) issue_tile(kt + 1, cur ^ 1);
         const char* sa = smem + cur * STAGE_BYTES;
         const char* sb = sa + BM * BK * 2;
 #pragma unroll
@@ -290,9 +300,8 @@ __global__ void __launch_bounds__(256) gemm_kernel(GemmArgs g) {
                 for (int j = 0; j < TN; ++j)
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[i], bf[j], acc[i][j], 0, 0, 0);
         }
-        if (more) store_tile(cur ^ 1);
-        __syncthreads();
     }
+    __syncthreads();  // every wave is done with the operand tiles before the staging buffer is reused
 
     // ---- epilogue through LDS: 64 rows (2 wave-rows x 32) x BN fp32 per pass ----------------
     constexpr int LDS_LD = BN + 4;
@@ -325,7 +334,12 @@ __global__ void __launch_bounds__(256) gemm_kernel(GemmArgs g) {
                 if (split) {
                     float* w = g.ws + ((int64_t)z * g.M + m) * g.N + n;
                     const int nv = (g.N - n) < 8 ? (g.N - n) : 8;
-                    for (int i = 0; i < nv; ++i) w[i] = v[i];
+                    if (nv == 8 && (g.N & 3) == 0) {
+                        *reinterpret_cast<float4*>(w) = t0;
+                        *reinterpret_cast<float4*>(w + 4) = t1;
+                    } else {
+                        for (int i = 0; i < nv; ++i) w[i] = v[i];
+                    }
                 } else {
                     epi_store8(g.epi, v, m, n, g.N, zb);
                 }
@@ -337,6 +351,7 @@ __global__ void __launch_bounds__(256) gemm_kernel(GemmArgs g) {
 __global__ void __launch_bounds__(256) splitk_reduce_kernel(const float* __restrict__ ws, int splitk, int M, int N, GemmEpi e) {
     const int CH = (N + 7) / 8;
     const int64_t total = (int64_t)M * CH;
+    const bool vec = (N & 3) == 0;
     for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * blockDim.x) {
         const int m = (int)(idx / CH);
         const int n = (int)(idx - (int64_t)m * CH) * 8;
@@ -344,9 +359,18 @@ __global__ void __launch_bounds__(256) splitk_reduce_kernel(const float* __restr
         float v[8];
 #pragma unroll
         for (int i = 0; i < 8; ++i) v[i] = 0.f;
-        for (int s = 0; s < splitk; ++s) {
-            const float* w = ws + ((int64_t)s * M + m) * N + n;
-            for (int i = 0; i < nv; ++i) v[i] += w[i];
+        if (vec && nv == 8) {
+            for (int s = 0; s < splitk; ++s) {
+                const float4* w = reinterpret_cast<const float4*>(ws + ((int64_t)s * M + m) * N + n);
+                const float4 a = w[0], b = w[1];
+                v[0] += a.x; v[1] += a.y; v[2] += a.z; v[3] += a.w;
+                v[4] += b.x; v[5] += b.y; v[6] += b.z; v[7] += b.w;
+            }
+        } else {
+            for (int s = 0; s < splitk; ++s) {
+                const float* w = ws + ((int64_t)s * M + m) * N + n;
+                for (int i = 0; i < nv; ++i) v[i] += w[i];
+            }
         }
         epi_store8(e, v, m, n, N, 0);
     }
@@ -362,33 +386,35 @@ static int launch_gemm_t(odise_hip_ctx* ctx, GemmArgs& g, int batch) {
     ODISE_CHECK_HIP(hipGetLastError());
     if (g.splitk > 1) {
         const int64_t total = (int64_t)g.M * ceil_div(g.N, 8);
-        const int blocks = (int)std::min<int64_t>(ceil_div(total, 256), 4096);
+        const int blocks = (int)std::min<int64_t>(ceil_div(total, 256), 2048);
         hipLaunchKernelGGL(splitk_reduce_kernel, dim3(blocks), dim3(256), 0, ctx->stream, g.ws, g.splitk, g.M, g.N, g.epi);
         ODISE_CHECK_HIP(hipGetLastError());
     }
     return ODISE_OK;
 }
 
-// tile / split-K heuristic: keep >= ~1.5 blocks per CU in flight.
+// tile / split-K heuristic.  Large tiles keep the MFMA pipe busy (4 ds_read_b128 per 4 MFMAs vs 2 per 1 for 64x64), so
+// prefer them and recover parallelism with split-K (fp32 partials + fused reduce) when the tile grid alone cannot fill
+// the 256 CUs; small-M layers always need it (weight streaming).
 template <bool CONV>
 static int launch_gemm(odise_hip_ctx* ctx, GemmArgs& g, int batch, int force_tile, int force_split) {
-    const int64_t target = (int64_t)ctx->cu_count * 3 / 2;
+    const int64_t cus = ctx->cu_count;
     auto blocks = [&](int bm, int bn) { return ceil_div(g.M, bm) * ceil_div(g.N, bn) * (int64_t)batch; };
-    int tile = 0;  // 0:128x128 1:64x128 2:64x64
-    if (g.M > 64 && blocks(128, 128) >= target) tile = 0;
-    else if (blocks(64, 128) >= target) tile = 1;
-    else tile = 2;
+    const int nk = (int)ceil_div(g.K, 64);
+    const int64_t max_split = batch == 1 ? std::max<int64_t>(1, nk / 3) : 1;
+    int tile = 2;  // 0:128x128 1:64x128 2:64x64
+    if (g.M > 64 && g.N > 64 && blocks(128, 128) * max_split >= cus) tile = 0;
+    else if (g.N > 64 && blocks(64, 128) * max_split >= cus) tile = 1;
+    if (g.M <= 64 && tile == 0) tile = 1;
     if (g.N <= 64) tile = 2;
     if (force_tile >= 0) tile = force_tile;
     const int bm = tile == 0 ? 128 : 64, bn = tile == 2 ? 64 : 128;
-    const int nk = (int)ceil_div(g.K, 64);
     g.splitk = 1;
     g.ktiles_per_split = nk;
     const int64_t nb = blocks(bm, bn);
-    if (batch == 1 && nb < ctx->cu_count && nk >= 8) {
-        int want = (int)std::min<int64_t>(ceil_div(target, nb), nk / 4);
+    if (batch == 1 && nb < cus && max_split > 1) {
+        int want = (int)std::min<int64_t>(ceil_div(cus * 3 / 2, nb), max_split);
         want = std::max(1, std::min(want, 64));
-        // workspace bound
         while (want > 1 && (size_t)want * g.M * g.N * sizeof(float) > ctx->ws_bytes) --want;
         if (want > 1) {
             g.ktiles_per_split = (int)ceil_div(nk, want);
@@ -402,6 +428,7 @@ static int launch_gemm(odise_hip_ctx* ctx, GemmArgs& g, int batch, int force_til
         ODISE_REQUIRE((size_t)g.splitk * g.M * g.N * sizeof(float) <= ctx->ws_bytes, "gemm: split-K workspace too small");
     }
     g.ws = (float*)ctx->ws;
+    g.zeros = (const f16*)ctx->zeros;
     switch (tile) {
         case 0: return launch_gemm_t<128, 128, CONV>(ctx, g, batch);
         case 1: return launch_gemm_t<64, 128, CONV>(ctx, g, batch);

@@ -2,45 +2,52 @@
 //
 // GroupNorm32 of the SD UNet ResBlock / SpatialTransformer (computed in fp32 and cast back — SURVEY.md
 // Appendix A.1), the VAE `Normalize` (eps 1e-6), detectron2 get_norm("GN") of the projection BottleneckBlocks
-// (feature_extractor.py:53-66) and the pixel decoder convs.  HBM-bound: two passes over x:
-//   1. gn_partial_kernel: per (image, pixel-chunk) partial (sum, sumsq) of every group, deterministic
-//      (no atomics; [N, chunks, G, 2] fp32 partials).
-//   2. gn_apply_kernel: every block re-reduces the (tiny) partials of its image into per-channel
-//      scale/shift in LDS, then streams x -> act(x*scale+shift) with 16-byte loads/stores.
+// (feature_extractor.py:53-66) and the pixel decoder convs.  HBM/L2-bound streaming, two launches:
+//   1. gn_partial_kernel: grid (chunks, N).  Each lane owns one 16-byte vector (8 channels) of a pixel and strides
+//      over the chunk's pixels; per-channel (sum, sumsq) go through LDS and are folded per group in a fixed order
+//      (deterministic, no atomics) into [N, chunks, G, 2] fp32 partials.
+//   2. gn_apply_kernel: every block folds the (small) partials of its image with all 256 lanes, builds per-channel
+//      scale/shift in LDS and streams x -> act(x*scale+shift) with 16-byte loads/stores.
+// LayerNorm keeps a row in registers (one wavefront per row, <= 3 vectors per lane) so x is read once.
 #include "common.h"
 
 namespace odise {
 
 constexpr int GN_MAX_C = 4096;
 
-// grid (chunks, N); block 256.  Thread owns channel pairs p = tid % PW (+k*PW) and pixel lane tid / PW.
-// LDS: [2][PL][C] fp32 (sum, sumsq) per pixel lane and channel, reduced per group in a fixed order.
 __global__ void __launch_bounds__(256) gn_partial_kernel(const f16* __restrict__ x, float* __restrict__ partial, int HW, int C,
                                                         int G, int pix_per_chunk) {
-    extern __shared__ float sred[];
+    extern __shared__ __attribute__((aligned(16))) float sred[];  // [2][PL][C]
     const int n = blockIdx.y, chunk = blockIdx.x, nchunks = gridDim.x;
     const int tid = threadIdx.x;
-    const int C2 = C >> 1;
-    const int PW = C2 < 256 ? C2 : 256;
-    const int PL = 256 / PW;  // >= 1
+    const int V = C >> 3;                   // 16-byte vectors per pixel
+    const int VW = V < 256 ? V : 256;       // vectors handled side by side
+    const int PL = 256 / VW;                // pixel lanes
     float* ssum = sred;
     float* ssq = sred + PL * C;
     const int p_begin = chunk * pix_per_chunk;
     const int p_end = min(HW, p_begin + pix_per_chunk);
-    const int cp = tid % PW;
-    const int pl = tid / PW;
+    const int pl = tid / VW;
     if (pl < PL) {
-        for (int cp0 = cp; cp0 < C2; cp0 += PW) {
-            float s0 = 0.f, s1 = 0.f, q0 = 0.f, q1 = 0.f;
-            const f16* xb = x + ((int64_t)n * HW) * C + 2 * cp0;
+        for (int v = tid - pl * VW; v < V; v += VW) {
+            float s[8], q[8];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) s[i] = q[i] = 0.f;
+            const f16* xb = x + ((int64_t)n * HW) * C + v * 8;
             for (int p = p_begin + pl; p < p_end; p += PL) {
-                const __half2 v = *reinterpret_cast<const __half2*>(xb + (int64_t)p * C);
-                const float a = __low2float(v), b = __high2float(v);
-                s0 += a; q0 += a * a;
-                s1 += b; q1 += b * b;
+                const f16x8 t = *reinterpret_cast<const f16x8*>(xb + (int64_t)p * C);
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+                    const float a = (float)t[i];
+                    s[i] += a;
+                    q[i] += a * a;
+                }
             }
-            ssum[pl * C + 2 * cp0] = s0; ssum[pl * C + 2 * cp0 + 1] = s1;
-            ssq[pl * C + 2 * cp0] = q0;  ssq[pl * C + 2 * cp0 + 1] = q1;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                ssum[pl * C + v * 8 + i] = s[i];
+                ssq[pl * C + v * 8 + i] = q[i];
+            }
         }
     }
     __syncthreads();
@@ -48,9 +55,13 @@ __global__ void __launch_bounds__(256) gn_partial_kernel(const f16* __restrict__
     if (tid < G) {
         float s = 0.f, q = 0.f;
         for (int t = 0; t < PL; ++t)
-            for (int c = tid * cpg; c < (tid + 1) * cpg; ++c) { s += ssum[t * C + c]; q += ssq[t * C + c]; }
+            for (int c = tid * cpg; c < (tid + 1) * cpg; ++c) {
+                s += ssum[t * C + c];
+                q += ssq[t * C + c];
+            }
         float* o = partial + (((int64_t)n * nchunks + chunk) * G + tid) * 2;
-        o[0] = s; o[1] = q;
+        o[0] = s;
+        o[1] = q;
     }
 }
 
@@ -59,18 +70,35 @@ __global__ void __launch_bounds__(256) gn_apply_kernel(const f16* __restrict__ x
                                                       const float* __restrict__ partial, const float* __restrict__ gamma,
                                                       const float* __restrict__ beta, int HW, int C, int G, int nchunks,
                                                       float eps, int act) {
-    extern __shared__ float sss[];  // scale[C], shift[C], mean[G], rstd[G]
+    extern __shared__ __attribute__((aligned(16))) float sss[];  // scale[C], shift[C], mean[G], rstd[G], red[2*256]
     float* scale = sss;
     float* shift = sss + C;
     float* mean = sss + 2 * C;
     float* rstd = mean + G;
+    double* red = reinterpret_cast<double*>(rstd + G + ((2 * C + 2 * G) & 1));  // 8-byte aligned
     const int n = blockIdx.y, tid = threadIdx.x;
     const int cpg = C / G;
+    // fold the partials: lane (g = tid % G, sub = tid / G) sums chunks sub, sub+nsub, ...; then a fixed-order fold over sub
+    const int nsub = 256 / G;
+    {
+        const int gI = tid % G, sub = tid / G;
+        double s = 0.0, q = 0.0;
+        if (sub < nsub) {
+            for (int ch = sub; ch < nchunks; ch += nsub) {
+                const float* o = partial + (((int64_t)n * nchunks + ch) * G + gI) * 2;
+                s += (double)o[0];
+                q += (double)o[1];
+            }
+        }
+        red[2 * tid] = s;
+        red[2 * tid + 1] = q;
+    }
+    __syncthreads();
     if (tid < G) {
         double s = 0.0, q = 0.0;
-        for (int ch = 0; ch < nchunks; ++ch) {
-            const float* o = partial + (((int64_t)n * nchunks + ch) * G + tid) * 2;
-            s += (double)o[0]; q += (double)o[1];
+        for (int sub = 0; sub < nsub; ++sub) {
+            s += red[2 * (sub * G + tid)];
+            q += red[2 * (sub * G + tid) + 1];
         }
         const double cnt = (double)HW * cpg;
         const double mu = s / cnt;
@@ -104,7 +132,8 @@ __global__ void __launch_bounds__(256) gn_apply_kernel(const f16* __restrict__ x
     }
 }
 
-// one wavefront per row; 4 rows per 256-thread block
+// one wavefront per row; 4 rows per 256-thread block; NV = 16-byte vectors per lane kept in registers (C <= 512*NV)
+template <int NV>
 __global__ void __launch_bounds__(256) layer_norm_kernel(const f16* __restrict__ x, f16* __restrict__ y,
                                                         const float* __restrict__ gamma, const float* __restrict__ beta,
                                                         int rows, int C, float eps) {
@@ -113,34 +142,48 @@ __global__ void __launch_bounds__(256) layer_norm_kernel(const f16* __restrict__
     if (row >= rows) return;
     const f16* xr = x + (int64_t)row * C;
     f16* yr = y + (int64_t)row * C;
+    f16x8 v[NV];
     float s = 0.f;
-    for (int c = lane * 8; c < C; c += 512) {
-        const f16x8 v = *reinterpret_cast<const f16x8*>(xr + c);
 #pragma unroll
-        for (int i = 0; i < 8; ++i) s += (float)v[i];
+    for (int k = 0; k < NV; ++k) {
+        const int c = (lane + 64 * k) * 8;
+        if (c < C) {
+            v[k] = *reinterpret_cast<const f16x8*>(xr + c);
+#pragma unroll
+            for (int i = 0; i < 8; ++i) s += (float)v[k][i];
+        }
     }
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
     const float mu = s / (float)C;
     float q = 0.f;
-    for (int c = lane * 8; c < C; c += 512) {
-        const f16x8 v = *reinterpret_cast<const f16x8*>(xr + c);
 #pragma unroll
-        for (int i = 0; i < 8; ++i) { const float d = (float)v[i] - mu; q += d * d; }
+    for (int k = 0; k < NV; ++k) {
+        const int c = (lane + 64 * k) * 8;
+        if (c < C) {
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const float d = (float)v[k][i] - mu;
+                q += d * d;
+            }
+        }
     }
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) q += __shfl_xor(q, o);
     const float rs = rsqrtf(q / (float)C + eps);
-    for (int c = lane * 8; c < C; c += 512) {
-        const f16x8 v = *reinterpret_cast<const f16x8*>(xr + c);
-        f16x8 o;
 #pragma unroll
-        for (int i = 0; i < 8; ++i) {
-            const float g = gamma ? gamma[c + i] : 1.f;
-            const float b = beta ? beta[c + i] : 0.f;
-            o[i] = (f16)(((float)v[i] - mu) * rs * g + b);
+    for (int k = 0; k < NV; ++k) {
+        const int c = (lane + 64 * k) * 8;
+        if (c < C) {
+            f16x8 o;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const float g = gamma ? gamma[c + i] : 1.f;
+                const float b = beta ? beta[c + i] : 0.f;
+                o[i] = (f16)(((float)v[k][i] - mu) * rs * g + b);
+            }
+            *reinterpret_cast<f16x8*>(yr + c) = o;
         }
-        *reinterpret_cast<f16x8*>(yr + c) = o;
     }
 }
 
@@ -154,24 +197,27 @@ extern "C" int odise_hip_group_norm(odise_hip_ctx* ctx, const void* x, void* y, 
     ODISE_REQUIRE(C % groups == 0 && C % 8 == 0 && C <= GN_MAX_C, "group_norm: C=%d must be a multiple of 8 and of groups=%d, <= %d", C, groups, GN_MAX_C);
     ODISE_REQUIRE(groups <= 256, "group_norm: groups=%d > 256", groups);
     if (N == 0) return ODISE_OK;
-    // chunking: aim for >= 2 blocks per CU in the stats pass, at least 64 pixels per chunk
-    int nchunks = (int)std::min<int64_t>(std::max<int64_t>(1, (int64_t)ctx->cu_count * 2 / N), ceil_div(HW, 64));
-    nchunks = std::max(1, std::min(nchunks, 256));
+    const int V = C / 8;
+    const int VW = V < 256 ? V : 256;
+    const int PL = 256 / VW;
+    // chunking: ~2 blocks per CU over the batch, every pixel lane gets at least ~2 pixels, at most 512 chunks per image
+    int64_t want = std::max<int64_t>(1, (int64_t)ctx->cu_count * 2 / N);
+    int64_t maxc = std::max<int64_t>(1, HW / (2 * PL));
+    int nchunks = (int)std::min<int64_t>(std::min<int64_t>(want, maxc), 128);
     const int ppc = (int)ceil_div(HW, nchunks);
     nchunks = (int)ceil_div(HW, ppc);
     const size_t pbytes = (size_t)N * nchunks * groups * 2 * sizeof(float);
     ODISE_REQUIRE(pbytes <= ctx->ws_bytes, "group_norm: workspace too small");
     float* partial = (float*)ctx->ws;
-    const int C2h = C / 2;
-    const int PLh = C2h < 256 ? 256 / C2h : 1;
-    hipLaunchKernelGGL(gn_partial_kernel, dim3(nchunks, N), dim3(256), 2 * (size_t)PLh * C * sizeof(float), ctx->stream, (const f16*)x, partial,
-                       HW, C, groups, ppc);
+    hipLaunchKernelGGL(gn_partial_kernel, dim3(nchunks, N), dim3(256), 2 * (size_t)PL * C * sizeof(float), ctx->stream, (const f16*)x,
+                       partial, HW, C, groups, ppc);
     ODISE_CHECK_HIP(hipGetLastError());
     const int64_t total = (int64_t)HW * (C / 8);
-    int bpi = (int)std::min<int64_t>(ceil_div(total, 256 * 4), std::max<int64_t>(1, (int64_t)ctx->cu_count * 8 / N));
+    int bpi = (int)std::min<int64_t>(ceil_div(total, 256 * 2), std::max<int64_t>(1, (int64_t)ctx->cu_count * 4 / N));
     bpi = std::max(1, bpi);
-    hipLaunchKernelGGL(gn_apply_kernel, dim3(bpi, N), dim3(256), (2 * C + 2 * groups) * sizeof(float), ctx->stream,
-                       (const f16*)x, (f16*)y, partial, gamma, beta, HW, C, groups, nchunks, eps, act);
+    const size_t lds = (2 * (size_t)C + 2 * groups + 2) * sizeof(float) + 2 * 256 * sizeof(double);
+    hipLaunchKernelGGL(gn_apply_kernel, dim3(bpi, N), dim3(256), lds, ctx->stream, (const f16*)x, (f16*)y, partial, gamma, beta, HW, C,
+                       groups, nchunks, eps, act);
     ODISE_CHECK_HIP(hipGetLastError());
     return ODISE_OK;
 }
@@ -180,10 +226,17 @@ extern "C" int odise_hip_layer_norm(odise_hip_ctx* ctx, const void* x, void* y, 
                                     int rows, int C, float eps) {
     using namespace odise;
     ODISE_REQUIRE(ctx && x && y, "layer_norm: null argument");
-    ODISE_REQUIRE(rows >= 0 && C > 0 && C % 8 == 0, "layer_norm: C=%d must be a positive multiple of 8", C);
+    ODISE_REQUIRE(rows >= 0 && C > 0 && C % 8 == 0 && C <= 4096, "layer_norm: C=%d must be a positive multiple of 8, <= 4096", C);
     if (rows == 0) return ODISE_OK;
-    hipLaunchKernelGGL(layer_norm_kernel, dim3((unsigned)ceil_div(rows, 4)), dim3(256), 0, ctx->stream, (const f16*)x, (f16*)y,
-                       gamma, beta, rows, C, eps);
+    const dim3 grid((unsigned)ceil_div(rows, 4));
+    if (C <= 512)
+        hipLaunchKernelGGL(layer_norm_kernel<1>, grid, dim3(256), 0, ctx->stream, (const f16*)x, (f16*)y, gamma, beta, rows, C, eps);
+    else if (C <= 1024)
+        hipLaunchKernelGGL(layer_norm_kernel<2>, grid, dim3(256), 0, ctx->stream, (const f16*)x, (f16*)y, gamma, beta, rows, C, eps);
+    else if (C <= 2048)
+        hipLaunchKernelGGL(layer_norm_kernel<4>, grid, dim3(256), 0, ctx->stream, (const f16*)x, (f16*)y, gamma, beta, rows, C, eps);
+    else
+        hipLaunchKernelGGL(layer_norm_kernel<8>, grid, dim3(256), 0, ctx->stream, (const f16*)x, (f16*)y, gamma, beta, rows, C, eps);
     ODISE_CHECK_HIP(hipGetLastError());
     return ODISE_OK;
 }

@@ -278,7 +278,8 @@ static int run_st(UNetRun& r, const STBlockW& w, const Act& x, Act& out) {
     f16* hs = (f16*)ex.alloc_bytes((size_t)M * C * 2);
     f16* nrm = (f16*)ex.alloc_bytes((size_t)M * C * 2);
     f16* qk = (f16*)ex.alloc_bytes((size_t)M * 2 * C * 2);
-    f16* vt = (f16*)ex.alloc_bytes((size_t)M * C * 2);
+    const int64_t ldvt = round_up(HW, 8);
+    f16* vt = (f16*)ex.alloc_bytes((size_t)x.n * C * ldvt * 2);
     f16* att = (f16*)ex.alloc_bytes((size_t)M * C * 2);
     f16* hs2 = (f16*)ex.alloc_bytes((size_t)M * C * 2);
     f16* ffh = (f16*)ex.alloc_bytes((size_t)M * 4 * C * 2);
@@ -293,7 +294,7 @@ static int run_st(UNetRun& r, const STBlockW& w, const Act& x, Act& out) {
         d.M = C; d.N = (int)HW; d.K = C;
         d.A = w.v1.w; d.lda = C; d.strideA = 0;
         d.W = nrm; d.ldw = C; d.strideW = HW * C;
-        d.C = vt; d.ldc = HW; d.strideC = (int64_t)C * HW; d.c_dtype = ODISE_F16;
+        d.C = vt; d.ldc = ldvt; d.strideC = (int64_t)C * ldvt; d.c_dtype = ODISE_F16;
         d.alpha = 1.f; d.batch = x.n;
         ODISE_TRY(ex.gemm(d));
         odise_attn_desc a;
@@ -301,7 +302,7 @@ static int run_st(UNetRun& r, const STBlockW& w, const Act& x, Act& out) {
         a.B = x.n; a.H = heads; a.Lq = (int)HW; a.Lk = (int)HW; a.D = D;
         a.Q = qk; a.ldq = 2 * C; a.strideQ = HW * 2 * C;
         a.K = qk + C; a.ldk = 2 * C; a.strideK = HW * 2 * C;
-        a.Vt = vt; a.ldvt = HW; a.strideVt = (int64_t)C * HW;
+        a.Vt = vt; a.ldvt = ldvt; a.strideVt = (int64_t)C * ldvt;
         a.O = att; a.ldo = C; a.strideO = HW * C;
         a.scale = 1.0f / sqrtf((float)D);
         ODISE_TRY(ex.attention(a));
