@@ -134,20 +134,27 @@ __device__ __forceinline__ void epi_store8(const GemmEpi& e, float (&v)[8], int 
     }
 }
 
-template <int BM, int BN, bool CONV>
-__global__ void __launch_bounds__(256) gemm_kernel(GemmArgs g) {
+// Block tile BM x BN x 64 computed by WAVES_M x WAVES_N wavefronts (each a (BM/WAVES_M) x (BN/WAVES_N) sub-tile of
+// 32x32x16 MFMAs).  Instantiated as 4-wave tiles (128x128, 64x128, 64x64: small problems, with split-K) and 8-wave
+// tiles (256x320 for the 320*k channel counts of the SD UNet, 256x256, 256x128): at 256 rows one K-tile carries
+// 2048-2560 MFMA cycles per SIMD, which covers an L2-miss round trip with a single tile of LDS-DMA prefetch in flight,
+// and halves the operand bytes per flop (29 B/clk/CU at peak vs the 64 B/clk/CU L1 limit).
+template <int BM, int BN, int WAVES_M, int WAVES_N, bool CONV, bool INTERLEAVE>
+__global__ void __launch_bounds__(64 * WAVES_M * WAVES_N) gemm_kernel(GemmArgs g) {
     constexpr int BK = 64;
-    constexpr int TM = BM / 64;  // 32-row MFMA tiles per wave (waves are 2x2)
-    constexpr int TN = BN / 64;
-    constexpr int JA = BM / 32;  // 16-byte loads per thread per K-tile for A
-    constexpr int JB = BN / 32;
+    constexpr int NT = 64 * WAVES_M * WAVES_N;
+    constexpr int WTM = BM / WAVES_M, WTN = BN / WAVES_N;  // wave sub-tile
+    constexpr int TM = WTM / 32, TN = WTN / 32;            // 32x32 MFMA tiles per wave
+    constexpr int RPI = NT / 8;                            // operand rows staged per load instruction sweep
+    constexpr int JA = BM / RPI, JB = BN / RPI;            // 16-byte LDS-DMA loads per thread per K-tile
     constexpr int STAGE_BYTES = (BM + BN) * BK * 2;
+    static_assert(WTM % 32 == 0 && WTN % 32 == 0 && BM % RPI == 0 && BN % RPI == 0 && RPI % 16 == 0, "bad tile");
     extern __shared__ __attribute__((aligned(16))) char smem[];
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = tid >> 6;
-    const int wm = wave >> 1, wn = wave & 1;
+    const int wm = wave / WAVES_N, wn = wave % WAVES_N;
     const int hi = lane >> 5, l31 = lane & 31;
     // XCD-aware tile order: the dispatcher round-robins workgroups over the 8 XCDs (private 4 MiB L2 each); remap so that
     // each XCD walks a contiguous run of tiles (n fastest): its co-resident blocks then share A row-panels and W
@@ -180,7 +187,7 @@ __global__ void __launch_bounds__(256) gemm_kernel(GemmArgs g) {
     const f16* Wb = g.W + (int64_t)zb * g.strideW;
 
     const int slot = tid & 7;
-    const int rbase = tid >> 3;  // 0..31
+    const int rbase = tid >> 3;  // 0..RPI-1
 
     // per-thread A row descriptors
     int64_t a_off[JA];
@@ -188,7 +195,7 @@ __global__ void __launch_bounds__(256) gemm_kernel(GemmArgs g) {
     bool a_ok[JA];
 #pragma unroll
     for (int j = 0; j < JA; ++j) {
-        const int m = m0 + rbase + 32 * j;
+        const int m = m0 + rbase + RPI * j;
         a_ok[j] = m < g.M;
         if (CONV) {
             const int ohw = g.cg.OH * g.cg.OW;
@@ -209,34 +216,44 @@ __global__ void __launch_bounds__(256) gemm_kernel(GemmArgs g) {
     bool b_ok[JB];
 #pragma unroll
     for (int j = 0; j < JB; ++j) {
-        const int n = n0 + rbase + 32 * j;
+        const int n = n0 + rbase + RPI * j;
         b_ok[j] = n < g.N;
         b_off[j] = (int64_t)n * g.ldw;
     }
 
     // ---- global -> LDS direct (LDS-DMA, 16 B per lane).  The LDS image of one instruction is lane-linear (wave base +
     // lane*16 = 8 rows x 128 B), so the bank swizzle is applied to the SOURCE: the lane that fills physical slot p of row r
-    // fetches logical k-slot p ^ ((r>>1)&7); (r>>1)&7 does not depend on j because rows advance by 32.  Rows / k beyond
-    // the problem and conv padding read from a zero line instead of being predicated (every lane must write its slot).
+    // fetches logical k-slot p ^ ((r>>1)&7); (r>>1)&7 does not depend on j because rows advance by RPI (a multiple of 16).
+    // Rows / k beyond the problem and conv padding read from a zero line instead of being predicated (every lane must
+    // write its slot).
     const int ls = slot ^ ((rbase >> 1) & 7);
     const int wave_u = __builtin_amdgcn_readfirstlane(wave);
-    auto issue_tile = [&](int kt, int stage) {
+    // per-K-tile decode shared by this lane's loads
+    int tk_k = 0, tk_ky = 0, tk_kx = 0, tk_c = 0;
+    bool tk_ok = false;
+    auto prep_tile = [&](int kt) {
+        tk_k = kt * BK + ls * 8;
+        tk_ok = tk_k < g.K;
+        if (CONV) {
+            tk_ky = tk_kx = tk_c = 0;
+            if (tk_ok) {
+                const int tap = tk_k / g.cg.Cin;
+                tk_c = tk_k - tap * g.cg.Cin;
+                tk_ky = tap / g.cg.KW;
+                tk_kx = tap - tk_ky * g.cg.KW;
+            }
+        }
+    };
+    // load #l of a tile: l < JA -> A rows sweep l, else W rows sweep l-JA
+    auto issue_load = [&](int l, int stage) {
         char* sa = smem + stage * STAGE_BYTES;
         char* sb = sa + BM * BK * 2;
-        const int k = kt * BK + ls * 8;
-        const bool kok = k < g.K;
-        if (CONV) {
-            int ky = 0, kx = 0, c = 0;
-            if (kok) {
-                const int tap = k / g.cg.Cin;
-                c = k - tap * g.cg.Cin;
-                ky = tap / g.cg.KW;
-                kx = tap - ky * g.cg.KW;
-            }
-#pragma unroll
-            for (int j = 0; j < JA; ++j) {
-                int iy = a_iy0[j] + ky, ix = a_ix0[j] + kx;
-                bool ok = a_ok[j] && kok;
+        if (l < JA) {
+            const int j = l;
+            const f16* src;
+            if (CONV) {
+                int iy = a_iy0[j] + tk_ky, ix = a_ix0[j] + tk_kx;
+                bool ok = a_ok[j] && tk_ok;
                 if (g.cg.ups) {
                     ok = ok && iy >= 0 && ix >= 0 && iy < 2 * g.cg.H && ix < 2 * g.cg.W;
                     iy >>= 1;
@@ -244,21 +261,22 @@ __global__ void __launch_bounds__(256) gemm_kernel(GemmArgs g) {
                 } else {
                     ok = ok && iy >= 0 && ix >= 0 && iy < g.cg.H && ix < g.cg.W;
                 }
-                const f16* src = ok ? Ab + a_off[j] + ((int64_t)iy * g.cg.W + ix) * g.cg.Cin + c : g.zeros;
-                glds16(src, sa + (j * 256 + wave_u * 64) * 16);
+                src = ok ? Ab + a_off[j] + ((int64_t)iy * g.cg.W + ix) * g.cg.Cin + tk_c : g.zeros;
+            } else {
+                src = (a_ok[j] && tk_ok) ? Ab + a_off[j] + tk_k : g.zeros;
             }
+            glds16(src, sa + (j * NT + wave_u * 64) * 16);
         } else {
-#pragma unroll
-            for (int j = 0; j < JA; ++j) {
-                const f16* src = (a_ok[j] && kok) ? Ab + a_off[j] + k : g.zeros;
-                glds16(src, sa + (j * 256 + wave_u * 64) * 16);
-            }
+            const int j = l - JA;
+            const f16* src = (b_ok[j] && tk_ok) ? Wb + b_off[j] + tk_k : g.zeros;
+            glds16(src, sb + (j * NT + wave_u * 64) * 16);
         }
+    };
+    constexpr int NL = JA + JB;
+    auto issue_tile = [&](int kt, int stage) {
+        prep_tile(kt);
 #pragma unroll
-        for (int j = 0; j < JB; ++j) {
-            const f16* src = (b_ok[j] && kok) ? Wb + b_off[j] + k : g.zeros;
-            glds16(src, sb + (j * 256 + wave_u * 64) * 16);
-        }
+        for (int l = 0; l < NL; ++l) issue_load(l, stage);
     };
 
     f32x16 acc[TM][TN];
@@ -269,6 +287,14 @@ __global__ void __launch_bounds__(256) gemm_kernel(GemmArgs g) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
+    // The swizzle key (r>>1)&7 of a fragment row r = wave_base + 32*tile + (lane&31) only depends on the lane (bases are
+    // multiples of 32), so the four k-step slot offsets are shared by every A and B fragment of this lane.
+    int koff[4];
+#pragma unroll
+    for (int s = 0; s < 4; ++s) koff[s] = ((s * 2 + hi) ^ ((l31 >> 1) & 7)) << 4;
+    const int a_lane_off = (wm * WTM + l31) * 128;
+    const int b_lane_off = (wn * WTN + l31) * 128;
+
     if (kt_begin < kt_end) issue_tile(kt_begin, 0);
 
     for (int kt = kt_begin; kt < kt_end; ++kt) {
@@ -278,70 +304,83 @@ __global__ void __launch_bounds__(256) gemm_kernel(GemmArgs g) {
         // the other buffer (they finished compute(kt-1) before arriving here), so it can be refilled.
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
-        if (more) issue_tile(kt + 1, cur ^ 1);
-        const char* sa = smem + cur * STAGE_BYTES;
-        const char* sb = sa + BM * BK * 2;
+        if (more) {
+            if (INTERLEAVE) prep_tile(kt + 1);
+            else issue_tile(kt + 1, cur ^ 1);
+        }
+        // fragment reads: per-lane base + per-k-step swizzled slot offset (loop invariant) + compile-time tile offset
+        const char* fa = smem + cur * STAGE_BYTES + a_lane_off;
+        const char* fb = smem + cur * STAGE_BYTES + BM * BK * 2 + b_lane_off;
 #pragma unroll
         for (int s = 0; s < 4; ++s) {
             f16x8 af[TM], bf[TN];
 #pragma unroll
-            for (int i = 0; i < TM; ++i) {
-                const int r = wm * (BM / 2) + i * 32 + l31;
-                af[i] = *reinterpret_cast<const f16x8*>(sa + r * 128 + (((s * 2 + hi) ^ ((r >> 1) & 7)) << 4));
-            }
+            for (int i = 0; i < TM; ++i) af[i] = *reinterpret_cast<const f16x8*>(fa + koff[s] + i * 4096);
 #pragma unroll
-            for (int j = 0; j < TN; ++j) {
-                const int r = wn * (BN / 2) + j * 32 + l31;
-                bf[j] = *reinterpret_cast<const f16x8*>(sb + r * 128 + (((s * 2 + hi) ^ ((r >> 1) & 7)) << 4));
-            }
+            for (int j = 0; j < TN; ++j) bf[j] = *reinterpret_cast<const f16x8*>(fb + koff[s] + j * 4096);
 #pragma unroll
             for (int i = 0; i < TM; ++i)
 #pragma unroll
                 for (int j = 0; j < TN; ++j)
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[i], bf[j], acc[i][j], 0, 0, 0);
+            if (INTERLEAVE) {
+                // next tile's LDS-DMA loads are issued in the shadow of this k-step's MFMAs (the matrix pipe keeps
+                // draining the queued MFMAs while the wave issues address math + global_load_lds)
+                if (more) {
+#pragma unroll
+                    for (int l = 0; l < NL; ++l)
+                        if ((l * 4) / NL == s) issue_load(l, cur ^ 1);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
         }
     }
     __syncthreads();  // every wave is done with the operand tiles before the staging buffer is reused
 
-    // ---- epilogue through LDS: 64 rows (2 wave-rows x 32) x BN fp32 per pass ----------------
+    // ---- epilogue through LDS: passes of 64 rows (two wave-rows x one 32-row MFMA tile) x BN fp32 -------------------
     constexpr int LDS_LD = BN + 4;
+    constexpr int CH = BN / 8;
     float* stg = reinterpret_cast<float*>(smem);
 #pragma unroll
-    for (int p = 0; p < TM; ++p) {
-        if (p > 0) __syncthreads();
+    for (int gp = 0; gp < WAVES_M / 2; ++gp) {
 #pragma unroll
-        for (int j = 0; j < TN; ++j) {
+        for (int p = 0; p < TM; ++p) {
+            if (gp > 0 || p > 0) __syncthreads();
+            if ((wm >> 1) == gp) {
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int row = wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
-                const int col = wn * (BN / 2) + j * 32 + l31;
-                stg[row * LDS_LD + col] = acc[p][j][r];
-            }
-        }
-        __syncthreads();
-        constexpr int CH = BN / 8;
-        for (int c = tid; c < 64 * CH; c += 256) {
-            const int row = c / CH;
-            const int c8 = c - row * CH;
-            const int m = m0 + (row >> 5) * (BM / 2) + p * 32 + (row & 31);
-            const int n = n0 + c8 * 8;
-            if (m < g.M && n < g.N) {
-                float v[8];
-                const float4 t0 = *reinterpret_cast<const float4*>(&stg[row * LDS_LD + c8 * 8]);
-                const float4 t1 = *reinterpret_cast<const float4*>(&stg[row * LDS_LD + c8 * 8 + 4]);
-                v[0] = t0.x; v[1] = t0.y; v[2] = t0.z; v[3] = t0.w;
-                v[4] = t1.x; v[5] = t1.y; v[6] = t1.z; v[7] = t1.w;
-                if (split) {
-                    float* w = g.ws + ((int64_t)z * g.M + m) * g.N + n;
-                    const int nv = (g.N - n) < 8 ? (g.N - n) : 8;
-                    if (nv == 8 && (g.N & 3) == 0) {
-                        *reinterpret_cast<float4*>(w) = t0;
-                        *reinterpret_cast<float4*>(w + 4) = t1;
-                    } else {
-                        for (int i = 0; i < nv; ++i) w[i] = v[i];
+                for (int j = 0; j < TN; ++j) {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int row = (wm & 1) * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+                        const int col = wn * WTN + j * 32 + l31;
+                        stg[row * LDS_LD + col] = acc[p][j][r];
                     }
-                } else {
-                    epi_store8(g.epi, v, m, n, g.N, zb);
+                }
+            }
+            __syncthreads();
+            for (int c = tid; c < 64 * CH; c += NT) {
+                const int row = c / CH;
+                const int c8 = c - row * CH;
+                const int m = m0 + (gp * 2 + (row >> 5)) * WTM + p * 32 + (row & 31);
+                const int n = n0 + c8 * 8;
+                if (m < g.M && n < g.N) {
+                    float v[8];
+                    const float4 t0 = *reinterpret_cast<const float4*>(&stg[row * LDS_LD + c8 * 8]);
+                    const float4 t1 = *reinterpret_cast<const float4*>(&stg[row * LDS_LD + c8 * 8 + 4]);
+                    v[0] = t0.x; v[1] = t0.y; v[2] = t0.z; v[3] = t0.w;
+                    v[4] = t1.x; v[5] = t1.y; v[6] = t1.z; v[7] = t1.w;
+                    if (split) {
+                        float* w = g.ws + ((int64_t)z * g.M + m) * g.N + n;
+                        const int nv = (g.N - n) < 8 ? (g.N - n) : 8;
+                        if (nv == 8 && (g.N & 3) == 0) {
+                            *reinterpret_cast<float4*>(w) = t0;
+                            *reinterpret_cast<float4*>(w + 4) = t1;
+                        } else {
+                            for (int i = 0; i < nv; ++i) w[i] = v[i];
+                        }
+                    } else {
+                        epi_store8(g.epi, v, m, n, g.N, zb);
+                    }
                 }
             }
         }
@@ -376,13 +415,22 @@ __global__ void __launch_bounds__(256) splitk_reduce_kernel(const float* __restr
     }
 }
 
-template <int BM, int BN, bool CONV>
+template <int BM, int BN, int WAVES_M, int WAVES_N, bool CONV, bool INTERLEAVE = true>
 static int launch_gemm_t(odise_hip_ctx* ctx, GemmArgs& g, int batch) {
+    constexpr int NT = 64 * WAVES_M * WAVES_N;
     constexpr int stage = (BM + BN) * 64 * 2 * 2;
     constexpr int epi = 64 * (BN + 4) * 4;
     constexpr int lds = stage > epi ? stage : epi;
+    auto kern = gemm_kernel<BM, BN, WAVES_M, WAVES_N, CONV, INTERLEAVE>;
+    if (lds > 65536) {
+        static bool attr_set = false;  // per instantiation
+        if (!attr_set) {
+            ODISE_CHECK_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+            attr_set = true;
+        }
+    }
     dim3 grid((unsigned)ceil_div(g.N, BN), (unsigned)ceil_div(g.M, BM), (unsigned)(g.splitk > 1 ? g.splitk : batch));
-    hipLaunchKernelGGL((gemm_kernel<BM, BN, CONV>), grid, dim3(256), lds, ctx->stream, g);
+    hipLaunchKernelGGL(kern, grid, dim3(NT), lds, ctx->stream, g);
     ODISE_CHECK_HIP(hipGetLastError());
     if (g.splitk > 1) {
         const int64_t total = (int64_t)g.M * ceil_div(g.N, 8);
@@ -393,46 +441,81 @@ static int launch_gemm_t(odise_hip_ctx* ctx, GemmArgs& g, int batch) {
     return ODISE_OK;
 }
 
-// tile / split-K heuristic.  Large tiles keep the MFMA pipe busy (4 ds_read_b128 per 4 MFMAs vs 2 per 1 for 64x64), so
-// prefer them and recover parallelism with split-K (fp32 partials + fused reduce) when the tile grid alone cannot fill
-// the 256 CUs; small-M layers always need it (weight streaming).
+// Tile ids: 0:128x128 1:64x128 2:64x64 (4 waves)  3:256x320 4:256x256 5:256x128 (8 waves)
+static const int kTileBM[6] = {128, 64, 64, 256, 256, 256};
+static const int kTileBN[6] = {128, 128, 64, 320, 256, 128};
+
+// Tile / split-K selection by a small cost model (times in microseconds, calibrated on MI355X with tools/gemm_bench.py):
+//   t = rounds * (k_tiles_per_split * t_ktile + t_fixed) + t_reduce,   rounds = ceil(blocks * split / resident slots)
+// t_ktile is the measured steady-state time of one 64-deep K-tile of a resident block, t_fixed the prologue + LDS-staged
+// epilogue, t_reduce the fp32 partial write + read of split-K.  Large tiles win whenever they can fill the CUs; split-K
+// recovers parallelism for the small-M (weight-streaming) layers; short-K layers avoid split-K because the partials
+// would cost more than the idle CUs.
+struct TileCost {
+    double t_ktile, t_fixed;
+    int slots_per_cu;
+};
+static const TileCost kTileCost[6] = {
+    {0.95, 3.5, 2},  // 128x128
+    {0.60, 3.0, 3},  // 64x128
+    {0.42, 2.5, 4},  // 64x64
+    {3.40, 7.0, 1},  // 256x320
+    {2.40, 6.0, 1},  // 256x256
+    {1.45, 5.0, 1},  // 256x128
+};
+
 template <bool CONV>
 static int launch_gemm(odise_hip_ctx* ctx, GemmArgs& g, int batch, int force_tile, int force_split) {
     const int64_t cus = ctx->cu_count;
-    auto blocks = [&](int bm, int bn) { return ceil_div(g.M, bm) * ceil_div(g.N, bn) * (int64_t)batch; };
+    auto blocks = [&](int t) { return ceil_div(g.M, kTileBM[t]) * ceil_div(g.N, kTileBN[t]) * (int64_t)batch; };
     const int nk = (int)ceil_div(g.K, 64);
-    const int64_t max_split = batch == 1 ? std::max<int64_t>(1, nk / 3) : 1;
-    int tile = 2;  // 0:128x128 1:64x128 2:64x64
-    if (g.M > 64 && g.N > 64 && blocks(128, 128) * max_split >= cus) tile = 0;
-    else if (g.N > 64 && blocks(64, 128) * max_split >= cus) tile = 1;
-    if (g.M <= 64 && tile == 0) tile = 1;
-    if (g.N <= 64) tile = 2;
-    if (force_tile >= 0) tile = force_tile;
-    const int bm = tile == 0 ? 128 : 64, bn = tile == 2 ? 64 : 128;
-    g.splitk = 1;
-    g.ktiles_per_split = nk;
-    const int64_t nb = blocks(bm, bn);
-    if (batch == 1 && nb < cus && max_split > 1) {
-        int want = (int)std::min<int64_t>(ceil_div(cus * 3 / 2, nb), max_split);
-        want = std::max(1, std::min(want, 64));
-        while (want > 1 && (size_t)want * g.M * g.N * sizeof(float) > ctx->ws_bytes) --want;
-        if (want > 1) {
-            g.ktiles_per_split = (int)ceil_div(nk, want);
-            g.splitk = (int)ceil_div(nk, g.ktiles_per_split);
+    const bool no_interleave = force_tile >= 16;  // test hook: tile + 16 selects the non-interleaved issue order
+    if (no_interleave) force_tile -= 16;
+    int tile = 2, best_split = 1;
+    double best = 1e30;
+    for (int t = 0; t < 6; ++t) {
+        if (force_tile >= 0 && force_tile <= 5 && t != force_tile) continue;
+        if (force_tile < 0) {
+            if (kTileBM[t] > 64 && g.M <= kTileBM[t] / 2) continue;            // mostly-empty row tiles
+            if (kTileBN[t] > 64 && g.N <= kTileBN[t] / 2 && t != 2) continue;  // mostly-empty column tiles
+        }
+        const int64_t nb = blocks(t);
+        const int64_t slots = cus * kTileCost[t].slots_per_cu;
+        const int max_split = (batch == 1) ? std::max(1, std::min(nk / 2, 32)) : 1;
+        for (int sp = 1; sp <= max_split; ++sp) {
+            if (force_split > 0 && sp != std::min(force_split, std::max(1, nk))) continue;
+            if (sp > 1 && (size_t)sp * g.M * g.N * sizeof(float) > ctx->ws_bytes) break;
+            const int per = (int)ceil_div(nk, sp);
+            const int eff_sp = (int)ceil_div(nk, per);
+            const double rounds = (double)ceil_div(nb * eff_sp, slots);
+            double t_us = rounds * (per * kTileCost[t].t_ktile + kTileCost[t].t_fixed);
+            if (eff_sp > 1) t_us += 4.0 + ((2.0 * eff_sp * 4.0 + 2.0) * (double)g.M * g.N) / 2.5e6;  // bytes / (2.5 TB/s) in us
+            if (t_us < best) { best = t_us; tile = t; best_split = eff_sp; }
         }
     }
-    if (force_split > 0 && batch == 1) {
-        int want = std::min(force_split, nk);
-        g.ktiles_per_split = (int)ceil_div(nk, want);
+    if (force_tile >= 0 && force_tile <= 5) tile = force_tile;
+    g.splitk = 1;
+    g.ktiles_per_split = nk;
+    if (force_split > 0 && batch == 1) best_split = std::min(force_split, nk);
+    if (best_split > 1 && batch == 1) {
+        g.ktiles_per_split = (int)ceil_div(nk, best_split);
         g.splitk = (int)ceil_div(nk, g.ktiles_per_split);
         ODISE_REQUIRE((size_t)g.splitk * g.M * g.N * sizeof(float) <= ctx->ws_bytes, "gemm: split-K workspace too small");
     }
     g.ws = (float*)ctx->ws;
     g.zeros = (const f16*)ctx->zeros;
+    if (no_interleave) {
+        if (tile == 3) return launch_gemm_t<256, 320, 4, 2, CONV, false>(ctx, g, batch);
+        if (tile == 4) return launch_gemm_t<256, 256, 4, 2, CONV, false>(ctx, g, batch);
+        if (tile == 0) return launch_gemm_t<128, 128, 2, 2, CONV, false>(ctx, g, batch);
+    }
     switch (tile) {
-        case 0: return launch_gemm_t<128, 128, CONV>(ctx, g, batch);
-        case 1: return launch_gemm_t<64, 128, CONV>(ctx, g, batch);
-        default: return launch_gemm_t<64, 64, CONV>(ctx, g, batch);
+        case 0: return launch_gemm_t<128, 128, 2, 2, CONV>(ctx, g, batch);
+        case 1: return launch_gemm_t<64, 128, 2, 2, CONV>(ctx, g, batch);
+        case 3: return launch_gemm_t<256, 320, 4, 2, CONV>(ctx, g, batch);
+        case 4: return launch_gemm_t<256, 256, 4, 2, CONV>(ctx, g, batch);
+        case 5: return launch_gemm_t<256, 128, 4, 2, CONV>(ctx, g, batch);
+        default: return launch_gemm_t<64, 64, 2, 2, CONV>(ctx, g, batch);
     }
 }
 

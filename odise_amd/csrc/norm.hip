@@ -132,57 +132,85 @@ __global__ void __launch_bounds__(256) gn_apply_kernel(const f16* __restrict__ x
     }
 }
 
-// one wavefront per row; 4 rows per 256-thread block; NV = 16-byte vectors per lane kept in registers (C <= 512*NV)
-template <int NV>
+// One wavefront handles R rows at a time (all R row loads are issued before the first reduction, for memory-level
+// parallelism); NV = 16-byte vectors per lane kept in registers (C <= 512*NV); x is read exactly once.
+template <int NV, int R>
 __global__ void __launch_bounds__(256) layer_norm_kernel(const f16* __restrict__ x, f16* __restrict__ y,
                                                         const float* __restrict__ gamma, const float* __restrict__ beta,
                                                         int rows, int C, float eps) {
     const int lane = threadIdx.x & 63;
-    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (row >= rows) return;
-    const f16* xr = x + (int64_t)row * C;
-    f16* yr = y + (int64_t)row * C;
-    f16x8 v[NV];
-    float s = 0.f;
+    const int row0 = (blockIdx.x * 4 + (threadIdx.x >> 6)) * R;
+    if (row0 >= rows) return;
+    f16x8 v[R][NV];
+    float s[R];
 #pragma unroll
-    for (int k = 0; k < NV; ++k) {
-        const int c = (lane + 64 * k) * 8;
-        if (c < C) {
-            v[k] = *reinterpret_cast<const f16x8*>(xr + c);
+    for (int r = 0; r < R; ++r) {
+        s[r] = 0.f;
+        const bool rok = row0 + r < rows;
 #pragma unroll
-            for (int i = 0; i < 8; ++i) s += (float)v[k][i];
+        for (int k = 0; k < NV; ++k) {
+            const int c = (lane + 64 * k) * 8;
+            if (rok && c < C) v[r][k] = *reinterpret_cast<const f16x8*>(x + (int64_t)(row0 + r) * C + c);
         }
     }
 #pragma unroll
-    for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
-    const float mu = s / (float)C;
-    float q = 0.f;
+    for (int r = 0; r < R; ++r) {
 #pragma unroll
-    for (int k = 0; k < NV; ++k) {
-        const int c = (lane + 64 * k) * 8;
-        if (c < C) {
+        for (int k = 0; k < NV; ++k) {
+            const int c = (lane + 64 * k) * 8;
+            if (c < C) {
 #pragma unroll
-            for (int i = 0; i < 8; ++i) {
-                const float d = (float)v[k][i] - mu;
-                q += d * d;
+                for (int i = 0; i < 8; ++i) s[r] += (float)v[r][k][i];
             }
         }
     }
 #pragma unroll
-    for (int o = 32; o > 0; o >>= 1) q += __shfl_xor(q, o);
-    const float rs = rsqrtf(q / (float)C + eps);
+    for (int o = 32; o > 0; o >>= 1) {
+#pragma unroll
+        for (int r = 0; r < R; ++r) s[r] += __shfl_xor(s[r], o);
+    }
+    float q[R], mu[R];
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        mu[r] = s[r] / (float)C;
+        q[r] = 0.f;
+#pragma unroll
+        for (int k = 0; k < NV; ++k) {
+            const int c = (lane + 64 * k) * 8;
+            if (c < C) {
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+                    const float d = (float)v[r][k][i] - mu[r];
+                    q[r] += d * d;
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+#pragma unroll
+        for (int r = 0; r < R; ++r) q[r] += __shfl_xor(q[r], o);
+    }
 #pragma unroll
     for (int k = 0; k < NV; ++k) {
         const int c = (lane + 64 * k) * 8;
         if (c < C) {
-            f16x8 o;
+            float gm[8], bt[8];
 #pragma unroll
             for (int i = 0; i < 8; ++i) {
-                const float g = gamma ? gamma[c + i] : 1.f;
-                const float b = beta ? beta[c + i] : 0.f;
-                o[i] = (f16)(((float)v[k][i] - mu) * rs * g + b);
+                gm[i] = gamma ? gamma[c + i] : 1.f;
+                bt[i] = beta ? beta[c + i] : 0.f;
             }
-            *reinterpret_cast<f16x8*>(yr + c) = o;
+#pragma unroll
+            for (int r = 0; r < R; ++r) {
+                if (row0 + r < rows) {
+                    const float rs = rsqrtf(q[r] / (float)C + eps);
+                    f16x8 o;
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) o[i] = (f16)(((float)v[r][k][i] - mu[r]) * rs * gm[i] + bt[i]);
+                    *reinterpret_cast<f16x8*>(y + (int64_t)(row0 + r) * C + c) = o;
+                }
+            }
         }
     }
 }
@@ -228,15 +256,15 @@ extern "C" int odise_hip_layer_norm(odise_hip_ctx* ctx, const void* x, void* y, 
     ODISE_REQUIRE(ctx && x && y, "layer_norm: null argument");
     ODISE_REQUIRE(rows >= 0 && C > 0 && C % 8 == 0 && C <= 4096, "layer_norm: C=%d must be a positive multiple of 8, <= 4096", C);
     if (rows == 0) return ODISE_OK;
-    const dim3 grid((unsigned)ceil_div(rows, 4));
-    if (C <= 512)
-        hipLaunchKernelGGL(layer_norm_kernel<1>, grid, dim3(256), 0, ctx->stream, (const f16*)x, (f16*)y, gamma, beta, rows, C, eps);
-    else if (C <= 1024)
-        hipLaunchKernelGGL(layer_norm_kernel<2>, grid, dim3(256), 0, ctx->stream, (const f16*)x, (f16*)y, gamma, beta, rows, C, eps);
-    else if (C <= 2048)
-        hipLaunchKernelGGL(layer_norm_kernel<4>, grid, dim3(256), 0, ctx->stream, (const f16*)x, (f16*)y, gamma, beta, rows, C, eps);
-    else
-        hipLaunchKernelGGL(layer_norm_kernel<8>, grid, dim3(256), 0, ctx->stream, (const f16*)x, (f16*)y, gamma, beta, rows, C, eps);
+    auto launch = [&](auto kern, int R) {
+        const dim3 grid((unsigned)ceil_div(rows, 4 * R));
+        hipLaunchKernelGGL(kern, grid, dim3(256), 0, ctx->stream, (const f16*)x, (f16*)y, gamma, beta, rows, C, eps);
+    };
+    const bool many = rows >= 8192;  // enough rows to keep every CU busy with 4 rows per wavefront
+    if (C <= 512) { if (many) launch(layer_norm_kernel<1, 4>, 4); else launch(layer_norm_kernel<1, 1>, 1); }
+    else if (C <= 1024) { if (many) launch(layer_norm_kernel<2, 4>, 4); else launch(layer_norm_kernel<2, 1>, 1); }
+    else if (C <= 2048) { if (many) launch(layer_norm_kernel<4, 2>, 2); else launch(layer_norm_kernel<4, 1>, 1); }
+    else launch(layer_norm_kernel<8, 1>, 1);
     ODISE_CHECK_HIP(hipGetLastError());
     return ODISE_OK;
 }

@@ -132,7 +132,7 @@ class Context:
 
     def gemm(self, A: DeviceArray, W: DeviceArray, *, bias_n=None, bias_m=None, scale_m=None, residual=None,
              rowgroup_add=None, rows_per_group=0, act=ACT_NONE, geglu=False, alpha=1.0, out_dtype=np.float16,
-             force_tile=-1, force_split=0) -> DeviceArray:
+             force_tile=-1, force_split=0, out=None) -> DeviceArray:
         """C[M,N] = epi(alpha * A[M,K] @ W[N,K]^T); 3-D inputs are batched over dim 0."""
         batched = len(A.shape) == 3 or len(W.shape) == 3
         batch = (A.shape[0] if len(A.shape) == 3 else W.shape[0]) if batched else 1
@@ -141,7 +141,7 @@ class Context:
         assert K == K2
         No = N // 2 if geglu else N
         oshape = (batch, M, No) if batched else (M, No)
-        out = self.empty(oshape, out_dtype)
+        out = out if out is not None else self.empty(oshape, out_dtype)
         d = GemmDesc()
         d.M, d.N, d.K = M, N, K
         d.A, d.lda = A.ptr, K
@@ -169,7 +169,7 @@ class Context:
 
     def conv2d(self, X: DeviceArray, Wt: DeviceArray, *, stride=1, pad=None, pad_tl=None, out_hw=None, upsample2x=False,
                bias=None, residual=None, per_image_add=None, act=ACT_NONE, out_dtype=np.float16, force_tile=-1,
-               force_split=0) -> DeviceArray:
+               force_split=0, out=None) -> DeviceArray:
         """NHWC conv: X [N,H,W,Cin] f16, Wt [Cout,KH,KW,Cin] f16 -> [N,OH,OW,Cout]."""
         N, H, W, Cin = X.shape
         Cout, KH, KW, Cin2 = Wt.shape
@@ -183,7 +183,7 @@ class Context:
             OW = (Win + 2 * pad - KW) // stride + 1
         else:
             OH, OW = out_hw
-        out = self.empty((N, OH, OW, Cout), out_dtype)
+        out = out if out is not None else self.empty((N, OH, OW, Cout), out_dtype)
         d = ConvDesc()
         d.N, d.H, d.W, d.Cin = N, H, W, Cin
         d.Cout, d.KH, d.KW, d.stride = Cout, KH, KW, stride

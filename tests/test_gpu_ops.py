@@ -87,6 +87,9 @@ GEMM_CASES = [
     (64, 128, 128, 1, 0), (100, 100, 256, 1, 0), (64, 64, 64, 2, 0), (37, 24, 40, 2, 0),
     (64, 1280, 2304, 2, 6), (77, 320, 768, 1, 3), (4096, 320, 320, -1, 0), (1, 1280, 320, -1, 0),
     (300, 250, 1000, -1, 0),
+    # 8-wave 256-row tiles (3: 256x320, 4: 256x256, 5: 256x128), incl. ragged edges and split-K
+    (512, 640, 320, 3, 0), (300, 330, 128, 3, 0), (512, 512, 256, 4, 0), (260, 130, 72, 5, 0), (1024, 320, 2880, 3, 3),
+    (256, 320, 64, 3, 0), (4096, 1280, 320, -1, 0), (700, 300, 200, 4, 2),
 ]
 
 
@@ -113,7 +116,7 @@ def test_gemm_asymmetric_identity(ctx):
     np.testing.assert_allclose(out, W.t().numpy(), rtol=0, atol=1e-3)
 
 
-@pytest.mark.parametrize("tile,split", [(0, 0), (2, 0), (2, 4)])
+@pytest.mark.parametrize("tile,split", [(0, 0), (2, 0), (2, 4), (3, 0), (4, 2)])
 def test_gemm_epilogues(ctx, tile, split):
     g = torch.Generator().manual_seed(5)
     M, N, K = 192, 160, 320
@@ -172,6 +175,8 @@ def _conv_ref(x_nhwc, w_okkc, stride, padding, bias=None):
 @pytest.mark.parametrize("N,H,W,Cin,Cout,k,tile,split", [
     (2, 16, 16, 32, 64, 3, -1, 0), (1, 64, 64, 320, 320, 3, -1, 0), (1, 8, 8, 1280, 640, 3, -1, 0), (3, 9, 7, 8, 24, 3, 2, 0),
     (1, 32, 32, 64, 128, 1, -1, 0), (2, 8, 8, 640, 320, 3, 2, 5), (1, 24, 40, 128, 136, 3, 0, 0),
+    (2, 32, 32, 64, 320, 3, 3, 0), (1, 17, 19, 32, 300, 3, 3, 2), (2, 16, 16, 128, 256, 3, 4, 0), (1, 20, 20, 64, 128, 3, 5, 0),
+    (4, 64, 64, 320, 320, 3, -1, 0),
 ])
 def test_conv3x3_and_1x1(ctx, N, H, W, Cin, Cout, k, tile, split):
     g = torch.Generator().manual_seed(N + H + Cin + Cout)
