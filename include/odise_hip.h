@@ -170,6 +170,19 @@ int odise_hip_unet_last_macs(odise_hip_ctx* ctx, double* macs);
 /* capture the unet forward for (B,h,w) into a hipGraph and replay it on subsequent calls (0 disables) */
 int odise_hip_unet_use_graph(odise_hip_ctx* ctx, int enable);
 
+/* ---- LdmImplicitCaptionerExtractor.forward (ldm.py:697-718 -> 543-621) ------------------------------ */
+/* Weights (host fp32, checkpoint keys): first_stage_model.* and model.diffusion_model.* (SD v1 ckpt "state_dict"),
+ * clip.visual.* (OpenAI ViT-L-14-336px archive, prefixed with "clip."), backbone.feature_extractor.{clip_project.*,
+ * alpha_cond, time_embed_project.*, alpha_cond_time_embed} (ODISE ckpt "model"), plus the two frozen buffers
+ * backbone.feature_extractor.ldm_extractor.{ldm.uncond_inputs [1,77,768], shared_noise [1,4,64,64]}. */
+int odise_hip_extractor_build(odise_hip_ctx* ctx);
+/* image [B,3,H,W] f32 device in [0,1] (H,W multiples of 64; reference crops are 512x512).  taps8: 8 device pointers
+ * (fp32 NCHW, any may be NULL) in the reference's order enc5, enc7, u2, u5, u8, u11, dec2, dec5 (ldm.py:608). */
+int odise_hip_extractor_forward(odise_hip_ctx* ctx, const float* image, int B, int H, int W, float** taps8);
+/* hot-path variant: taps stay fp16 NHWC inside the library arena; returns pointers and [n,c,h,w] per tap */
+int odise_hip_extractor_forward_nhwc(odise_hip_ctx* ctx, const float* image, int B, int H, int W, void** taps8, int* shapes8x4);
+int odise_hip_extractor_last_macs(odise_hip_ctx* ctx, double* macs);
+
 #ifdef __cplusplus
 }
 #endif

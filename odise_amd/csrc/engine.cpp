@@ -5,7 +5,8 @@
 
 namespace odise {
 
-void unet_destroy(ModelStore* ms);  // unet.cpp
+void unet_destroy(ModelStore* ms);       // unet.cpp
+void extractor_destroy(ModelStore* ms);  // extractor.cpp
 
 ModelStore* store_of(odise_hip_ctx* ctx) {
     if (!ctx->models) ctx->models = new ModelStore();
@@ -16,6 +17,7 @@ void models_destroy(odise_hip_ctx* ctx) {
     if (!ctx->models) return;
     ModelStore* ms = (ModelStore*)ctx->models;
     unet_destroy(ms);
+    extractor_destroy(ms);
     for (void* p : ms->dev_allocs) hipFree(p);
     if (ms->arena.base) hipFree(ms->arena.base);
     delete ms;

@@ -76,6 +76,7 @@ struct ModelStore {
     std::vector<void*> dev_allocs;
     Arena arena;
     UNetModel* unet = nullptr;
+    struct ExtractorModel* extractor = nullptr;
     double macs = 0.0;  // analytic MACs of the ops launched since the last reset
 };
 
@@ -114,5 +115,31 @@ struct Exec {
     int gemm(const odise_gemm_desc& d);
     int attention(const odise_attn_desc& d);
 };
+
+
+// ---- stage entry points shared between translation units --------------------------------------------------------
+int ensure_arena(odise_hip_ctx* ctx, ModelStore* ms, size_t bytes);
+int unet_build(odise_hip_ctx* ctx, const char* prefix);
+int unet_prepare_timestep(odise_hip_ctx* ctx, ModelStore* ms, UNetModel* u, int B, int t);
+int unet_launch(odise_hip_ctx* ctx, ModelStore* ms, UNetModel* u, const float* x_t, const f16* x_nhwc, const float* context,
+                const float* cond_emb, int B, int h, int w, bool standalone);
+const Act* unet_taps(ModelStore* ms);
+
+// misc.hip
+struct LatentW {
+    float wq[4][8];   // quant_conv rows 0..3 (the posterior mean)
+    float bq[4];
+    float wp[4][4];   // post_quant_conv
+    float bp[4];
+    float scale, qa, qb;  // scale_factor, sqrt(alpha_bar_t), sqrt(1 - alpha_bar_t)
+};
+int launch_latent_heads(odise_hip_ctx* ctx, const f16* h, const float* noise, f16* xt, f16* zdec, float* latent, int B, int P,
+                        const LatentW& w);
+int launch_image_to_nhwc(odise_hip_ctx* ctx, const float* x, f16* y, int N, int C, int HW, int Cpad, const float* scale3,
+                         const float* shift3);
+int launch_clip_preprocess(odise_hip_ctx* ctx, const float* x, f16* y, int N, int H, int W, int S);
+int launch_softmax_rows(odise_hip_ctx* ctx, const f16* x, f16* y, int64_t rows, int cols, int64_t ld, float scale);
+int launch_clip_assemble(odise_hip_ctx* ctx, const f16* patches, const float* cls, const float* pos, f16* tok, int B, int T, int Cw);
+int launch_cond_inputs(odise_hip_ctx* ctx, const float* proj, const float* A1, const float* A2, float* out, int B, int T, int Cw);
 
 }  // namespace odise

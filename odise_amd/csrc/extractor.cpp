@@ -1,0 +1,550 @@
+// extractor.cpp — LdmImplicitCaptionerExtractor.forward on the device (odise/modeling/meta_arch/ldm.py:697-718 -> 543-621):
+//
+//   image [B,3,H,W] in [0,1]
+//     |- CLIP ViT-L/14@336 image embed (clip.py:177-231)  -> prefix [B,768]
+//     |     cond_inputs = uncond + tanh(alpha_cond) * (Linear(prefix)[:,None] + pos)       (ldm.py:705-709)
+//     |     cond_emb    = tanh(alpha_t) * (Linear(prefix) + pos_t)                          (ldm.py:711-714)
+//     |- (image-0.5)/0.5 -> AutoencoderKL.encoder (taps = inputs of down blocks 5, 7; ldm.py:424-457) -> quant_conv mean
+//     |     latent = 0.18215 * mean;  x_t = q_sample(latent, t=0, shared noise seed 42)      (ldm.py:459-467, 577-598)
+//     |- UNet single step (unet.cpp; taps = concat inputs of output blocks 2,5,8,11)
+//     `- post_quant_conv(latent/0.18215) -> AutoencoderKL.decoder up to the INPUT of up-block 5 (taps 2, 5; ldm.py:493-533).
+//        Everything after the last tap only feeds the discarded reconstruction (ldm.py:606) and is not executed.
+//
+// Architectures restated from SURVEY.md Appendix A.2 / A.3 (ldm AutoencoderKL, OpenAI CLIP ViT); weights addressed by
+// checkpoint keys: first_stage_model.*, model.diffusion_model.*, clip.visual.*, backbone.feature_extractor.*.
+// All crops of a call run as ONE batch through every stage (the reference loops crops sequentially,
+// feature_extractor.py:216-227).
+#include <math.h>
+#include <string.h>
+
+#include "engine.h"
+
+namespace odise {
+
+struct VaeRes {
+    NormW n1, n2;
+    ConvW c1, c2, nin;
+    bool has_nin = false;
+};
+struct VaeAttn {
+    NormW norm;
+    LinW qk, v, proj;  // q|k stacked [2C,C] with bias, v [C,C] (+bias applied along M of the swapped GEMM), proj_out
+    float* v_bias = nullptr;
+    int c = 0;
+};
+struct ClipBlock {
+    NormW ln1, ln2;
+    LinW qk, v, out, fc, proj;
+    float* v_bias = nullptr;
+};
+
+struct ExtractorModel {
+    bool built = false;
+    // VAE encoder
+    ConvW enc_conv_in, enc_conv_out;
+    VaeRes enc_blocks[4][2];
+    ConvW enc_down[3];
+    VaeRes enc_mid1, enc_mid2;
+    VaeAttn enc_attn;
+    NormW enc_norm_out;
+    // VAE decoder (live part)
+    ConvW dec_conv_in;
+    VaeRes dec_mid1, dec_mid2;
+    VaeAttn dec_attn;
+    VaeRes dec_l3[3], dec_l2[2];
+    ConvW dec_up3;
+    LatentW lat;
+    float* noise = nullptr;  // [4, 64*64]
+    int noise_hw = 0;
+    // CLIP
+    ConvW clip_conv1;
+    float *clip_cls = nullptr, *clip_pos = nullptr;
+    NormW clip_ln_pre, clip_ln_post;
+    std::vector<ClipBlock> clip_blocks;
+    LinW clip_proj;
+    int clip_width = 0, clip_heads = 16, clip_tokens = 0, clip_image = 336, clip_patch = 14, clip_out = 768;
+    // captioner
+    LinW cap_proj;   // clip_project.linear
+    LinW cap_time;   // time_embed_project folded with tanh(alpha) and positional embedding
+    float *cap_A1 = nullptr, *cap_A2 = nullptr;
+    int ctx_dim = 768, ted = 1280;
+    // outputs of the last forward
+    Act taps[8];
+    double last_macs = 0.0;
+};
+
+void extractor_destroy(ModelStore* ms) {
+    delete ms->extractor;
+    ms->extractor = nullptr;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+static int build_vae_res(Packer& pk, const std::string& key, VaeRes& r) {
+    ODISE_TRY(pk.norm(key + ".norm1", r.n1));
+    ODISE_TRY(pk.conv(key + ".conv1", r.c1));
+    ODISE_TRY(pk.norm(key + ".norm2", r.n2));
+    ODISE_TRY(pk.conv(key + ".conv2", r.c2));
+    r.has_nin = pk.find(key + ".nin_shortcut.weight") != nullptr;
+    if (r.has_nin) ODISE_TRY(pk.conv(key + ".nin_shortcut", r.nin));
+    return ODISE_OK;
+}
+
+static int build_vae_attn(Packer& pk, const std::string& key, VaeAttn& a) {
+    ODISE_TRY(pk.norm(key + ".norm", a.norm));
+    a.c = a.norm.c;
+    const HostTensor *wq = pk.find(key + ".q.weight"), *wk = pk.find(key + ".k.weight"), *bq = pk.find(key + ".q.bias"),
+                     *bk = pk.find(key + ".k.bias");
+    const size_t cc = (size_t)a.c * a.c;
+    if (!wq || !wk || !bq || !bk || (size_t)wq->numel() != cc || (size_t)wk->numel() != cc) {
+        set_error("vae: bad or missing '%s.q/k'", key.c_str());
+        return ODISE_ERR_STATE;
+    }
+    std::vector<f16> qk(2 * cc);
+    std::vector<float> b(2 * (size_t)a.c);
+    for (size_t i = 0; i < cc; ++i) { qk[i] = (f16)wq->data[i]; qk[cc + i] = (f16)wk->data[i]; }
+    for (int i = 0; i < a.c; ++i) { b[i] = bq->data[i]; b[a.c + i] = bk->data[i]; }
+    a.qk.in = a.c; a.qk.out = 2 * a.c;
+    ODISE_TRY(pk.upload(qk.data(), qk.size() * sizeof(f16), (void**)&a.qk.w));
+    ODISE_TRY(pk.upload(b.data(), b.size() * sizeof(float), (void**)&a.qk.b));
+    ODISE_TRY(pk.linear(key + ".v", a.v, false));
+    ODISE_TRY(pk.vec_f32(key + ".v.bias", &a.v_bias, a.c));
+    ODISE_TRY(pk.linear(key + ".proj_out", a.proj));
+    return ODISE_OK;
+}
+
+static int build_clip_block(Packer& pk, const std::string& key, ClipBlock& b, int W) {
+    ODISE_TRY(pk.norm(key + ".ln_1", b.ln1));
+    ODISE_TRY(pk.norm(key + ".ln_2", b.ln2));
+    const HostTensor* w = pk.find(key + ".attn.in_proj_weight");
+    const HostTensor* bias = pk.find(key + ".attn.in_proj_bias");
+    if (!w || !bias || w->numel() != (int64_t)3 * W * W || bias->numel() != 3 * W) {
+        set_error("clip: bad or missing '%s.attn.in_proj_*'", key.c_str());
+        return ODISE_ERR_STATE;
+    }
+    const size_t ww = (size_t)W * W;
+    std::vector<f16> qk(2 * ww), v(ww);
+    for (size_t i = 0; i < 2 * ww; ++i) qk[i] = (f16)w->data[i];
+    for (size_t i = 0; i < ww; ++i) v[i] = (f16)w->data[2 * ww + i];
+    b.qk.in = W; b.qk.out = 2 * W;
+    ODISE_TRY(pk.upload(qk.data(), qk.size() * sizeof(f16), (void**)&b.qk.w));
+    ODISE_TRY(pk.upload(bias->data.data(), (size_t)2 * W * sizeof(float), (void**)&b.qk.b));
+    b.v.in = W; b.v.out = W; b.v.b = nullptr;
+    ODISE_TRY(pk.upload(v.data(), v.size() * sizeof(f16), (void**)&b.v.w));
+    ODISE_TRY(pk.upload(bias->data.data() + 2 * W, (size_t)W * sizeof(float), (void**)&b.v_bias));
+    ODISE_TRY(pk.linear(key + ".attn.out_proj", b.out));
+    ODISE_TRY(pk.linear(key + ".mlp.c_fc", b.fc));
+    ODISE_TRY(pk.linear(key + ".mlp.c_proj", b.proj));
+    return ODISE_OK;
+}
+
+static int extractor_build(odise_hip_ctx* ctx) {
+    ModelStore* ms = store_of(ctx);
+    extractor_destroy(ms);
+    ExtractorModel* e = new ExtractorModel();
+    ms->extractor = e;
+    // ---- UNet --------------------------------------------------------------------------------------------------
+    ODISE_TRY(unet_build(ctx, "model.diffusion_model."));
+    // ---- VAE ---------------------------------------------------------------------------------------------------
+    Packer pk{ctx, ms, "first_stage_model.", ""};
+    ODISE_TRY(pk.conv("encoder.conv_in", e->enc_conv_in));
+    for (int l = 0; l < 4; ++l) {
+        for (int b = 0; b < 2; ++b)
+            ODISE_TRY(build_vae_res(pk, "encoder.down." + std::to_string(l) + ".block." + std::to_string(b), e->enc_blocks[l][b]));
+        if (l < 3) ODISE_TRY(pk.conv("encoder.down." + std::to_string(l) + ".downsample.conv", e->enc_down[l]));
+    }
+    ODISE_TRY(build_vae_res(pk, "encoder.mid.block_1", e->enc_mid1));
+    ODISE_TRY(build_vae_attn(pk, "encoder.mid.attn_1", e->enc_attn));
+    ODISE_TRY(build_vae_res(pk, "encoder.mid.block_2", e->enc_mid2));
+    ODISE_TRY(pk.norm("encoder.norm_out", e->enc_norm_out));
+    ODISE_TRY(pk.conv("encoder.conv_out", e->enc_conv_out));
+    ODISE_TRY(pk.conv("decoder.conv_in", e->dec_conv_in));
+    ODISE_TRY(build_vae_res(pk, "decoder.mid.block_1", e->dec_mid1));
+    ODISE_TRY(build_vae_attn(pk, "decoder.mid.attn_1", e->dec_attn));
+    ODISE_TRY(build_vae_res(pk, "decoder.mid.block_2", e->dec_mid2));
+    for (int b = 0; b < 3; ++b) ODISE_TRY(build_vae_res(pk, "decoder.up.3.block." + std::to_string(b), e->dec_l3[b]));
+    ODISE_TRY(pk.conv("decoder.up.3.upsample.conv", e->dec_up3));
+    for (int b = 0; b < 2; ++b) ODISE_TRY(build_vae_res(pk, "decoder.up.2.block." + std::to_string(b), e->dec_l2[b]));
+    {
+        const HostTensor *wq = pk.find("quant_conv.weight"), *bq = pk.find("quant_conv.bias"), *wp = pk.find("post_quant_conv.weight"),
+                         *bp = pk.find("post_quant_conv.bias");
+        if (!wq || !bq || !wp || !bp || wq->numel() != 64 || bq->numel() != 8 || wp->numel() != 16 || bp->numel() != 4) {
+            set_error("vae: bad or missing quant_conv / post_quant_conv (expected 8x8 and 4x4 1x1 convs)");
+            return ODISE_ERR_STATE;
+        }
+        for (int c = 0; c < 4; ++c) {
+            for (int k = 0; k < 8; ++k) e->lat.wq[c][k] = wq->data[c * 8 + k];
+            e->lat.bq[c] = bq->data[c];
+            for (int k = 0; k < 4; ++k) e->lat.wp[c][k] = wp->data[c * 4 + k];
+            e->lat.bp[c] = bp->data[c];
+        }
+        e->lat.scale = 0.18215f;
+        // "ldm_linear" schedule (gaussian_diffusion.py:125-135), t = 0: alpha_bar_0 = 1 - beta_0
+        const double beta0 = pow(sqrt(0.00085), 2.0);
+        e->lat.qa = (float)sqrt(1.0 - beta0);
+        e->lat.qb = (float)sqrt(1.0 - (1.0 - beta0));
+    }
+    // ---- CLIP image tower ------------------------------------------------------------------------------------------
+    Packer pc{ctx, ms, "clip.visual.", ""};
+    ODISE_TRY(pc.conv("conv1", e->clip_conv1, false));
+    e->clip_width = e->clip_conv1.cout;
+    e->clip_patch = e->clip_conv1.k;
+    const HostTensor* pos = pc.find("positional_embedding");
+    if (!pos || pos->shape.size() != 2 || pos->shape[1] != e->clip_width) {
+        set_error("clip: bad or missing visual.positional_embedding");
+        return ODISE_ERR_STATE;
+    }
+    e->clip_tokens = (int)pos->shape[0];
+    {
+        const int grid = (int)lround(sqrt((double)(e->clip_tokens - 1)));
+        e->clip_image = grid * e->clip_patch;
+    }
+    ODISE_TRY(pc.vec_f32("positional_embedding", &e->clip_pos, (int64_t)e->clip_tokens * e->clip_width));
+    ODISE_TRY(pc.vec_f32("class_embedding", &e->clip_cls, e->clip_width));
+    ODISE_TRY(pc.norm("ln_pre", e->clip_ln_pre));
+    ODISE_TRY(pc.norm("ln_post", e->clip_ln_post));
+    for (int i = 0;; ++i) {
+        const std::string key = "transformer.resblocks." + std::to_string(i);
+        if (!pc.find(key + ".ln_1.weight")) break;
+        ClipBlock b;
+        ODISE_TRY(build_clip_block(pc, key, b, e->clip_width));
+        e->clip_blocks.push_back(b);
+    }
+    if (e->clip_blocks.empty()) {
+        set_error("clip: no transformer.resblocks found");
+        return ODISE_ERR_STATE;
+    }
+    e->clip_heads = e->clip_width / 64;
+    {
+        const HostTensor* pr = pc.find("proj");
+        if (!pr || pr->shape.size() != 2 || pr->shape[0] != e->clip_width) {
+            set_error("clip: bad or missing visual.proj");
+            return ODISE_ERR_STATE;
+        }
+        e->clip_out = (int)pr->shape[1];
+        std::vector<f16> wt((size_t)e->clip_out * e->clip_width);
+        for (int o = 0; o < e->clip_out; ++o)
+            for (int i = 0; i < e->clip_width; ++i) wt[(size_t)o * e->clip_width + i] = (f16)pr->data[(size_t)i * e->clip_out + o];
+        e->clip_proj.in = e->clip_width; e->clip_proj.out = e->clip_out; e->clip_proj.b = nullptr;
+        ODISE_TRY(pc.upload(wt.data(), wt.size() * sizeof(f16), (void**)&e->clip_proj.w));
+    }
+    // ---- implicit captioner (trainable part of backbone.feature_extractor) -------------------------------------------
+    Packer pf{ctx, ms, "backbone.feature_extractor.", ""};
+    ODISE_TRY(pf.linear("clip_project.linear", e->cap_proj));
+    e->ctx_dim = e->cap_proj.out;
+    {
+        const HostTensor *unc = pf.find("ldm_extractor.ldm.uncond_inputs"), *alpha = pf.find("alpha_cond"),
+                         *posc = pf.find("clip_project.positional_embedding");
+        const int64_t n = (int64_t)77 * e->ctx_dim;
+        if (!unc || !alpha || !posc || unc->numel() != n || alpha->numel() != n || posc->numel() != n) {
+            set_error("captioner: bad or missing uncond_inputs / alpha_cond / clip_project.positional_embedding");
+            return ODISE_ERR_STATE;
+        }
+        std::vector<float> A1(n), A2(n);
+        for (int64_t i = 0; i < n; ++i) {
+            A2[i] = tanhf(alpha->data[i]);
+            A1[i] = unc->data[i] + A2[i] * posc->data[i];
+        }
+        ODISE_TRY(pf.upload(A1.data(), n * sizeof(float), (void**)&e->cap_A1));
+        ODISE_TRY(pf.upload(A2.data(), n * sizeof(float), (void**)&e->cap_A2));
+    }
+    {
+        const HostTensor *w = pf.find("time_embed_project.linear.weight"), *b = pf.find("time_embed_project.linear.bias"),
+                         *post = pf.find("time_embed_project.positional_embedding"), *al = pf.find("alpha_cond_time_embed");
+        if (!w || !b || !post || !al || w->shape.size() != 2 || post->numel() != w->shape[0] || al->numel() != w->shape[0]) {
+            set_error("captioner: bad or missing time_embed_project / alpha_cond_time_embed (num_timesteps must be 1)");
+            return ODISE_ERR_STATE;
+        }
+        e->ted = (int)w->shape[0];
+        const int in = (int)w->shape[1];
+        std::vector<f16> wf((size_t)e->ted * in);
+        std::vector<float> bf(e->ted);
+        for (int o = 0; o < e->ted; ++o) {
+            const float t = tanhf(al->data[o]);
+            for (int i = 0; i < in; ++i) wf[(size_t)o * in + i] = (f16)(t * w->data[(size_t)o * in + i]);
+            bf[o] = t * (b->data[o] + post->data[o]);
+        }
+        e->cap_time.in = in; e->cap_time.out = e->ted;
+        ODISE_TRY(pf.upload(wf.data(), wf.size() * sizeof(f16), (void**)&e->cap_time.w));
+        ODISE_TRY(pf.upload(bf.data(), bf.size() * sizeof(float), (void**)&e->cap_time.b));
+    }
+    {
+        const HostTensor* nz = pf.find("ldm_extractor.shared_noise");
+        if (!nz || nz->shape.size() != 4 || nz->shape[1] != 4) {
+            set_error("extractor: bad or missing ldm_extractor.shared_noise [1,4,h,w]");
+            return ODISE_ERR_STATE;
+        }
+        e->noise_hw = (int)(nz->shape[2] * nz->shape[3]);
+        ODISE_TRY(pf.upload(nz->data.data(), nz->data.size() * sizeof(float), (void**)&e->noise));
+    }
+    e->built = true;
+    return ODISE_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+static int run_vae_res(Exec& ex, const VaeRes& w, const Act& x, Act& out) {
+    ODISE_TRY(ex.alloc(out, x.n, x.h, x.w, w.c1.cout));
+    const size_t mk = ex.ms->arena.mark();
+    Act t1, h, t2, sk;
+    ODISE_TRY(ex.group_norm(x, w.n1, t1, 1e-6f, ODISE_ACT_SILU));
+    ODISE_TRY(ex.conv(t1, w.c1, h, 1, 1));
+    ODISE_TRY(ex.group_norm(h, w.n2, t2, 1e-6f, ODISE_ACT_SILU));
+    const Act* resid = &x;
+    if (w.has_nin) {
+        ODISE_TRY(ex.conv(x, w.nin, sk, 1, 0));
+        resid = &sk;
+    }
+    ODISE_TRY(ex.conv(t2, w.c2, out, 1, 1, false, resid));
+    ex.ms->arena.release(mk);
+    return ODISE_OK;
+}
+
+// single-head attention of width C over HW tokens: S = (q k^T) C^-0.5 materialised per image (HW x HW fp16), row softmax, P v
+static int run_vae_attn(Exec& ex, const VaeAttn& w, const Act& x, Act& out) {
+    const int C = w.c;
+    const int64_t HW = (int64_t)x.h * x.w, M = x.pixels();
+    ODISE_TRY(ex.alloc(out, x.n, x.h, x.w, C));
+    const size_t mk = ex.ms->arena.mark();
+    Act t;
+    ODISE_TRY(ex.group_norm(x, w.norm, t, 1e-6f, ODISE_ACT_NONE));
+    const int64_t ldv = round_up(HW, 8);
+    ODISE_REQUIRE(HW % 8 == 0, "vae attention: H*W=%lld must be a multiple of 8", (long long)HW);
+    f16* qk = (f16*)ex.alloc_bytes((size_t)M * 2 * C * 2);
+    f16* vt = (f16*)ex.alloc_bytes((size_t)x.n * C * ldv * 2);
+    f16* S = (f16*)ex.alloc_bytes((size_t)x.n * HW * ldv * 2);
+    f16* o = (f16*)ex.alloc_bytes((size_t)M * C * 2);
+    if (!qk || !vt || !S || !o) return ODISE_ERR_NOMEM;
+    ODISE_TRY(ex.linear(t.p, M, w.qk, qk));
+    odise_gemm_desc d;
+    memset(&d, 0, sizeof(d));  // V^T[b] = Wv n[b]^T + bv (bias along rows)
+    d.M = C; d.N = (int)HW; d.K = C;
+    d.A = w.v.w; d.lda = C; d.W = t.p; d.ldw = C; d.strideW = HW * C;
+    d.C = vt; d.ldc = ldv; d.strideC = (int64_t)C * ldv; d.c_dtype = ODISE_F16;
+    d.bias_m = w.v_bias; d.alpha = 1.f; d.batch = x.n;
+    ODISE_TRY(ex.gemm(d));
+    memset(&d, 0, sizeof(d));  // S[b] = q[b] k[b]^T * C^-0.5
+    d.M = (int)HW; d.N = (int)HW; d.K = C;
+    d.A = qk; d.lda = 2 * C; d.strideA = HW * 2 * C;
+    d.W = qk + C; d.ldw = 2 * C; d.strideW = HW * 2 * C;
+    d.C = S; d.ldc = ldv; d.strideC = HW * ldv; d.c_dtype = ODISE_F16;
+    d.alpha = 1.0f / sqrtf((float)C); d.batch = x.n;
+    ODISE_TRY(ex.gemm(d));
+    ODISE_TRY(launch_softmax_rows(ex.ctx, S, S, (int64_t)x.n * HW, (int)HW, ldv, 1.0f));
+    memset(&d, 0, sizeof(d));  // o[b] = P[b] v[b]  (W operand = V^T)
+    d.M = (int)HW; d.N = C; d.K = (int)HW;
+    d.A = S; d.lda = ldv; d.strideA = HW * ldv;
+    d.W = vt; d.ldw = ldv; d.strideW = (int64_t)C * ldv;
+    d.C = o; d.ldc = C; d.strideC = HW * C; d.c_dtype = ODISE_F16;
+    d.alpha = 1.f; d.batch = x.n;
+    ODISE_TRY(ex.gemm(d));
+    ODISE_TRY(ex.linear(o, M, w.proj, out.p, ODISE_ACT_NONE, x.p));
+    ex.ms->arena.release(mk);
+    return ODISE_OK;
+}
+
+static int run_clip(Exec& ex, ExtractorModel* e, const float* image, int B, int H, int W, f16* prefix16 /*[B, clip_out]*/) {
+    const int S = e->clip_image, Wd = e->clip_width, T = e->clip_tokens, G = S / e->clip_patch;
+    const size_t mk = ex.ms->arena.mark();
+    Act img, patches;
+    ODISE_TRY(ex.alloc(img, B, S, S, 8));
+    ODISE_TRY(launch_clip_preprocess(ex.ctx, image, img.p, B, H, W, S));
+    ODISE_TRY(ex.conv(img, e->clip_conv1, patches, e->clip_patch, 0, false, nullptr, nullptr, 0, ODISE_ACT_NONE, 0, 0, G, G));
+    const int64_t M = (int64_t)B * T;
+    const int64_t ldvt = round_up(T, 8);
+    f16* x = (f16*)ex.alloc_bytes((size_t)M * Wd * 2);
+    f16* x2 = (f16*)ex.alloc_bytes((size_t)M * Wd * 2);
+    f16* n = (f16*)ex.alloc_bytes((size_t)M * Wd * 2);
+    f16* qk = (f16*)ex.alloc_bytes((size_t)M * 2 * Wd * 2);
+    f16* vt = (f16*)ex.alloc_bytes((size_t)B * Wd * ldvt * 2);
+    f16* att = (f16*)ex.alloc_bytes((size_t)M * Wd * 2);
+    f16* hid = (f16*)ex.alloc_bytes((size_t)M * 4 * Wd * 2);
+    if (!x || !x2 || !n || !qk || !vt || !att || !hid) return ODISE_ERR_NOMEM;
+    ODISE_TRY(launch_clip_assemble(ex.ctx, patches.p, e->clip_cls, e->clip_pos, n, B, T, Wd));
+    ODISE_TRY(ex.layer_norm(n, x, M, e->clip_ln_pre, 1e-5f));
+    const int heads = e->clip_heads, D = Wd / heads;
+    for (const ClipBlock& b : e->clip_blocks) {
+        ODISE_TRY(ex.layer_norm(x, n, M, b.ln1, 1e-5f));
+        ODISE_TRY(ex.linear(n, M, b.qk, qk));
+        odise_gemm_desc d;
+        memset(&d, 0, sizeof(d));
+        d.M = Wd; d.N = T; d.K = Wd;
+        d.A = b.v.w; d.lda = Wd; d.W = n; d.ldw = Wd; d.strideW = (int64_t)T * Wd;
+        d.C = vt; d.ldc = ldvt; d.strideC = (int64_t)Wd * ldvt; d.c_dtype = ODISE_F16;
+        d.bias_m = b.v_bias; d.alpha = 1.f; d.batch = B;
+        ODISE_TRY(ex.gemm(d));
+        odise_attn_desc a;
+        memset(&a, 0, sizeof(a));
+        a.B = B; a.H = heads; a.Lq = T; a.Lk = T; a.D = D;
+        a.Q = qk; a.ldq = 2 * Wd; a.strideQ = (int64_t)T * 2 * Wd;
+        a.K = qk + Wd; a.ldk = 2 * Wd; a.strideK = (int64_t)T * 2 * Wd;
+        a.Vt = vt; a.ldvt = ldvt; a.strideVt = (int64_t)Wd * ldvt;
+        a.O = att; a.ldo = Wd; a.strideO = (int64_t)T * Wd;
+        a.scale = 1.0f / sqrtf((float)D);
+        ODISE_TRY(ex.attention(a));
+        ODISE_TRY(ex.linear(att, M, b.out, x2, ODISE_ACT_NONE, x));          // x2 = x + attn
+        ODISE_TRY(ex.layer_norm(x2, n, M, b.ln2, 1e-5f));
+        ODISE_TRY(ex.linear(n, M, b.fc, hid, ODISE_ACT_QUICKGELU));
+        ODISE_TRY(ex.linear(hid, M, b.proj, x, ODISE_ACT_NONE, x2));         // x = x2 + mlp
+    }
+    // ln_post + proj on the class token of every image (row stride T*Wd picks token 0)
+    ODISE_TRY(ex.layer_norm(x, n, M, e->clip_ln_post, 1e-5f));
+    odise_gemm_desc d;
+    memset(&d, 0, sizeof(d));
+    d.M = B; d.N = e->clip_out; d.K = Wd;
+    d.A = n; d.lda = (int64_t)T * Wd; d.W = e->clip_proj.w; d.ldw = Wd;
+    d.C = prefix16; d.ldc = e->clip_out; d.c_dtype = ODISE_F16; d.alpha = 1.f; d.batch = 1;
+    ODISE_TRY(ex.gemm(d));
+    ex.ms->arena.release(mk);
+    return ODISE_OK;
+}
+
+static int extractor_launch(odise_hip_ctx* ctx, ModelStore* ms, ExtractorModel* e, const float* image, int B, int H, int W) {
+    Exec ex{ctx, ms};
+    ms->arena.reset();
+    ms->macs = 0.0;
+    const int lh = H / 8, lw = W / 8;
+    // ---- implicit captioner conditioning --------------------------------------------------------------------------
+    f16* prefix16 = (f16*)ex.alloc_bytes((size_t)B * e->clip_out * 2);
+    float* proj = (float*)ex.alloc_bytes((size_t)B * e->ctx_dim * 4);
+    float* cond_inputs = (float*)ex.alloc_bytes((size_t)B * 77 * e->ctx_dim * 4);
+    float* cond_emb = (float*)ex.alloc_bytes((size_t)B * e->ted * 4);
+    if (!prefix16 || !proj || !cond_inputs || !cond_emb) return ODISE_ERR_NOMEM;
+    ODISE_TRY(run_clip(ex, e, image, B, H, W, prefix16));
+    odise_gemm_desc d;
+    memset(&d, 0, sizeof(d));
+    d.M = B; d.N = e->ctx_dim; d.K = e->cap_proj.in;
+    d.A = prefix16; d.lda = e->cap_proj.in; d.W = e->cap_proj.w; d.ldw = e->cap_proj.in;
+    d.C = proj; d.ldc = e->ctx_dim; d.c_dtype = ODISE_F32; d.bias_n = e->cap_proj.b; d.alpha = 1.f; d.batch = 1;
+    ODISE_TRY(ex.gemm(d));
+    ODISE_TRY(launch_cond_inputs(ctx, proj, e->cap_A1, e->cap_A2, cond_inputs, B, 77, e->ctx_dim));
+    memset(&d, 0, sizeof(d));
+    d.M = B; d.N = e->ted; d.K = e->cap_time.in;
+    d.A = prefix16; d.lda = e->cap_time.in; d.W = e->cap_time.w; d.ldw = e->cap_time.in;
+    d.C = cond_emb; d.ldc = e->ted; d.c_dtype = ODISE_F32; d.bias_n = e->cap_time.b; d.alpha = 1.f; d.batch = 1;
+    ODISE_TRY(ex.gemm(d));
+
+    // ---- VAE encoder ------------------------------------------------------------------------------------------------
+    Act x;
+    ODISE_TRY(ex.alloc(x, B, H, W, 8));
+    {
+        const float sc[3] = {2.f, 2.f, 2.f}, sh[3] = {-1.f, -1.f, -1.f};  // (img - 0.5) / 0.5  (ldm.py:556)
+        ODISE_TRY(launch_image_to_nhwc(ctx, image, x.p, B, 3, H * W, 8, sc, sh));
+    }
+    Act cur;
+    ODISE_TRY(ex.conv(x, e->enc_conv_in, cur, 1, 1));
+    int flat = 0;
+    for (int l = 0; l < 4; ++l) {
+        for (int b = 0; b < 2; ++b) {
+            if (flat == 5) e->taps[0] = cur;  // input of down block 5 (ldm.py:437-438)
+            if (flat == 7) e->taps[1] = cur;
+            Act nxt;
+            ODISE_TRY(run_vae_res(ex, e->enc_blocks[l][b], cur, nxt));
+            cur = nxt;
+            ++flat;
+        }
+        if (l < 3) {
+            Act nxt;  // F.pad (0,1,0,1) + conv3x3 stride 2 pad 0
+            ODISE_TRY(ex.conv(cur, e->enc_down[l], nxt, 2, 0, false, nullptr, nullptr, 0, ODISE_ACT_NONE, 0, 0, cur.h / 2, cur.w / 2));
+            cur = nxt;
+        }
+    }
+    {
+        Act a, b2, c, nrm, h8;
+        ODISE_TRY(run_vae_res(ex, e->enc_mid1, cur, a));
+        ODISE_TRY(run_vae_attn(ex, e->enc_attn, a, b2));
+        ODISE_TRY(run_vae_res(ex, e->enc_mid2, b2, c));
+        ODISE_TRY(ex.group_norm(c, e->enc_norm_out, nrm, 1e-6f, ODISE_ACT_SILU));
+        ODISE_TRY(ex.conv(nrm, e->enc_conv_out, h8, 1, 1));
+        cur = h8;  // [B, lh, lw, 8]
+    }
+    // ---- latent: posterior mean * scale, q_sample(t=0), post_quant_conv -----------------------------------------------
+    if (e->noise_hw != lh * lw) {
+        set_error("extractor: latent %dx%d differs from the shared-noise size (%d elements); only the reference crop size is supported", lh, lw,
+                  e->noise_hw);
+        return ODISE_ERR_ARG;
+    }
+    Act xt, zdec;
+    ODISE_TRY(ex.alloc(xt, B, lh, lw, 8));
+    ODISE_TRY(ex.alloc(zdec, B, lh, lw, 8));
+    ODISE_TRY(launch_latent_heads(ctx, cur.p, e->noise, xt.p, zdec.p, nullptr, B, lh * lw, e->lat));
+    // ---- UNet (t = 0) -------------------------------------------------------------------------------------------------
+    ODISE_TRY(unet_launch(ctx, ms, ms->unet, nullptr, xt.p, cond_inputs, cond_emb, B, lh, lw, false));
+    const Act* ut = unet_taps(ms);
+    for (int i = 0; i < 4; ++i) e->taps[2 + i] = ut[i];
+    // ---- VAE decoder up to the last tap ----------------------------------------------------------------------------------
+    {
+        Act h, a, b2, c;
+        ODISE_TRY(ex.conv(zdec, e->dec_conv_in, h, 1, 1));
+        ODISE_TRY(run_vae_res(ex, e->dec_mid1, h, a));
+        ODISE_TRY(run_vae_attn(ex, e->dec_attn, a, b2));
+        ODISE_TRY(run_vae_res(ex, e->dec_mid2, b2, c));
+        Act l0, l1, l2, up, m0, m1;
+        ODISE_TRY(run_vae_res(ex, e->dec_l3[0], c, l0));
+        ODISE_TRY(run_vae_res(ex, e->dec_l3[1], l0, l1));
+        e->taps[6] = l1;  // input of up block 2 (ldm.py:515-516)
+        ODISE_TRY(run_vae_res(ex, e->dec_l3[2], l1, l2));
+        ODISE_TRY(ex.conv(l2, e->dec_up3, up, 1, 1, true));
+        ODISE_TRY(run_vae_res(ex, e->dec_l2[0], up, m0));
+        ODISE_TRY(run_vae_res(ex, e->dec_l2[1], m0, m1));
+        e->taps[7] = m1;  // input of up block 5
+    }
+    e->last_macs = ms->macs;
+    return ODISE_OK;
+}
+
+static int extractor_forward(odise_hip_ctx* ctx, const float* image, int B, int H, int W) {
+    ModelStore* ms = store_of(ctx);
+    ExtractorModel* e = ms->extractor;
+    if (!e || !e->built) {
+        set_error("extractor_forward: call odise_hip_extractor_build first");
+        return ODISE_ERR_STATE;
+    }
+    ODISE_REQUIRE(image && B >= 1 && H >= 64 && W >= 64 && H % 64 == 0 && W % 64 == 0, "extractor_forward: image %dx%d must be a multiple of 64", H, W);
+    ODISE_TRY(unet_prepare_timestep(ctx, ms, ms->unet, B, 0));
+    // arena: the VAE levels at full resolution dominate (128-channel maps of H x W, ~4 live at a time) + UNet + CLIP
+    const size_t per = (size_t)H * W * 128 * 2 * 6 + ((size_t)900 << 20);
+    ODISE_TRY(ensure_arena(ctx, ms, per * B + ((size_t)256 << 20)));
+    return extractor_launch(ctx, ms, e, image, B, H, W);
+}
+
+}  // namespace odise
+
+using namespace odise;
+
+extern "C" int odise_hip_extractor_build(odise_hip_ctx* ctx) {
+    ODISE_REQUIRE(ctx, "extractor_build: null context");
+    ODISE_CHECK_HIP(hipSetDevice(ctx->device));
+    return extractor_build(ctx);
+}
+
+extern "C" int odise_hip_extractor_forward_nhwc(odise_hip_ctx* ctx, const float* image, int B, int H, int W, void** taps8, int* shapes8x4) {
+    ODISE_REQUIRE(ctx, "extractor_forward: null context");
+    ODISE_TRY(extractor_forward(ctx, image, B, H, W));
+    ExtractorModel* e = store_of(ctx)->extractor;
+    for (int i = 0; i < 8; ++i) {
+        if (taps8) taps8[i] = e->taps[i].p;
+        if (shapes8x4) {
+            shapes8x4[4 * i + 0] = e->taps[i].n; shapes8x4[4 * i + 1] = e->taps[i].c;
+            shapes8x4[4 * i + 2] = e->taps[i].h; shapes8x4[4 * i + 3] = e->taps[i].w;
+        }
+    }
+    return ODISE_OK;
+}
+
+extern "C" int odise_hip_extractor_forward(odise_hip_ctx* ctx, const float* image, int B, int H, int W, float** taps8) {
+    ODISE_REQUIRE(ctx && taps8, "extractor_forward: null argument");
+    ODISE_TRY(extractor_forward(ctx, image, B, H, W));
+    ExtractorModel* e = store_of(ctx)->extractor;
+    for (int i = 0; i < 8; ++i) {
+        if (!taps8[i]) continue;
+        const Act& a = e->taps[i];
+        ODISE_TRY(odise_hip_nhwc_f16_to_nchw_f32(ctx, a.p, taps8[i], a.n, a.c, a.h, a.w));
+    }
+    return ODISE_OK;
+}
+
+extern "C" int odise_hip_extractor_last_macs(odise_hip_ctx* ctx, double* macs) {
+    ODISE_REQUIRE(ctx && macs, "extractor_last_macs: null argument");
+    ExtractorModel* e = store_of(ctx)->extractor;
+    *macs = e ? e->last_macs : 0.0;
+    return ODISE_OK;
+}

@@ -65,6 +65,9 @@ struct UNetModel {
     double last_macs = 0.0;
 };
 
+const Act* unet_taps(ModelStore* ms) { return ms->unet ? ms->unet->taps : nullptr; }
+double unet_last_macs(ModelStore* ms) { return ms->unet ? ms->unet->last_macs : 0.0; }
+
 void unet_destroy(ModelStore* ms) {
     if (!ms->unet) return;
     if (ms->unet->graph_exec) hipGraphExecDestroy(ms->unet->graph_exec);
@@ -159,12 +162,12 @@ static int build_st(Packer& pk, const std::string& key, STBlockW& s, int& n_slot
     return ODISE_OK;
 }
 
-static int unet_build(odise_hip_ctx* ctx) {
+int unet_build(odise_hip_ctx* ctx, const char* prefix) {
     ModelStore* ms = store_of(ctx);
     unet_destroy(ms);
     UNetModel* u = new UNetModel();
     ms->unet = u;
-    Packer pk{ctx, ms, "", ""};
+    Packer pk{ctx, ms, prefix, ""};
     std::vector<const HostTensor*> emb_w, emb_b;
     ODISE_TRY(pk.linear("time_embed.0", u->te0));
     ODISE_TRY(pk.linear("time_embed.2", u->te2));
@@ -332,7 +335,7 @@ static int run_st(UNetRun& r, const STBlockW& w, const Act& x, Act& out) {
     return ODISE_OK;
 }
 
-static int ensure_arena(odise_hip_ctx* ctx, ModelStore* ms, size_t bytes) {
+int ensure_arena(odise_hip_ctx* ctx, ModelStore* ms, size_t bytes) {
     if (ms->arena.cap >= bytes) return ODISE_OK;
     ODISE_CHECK_HIP(hipStreamSynchronize(ctx->stream));
     if (ms->arena.base) ODISE_CHECK_HIP(hipFree(ms->arena.base));
@@ -343,15 +346,19 @@ static int ensure_arena(odise_hip_ctx* ctx, ModelStore* ms, size_t bytes) {
 }
 
 // the launch sequence proper (graph-capturable: no allocation, no sync, no host<->device copy)
-static int unet_launch(odise_hip_ctx* ctx, ModelStore* ms, UNetModel* u, const float* x_t, const float* context, const float* cond_emb,
-                       int B, int h, int w) {
+// x_nhwc (optional): x_t already as NHWC fp16 with 8 channels (4 + zero pad) — the in-library path of the feature
+// extractor; otherwise x_t is fp32 NCHW.  standalone=false keeps the caller's arena contents and MAC counter.
+int unet_launch(odise_hip_ctx* ctx, ModelStore* ms, UNetModel* u, const float* x_t, const f16* x_nhwc, const float* context,
+                const float* cond_emb, int B, int h, int w, bool standalone) {
     UNetRun r;
     r.ex = Exec{ctx, ms};
     r.u = u;
     r.B = B;
     Exec& ex = r.ex;
-    ms->arena.reset();
-    ms->macs = 0.0;
+    if (standalone) {
+        ms->arena.reset();
+        ms->macs = 0.0;
+    }
 
     // ---- time embedding: emb = time_embed(t_emb) + cond_emb; every ResBlock consumes Linear(SiLU(emb)) -------------
     f16* te_h = (f16*)ex.alloc_bytes((size_t)B * u->ted * 2);
@@ -410,8 +417,12 @@ static int unet_launch(odise_hip_ctx* ctx, ModelStore* ms, UNetModel* u, const f
 
     // ---- input blocks --------------------------------------------------------------------------------------
     Act x0;
-    ODISE_TRY(ex.alloc(x0, B, h, w, 8));
-    ODISE_TRY(odise_hip_nchw_f32_to_nhwc_f16(ctx, x_t, x0.p, B, 4, h, w, 8));
+    if (x_nhwc) {
+        x0.p = const_cast<f16*>(x_nhwc); x0.n = B; x0.h = h; x0.w = w; x0.c = 8;
+    } else {
+        ODISE_TRY(ex.alloc(x0, B, h, w, 8));
+        ODISE_TRY(odise_hip_nchw_f32_to_nhwc_f16(ctx, x_t, x0.p, B, 4, h, w, 8));
+    }
     std::vector<Act> hs;
     Act cur = x0;
     for (auto& b : u->in_blocks) {
@@ -468,16 +479,8 @@ static int unet_launch(odise_hip_ctx* ctx, ModelStore* ms, UNetModel* u, const f
     return ODISE_OK;
 }
 
-static int unet_forward(odise_hip_ctx* ctx, const float* x_t, const float* context, const float* cond_emb, int B, int h, int w, int t) {
-    ModelStore* ms = store_of(ctx);
-    UNetModel* u = ms->unet;
-    if (!u || !u->built) {
-        set_error("unet_features: call odise_hip_unet_build first");
-        return ODISE_ERR_STATE;
-    }
-    ODISE_REQUIRE(B >= 1 && h >= 8 && w >= 8 && h % 8 == 0 && w % 8 == 0, "unet_features: latent %dx%d (batch %d) must be multiples of 8", h, w, B);
-    ODISE_REQUIRE(x_t && context, "unet_features: null device pointer");
-    // timestep embedding input: cat[cos(t f), sin(t f)], f_i = exp(-ln(10000) i / 160)  (ldm timestep_embedding)
+// timestep embedding input: cat[cos(t f), sin(t f)], f_i = exp(-ln(10000) i / half)  (ldm timestep_embedding); cached per t
+int unet_prepare_timestep(odise_hip_ctx* ctx, ModelStore* ms, UNetModel* u, int B, int t) {
     if (u->cached_t != t || u->cached_B < B) {
         std::vector<f16> te((size_t)B * u->mc);
         const int half = u->mc / 2;
@@ -496,12 +499,25 @@ static int unet_forward(odise_hip_ctx* ctx, const float* x_t, const float* conte
         u->cached_B = B;
         if (u->graph_exec) { hipGraphExecDestroy(u->graph_exec); u->graph_exec = nullptr; }
     }
+    return ODISE_OK;
+}
+
+static int unet_forward(odise_hip_ctx* ctx, const float* x_t, const float* context, const float* cond_emb, int B, int h, int w, int t) {
+    ModelStore* ms = store_of(ctx);
+    UNetModel* u = ms->unet;
+    if (!u || !u->built) {
+        set_error("unet_features: call odise_hip_unet_build first");
+        return ODISE_ERR_STATE;
+    }
+    ODISE_REQUIRE(B >= 1 && h >= 8 && w >= 8 && h % 8 == 0 && w % 8 == 0, "unet_features: latent %dx%d (batch %d) must be multiples of 8", h, w, B);
+    ODISE_REQUIRE(x_t && context, "unet_features: null device pointer");
+    ODISE_TRY(unet_prepare_timestep(ctx, ms, u, B, t));
     // arena: ~0.6 GB per 64x64-latent crop is ample (peak is tracked; see odise_hip_unet_last_macs)
     const size_t per_crop = (size_t)640 << 20;
     const double scale = ((double)h * w) / (64.0 * 64.0);
     ODISE_TRY(ensure_arena(ctx, ms, (size_t)(per_crop * (scale < 0.25 ? 0.25 : scale)) * B + ((size_t)64 << 20)));
 
-    if (!u->use_graph) return unet_launch(ctx, ms, u, x_t, context, cond_emb, B, h, w);
+    if (!u->use_graph) return unet_launch(ctx, ms, u, x_t, nullptr, context, cond_emb, B, h, w, true);
 
     const bool same = u->graph_exec && u->graph_B == B && u->graph_h == h && u->graph_w == w && u->graph_x == x_t &&
                       u->graph_ctx == context && u->graph_ce == cond_emb && u->graph_arena == ms->arena.base;
@@ -509,7 +525,7 @@ static int unet_forward(odise_hip_ctx* ctx, const float* x_t, const float* conte
         if (u->graph_exec) { hipGraphExecDestroy(u->graph_exec); u->graph_exec = nullptr; }
         hipGraph_t graph = nullptr;
         ODISE_CHECK_HIP(hipStreamBeginCapture(ctx->stream, hipStreamCaptureModeThreadLocal));
-        const int rc = unet_launch(ctx, ms, u, x_t, context, cond_emb, B, h, w);
+        const int rc = unet_launch(ctx, ms, u, x_t, nullptr, context, cond_emb, B, h, w, true);
         const hipError_t e = hipStreamEndCapture(ctx->stream, &graph);
         if (rc != ODISE_OK) {
             if (graph) hipGraphDestroy(graph);
@@ -532,7 +548,7 @@ using namespace odise;
 extern "C" int odise_hip_unet_build(odise_hip_ctx* ctx) {
     ODISE_REQUIRE(ctx, "unet_build: null context");
     ODISE_CHECK_HIP(hipSetDevice(ctx->device));
-    return unet_build(ctx);
+    return unet_build(ctx, "");
 }
 
 extern "C" int odise_hip_unet_use_graph(odise_hip_ctx* ctx, int enable) {
