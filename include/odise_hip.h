@@ -117,6 +117,10 @@ int odise_hip_conv2d(odise_hip_ctx* ctx, const odise_conv_desc* d);
 /* GroupNorm over NHWC f16 x[N,HW,C]; stats in fp32; y = act(gn(x)*gamma+beta) (f16) */
 int odise_hip_group_norm(odise_hip_ctx* ctx, const void* x, void* y, const float* gamma, const float* beta,
                          int N, int HW, int C, int groups, float eps, int act);
+/* y = act(GroupNorm(x) + residual) + accum; residual / accum optional f16 tensors shaped like x
+ * (detectron2 BottleneckBlock tail and the per-stride sum of feature_extractor.py:171-176) */
+int odise_hip_group_norm_ex(odise_hip_ctx* ctx, const void* x, void* y, const float* gamma, const float* beta,
+                            int N, int HW, int C, int groups, float eps, int act, const void* residual, const void* accum);
 /* LayerNorm over the last dim of x[rows, C] f16 -> y f16 */
 int odise_hip_layer_norm(odise_hip_ctx* ctx, const void* x, void* y, const float* gamma, const float* beta,
                          int rows, int C, float eps);
@@ -182,6 +186,23 @@ int odise_hip_extractor_forward(odise_hip_ctx* ctx, const float* image, int B, i
 /* hot-path variant: taps stay fp16 NHWC inside the library arena; returns pointers and [n,c,h,w] per tap */
 int odise_hip_extractor_forward_nhwc(odise_hip_ctx* ctx, const float* image, int B, int H, int W, void** taps8, int* shapes8x4);
 int odise_hip_extractor_last_macs(odise_hip_ctx* ctx, double* macs);
+
+/* ---- FeatureExtractorBackbone (feature_extractor.py:139-250): slide-window crops -> extractor -> projections -> stitch ---- */
+/* extra weights: backbone.feature_projections.{0..7}.0.{conv1,conv2,conv3[,shortcut]}.{weight,norm.weight,norm.bias} */
+int odise_hip_backbone_build(odise_hip_ctx* ctx);
+/* image [B,3,H,W] f32 device in [0,1], H,W >= 512 and multiples of 64.  out4: s2,s3,s4,s5 fp32 NCHW [B,512,H/4..H/32,..]
+ * device pointers (array or entries may be NULL); fp16 NHWC copies stay inside the library for odise_hip_head_forward. */
+int odise_hip_backbone_forward(odise_hip_ctx* ctx, const float* image, int B, int H, int W, float** out4);
+
+/* ---- MaskFormerHead: MSDeformAttn pixel decoder + ODISE masked transformer decoder (msdeformattn.py:314-358, odise.py:642-776) */
+/* weights: sem_seg_head.pixel_decoder.*, sem_seg_head.predictor.* */
+int odise_hip_head_build(odise_hip_ctx* ctx);
+/* feats4: s2..s5 fp32 NCHW device pointers [B,Cin,H4>>i,W4>>i], or NULL to consume the last backbone_forward.
+ * outputs (device fp32, any may be NULL): pred_masks [B,Q,H4,W4] logits, mask_embed [B,Q,C], mask_pooled_features [B,Q,C];
+ * logit_scale (host) = clamp(exp(logit_scale), max=100). */
+int odise_hip_head_forward(odise_hip_ctx* ctx, const float* const* feats4, int B, int Cin, int H4, int W4, float* pred_masks,
+                           float* mask_embed, float* mask_pooled, float* logit_scale);
+int odise_hip_maskgen_info(odise_hip_ctx* ctx, int* num_queries, int* hidden_dim, double* last_macs);
 
 #ifdef __cplusplus
 }

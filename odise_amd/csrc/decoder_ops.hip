@@ -1,0 +1,289 @@
+// decoder_ops.hip — streaming kernels of the backbone projection / stitching stage and of the Mask2Former heads.
+// All are HBM/L2-bound gathers or elementwise passes over NHWC fp16 maps; 16-byte accesses per lane.
+//   crop_extract        slide-window crops of the input image (feature_extractor.py:216-224)
+//   upsample_nearest    F.interpolate(..., size) default mode (feature_extractor.py:165-168)
+//   stitch_crops        overlap-add of per-crop features / count_mats (feature_extractor.py:229-248)
+//   add_vec_table       src + level_embed (+ positional table)       (msdeformattn.py:71-75, odise.py:657-660)
+//   msda_prepare        softmax over (levels*points) + sampling locations (ms_deform_attn.py:103-110)
+//   bilinear_add        cur_fpn + bilinear(out[-1])                   (msdeformattn.py:347)
+//   mask_binarize_f16   MaskPooling prologue on fp16 logits           (odise.py:949-955)
+//   attn_mask           bilinear(mask logits -> level size).sigmoid() < 0.5, rows that mask everything are cleared
+//                       (odise.py:760-774, 683)
+#include "engine.h"
+
+namespace odise {
+
+__global__ void __launch_bounds__(256) crop_extract_kernel(const float* __restrict__ img, float* __restrict__ crops, int C, int H, int W,
+                                                          int S, int K, const int* __restrict__ boxes /*[K][2] y1,x1*/, int64_t total) {
+    for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * blockDim.x) {
+        const int x = (int)(idx % S);
+        int64_t t = idx / S;
+        const int y = (int)(t % S); t /= S;
+        const int c = (int)(t % C); t /= C;
+        const int k = (int)(t % K);
+        const int64_t b = t / K;
+        crops[idx] = img[((b * C + c) * H + boxes[2 * k] + y) * W + boxes[2 * k + 1] + x];
+    }
+}
+
+// y [N,OH,OW,C] = x [N,H,W,C] nearest (src = floor(dst * in / out))
+__global__ void __launch_bounds__(256) upsample_nearest_kernel(const f16* __restrict__ x, f16* __restrict__ y, int H, int W, int OH, int OW,
+                                                              int C8, int64_t total) {
+    for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * blockDim.x) {
+        const int c = (int)(idx % C8);
+        int64_t t = idx / C8;
+        const int ox = (int)(t % OW); t /= OW;
+        const int oy = (int)(t % OH);
+        const int64_t n = t / OH;
+        const int sy = min((int)floorf(oy * ((float)H / OH)), H - 1), sx = min((int)floorf(ox * ((float)W / OW)), W - 1);
+        *reinterpret_cast<f16x8*>(y + idx * 8) = *reinterpret_cast<const f16x8*>(x + (((n * H + sy) * W + sx) * C8 + c) * 8);
+    }
+}
+
+// out [B,OH,OW,C] = sum over crops covering the pixel of feat [(b*K+k), ch, cw, C] / count
+__global__ void __launch_bounds__(256) stitch_kernel(const f16* __restrict__ feat, f16* __restrict__ out, float* __restrict__ out_nchw,
+                                                    int K, const int* __restrict__ boxes /*[K][2] in feature pixels*/, int ch, int cw,
+                                                    int OH, int OW, int C8, int64_t total) {
+    for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * blockDim.x) {
+        const int c = (int)(idx % C8);
+        int64_t t = idx / C8;
+        const int ox = (int)(t % OW); t /= OW;
+        const int oy = (int)(t % OH);
+        const int64_t b = t / OH;
+        float acc[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) acc[i] = 0.f;
+        int cnt = 0;
+        for (int k = 0; k < K; ++k) {
+            const int yy = oy - boxes[2 * k], xx = ox - boxes[2 * k + 1];
+            if (yy >= 0 && yy < ch && xx >= 0 && xx < cw) {
+                const f16x8 v = *reinterpret_cast<const f16x8*>(feat + ((((b * K + k) * ch + yy) * cw + xx) * (int64_t)C8 + c) * 8);
+#pragma unroll
+                for (int i = 0; i < 8; ++i) acc[i] += (float)v[i];
+                ++cnt;
+            }
+        }
+        const float inv = cnt > 0 ? 1.f / (float)cnt : 0.f;
+        f16x8 o;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) o[i] = (f16)(acc[i] * inv);
+        if (out) *reinterpret_cast<f16x8*>(out + idx * 8) = o;
+        if (out_nchw) {
+#pragma unroll
+            for (int i = 0; i < 8; ++i) out_nchw[((b * (int64_t)C8 * 8 + c * 8 + i) * OH + oy) * OW + ox] = acc[i] * inv;
+        }
+    }
+}
+
+// y[b,p,:] = x[b,p,:] + vec[:] (+ table[p,:])
+__global__ void __launch_bounds__(256) add_vec_table_kernel(const f16* __restrict__ x, const float* __restrict__ vec,
+                                                           const float* __restrict__ table, f16* __restrict__ y, int P, int C8,
+                                                           int64_t total) {
+    for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * blockDim.x) {
+        const int c = (int)(idx % C8) * 8;
+        const int p = (int)((idx / C8) % P);
+        const f16x8 v = *reinterpret_cast<const f16x8*>(x + idx * 8);
+        f16x8 o;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            float t = (float)v[i] + (vec ? vec[c + i] : 0.f);
+            if (table) t += table[(int64_t)p * C8 * 8 + c + i];
+            o[i] = (f16)t;
+        }
+        *reinterpret_cast<f16x8*>(y + idx * 8) = o;
+    }
+}
+
+struct MsdaPrep {
+    int L, P, M;
+    int H[8], W[8], start[8];
+};
+
+// off [R, M*L*P*2] f32, aw [R, M*L*P] f32 (R = B*Lq rows; query q = r % Lq) -> loc [R,M,L,P,2], w [R,M,L,P]
+// reference point of query q = centre of its own cell at its own level, identical for every sampled level (valid ratios 1)
+__global__ void __launch_bounds__(256) msda_prepare_kernel(const float* __restrict__ off, const float* __restrict__ aw, float* __restrict__ loc,
+                                                          float* __restrict__ w, int Lq, int64_t rows_heads, MsdaPrep g) {
+    for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < rows_heads; idx += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t r = idx / g.M;
+        const int q = (int)(r % Lq);
+        int lvl = 0;
+        for (int l = 1; l < g.L; ++l)
+            if (q >= g.start[l]) lvl = l;
+        const int local = q - g.start[lvl];
+        const float ref_y = ((float)(local / g.W[lvl]) + 0.5f) / (float)g.H[lvl];
+        const float ref_x = ((float)(local % g.W[lvl]) + 0.5f) / (float)g.W[lvl];
+        const int LP = g.L * g.P;
+        const float* a = aw + idx * LP;
+        float mx = -INFINITY;
+        for (int i = 0; i < LP; ++i) mx = fmaxf(mx, a[i]);
+        float e[32];
+        float sum = 0.f;
+        for (int i = 0; i < LP; ++i) { e[i] = expf(a[i] - mx); sum += e[i]; }
+        const float inv = 1.f / sum;
+        const float* o = off + idx * LP * 2;
+        for (int l = 0; l < g.L; ++l)
+            for (int p = 0; p < g.P; ++p) {
+                const int i = l * g.P + p;
+                w[idx * LP + i] = e[i] * inv;
+                loc[(idx * LP + i) * 2 + 0] = ref_x + o[2 * i + 0] / (float)g.W[l];
+                loc[(idx * LP + i) * 2 + 1] = ref_y + o[2 * i + 1] / (float)g.H[l];
+            }
+    }
+}
+
+__device__ __forceinline__ void bilinear_setup(int o, int in, int out, int& i0, int& i1, float& t) {
+    // F.interpolate(mode="bilinear", align_corners=False): src = max((o + 0.5) * in/out - 0.5, 0)
+    float s = ((float)o + 0.5f) * ((float)in / (float)out) - 0.5f;
+    s = s < 0.f ? 0.f : s;
+    i0 = (int)s;
+    i0 = i0 < in - 1 ? i0 : in - 1;
+    i1 = i0 < in - 1 ? i0 + 1 : i0;
+    t = s - (float)i0;
+}
+
+// y [N,OH,OW,C] = a [N,OH,OW,C] + bilinear(b [N,H,W,C] -> OH x OW)
+__global__ void __launch_bounds__(256) bilinear_add_kernel(const f16* __restrict__ a, const f16* __restrict__ b, f16* __restrict__ y, int H,
+                                                          int W, int OH, int OW, int C8, int64_t total) {
+    for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * blockDim.x) {
+        const int c = (int)(idx % C8);
+        int64_t t = idx / C8;
+        const int ox = (int)(t % OW); t /= OW;
+        const int oy = (int)(t % OH);
+        const int64_t n = t / OH;
+        int y0, y1, x0, x1;
+        float ty, tx;
+        bilinear_setup(oy, H, OH, y0, y1, ty);
+        bilinear_setup(ox, W, OW, x0, x1, tx);
+        const f16* bb = b + n * H * W * (int64_t)C8 * 8 + c * 8;
+        const f16x8 v00 = *reinterpret_cast<const f16x8*>(bb + ((int64_t)y0 * W + x0) * C8 * 8);
+        const f16x8 v01 = *reinterpret_cast<const f16x8*>(bb + ((int64_t)y0 * W + x1) * C8 * 8);
+        const f16x8 v10 = *reinterpret_cast<const f16x8*>(bb + ((int64_t)y1 * W + x0) * C8 * 8);
+        const f16x8 v11 = *reinterpret_cast<const f16x8*>(bb + ((int64_t)y1 * W + x1) * C8 * 8);
+        const f16x8 va = *reinterpret_cast<const f16x8*>(a + idx * 8);
+        f16x8 o;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const float top = (float)v00[i] + tx * ((float)v01[i] - (float)v00[i]);
+            const float bot = (float)v10[i] + tx * ((float)v11[i] - (float)v10[i]);
+            o[i] = (f16)((float)va[i] + top + ty * (bot - top));
+        }
+        *reinterpret_cast<f16x8*>(y + idx * 8) = o;
+    }
+}
+
+// one block per (b,q) row of HW fp16 logits: m01 = sigmoid(x) > 0.5, inv = 1 / (sum m01 + 1e-8)
+__global__ void __launch_bounds__(256) mask_binarize_f16_kernel(const f16* __restrict__ mask, f16* __restrict__ m01, float* __restrict__ inv,
+                                                               int HW) {
+    __shared__ float red[4];
+    const int64_t row = blockIdx.x;
+    const f16* mr = mask + row * HW;
+    f16* orow = m01 + row * HW;
+    float cnt = 0.f;
+    for (int i = threadIdx.x * 8; i < HW; i += blockDim.x * 8) {
+        const f16x8 v = *reinterpret_cast<const f16x8*>(mr + i);
+        f16x8 o;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const float b = (1.f / (1.f + expf(-(float)v[k]))) > 0.5f ? 1.f : 0.f;
+            o[k] = (f16)b;
+            cnt += b;
+        }
+        *reinterpret_cast<f16x8*>(orow + i) = o;
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) cnt += __shfl_xor(cnt, o);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = cnt;
+    __syncthreads();
+    if (threadIdx.x == 0) inv[row] = 1.f / (red[0] + red[1] + red[2] + red[3] + 1e-8f);
+}
+
+// one block per (b,q): logits [H,W] fp16 -> u8 mask [oh*ow] (1 = key masked out); a row that masks every key is cleared
+__global__ void __launch_bounds__(256) attn_mask_kernel(const f16* __restrict__ logits, uint8_t* __restrict__ out, int H, int W, int oh, int ow,
+                                                       int64_t ldm) {
+    __shared__ int red[4];
+    const int64_t row = blockIdx.x;
+    const f16* lr = logits + row * H * W;
+    uint8_t* orow = out + row * ldm;
+    const int n = oh * ow;
+    int masked = 0;
+    for (int i = threadIdx.x; i < n; i += blockDim.x) {
+        const int oy = i / ow, ox = i - oy * ow;
+        int y0, y1, x0, x1;
+        float ty, tx;
+        bilinear_setup(oy, H, oh, y0, y1, ty);
+        bilinear_setup(ox, W, ow, x0, x1, tx);
+        const float v00 = (float)lr[y0 * W + x0], v01 = (float)lr[y0 * W + x1], v10 = (float)lr[y1 * W + x0], v11 = (float)lr[y1 * W + x1];
+        const float top = v00 + tx * (v01 - v00), bot = v10 + tx * (v11 - v10);
+        const float v = top + ty * (bot - top);
+        const int m = (1.f / (1.f + expf(-v))) < 0.5f ? 1 : 0;
+        orow[i] = (uint8_t)m;
+        masked += m;
+    }
+    for (int i = n + threadIdx.x; i < ldm; i += blockDim.x) orow[i] = 1;  // padding columns never visible
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) masked += __shfl_xor(masked, o);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = masked;
+    __syncthreads();
+    const int total = red[0] + red[1] + red[2] + red[3];
+    if (total == n) {
+        for (int i = threadIdx.x; i < n; i += blockDim.x) orow[i] = 0;
+    }
+}
+
+static int g1(int64_t n) { return (int)std::min<int64_t>(ceil_div(n, 256), 8192); }
+
+int launch_crop_extract(odise_hip_ctx* ctx, const float* img, float* crops, int B, int C, int H, int W, int S, int K, const int* boxes_dev) {
+    const int64_t total = (int64_t)B * K * C * S * S;
+    hipLaunchKernelGGL(crop_extract_kernel, dim3(g1(total)), dim3(256), 0, ctx->stream, img, crops, C, H, W, S, K, boxes_dev, total);
+    ODISE_CHECK_HIP(hipGetLastError());
+    return ODISE_OK;
+}
+int launch_upsample_nearest(odise_hip_ctx* ctx, const f16* x, f16* y, int N, int H, int W, int OH, int OW, int C) {
+    const int64_t total = (int64_t)N * OH * OW * (C / 8);
+    hipLaunchKernelGGL(upsample_nearest_kernel, dim3(g1(total)), dim3(256), 0, ctx->stream, x, y, H, W, OH, OW, C / 8, total);
+    ODISE_CHECK_HIP(hipGetLastError());
+    return ODISE_OK;
+}
+int launch_stitch(odise_hip_ctx* ctx, const f16* feat, f16* out, float* out_nchw, int B, int K, const int* boxes_dev, int ch, int cw, int OH,
+                  int OW, int C) {
+    const int64_t total = (int64_t)B * OH * OW * (C / 8);
+    hipLaunchKernelGGL(stitch_kernel, dim3(g1(total)), dim3(256), 0, ctx->stream, feat, out, out_nchw, K, boxes_dev, ch, cw, OH, OW, C / 8, total);
+    ODISE_CHECK_HIP(hipGetLastError());
+    return ODISE_OK;
+}
+int launch_add_vec_table(odise_hip_ctx* ctx, const f16* x, const float* vec, const float* table, f16* y, int64_t N, int P, int C) {
+    const int64_t total = N * P * (C / 8);
+    hipLaunchKernelGGL(add_vec_table_kernel, dim3(g1(total)), dim3(256), 0, ctx->stream, x, vec, table, y, P, C / 8, total);
+    ODISE_CHECK_HIP(hipGetLastError());
+    return ODISE_OK;
+}
+int launch_msda_prepare(odise_hip_ctx* ctx, const float* off, const float* aw, float* loc, float* w, int B, int Lq, int M, int L, int P,
+                        const int* Hs, const int* Ws, const int* starts) {
+    ODISE_REQUIRE(L * P <= 32 && L <= 8, "msda_prepare: levels*points must be <= 32");
+    MsdaPrep g;
+    g.L = L; g.P = P; g.M = M;
+    for (int l = 0; l < L; ++l) { g.H[l] = Hs[l]; g.W[l] = Ws[l]; g.start[l] = starts[l]; }
+    const int64_t rh = (int64_t)B * Lq * M;
+    hipLaunchKernelGGL(msda_prepare_kernel, dim3(g1(rh)), dim3(256), 0, ctx->stream, off, aw, loc, w, Lq, rh, g);
+    ODISE_CHECK_HIP(hipGetLastError());
+    return ODISE_OK;
+}
+int launch_bilinear_add(odise_hip_ctx* ctx, const f16* a, const f16* b, f16* y, int N, int H, int W, int OH, int OW, int C) {
+    const int64_t total = (int64_t)N * OH * OW * (C / 8);
+    hipLaunchKernelGGL(bilinear_add_kernel, dim3(g1(total)), dim3(256), 0, ctx->stream, a, b, y, H, W, OH, OW, C / 8, total);
+    ODISE_CHECK_HIP(hipGetLastError());
+    return ODISE_OK;
+}
+int launch_mask_binarize_f16(odise_hip_ctx* ctx, const f16* mask, f16* m01, float* inv, int64_t rows, int HW) {
+    ODISE_REQUIRE(HW % 8 == 0, "mask_binarize: H*W must be a multiple of 8");
+    hipLaunchKernelGGL(mask_binarize_f16_kernel, dim3((unsigned)rows), dim3(256), 0, ctx->stream, mask, m01, inv, HW);
+    ODISE_CHECK_HIP(hipGetLastError());
+    return ODISE_OK;
+}
+int launch_attn_mask(odise_hip_ctx* ctx, const f16* logits, uint8_t* out, int64_t rows, int H, int W, int oh, int ow, int64_t ldm) {
+    hipLaunchKernelGGL(attn_mask_kernel, dim3((unsigned)rows), dim3(256), 0, ctx->stream, logits, out, H, W, oh, ow, ldm);
+    ODISE_CHECK_HIP(hipGetLastError());
+    return ODISE_OK;
+}
+
+}  // namespace odise

@@ -7,6 +7,7 @@ namespace odise {
 
 void unet_destroy(ModelStore* ms);       // unet.cpp
 void extractor_destroy(ModelStore* ms);  // extractor.cpp
+void maskgen_destroy(ModelStore* ms);    // maskgen.cpp
 
 ModelStore* store_of(odise_hip_ctx* ctx) {
     if (!ctx->models) ctx->models = new ModelStore();
@@ -18,6 +19,7 @@ void models_destroy(odise_hip_ctx* ctx) {
     ModelStore* ms = (ModelStore*)ctx->models;
     unet_destroy(ms);
     extractor_destroy(ms);
+    maskgen_destroy(ms);
     for (void* p : ms->dev_allocs) hipFree(p);
     if (ms->arena.base) hipFree(ms->arena.base);
     delete ms;

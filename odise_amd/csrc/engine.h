@@ -77,6 +77,7 @@ struct ModelStore {
     Arena arena;
     UNetModel* unet = nullptr;
     struct ExtractorModel* extractor = nullptr;
+    struct MaskGenModel* maskgen = nullptr;
     double macs = 0.0;  // analytic MACs of the ops launched since the last reset
 };
 
@@ -124,6 +125,10 @@ int unet_prepare_timestep(odise_hip_ctx* ctx, ModelStore* ms, UNetModel* u, int 
 int unet_launch(odise_hip_ctx* ctx, ModelStore* ms, UNetModel* u, const float* x_t, const f16* x_nhwc, const float* context,
                 const float* cond_emb, int B, int h, int w, bool standalone);
 const Act* unet_taps(ModelStore* ms);
+size_t extractor_arena_bytes(int B, int H, int W);
+const Act* extractor_taps(ModelStore* ms);
+bool extractor_ready(ModelStore* ms);
+int extractor_launch(odise_hip_ctx* ctx, ModelStore* ms, const float* image, int B, int H, int W, bool standalone);
 
 // misc.hip
 struct LatentW {
@@ -141,5 +146,18 @@ int launch_clip_preprocess(odise_hip_ctx* ctx, const float* x, f16* y, int N, in
 int launch_softmax_rows(odise_hip_ctx* ctx, const f16* x, f16* y, int64_t rows, int cols, int64_t ld, float scale);
 int launch_clip_assemble(odise_hip_ctx* ctx, const f16* patches, const float* cls, const float* pos, f16* tok, int B, int T, int Cw);
 int launch_cond_inputs(odise_hip_ctx* ctx, const float* proj, const float* A1, const float* A2, float* out, int B, int T, int Cw);
+
+
+// decoder_ops.hip
+int launch_crop_extract(odise_hip_ctx* ctx, const float* img, float* crops, int B, int C, int H, int W, int S, int K, const int* boxes_dev);
+int launch_upsample_nearest(odise_hip_ctx* ctx, const f16* x, f16* y, int N, int H, int W, int OH, int OW, int C);
+int launch_stitch(odise_hip_ctx* ctx, const f16* feat, f16* out, float* out_nchw, int B, int K, const int* boxes_dev, int ch, int cw, int OH,
+                  int OW, int C);
+int launch_add_vec_table(odise_hip_ctx* ctx, const f16* x, const float* vec, const float* table, f16* y, int64_t N, int P, int C);
+int launch_msda_prepare(odise_hip_ctx* ctx, const float* off, const float* aw, float* loc, float* w, int B, int Lq, int M, int L, int P,
+                        const int* Hs, const int* Ws, const int* starts);
+int launch_bilinear_add(odise_hip_ctx* ctx, const f16* a, const f16* b, f16* y, int N, int H, int W, int OH, int OW, int C);
+int launch_mask_binarize_f16(odise_hip_ctx* ctx, const f16* mask, f16* m01, float* inv, int64_t rows, int HW);
+int launch_attn_mask(odise_hip_ctx* ctx, const f16* logits, uint8_t* out, int64_t rows, int H, int W, int oh, int ow, int64_t ldm);
 
 }  // namespace odise

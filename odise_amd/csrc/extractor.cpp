@@ -397,10 +397,23 @@ static int run_clip(Exec& ex, ExtractorModel* e, const float* image, int B, int 
     return ODISE_OK;
 }
 
-static int extractor_launch(odise_hip_ctx* ctx, ModelStore* ms, ExtractorModel* e, const float* image, int B, int H, int W) {
+size_t extractor_arena_bytes(int B, int H, int W) {
+    // the VAE levels at full resolution dominate (128-channel maps of H x W, ~4 live at a time) + UNet + CLIP
+    const size_t per = (size_t)H * W * 128 * 2 * 6 + ((size_t)900 << 20);
+    return per * B + ((size_t)256 << 20);
+}
+
+const Act* extractor_taps(ModelStore* ms) { return ms->extractor ? ms->extractor->taps : nullptr; }
+bool extractor_ready(ModelStore* ms) { return ms->extractor && ms->extractor->built; }
+
+// standalone=false: called from the backbone stage, which owns the arena and the MAC counter
+int extractor_launch(odise_hip_ctx* ctx, ModelStore* ms, const float* image, int B, int H, int W, bool standalone) {
+    ExtractorModel* e = ms->extractor;
     Exec ex{ctx, ms};
-    ms->arena.reset();
-    ms->macs = 0.0;
+    if (standalone) {
+        ms->arena.reset();
+        ms->macs = 0.0;
+    }
     const int lh = H / 8, lw = W / 8;
     // ---- implicit captioner conditioning --------------------------------------------------------------------------
     f16* prefix16 = (f16*)ex.alloc_bytes((size_t)B * e->clip_out * 2);
@@ -500,10 +513,8 @@ static int extractor_forward(odise_hip_ctx* ctx, const float* image, int B, int 
     }
     ODISE_REQUIRE(image && B >= 1 && H >= 64 && W >= 64 && H % 64 == 0 && W % 64 == 0, "extractor_forward: image %dx%d must be a multiple of 64", H, W);
     ODISE_TRY(unet_prepare_timestep(ctx, ms, ms->unet, B, 0));
-    // arena: the VAE levels at full resolution dominate (128-channel maps of H x W, ~4 live at a time) + UNet + CLIP
-    const size_t per = (size_t)H * W * 128 * 2 * 6 + ((size_t)900 << 20);
-    ODISE_TRY(ensure_arena(ctx, ms, per * B + ((size_t)256 << 20)));
-    return extractor_launch(ctx, ms, e, image, B, H, W);
+    ODISE_TRY(ensure_arena(ctx, ms, extractor_arena_bytes(B, H, W)));
+    return extractor_launch(ctx, ms, image, B, H, W, true);
 }
 
 }  // namespace odise

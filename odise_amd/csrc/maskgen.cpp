@@ -1,0 +1,653 @@
+// maskgen.cpp — the mask generator of ODISE on the device:
+//   FeatureExtractorBackbone.slide_forward / single_forward / forward_features   (odise/modeling/backbone/feature_extractor.py:139-250)
+//   MSDeformAttnPixelDecoder.forward_features                                     (M2F/modeling/pixel_decoder/msdeformattn.py:314-358)
+//   ODISEMultiScaleMaskedTransformerDecoder.forward / forward_prediction_heads    (odise/modeling/meta_arch/odise.py:642-776)
+//   PooledMaskEmbed / MaskPooling                                                  (odise/modeling/meta_arch/odise.py:937-1015)
+//
+// All crops of all images of a call go through the extractor as one batch (n = image*K + crop); the 8 taps are projected by
+// detectron2 BottleneckBlocks (1x1 -> 3x3 -> 1x1, GroupNorm 32), summed per stride group and
+// overlap-averaged into s2..s5.  The deformable-attention encoder runs on [B, 21504, 256] token matrices; the decoder's masked
+// cross-attention uses attn.hip with a u8 visibility mask computed straight from the mask logits.  PooledMaskEmbed is evaluated
+// only for the final prediction head: the nine intermediate evaluations of the reference feed `aux_outputs`, which inference
+// never reads (odise.py:713-727).
+#include <math.h>
+#include <string.h>
+
+#include "engine.h"
+
+namespace odise {
+
+struct BottleneckW {
+    ConvW c1, c2, c3, sc;
+    NormW n1, n2, n3, nsc;
+    bool has_sc = false;
+};
+struct MsdaLayerW {
+    LinW off, aw, value, out, lin1, lin2;
+    NormW norm1, norm2;
+};
+struct MhaW {
+    LinW q, k, v, qk, out;  // q [C,C]+bq, k, v (bias applied along M of the swapped GEMM), stacked q|k for self-attention
+    float* v_bias = nullptr;
+    NormW norm;
+};
+struct DecLayerW {
+    MhaW cross, self;
+    LinW lin1, lin2;
+    NormW ffn_norm;
+};
+
+struct MaskGenModel {
+    bool backbone_built = false, head_built = false;
+    BottleneckW proj[8];
+    int proj_dim = 512;
+    // pixel decoder
+    ConvW in_proj[3];
+    NormW in_proj_gn[3];
+    float* enc_level_embed = nullptr;  // [3, C]
+    std::vector<MsdaLayerW> enc_layers;
+    ConvW adapter, layer1, mask_feat;
+    NormW adapter_gn, layer1_gn;
+    f16* mask_feat_wT = nullptr;  // mask_features weight as the A operand of the swapped GEMM (same [C,C] matrix)
+    int C = 256, enc_heads = 8, enc_points = 4;
+    // transformer decoder
+    std::vector<DecLayerW> dec_layers;
+    NormW decoder_norm;
+    float *query_feat = nullptr, *query_embed = nullptr, *dec_level_embed = nullptr;
+    f16* query_feat16 = nullptr;
+    LinW mask_mlp[3], pool_proj, post_mlp[3];
+    NormW pool_ln, post_ln;
+    float logit_scale = 0.f;
+    int Q = 100, dec_heads = 8;
+    // caches keyed by feature-map shape
+    int pe_h[4] = {0, 0, 0, 0}, pe_w[4] = {0, 0, 0, 0};
+    float* pe[4] = {nullptr, nullptr, nullptr, nullptr};  // sine PE [h*w, C] for the 3 transformer levels (+ spare)
+    float* enc_pos_all = nullptr;                         // [Lq, C] = PE + encoder level_embed
+    int enc_pos_key = 0;
+    int* boxes_dev = nullptr;  // [4 groups + image][K][2]
+    int boxes_key_h = 0, boxes_key_w = 0, boxes_K = 0;
+    // outputs of the last calls (arena)
+    Act feats[4];              // s2..s5 NHWC fp16
+    f16* pred_masks = nullptr;   // [B, Q, H4*W4] logits
+    f16* mask_embed = nullptr;   // [B, Q, C]
+    f16* mask_pooled = nullptr;  // [B, Q, C]
+    int out_B = 0, out_h = 0, out_w = 0;
+    double last_macs = 0.0;
+};
+
+void maskgen_destroy(ModelStore* ms) {
+    delete ms->maskgen;
+    ms->maskgen = nullptr;
+}
+
+static MaskGenModel* maskgen_of(ModelStore* ms) {
+    if (!ms->maskgen) ms->maskgen = new MaskGenModel();
+    return ms->maskgen;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+static int build_convnorm(Packer& pk, const std::string& key, ConvW& c, NormW& n) {
+    ODISE_TRY(pk.conv(key, c, false));
+    ODISE_TRY(pk.norm(key + ".norm", n));
+    return ODISE_OK;
+}
+
+static int build_mha(Packer& pk, const std::string& key, MhaW& m, int C, bool stack_qk) {
+    const HostTensor* w = pk.find(key + ".in_proj_weight");
+    const HostTensor* b = pk.find(key + ".in_proj_bias");
+    if (!w || !b || w->numel() != (int64_t)3 * C * C || b->numel() != 3 * C) {
+        set_error("decoder: bad or missing '%s.in_proj_*'", key.c_str());
+        return ODISE_ERR_STATE;
+    }
+    const size_t cc = (size_t)C * C;
+    std::vector<f16> t(3 * cc);
+    for (size_t i = 0; i < 3 * cc; ++i) t[i] = (f16)w->data[i];
+    if (stack_qk) {
+        m.qk.in = C; m.qk.out = 2 * C;
+        ODISE_TRY(pk.upload(t.data(), 2 * cc * sizeof(f16), (void**)&m.qk.w));
+        ODISE_TRY(pk.upload(b->data.data(), (size_t)2 * C * sizeof(float), (void**)&m.qk.b));
+    } else {
+        m.q.in = C; m.q.out = C;
+        ODISE_TRY(pk.upload(t.data(), cc * sizeof(f16), (void**)&m.q.w));
+        ODISE_TRY(pk.upload(b->data.data(), (size_t)C * sizeof(float), (void**)&m.q.b));
+        m.k.in = C; m.k.out = C;
+        ODISE_TRY(pk.upload(t.data() + cc, cc * sizeof(f16), (void**)&m.k.w));
+        ODISE_TRY(pk.upload(b->data.data() + C, (size_t)C * sizeof(float), (void**)&m.k.b));
+    }
+    m.v.in = C; m.v.out = C; m.v.b = nullptr;
+    ODISE_TRY(pk.upload(t.data() + 2 * cc, cc * sizeof(f16), (void**)&m.v.w));
+    ODISE_TRY(pk.upload(b->data.data() + 2 * C, (size_t)C * sizeof(float), (void**)&m.v_bias));
+    ODISE_TRY(pk.linear(key + ".out_proj", m.out));
+    return ODISE_OK;
+}
+
+static int maskgen_build_backbone(odise_hip_ctx* ctx) {
+    ModelStore* ms = store_of(ctx);
+    MaskGenModel* g = maskgen_of(ms);
+    Packer pk{ctx, ms, "backbone.feature_projections.", ""};
+    for (int i = 0; i < 8; ++i) {
+        const std::string k = std::to_string(i) + ".0";
+        BottleneckW& b = g->proj[i];
+        ODISE_TRY(build_convnorm(pk, k + ".conv1", b.c1, b.n1));
+        ODISE_TRY(build_convnorm(pk, k + ".conv2", b.c2, b.n2));
+        ODISE_TRY(build_convnorm(pk, k + ".conv3", b.c3, b.n3));
+        b.has_sc = pk.find(k + ".shortcut.weight") != nullptr;
+        if (b.has_sc) ODISE_TRY(build_convnorm(pk, k + ".shortcut", b.sc, b.nsc));
+    }
+    g->proj_dim = g->proj[0].c3.cout;
+    g->backbone_built = true;
+    return ODISE_OK;
+}
+
+static int maskgen_build_head(odise_hip_ctx* ctx) {
+    ModelStore* ms = store_of(ctx);
+    MaskGenModel* g = maskgen_of(ms);
+    Packer pk{ctx, ms, "sem_seg_head.pixel_decoder.", ""};
+    for (int i = 0; i < 3; ++i) {
+        ODISE_TRY(pk.conv("input_proj." + std::to_string(i) + ".0", g->in_proj[i]));
+        ODISE_TRY(pk.norm("input_proj." + std::to_string(i) + ".1", g->in_proj_gn[i]));
+    }
+    g->C = g->in_proj[0].cout;
+    const int C = g->C;
+    ODISE_TRY(pk.vec_f32("transformer.level_embed", &g->enc_level_embed, 3 * C));
+    g->enc_layers.clear();
+    for (int i = 0;; ++i) {
+        const std::string k = "transformer.encoder.layers." + std::to_string(i);
+        if (!pk.find(k + ".norm1.weight")) break;
+        MsdaLayerW L;
+        ODISE_TRY(pk.linear(k + ".self_attn.sampling_offsets", L.off));
+        ODISE_TRY(pk.linear(k + ".self_attn.attention_weights", L.aw));
+        ODISE_TRY(pk.linear(k + ".self_attn.value_proj", L.value));
+        ODISE_TRY(pk.linear(k + ".self_attn.output_proj", L.out));
+        ODISE_TRY(pk.norm(k + ".norm1", L.norm1));
+        ODISE_TRY(pk.linear(k + ".linear1", L.lin1));
+        ODISE_TRY(pk.linear(k + ".linear2", L.lin2));
+        ODISE_TRY(pk.norm(k + ".norm2", L.norm2));
+        g->enc_layers.push_back(L);
+    }
+    if (g->enc_layers.empty()) {
+        set_error("pixel decoder: no transformer.encoder.layers found");
+        return ODISE_ERR_STATE;
+    }
+    g->enc_points = g->enc_layers[0].aw.out / (g->enc_heads * 3);
+    ODISE_TRY(build_convnorm(pk, "adapter_1", g->adapter, g->adapter_gn));
+    ODISE_TRY(build_convnorm(pk, "layer_1", g->layer1, g->layer1_gn));
+    ODISE_TRY(pk.conv("mask_features", g->mask_feat));
+    g->mask_feat_wT = g->mask_feat.w;  // a 1x1 conv weight [Cout][1][1][Cin] is already the [Cout, Cin] A operand
+    // ---- transformer decoder -----------------------------------------------------------------------------------------
+    Packer pd{ctx, ms, "sem_seg_head.predictor.", ""};
+    g->dec_layers.clear();
+    for (int i = 0;; ++i) {
+        const std::string si = std::to_string(i);
+        if (!pd.find("transformer_ffn_layers." + si + ".norm.weight")) break;
+        DecLayerW L;
+        ODISE_TRY(build_mha(pd, "transformer_cross_attention_layers." + si + ".multihead_attn", L.cross, C, false));
+        ODISE_TRY(pd.norm("transformer_cross_attention_layers." + si + ".norm", L.cross.norm));
+        ODISE_TRY(build_mha(pd, "transformer_self_attention_layers." + si + ".self_attn", L.self, C, true));
+        ODISE_TRY(pd.norm("transformer_self_attention_layers." + si + ".norm", L.self.norm));
+        ODISE_TRY(pd.linear("transformer_ffn_layers." + si + ".linear1", L.lin1));
+        ODISE_TRY(pd.linear("transformer_ffn_layers." + si + ".linear2", L.lin2));
+        ODISE_TRY(pd.norm("transformer_ffn_layers." + si + ".norm", L.ffn_norm));
+        g->dec_layers.push_back(L);
+    }
+    if (g->dec_layers.empty()) {
+        set_error("decoder: no transformer layers found");
+        return ODISE_ERR_STATE;
+    }
+    ODISE_TRY(pd.norm("decoder_norm", g->decoder_norm));
+    const HostTensor* qf = pd.find("query_feat.weight");
+    if (!qf || qf->shape.size() != 2 || qf->shape[1] != C) {
+        set_error("decoder: bad or missing query_feat.weight");
+        return ODISE_ERR_STATE;
+    }
+    g->Q = (int)qf->shape[0];
+    ODISE_TRY(pd.vec_f32("query_feat.weight", &g->query_feat, (int64_t)g->Q * C));
+    ODISE_TRY(pd.vec_f32("query_embed.weight", &g->query_embed, (int64_t)g->Q * C));
+    ODISE_TRY(pd.vec_f32("level_embed.weight", &g->dec_level_embed, 3 * C));
+    {
+        std::vector<f16> q16((size_t)g->Q * C);
+        for (size_t i = 0; i < q16.size(); ++i) q16[i] = (f16)qf->data[i];
+        ODISE_TRY(pd.upload(q16.data(), q16.size() * sizeof(f16), (void**)&g->query_feat16));
+    }
+    for (int i = 0; i < 3; ++i) ODISE_TRY(pd.linear("mask_embed.layers." + std::to_string(i), g->mask_mlp[i]));
+    ODISE_TRY(pd.norm("post_mask_embed.pool_proj.0", g->pool_ln));
+    ODISE_TRY(pd.linear("post_mask_embed.pool_proj.1", g->pool_proj));
+    ODISE_TRY(pd.norm("post_mask_embed.mask_embed.0", g->post_ln));
+    for (int i = 0; i < 3; ++i) ODISE_TRY(pd.linear("post_mask_embed.mask_embed.1.layers." + std::to_string(i), g->post_mlp[i]));
+    const HostTensor* ls = pd.find("post_mask_embed.logit_scale");
+    if (!ls || ls->numel() != 1) {
+        set_error("decoder: bad or missing post_mask_embed.logit_scale");
+        return ODISE_ERR_STATE;
+    }
+    g->logit_scale = std::min(expf(ls->data[0]), 100.0f);  // torch.clamp(logit_scale.exp(), max=100)  (odise.py:1004)
+    g->head_built = true;
+    return ODISE_OK;
+}
+
+// ---- host-side tables --------------------------------------------------------------------------------------------------
+// PositionEmbeddingSine(normalize=True, scale=2*pi, temperature=10000), position_encoding.py:29-52 -> [h*w, 2*npf] (y half | x half)
+static void sine_pe(int h, int w, int npf, std::vector<float>& out) {
+    out.assign((size_t)h * w * 2 * npf, 0.f);
+    const float scale = 2.0f * (float)M_PI, eps = 1e-6f;
+    for (int y = 0; y < h; ++y)
+        for (int x = 0; x < w; ++x) {
+            const float ye = (float)(y + 1) / ((float)h + eps) * scale, xe = (float)(x + 1) / ((float)w + eps) * scale;
+            float* o = out.data() + ((size_t)y * w + x) * 2 * npf;
+            for (int i = 0; i < npf; ++i) {
+                const float dim_t = powf(10000.0f, (float)(2 * (i / 2)) / (float)npf);
+                const float py = ye / dim_t, px = xe / dim_t;
+                o[i] = (i % 2 == 0) ? sinf(py) : cosf(py);
+                o[npf + i] = (i % 2 == 0) ? sinf(px) : cosf(px);
+            }
+        }
+}
+
+static int upload_new(odise_hip_ctx* ctx, ModelStore* ms, const void* host, size_t bytes, void** dev) {
+    ODISE_CHECK_HIP(hipStreamSynchronize(ctx->stream));
+    ODISE_CHECK_HIP(hipMalloc(dev, bytes));
+    ms->dev_allocs.push_back(*dev);
+    ODISE_CHECK_HIP(hipMemcpy(*dev, host, bytes, hipMemcpyHostToDevice));
+    return ODISE_OK;
+}
+
+// ---- BottleneckBlock: 1x1+GN+ReLU -> 3x3+GN+ReLU -> 1x1+GN ; ReLU(out + shortcut) (+ accum of the stride group) ----------
+static int run_bottleneck(Exec& ex, const BottleneckW& w, const Act& x, const Act* accum, Act& out) {
+    ODISE_TRY(ex.alloc(out, x.n, x.h, x.w, w.c3.cout));
+    const size_t mk = ex.ms->arena.mark();
+    Act a, an, b, bn, c, s, sn;
+    ODISE_TRY(ex.conv(x, w.c1, a, 1, 0));
+    ODISE_TRY(ex.group_norm(a, w.n1, an, 1e-5f, ODISE_ACT_RELU));
+    ODISE_TRY(ex.conv(an, w.c2, b, 1, 1));
+    ODISE_TRY(ex.group_norm(b, w.n2, bn, 1e-5f, ODISE_ACT_RELU));
+    ODISE_TRY(ex.conv(bn, w.c3, c, 1, 0));
+    const f16* resid = x.p;
+    if (w.has_sc) {
+        ODISE_TRY(ex.conv(x, w.sc, s, 1, 0));
+        ODISE_TRY(ex.group_norm(s, w.nsc, sn, 1e-5f, ODISE_ACT_NONE));
+        resid = sn.p;
+    }
+    ODISE_TRY(odise_hip_group_norm_ex(ex.ctx, c.p, out.p, w.n3.g, w.n3.b, c.n, c.h * c.w, c.c, 32, 1e-5f, ODISE_ACT_RELU, resid,
+                                      accum ? accum->p : nullptr));
+    ex.ms->arena.release(mk);
+    return ODISE_OK;
+}
+
+static const int kFeatStride[8] = {4, 8, 32, 32, 16, 8, 8, 4};  // LdmExtractor strides clamped to [4,32] (feature_extractor.py:91-93)
+static const int kGroups[4][3] = {{0, 7, -1}, {1, 5, 6}, {4, -1, -1}, {2, 3, -1}};  // s2, s3, s4, s5 in summation order
+static const int kGroupStride[4] = {4, 8, 16, 32};
+
+static int backbone_forward(odise_hip_ctx* ctx, const float* image, int B, int H, int W, float** out4) {
+    ModelStore* ms = store_of(ctx);
+    MaskGenModel* g = ms->maskgen;
+    if (!g || !g->backbone_built || !extractor_ready(ms)) {
+        set_error("backbone_forward: call odise_hip_extractor_build and odise_hip_backbone_build first");
+        return ODISE_ERR_STATE;
+    }
+    ODISE_REQUIRE(image && B >= 1 && H % 64 == 0 && W % 64 == 0 && H >= 512 && W >= 512,
+                  "backbone_forward: image %dx%d must be >= 512 and a multiple of 64 (the caller pads, odise.py:238-242)", H, W);
+    const int S = 512;
+    // slide-window boxes (feature_extractor.py:197-222)
+    std::vector<int> boxes;
+    const int hg = (std::max(H - S + S - 1, 0)) / S + 1, wg = (std::max(W - S + S - 1, 0)) / S + 1;
+    for (int hi = 0; hi < hg; ++hi)
+        for (int wi = 0; wi < wg; ++wi) {
+            const int y2 = std::min(hi * S + S, H), x2 = std::min(wi * S + S, W);
+            boxes.push_back(std::max(y2 - S, 0));
+            boxes.push_back(std::max(x2 - S, 0));
+        }
+    const int K = (int)boxes.size() / 2;
+    if (g->boxes_key_h != H || g->boxes_key_w != W) {
+        std::vector<int> all;  // [5][K][2]: image pixels, then s2..s5 feature pixels
+        for (int k = 0; k < 2 * K; ++k) all.push_back(boxes[k]);
+        for (int gi = 0; gi < 4; ++gi)
+            for (int k = 0; k < 2 * K; ++k) all.push_back(boxes[k] / kGroupStride[gi]);
+        ODISE_TRY(upload_new(ctx, ms, all.data(), all.size() * sizeof(int), (void**)&g->boxes_dev));
+        g->boxes_key_h = H; g->boxes_key_w = W; g->boxes_K = K;
+    }
+    ODISE_TRY(unet_prepare_timestep(ctx, ms, ms->unet, B * K, 0));
+    size_t need = extractor_arena_bytes(B * K, S, S) + (size_t)B * K * 3 * S * S * 4;
+    need += (size_t)B * K * (128 * 128 + 64 * 64 + 32 * 32 + 16 * 16) * 512 * 2 * 4;   // projections + temporaries
+    need += (size_t)B * (H / 4) * (W / 4) * 512 * 2 * 2;                                 // stitched outputs
+    need += (size_t)B * (H / 4) * (W / 4) * 256 * 2 * 24 + ((size_t)512 << 20);          // head working set (conservative)
+    ODISE_TRY(ensure_arena(ctx, ms, need));
+    Exec ex{ctx, ms};
+    ms->arena.reset();
+    ms->macs = 0.0;
+    // outputs first (they must outlive everything else of this call)
+    for (int gi = 0; gi < 4; ++gi) ODISE_TRY(ex.alloc(g->feats[gi], B, H / kGroupStride[gi], W / kGroupStride[gi], g->proj_dim));
+    const size_t mk = ms->arena.mark();
+    float* crops = (float*)ex.alloc_bytes((size_t)B * K * 3 * S * S * 4);
+    if (!crops) return ODISE_ERR_NOMEM;
+    ODISE_TRY(launch_crop_extract(ctx, image, crops, B, 3, H, W, S, K, g->boxes_dev));
+    ODISE_TRY(extractor_launch(ctx, ms, crops, B * K, S, S, false));
+    const Act* taps = extractor_taps(ms);
+    for (int gi = 0; gi < 4; ++gi) {
+        const int stride = kGroupStride[gi], fs = S / stride;
+        Act acc;
+        bool have = false;
+        for (int j = 0; j < 3 && kGroups[gi][j] >= 0; ++j) {
+            const int idx = kGroups[gi][j];
+            Act x = taps[idx];
+            if (x.h != fs || x.w != fs) {  // restore to crop/stride (nearest; only u2: 8x8 -> 16x16)
+                Act up;
+                ODISE_TRY(ex.alloc(up, x.n, fs, fs, x.c));
+                ODISE_TRY(launch_upsample_nearest(ctx, x.p, up.p, x.n, x.h, x.w, fs, fs, x.c));
+                x = up;
+            }
+            Act o;
+            ODISE_TRY(run_bottleneck(ex, g->proj[idx], x, have ? &acc : nullptr, o));
+            acc = o;
+            have = true;
+        }
+        ODISE_TRY(launch_stitch(ctx, acc.p, g->feats[gi].p, out4 ? out4[gi] : nullptr, B, K, g->boxes_dev + (size_t)(1 + gi) * 2 * K, fs, fs,
+                                H / stride, W / stride, g->proj_dim));
+    }
+    ms->arena.release(mk);
+    g->last_macs = ms->macs;
+    (void)kFeatStride;
+    return ODISE_OK;
+}
+
+// ---- sem_seg_head ------------------------------------------------------------------------------------------------------
+static int copy_rows_2d(odise_hip_ctx* ctx, void* dst, size_t dpitch, const void* src, size_t spitch, size_t width, size_t height) {
+    ODISE_CHECK_HIP(hipMemcpy2DAsync(dst, dpitch, src, spitch, width, height, hipMemcpyDeviceToDevice, ctx->stream));
+    return ODISE_OK;
+}
+
+static int gemm_f32out(Exec& ex, const f16* x, int64_t M, const LinW& w, float* y) {
+    odise_gemm_desc d;
+    memset(&d, 0, sizeof(d));
+    d.M = (int)M; d.N = w.out; d.K = w.in;
+    d.A = x; d.lda = w.in; d.W = w.w; d.ldw = w.in;
+    d.C = y; d.ldc = w.out; d.c_dtype = ODISE_F32; d.bias_n = w.b; d.alpha = 1.f; d.batch = 1;
+    return ex.gemm(d);
+}
+
+// V^T[b] = Wv x[b]^T + bv  -> [B, C, ldvt]
+static int gemm_vt(Exec& ex, const LinW& v, const float* v_bias, const f16* x, int B, int64_t L, int64_t ldvt, f16* vt) {
+    odise_gemm_desc d;
+    memset(&d, 0, sizeof(d));
+    d.M = v.out; d.N = (int)L; d.K = v.in;
+    d.A = v.w; d.lda = v.in; d.W = x; d.ldw = v.in; d.strideW = L * v.in;
+    d.C = vt; d.ldc = ldvt; d.strideC = (int64_t)v.out * ldvt; d.c_dtype = ODISE_F16;
+    d.bias_m = v_bias; d.alpha = 1.f; d.batch = B;
+    return ex.gemm(d);
+}
+
+static int mlp3(Exec& ex, const LinW* w, const f16* x, int64_t M, f16* t1, f16* t2, f16* y) {
+    ODISE_TRY(ex.linear(x, M, w[0], t1, ODISE_ACT_RELU));
+    ODISE_TRY(ex.linear(t1, M, w[1], t2, ODISE_ACT_RELU));
+    ODISE_TRY(ex.linear(t2, M, w[2], y));
+    return ODISE_OK;
+}
+
+static int head_forward(odise_hip_ctx* ctx, const Act feats[4]) {
+    ModelStore* ms = store_of(ctx);
+    MaskGenModel* g = ms->maskgen;
+    Exec ex{ctx, ms};
+    const int C = g->C, B = feats[0].n, Q = g->Q;
+    const int hs[3] = {feats[3].h, feats[2].h, feats[1].h}, ws[3] = {feats[3].w, feats[2].w, feats[1].w};  // s5, s4, s3
+    int starts[3], Lq = 0;
+    for (int l = 0; l < 3; ++l) { starts[l] = Lq; Lq += hs[l] * ws[l]; }
+    // ---- tables: sine PE per level, encoder positional table -------------------------------------------------------------
+    const int key = (hs[0] << 20) ^ (ws[0] << 10) ^ hs[2] ^ (ws[2] << 5);
+    if (g->enc_pos_key != key || !g->enc_pos_all) {
+        std::vector<float> all((size_t)Lq * C), lvl, emb((size_t)3 * C);
+        ODISE_CHECK_HIP(hipStreamSynchronize(ctx->stream));
+        ODISE_CHECK_HIP(hipMemcpy(emb.data(), g->enc_level_embed, emb.size() * 4, hipMemcpyDeviceToHost));
+        for (int l = 0; l < 3; ++l) {
+            sine_pe(hs[l], ws[l], C / 2, lvl);
+            ODISE_TRY(upload_new(ctx, ms, lvl.data(), lvl.size() * 4, (void**)&g->pe[l]));
+            g->pe_h[l] = hs[l]; g->pe_w[l] = ws[l];
+            for (size_t p = 0; p < (size_t)hs[l] * ws[l]; ++p)
+                for (int c = 0; c < C; ++c) all[((size_t)starts[l] + p) * C + c] = lvl[p * C + c] + emb[(size_t)l * C + c];
+        }
+        ODISE_TRY(upload_new(ctx, ms, all.data(), all.size() * 4, (void**)&g->enc_pos_all));
+        g->enc_pos_key = key;
+    }
+    const int64_t MT = (int64_t)B * Lq;
+    // ---- pixel decoder: input_proj (1x1 + GN) into one [B, Lq, C] token matrix ----------------------------------------------
+    f16* src = (f16*)ex.alloc_bytes((size_t)MT * C * 2);
+    f16* qin = (f16*)ex.alloc_bytes((size_t)MT * C * 2);
+    f16* x1 = (f16*)ex.alloc_bytes((size_t)MT * C * 2);
+    f16* val = (f16*)ex.alloc_bytes((size_t)MT * C * 2);
+    f16* samp = (f16*)ex.alloc_bytes((size_t)MT * C * 2);
+    f16* hid = (f16*)ex.alloc_bytes((size_t)MT * g->enc_layers[0].lin1.out * 2);
+    const int M8 = g->enc_heads, LP = 3 * g->enc_points;
+    float* off = (float*)ex.alloc_bytes((size_t)MT * M8 * LP * 2 * 4);
+    float* aw = (float*)ex.alloc_bytes((size_t)MT * M8 * LP * 4);
+    float* loc = (float*)ex.alloc_bytes((size_t)MT * M8 * LP * 2 * 4);
+    float* wts = (float*)ex.alloc_bytes((size_t)MT * M8 * LP * 4);
+    if (!src || !qin || !x1 || !val || !samp || !hid || !off || !aw || !loc || !wts) return ODISE_ERR_NOMEM;
+    for (int l = 0; l < 3; ++l) {
+        const Act& f = feats[3 - l];
+        const size_t mk = ms->arena.mark();
+        Act t, tn;
+        ODISE_TRY(ex.conv(f, g->in_proj[l], t, 1, 0));
+        ODISE_TRY(ex.group_norm(t, g->in_proj_gn[l], tn, 1e-5f, ODISE_ACT_NONE));
+        const size_t rowb = (size_t)hs[l] * ws[l] * C * 2;
+        ODISE_TRY(copy_rows_2d(ctx, src + (size_t)starts[l] * C, (size_t)Lq * C * 2, tn.p, rowb, rowb, B));
+        ms->arena.release(mk);
+    }
+    int64_t ss[6], ls[3];
+    for (int l = 0; l < 3; ++l) { ss[2 * l] = hs[l]; ss[2 * l + 1] = ws[l]; ls[l] = starts[l]; }
+    for (const MsdaLayerW& L : g->enc_layers) {
+        ODISE_TRY(launch_add_vec_table(ctx, src, nullptr, g->enc_pos_all, qin, B, Lq, C));       // query = src + pos
+        ODISE_TRY(ex.linear(src, MT, L.value, val));
+        ODISE_TRY(gemm_f32out(ex, qin, MT, L.off, off));
+        ODISE_TRY(gemm_f32out(ex, qin, MT, L.aw, aw));
+        ODISE_TRY(launch_msda_prepare(ctx, off, aw, loc, wts, B, Lq, M8, 3, g->enc_points, hs, ws, starts));
+        ODISE_TRY(odise_hip_ms_deform_attn_forward(ctx, val, ss, ls, loc, wts, B, Lq, M8, C / M8, Lq, 3, g->enc_points, 128, ODISE_F16, samp));
+        ms->macs += (double)MT * M8 * LP * 4 * (C / M8);                                           // bilinear taps
+        ODISE_TRY(ex.linear(samp, MT, L.out, x1, ODISE_ACT_NONE, src));
+        ODISE_TRY(ex.layer_norm(x1, src, MT, L.norm1, 1e-5f));
+        ODISE_TRY(ex.linear(src, MT, L.lin1, hid, ODISE_ACT_RELU));
+        ODISE_TRY(ex.linear(hid, MT, L.lin2, x1, ODISE_ACT_NONE, src));
+        ODISE_TRY(ex.layer_norm(x1, src, MT, L.norm2, 1e-5f));
+    }
+    // multi-scale features (contiguous per level) = split of the encoder output
+    Act ms_feat[3];
+    for (int l = 0; l < 3; ++l) {
+        ODISE_TRY(ex.alloc(ms_feat[l], B, hs[l], ws[l], C));
+        const size_t rowb = (size_t)hs[l] * ws[l] * C * 2;
+        ODISE_TRY(copy_rows_2d(ctx, ms_feat[l].p, rowb, src + (size_t)starts[l] * C, (size_t)Lq * C * 2, rowb, B));
+    }
+    // FPN level on s2 + mask features (both layouts)
+    const Act& s2 = feats[0];
+    const int64_t HW4 = (int64_t)s2.h * s2.w;
+    Act lat, latn, fsum, o3, o3n, mf;
+    ODISE_TRY(ex.conv(s2, g->adapter, lat, 1, 0));
+    ODISE_TRY(ex.group_norm(lat, g->adapter_gn, latn, 1e-5f, ODISE_ACT_NONE));
+    ODISE_TRY(ex.alloc(fsum, B, s2.h, s2.w, C));
+    ODISE_TRY(launch_bilinear_add(ctx, latn.p, ms_feat[2].p, fsum.p, B, hs[2], ws[2], s2.h, s2.w, C));
+    ODISE_TRY(ex.conv(fsum, g->layer1, o3, 1, 1));
+    ODISE_TRY(ex.group_norm(o3, g->layer1_gn, o3n, 1e-5f, ODISE_ACT_RELU));
+    ODISE_TRY(ex.conv(o3n, g->mask_feat, mf, 1, 0));                     // [B, HW4, C]  (pixel-major: W operand of the mask-logit GEMM)
+    f16* mfT = (f16*)ex.alloc_bytes((size_t)B * C * HW4 * 2);            // [B, C, HW4] (channel-major: W operand of the pooling GEMM)
+    if (!mfT) return ODISE_ERR_NOMEM;
+    {
+        LinW v; v.w = g->mask_feat_wT; v.in = C; v.out = g->mask_feat.cout; v.b = nullptr;
+        ODISE_TRY(gemm_vt(ex, v, g->mask_feat.b, o3n.p, B, HW4, HW4, mfT));
+    }
+    // ---- masked transformer decoder ----------------------------------------------------------------------------------------
+    const int64_t MQ = (int64_t)B * Q;
+    f16* valin[3]; f16* keyin[3];
+    for (int l = 0; l < 3; ++l) {
+        const int64_t P = (int64_t)hs[l] * ws[l];
+        valin[l] = (f16*)ex.alloc_bytes((size_t)B * P * C * 2);
+        keyin[l] = (f16*)ex.alloc_bytes((size_t)B * P * C * 2);
+        if (!valin[l] || !keyin[l]) return ODISE_ERR_NOMEM;
+        ODISE_TRY(launch_add_vec_table(ctx, ms_feat[l].p, g->dec_level_embed + (size_t)l * C, nullptr, valin[l], B, (int)P, C));
+        ODISE_TRY(launch_add_vec_table(ctx, valin[l], nullptr, g->pe[l], keyin[l], B, (int)P, C));
+    }
+    const int64_t maxP = (int64_t)hs[2] * ws[2];
+    const int64_t ldm = round_up(maxP, 8);
+    f16* out = (f16*)ex.alloc_bytes((size_t)MQ * C * 2);
+    f16* tq = (f16*)ex.alloc_bytes((size_t)MQ * C * 2);
+    f16* t1 = (f16*)ex.alloc_bytes((size_t)MQ * 2048 * 2);
+    f16* t2 = (f16*)ex.alloc_bytes((size_t)MQ * 2 * C * 2);
+    f16* dn = (f16*)ex.alloc_bytes((size_t)MQ * C * 2);
+    f16* me = (f16*)ex.alloc_bytes((size_t)MQ * C * 2);
+    f16* att = (f16*)ex.alloc_bytes((size_t)MQ * C * 2);
+    f16* qb = (f16*)ex.alloc_bytes((size_t)MQ * 2 * C * 2);
+    f16* kbuf = (f16*)ex.alloc_bytes((size_t)B * maxP * C * 2);
+    f16* vtb = (f16*)ex.alloc_bytes((size_t)B * C * ldm * 2);
+    f16* masks = (f16*)ex.alloc_bytes((size_t)MQ * HW4 * 2);
+    uint8_t* amask = (uint8_t*)ex.alloc_bytes((size_t)MQ * ldm);
+    f16* m01 = (f16*)ex.alloc_bytes((size_t)MQ * HW4 * 2);
+    float* inv = (float*)ex.alloc_bytes((size_t)MQ * 4);
+    f16* pooled = (f16*)ex.alloc_bytes((size_t)MQ * C * 2);
+    f16* pooled_x = (f16*)ex.alloc_bytes((size_t)MQ * C * 2);
+    f16* mask_embed = (f16*)ex.alloc_bytes((size_t)MQ * C * 2);
+    if (!out || !tq || !t1 || !t2 || !dn || !me || !att || !qb || !kbuf || !vtb || !masks || !amask || !m01 || !inv || !pooled || !pooled_x ||
+        !mask_embed)
+        return ODISE_ERR_NOMEM;
+    // output = query_feat broadcast over the batch
+    for (int b = 0; b < B; ++b)
+        ODISE_CHECK_HIP(hipMemcpyAsync(out + (size_t)b * Q * C, g->query_feat16, (size_t)Q * C * 2, hipMemcpyDeviceToDevice, ctx->stream));
+
+    auto prediction_heads = [&](int target_level) -> int {  // forward_prediction_heads (odise.py:729-776), mask branch only
+        ODISE_TRY(ex.layer_norm(out, dn, MQ, g->decoder_norm, 1e-5f));
+        ODISE_TRY(mlp3(ex, g->mask_mlp, dn, MQ, t1, t2, me));
+        odise_gemm_desc d;
+        memset(&d, 0, sizeof(d));  // outputs_mask[b] = mask_embed[b] (Q x C) . mask_features[b]^T (HW4 x C)
+        d.M = Q; d.N = (int)HW4; d.K = C;
+        d.A = me; d.lda = C; d.strideA = (int64_t)Q * C;
+        d.W = mf.p; d.ldw = C; d.strideW = HW4 * C;
+        d.C = masks; d.ldc = HW4; d.strideC = (int64_t)Q * HW4; d.c_dtype = ODISE_F16; d.alpha = 1.f; d.batch = B;
+        ODISE_TRY(ex.gemm(d));
+        if (target_level >= 0)
+            ODISE_TRY(launch_attn_mask(ctx, masks, amask, MQ, s2.h, s2.w, hs[target_level], ws[target_level], ldm));
+        return ODISE_OK;
+    };
+    ODISE_TRY(prediction_heads(0));
+    const int heads = g->dec_heads, D = C / heads;
+    const int nl = (int)g->dec_layers.size();
+    for (int i = 0; i < nl; ++i) {
+        const DecLayerW& L = g->dec_layers[i];
+        const int l = i % 3;
+        const int64_t P = (int64_t)hs[l] * ws[l];
+        const int64_t ldv = round_up(P, 8);
+        // masked cross-attention (keys = level l)
+        ODISE_TRY(launch_add_vec_table(ctx, out, nullptr, g->query_embed, tq, B, Q, C));
+        ODISE_TRY(ex.linear(tq, MQ, L.cross.q, qb));
+        ODISE_TRY(ex.linear(keyin[l], B * P, L.cross.k, kbuf));
+        ODISE_TRY(gemm_vt(ex, L.cross.v, L.cross.v_bias, valin[l], B, P, ldv, vtb));
+        odise_attn_desc a;
+        memset(&a, 0, sizeof(a));
+        a.B = B; a.H = heads; a.Lq = Q; a.Lk = (int)P; a.D = D;
+        a.Q = qb; a.ldq = C; a.strideQ = (int64_t)Q * C;
+        a.K = kbuf; a.ldk = C; a.strideK = P * C;
+        a.Vt = vtb; a.ldvt = ldv; a.strideVt = (int64_t)C * ldv;
+        a.O = att; a.ldo = C; a.strideO = (int64_t)Q * C;
+        a.mask = amask; a.ldmask = ldm; a.strideMask = (int64_t)Q * ldm;
+        a.scale = 1.0f / sqrtf((float)D);
+        ODISE_TRY(ex.attention(a));
+        ODISE_TRY(ex.linear(att, MQ, L.cross.out, tq, ODISE_ACT_NONE, out));
+        ODISE_TRY(ex.layer_norm(tq, out, MQ, L.cross.norm, 1e-5f));
+        // self-attention over the queries
+        ODISE_TRY(launch_add_vec_table(ctx, out, nullptr, g->query_embed, tq, B, Q, C));
+        ODISE_TRY(ex.linear(tq, MQ, L.self.qk, qb));
+        const int64_t ldq = round_up(Q, 8);
+        ODISE_TRY(gemm_vt(ex, L.self.v, L.self.v_bias, out, B, Q, ldq, vtb));
+        memset(&a, 0, sizeof(a));
+        a.B = B; a.H = heads; a.Lq = Q; a.Lk = Q; a.D = D;
+        a.Q = qb; a.ldq = 2 * C; a.strideQ = (int64_t)Q * 2 * C;
+        a.K = qb + C; a.ldk = 2 * C; a.strideK = (int64_t)Q * 2 * C;
+        a.Vt = vtb; a.ldvt = ldq; a.strideVt = (int64_t)C * ldq;
+        a.O = att; a.ldo = C; a.strideO = (int64_t)Q * C;
+        a.scale = 1.0f / sqrtf((float)D);
+        ODISE_TRY(ex.attention(a));
+        ODISE_TRY(ex.linear(att, MQ, L.self.out, tq, ODISE_ACT_NONE, out));
+        ODISE_TRY(ex.layer_norm(tq, out, MQ, L.self.norm, 1e-5f));
+        // FFN
+        ODISE_TRY(ex.linear(out, MQ, L.lin1, t1, ODISE_ACT_RELU));
+        ODISE_TRY(ex.linear(t1, MQ, L.lin2, tq, ODISE_ACT_NONE, out));
+        ODISE_TRY(ex.layer_norm(tq, out, MQ, L.ffn_norm, 1e-5f));
+        ODISE_TRY(prediction_heads(i + 1 < nl ? (i + 1) % 3 : -1));
+    }
+    // ---- PooledMaskEmbed on the final prediction (odise.py:984-1015) ------------------------------------------------------------
+    ODISE_TRY(launch_mask_binarize_f16(ctx, masks, m01, inv, MQ, (int)HW4));
+    for (int b = 0; b < B; ++b) {
+        odise_gemm_desc d;
+        memset(&d, 0, sizeof(d));  // pooled[b] = (m01[b] (Q x HW4) . x[b]^T (C x HW4)) / count
+        d.M = Q; d.N = C; d.K = (int)HW4;
+        d.A = m01 + (size_t)b * Q * HW4; d.lda = HW4;
+        d.W = mfT + (size_t)b * C * HW4; d.ldw = HW4;
+        d.C = pooled + (size_t)b * Q * C; d.ldc = C; d.c_dtype = ODISE_F16;
+        d.scale_m = inv + (size_t)b * Q; d.alpha = 1.f; d.batch = 1;
+        ODISE_TRY(ex.gemm(d));
+    }
+    ODISE_TRY(ex.layer_norm(pooled, tq, MQ, g->pool_ln, 1e-5f));
+    ODISE_TRY(ex.linear(tq, MQ, g->pool_proj, pooled_x, ODISE_ACT_NONE, dn));   // mask_pooled_x = pool_proj(pooled) + decoder_output
+    ODISE_TRY(ex.layer_norm(pooled_x, tq, MQ, g->post_ln, 1e-5f));
+    ODISE_TRY(mlp3(ex, g->post_mlp, tq, MQ, t1, t2, mask_embed));
+    g->pred_masks = masks; g->mask_embed = mask_embed; g->mask_pooled = pooled_x;
+    g->out_B = B; g->out_h = s2.h; g->out_w = s2.w;
+    g->last_macs = ms->macs;
+    return ODISE_OK;
+}
+
+}  // namespace odise
+
+using namespace odise;
+
+extern "C" int odise_hip_backbone_build(odise_hip_ctx* ctx) {
+    ODISE_REQUIRE(ctx, "backbone_build: null context");
+    return maskgen_build_backbone(ctx);
+}
+extern "C" int odise_hip_head_build(odise_hip_ctx* ctx) {
+    ODISE_REQUIRE(ctx, "head_build: null context");
+    return maskgen_build_head(ctx);
+}
+
+extern "C" int odise_hip_backbone_forward(odise_hip_ctx* ctx, const float* image, int B, int H, int W, float** out4) {
+    ODISE_REQUIRE(ctx, "backbone_forward: null context");
+    return backbone_forward(ctx, image, B, H, W, out4);
+}
+
+// feats4: s2,s3,s4,s5 fp32 NCHW [B,Cin,H/4..H/32,W/4..W/32] on the device, or NULL to use the maps of the last backbone_forward.
+// outputs (device, any may be NULL): pred_masks [B,Q,H/4,W/4] f32, mask_embed [B,Q,C] f32, mask_pooled [B,Q,C] f32; logit_scale (host)
+extern "C" int odise_hip_head_forward(odise_hip_ctx* ctx, const float* const* feats4, int B, int Cin, int H4, int W4, float* pred_masks,
+                                      float* mask_embed, float* mask_pooled, float* logit_scale) {
+    ODISE_REQUIRE(ctx, "head_forward: null context");
+    ModelStore* ms = store_of(ctx);
+    MaskGenModel* g = ms->maskgen;
+    if (!g || !g->head_built) {
+        set_error("head_forward: call odise_hip_head_build first");
+        return ODISE_ERR_STATE;
+    }
+    Act feats[4];
+    Exec ex{ctx, ms};
+    if (feats4) {
+        ODISE_REQUIRE(B >= 1 && Cin % 8 == 0 && H4 % 8 == 0 && W4 % 8 == 0, "head_forward: bad feature shapes");
+        size_t need = (size_t)B * H4 * W4 * 256 * 2 * 40 + ((size_t)512 << 20);
+        ODISE_TRY(ensure_arena(ctx, ms, need));
+        ms->arena.reset();
+        ms->macs = 0.0;
+        for (int i = 0; i < 4; ++i) {
+            const int h = H4 >> i, w = W4 >> i;
+            ODISE_TRY(ex.alloc(feats[i], B, h, w, Cin));
+            ODISE_TRY(odise_hip_nchw_f32_to_nhwc_f16(ctx, feats4[i], feats[i].p, B, Cin, h, w, Cin));
+        }
+    } else {
+        ODISE_REQUIRE(g->feats[0].p != nullptr, "head_forward: no backbone features available");
+        for (int i = 0; i < 4; ++i) feats[i] = g->feats[i];
+    }
+    ODISE_TRY(head_forward(ctx, feats));
+    const int64_t MQ = (int64_t)g->out_B * g->Q;
+    if (pred_masks) ODISE_TRY(odise_hip_cast_f16_to_f32(ctx, g->pred_masks, pred_masks, (size_t)MQ * g->out_h * g->out_w));
+    if (mask_embed) ODISE_TRY(odise_hip_cast_f16_to_f32(ctx, g->mask_embed, mask_embed, (size_t)MQ * g->C));
+    if (mask_pooled) ODISE_TRY(odise_hip_cast_f16_to_f32(ctx, g->mask_pooled, mask_pooled, (size_t)MQ * g->C));
+    if (logit_scale) *logit_scale = g->logit_scale;
+    return ODISE_OK;
+}
+
+extern "C" int odise_hip_maskgen_info(odise_hip_ctx* ctx, int* num_queries, int* hidden_dim, double* last_macs) {
+    ODISE_REQUIRE(ctx, "maskgen_info: null context");
+    MaskGenModel* g = store_of(ctx)->maskgen;
+    if (num_queries) *num_queries = g ? g->Q : 0;
+    if (hidden_dim) *hidden_dim = g ? g->C : 0;
+    if (last_macs) *last_macs = g ? g->last_macs : 0.0;
+    return ODISE_OK;
+}

@@ -69,7 +69,8 @@ __global__ void __launch_bounds__(256) gn_partial_kernel(const f16* __restrict__
 __global__ void __launch_bounds__(256) gn_apply_kernel(const f16* __restrict__ x, f16* __restrict__ y,
                                                       const float* __restrict__ partial, const float* __restrict__ gamma,
                                                       const float* __restrict__ beta, int HW, int C, int G, int nchunks,
-                                                      float eps, int act) {
+                                                      float eps, int act, const f16* __restrict__ residual,
+                                                      const f16* __restrict__ accum) {
     extern __shared__ __attribute__((aligned(16))) float sss[];  // scale[C], shift[C], mean[G], rstd[G], red[2*256]
     float* scale = sss;
     float* shift = sss + C;
@@ -122,11 +123,14 @@ __global__ void __launch_bounds__(256) gn_apply_kernel(const f16* __restrict__ x
     for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + tid; idx < total; idx += (int64_t)gridDim.x * blockDim.x) {
         const int c0 = (int)(idx % C8) * 8;
         const f16x8 v = *reinterpret_cast<const f16x8*>(xb + idx * 8);
+        f16x8 r = {0, 0, 0, 0, 0, 0, 0, 0}, a = {0, 0, 0, 0, 0, 0, 0, 0};
+        if (residual) r = *reinterpret_cast<const f16x8*>(residual + (int64_t)n * HW * C + idx * 8);
+        if (accum) a = *reinterpret_cast<const f16x8*>(accum + (int64_t)n * HW * C + idx * 8);
         f16x8 o;
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
-            const float t = (float)v[i] * scale[c0 + i] + shift[c0 + i];
-            o[i] = (f16)act_apply(t, act);
+            const float t = (float)v[i] * scale[c0 + i] + shift[c0 + i] + (float)r[i];   // y = act(gn(x) + residual) + accum
+            o[i] = (f16)(act_apply(t, act) + (float)a[i]);
         }
         *reinterpret_cast<f16x8*>(yb + idx * 8) = o;
     }
@@ -217,8 +221,17 @@ __global__ void __launch_bounds__(256) layer_norm_kernel(const f16* __restrict__
 
 }  // namespace odise
 
+extern "C" int odise_hip_group_norm_ex(odise_hip_ctx* ctx, const void* x, void* y, const float* gamma, const float* beta, int N,
+                                       int HW, int C, int groups, float eps, int act, const void* residual, const void* accum);
+
 extern "C" int odise_hip_group_norm(odise_hip_ctx* ctx, const void* x, void* y, const float* gamma, const float* beta, int N,
                                     int HW, int C, int groups, float eps, int act) {
+    return odise_hip_group_norm_ex(ctx, x, y, gamma, beta, N, HW, C, groups, eps, act, nullptr, nullptr);
+}
+
+// y = act(GroupNorm(x) + residual) + accum   (residual / accum: optional fp16 tensors shaped like x)
+extern "C" int odise_hip_group_norm_ex(odise_hip_ctx* ctx, const void* x, void* y, const float* gamma, const float* beta, int N,
+                                       int HW, int C, int groups, float eps, int act, const void* residual, const void* accum) {
     using namespace odise;
     ODISE_REQUIRE(ctx && x && y, "group_norm: null argument");
     ODISE_REQUIRE(N >= 0 && HW > 0 && C > 0 && groups > 0, "group_norm: bad dims");
@@ -245,7 +258,7 @@ extern "C" int odise_hip_group_norm(odise_hip_ctx* ctx, const void* x, void* y, 
     bpi = std::max(1, bpi);
     const size_t lds = (2 * (size_t)C + 2 * groups + 2) * sizeof(float) + 2 * 256 * sizeof(double);
     hipLaunchKernelGGL(gn_apply_kernel, dim3(bpi, N), dim3(256), lds, ctx->stream, (const f16*)x, (f16*)y, partial, gamma, beta, HW, C,
-                       groups, nchunks, eps, act);
+                       groups, nchunks, eps, act, (const f16*)residual, (const f16*)accum);
     ODISE_CHECK_HIP(hipGetLastError());
     return ODISE_OK;
 }
