@@ -204,6 +204,34 @@ int odise_hip_head_forward(odise_hip_ctx* ctx, const float* const* feats4, int B
                            float* mask_embed, float* mask_pooled, float* logit_scale);
 int odise_hip_maskgen_info(odise_hip_ctx* ctx, int* num_queries, int* hidden_dim, double* last_macs);
 
+/* ---- open-vocabulary classification (odise.py:285-323; clip.py:252-361; helper.py:79-109) ---------------------------- */
+/* weights: category_head.text_proj.{weight,bias}, category_head.null_embed (ODISE ckpt) + the CLIP tower of the extractor */
+int odise_hip_classify_build(odise_hip_ctx* ctx);
+/* vocabulary = CLIP text embeddings (HOST fp32) of the two prompt sets the reference builds per label tuple
+ * (category_head: plain labels; clip_head: "a photo of a {}."), K synonym groups of group_sizes[k] strings each,
+ * overlap[k] = 1 if the class overlaps a training class (category_overlapping_mask, odise.py:1479-1491), alpha/beta of clip_head */
+int odise_hip_set_vocabulary(odise_hip_ctx* ctx, const float* cat_text, const float* clip_text, int K_tot, int dim,
+                             const int* group_sizes, const int* overlap, int K, float alpha, float beta);
+/* image [B,3,H,W] fp32 device in [0,1]; uses the last head_forward; mask_cls [B,Q,K+1] fp32 device (log-probabilities);
+ * clip_embed (optional) [B,Q,dim] fp32 device = MaskCLIP.get_mask_embed */
+int odise_hip_classify(odise_hip_ctx* ctx, const float* image, int B, int H, int W, float* mask_cls, float* clip_embed);
+
+/* ---- post-processing (odise.py:326-370; maskformer_model.py:280-380) ------------------------------------------------- */
+/* fused mask upsample (x4 bilinear to pad_h x pad_w, crop img_h x img_w, bilinear to out_h x out_w) + sigmoid +
+ * semantic einsum + panoptic argmax and area counters for image b of the last head_forward.
+ *   kscore [Q] fp32 device: score of kept queries (label != null, score > object_mask_threshold), < 0 for dropped queries
+ *   semT   [K,Q] fp32 device = softmax(mask_cls)[:, :-1]^T, or NULL
+ *   sem_seg [K,out_h,out_w] fp32 / ids [out_h*out_w] int32 (kept-query index | 1<<16 if inside the mask, -1 if none) /
+ *   counts [3*Q] int32 (mask_area, original_area, intersection) / inst_stats [2*Qpad] fp32 (sum of prob over positive pixels,
+ *   positive pixel count; Qpad = Q rounded up to 8): device pointers, each optional */
+int odise_hip_postprocess_pixels(odise_hip_ctx* ctx, int b, const float* kscore, const float* semT, int K, int pad_h, int pad_w,
+                                 int img_h, int img_w, int out_h, int out_w, float* sem_seg, int* ids, int* counts, float* inst_stats);
+/* seg[p] = map[q] for pixels whose argmax query q is inside its own mask, else 0 (maskformer_model.py:321-333) */
+int odise_hip_panoptic_write(odise_hip_ctx* ctx, const int* ids, const int* map, int* seg, int npix);
+/* out [n,out_h,out_w] fp32 = (upsampled mask logit of query idx[i] > 0)  (maskformer_model.py:371) */
+int odise_hip_instance_masks(odise_hip_ctx* ctx, int b, const int* idx, int n, int pad_h, int pad_w, int img_h, int img_w, int out_h,
+                             int out_w, float* out);
+
 #ifdef __cplusplus
 }
 #endif

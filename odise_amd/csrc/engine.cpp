@@ -8,6 +8,7 @@ namespace odise {
 void unet_destroy(ModelStore* ms);       // unet.cpp
 void extractor_destroy(ModelStore* ms);  // extractor.cpp
 void maskgen_destroy(ModelStore* ms);    // maskgen.cpp
+void classify_destroy(ModelStore* ms);   // classify.cpp
 
 ModelStore* store_of(odise_hip_ctx* ctx) {
     if (!ctx->models) ctx->models = new ModelStore();
@@ -20,6 +21,7 @@ void models_destroy(odise_hip_ctx* ctx) {
     unet_destroy(ms);
     extractor_destroy(ms);
     maskgen_destroy(ms);
+    classify_destroy(ms);
     for (void* p : ms->dev_allocs) hipFree(p);
     if (ms->arena.base) hipFree(ms->arena.base);
     delete ms;

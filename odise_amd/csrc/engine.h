@@ -78,6 +78,7 @@ struct ModelStore {
     UNetModel* unet = nullptr;
     struct ExtractorModel* extractor = nullptr;
     struct MaskGenModel* maskgen = nullptr;
+    struct ClassifyModel* classify = nullptr;
     double macs = 0.0;  // analytic MACs of the ops launched since the last reset
 };
 
@@ -144,7 +145,10 @@ int launch_image_to_nhwc(odise_hip_ctx* ctx, const float* x, f16* y, int N, int 
                          const float* shift3);
 int launch_clip_preprocess(odise_hip_ctx* ctx, const float* x, f16* y, int N, int H, int W, int S);
 int launch_softmax_rows(odise_hip_ctx* ctx, const f16* x, f16* y, int64_t rows, int cols, int64_t ld, float scale);
-int launch_clip_assemble(odise_hip_ctx* ctx, const f16* patches, const float* cls, const float* pos, f16* tok, int B, int T, int Cw);
+int launch_clip_assemble(odise_hip_ctx* ctx, const f16* patches, const float* cls, const float* pos, f16* tok, int B, int T, int extra,
+                         int Cw);
+int clip_tower(Exec& ex, const Act& img, int extra, const uint8_t* mask, int64_t ldm, f16* out);
+int clip_dims(ModelStore* ms, int* image, int* patch, int* tokens, int* out_dim);
 int launch_cond_inputs(odise_hip_ctx* ctx, const float* proj, const float* A1, const float* A2, float* out, int B, int T, int Cw);
 
 
@@ -159,5 +163,34 @@ int launch_msda_prepare(odise_hip_ctx* ctx, const float* off, const float* aw, f
 int launch_bilinear_add(odise_hip_ctx* ctx, const f16* a, const f16* b, f16* y, int N, int H, int W, int OH, int OW, int C);
 int launch_mask_binarize_f16(odise_hip_ctx* ctx, const f16* mask, f16* m01, float* inv, int64_t rows, int HW);
 int launch_attn_mask(odise_hip_ctx* ctx, const f16* logits, uint8_t* out, int64_t rows, int H, int W, int oh, int ow, int64_t ldm);
+
+
+// classify_ops.hip
+struct PostGeom {
+    int h4, w4;      // mask logits resolution
+    int ph, pw;      // padded network input size (first bilinear target, odise.py:326-331)
+    int ih, iw;      // true image size (crop, sem_seg_postprocess)
+    int oh, ow;      // requested output size
+    int Q, Qpad;
+};
+int launch_resize_bilinear_norm(odise_hip_ctx* ctx, const float* x, f16* y, int B, int H, int W, int S);
+int launch_maskclip_token_mask(odise_hip_ctx* ctx, const f16* logits, uint8_t* out, int B, int Q, int h, int w, int S, int patch, int T,
+                               int64_t ldm);
+int launch_l2_normalize_f16(odise_hip_ctx* ctx, const f16* x, f16* y, int64_t rows, int C);
+int launch_l2_normalize_f32(odise_hip_ctx* ctx, const float* x, f16* y, int64_t rows, int C);
+int launch_classify_rows(odise_hip_ctx* ctx, const float* L1, const float* L2, const int* seg, const int* ovl, float* out, int64_t rows, int K,
+                         int Ktot, float ls1, float ls2, float alpha, float beta);
+int launch_postprocess_pixels(odise_hip_ctx* ctx, const f16* logits, const float* kscore, f16* S, int* ids, int* counts, const PostGeom& g);
+int launch_column_stats(odise_hip_ctx* ctx, const f16* S, float* partial, float* out2, int npix, int Qpad);
+int launch_panoptic_write(odise_hip_ctx* ctx, const int* ids, const int* map, int* seg, int npix);
+int launch_instance_masks(odise_hip_ctx* ctx, const f16* logits, const int* idx, float* out, int n, const PostGeom& g);
+// maskgen.cpp accessors used by classify.cpp
+struct HeadOutputs {
+    const f16* pred_masks;   // [B, Q, h4*w4] logits
+    const f16* mask_embed;   // [B, Q, C]
+    int B, Q, C, h4, w4;
+    float logit_scale;
+};
+int head_outputs(ModelStore* ms, HeadOutputs* out);
 
 }  // namespace odise

