@@ -1,16 +1,20 @@
 #!/usr/bin/env python3
 """bench.py — hot-path benchmark of the MI355X-native ODISE inference path.
 
-Round-1 workload (BASELINE.json configs[1]): SD-v1 UNet single-step feature extraction (LdmExtractor.unet_forward,
-odise/modeling/meta_arch/ldm.py:469-491), bs=1 512x512 crop (64x64 latent) per GPU, fp16 MFMA, synthetic
-SD-v1-shaped weights (859.5 M parameters, seed 1234) and synthetic inputs.  One "step" = one
-pass of the UNet tap extraction over `--crops` crops, inputs already resident in HBM.
+Default workload (BASELINE.json configs[2], the configuration the metric "panoptic-inference images/sec @1024x1024" is quoted on):
+full ODISE(label) panoptic inference, B=4 images of 1024x1024 per GPU per step, fp16 MFMA, COCO-133 vocabulary shape
+(133 classes / 254 prompt strings), semantic + panoptic + instance outputs on — CategoryODISE.forward eval branch
+(odise/modeling/meta_arch/odise.py:236-372).  One "step" = one pass of the whole path over the batch with the images already
+resident in HBM; results stay on the device like the reference's outputs.  Weights are random-init tensors of the real
+architectures (SD-v1 UNet 859.5M, AutoencoderKL, CLIP ViT-L/14@336, ODISE heads 28M; no network for checkpoints) and the
+vocabulary is a seeded random text bank of the real shape (the CLIP text tower is a later row of SURVEY.md §8f).
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--crops C] [--no-graph] [--no-cpu-baseline]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--images B] [--size S] [--stage full|unet] [--no-cpu-baseline]
 
-Multi-GPU: one process per GPU (torch.distributed.run), crops are independent units sharded across ranks with no
-data-path collective (weak scaling: fixed crops per GPU); the only collective is the timing barrier / max.
-Prints ONE JSON line on rank 0.
+`--stage unet` runs BASELINE configs[1] instead (SD-UNet single-step feature extraction, `--images` = crops of 512x512).
+Multi-GPU: one process per GPU (torch.distributed.run); images are independent units sharded across ranks with no collective
+inside the model forward; after the timed steps of the full path every rank all-gathers its panoptic prediction records over
+RCCL (one collective per step, inside the timed region).  Weak scaling: fixed images per GPU.  Prints ONE JSON line on rank 0.
 """
 import argparse
 import json
@@ -23,47 +27,68 @@ sys.path.insert(0, ROOT)
 
 import numpy as np  # noqa: E402
 
-# analytic work per 512x512 crop (SURVEY.md §8d / BASELINE.md §2)
-UNET_FLOPS_LIVE = 0.7401e12      # taps only (output_blocks[11] + out skipped — their results are discarded by the reference)
-UNET_FLOPS_REFERENCE = 0.8033e12  # as the reference executes it
-MFMA_F16_PEAK = 2.5e15           # dense fp16 MFMA, /opt/skills/guides/MI355X_MICROARCH.md
+# analytic live work (SURVEY.md §8d / BASELINE.md §2)
+FLOPS_PER_IMAGE_1024 = 12.5e12    # 4 crops x (CLIP 0.382 + VAE-enc 1.117 + UNet 0.740 + VAE-dec 0.623) + heads ~1.05 TFLOP
+UNET_FLOPS_LIVE = 0.7401e12
+MFMA_F16_PEAK = 2.5e15            # dense fp16 MFMA, /opt/skills/guides/MI355X_MICROARCH.md
 
 
 def parse():
     p = argparse.ArgumentParser()
     p.add_argument("--gpus", type=int, default=1)
-    p.add_argument("--steps", type=int, default=20)
-    p.add_argument("--warmup", type=int, default=5)
-    p.add_argument("--crops", type=int, default=1, help="512x512 crops per step per GPU (configs[1] = 1; a 1024^2 image = 4)")
-    p.add_argument("--no-graph", action="store_true", help="launch kernels eagerly instead of replaying the captured hipGraph")
+    p.add_argument("--steps", type=int, default=5)
+    p.add_argument("--warmup", type=int, default=2)
+    p.add_argument("--images", type=int, default=4, help="images (or 512^2 crops with --stage unet) per step per GPU")
+    p.add_argument("--size", type=int, default=1024)
+    p.add_argument("--stage", choices=["full", "unet"], default="full")
     p.add_argument("--no-cpu-baseline", action="store_true")
-    p.add_argument("--cpu-steps", type=int, default=2)
     return p.parse_args()
 
 
-def cpu_baseline(model, steps):
-    """The oracle restatement (kind='port') timed on the host cores: bounded sample = 1 warm-up + `steps` crops."""
-    import torch
-    from oracle.sd_unet import config2_inputs, unet_forward
+def _threads():
     try:
         avail = len(os.sched_getaffinity(0))
     except AttributeError:
         avail = os.cpu_count() or 1
-    cores = max(1, min(avail, 16))  # torch's intra-op pool stops scaling (and thrashes) far below a 256-thread host
+    return max(1, min(avail, 16))  # torch's intra-op pool stops scaling (and thrashes) far below a 256-thread host
+
+
+def cpu_baseline_full(ext):
+    """Oracle restatement (kind='port') on the host cores.  Bounded sample: ONE 512x512 crop through the feature extractor
+    (CLIP + VAE encoder + UNet + truncated VAE decoder = 2.86 of the 3.13 TFLOP a crop costs end to end, i.e. 92 % of an image's
+    work); images/s is extrapolated as crops/s / 4 and therefore an upper bound of the CPU rate."""
+    import torch
+    cores = _threads()
+    torch.set_num_threads(cores)
+    img = torch.rand(1, 3, 512, 512, generator=torch.Generator().manual_seed(0))
+    t0 = time.perf_counter()
+    ext(img)
+    dt = time.perf_counter() - t0
+    if dt < 8.0:  # fast host: take a second, warm sample
+        t0 = time.perf_counter()
+        ext(img)
+        dt = time.perf_counter() - t0
+    return {"value": 1.0 / dt / 4.0, "unit": "images/s", "cores": cores, "kind": "port",
+            "sample": "1 timed 512x512 crop through the fp32 torch CPU oracle of LdmImplicitCaptionerExtractor (92% of a 1024^2 image's "
+                      "work is 4 such crops); images/s = crops/s / 4, heads and post-processing excluded"}
+
+
+def cpu_baseline_unet(model):
+    import torch
+    from oracle.sd_unet import config2_inputs, unet_forward
+    cores = _threads()
     torch.set_num_threads(cores)
     x, context, cond_emb = config2_inputs(1, 64)
     t = torch.zeros(1, dtype=torch.long)
     t0 = time.perf_counter()
-    unet_forward(model, x, t, context, cond_emb)  # warm-up (also bounds the sample: a slow host gets 1 timed step)
-    warm = time.perf_counter() - t0
-    if warm > 12.0:
-        steps = 1
-    t0 = time.perf_counter()
-    for _ in range(steps):
+    unet_forward(model, x, t, context, cond_emb)
+    dt = time.perf_counter() - t0
+    if dt < 8.0:
+        t0 = time.perf_counter()
         unet_forward(model, x, t, context, cond_emb)
-    dt = (time.perf_counter() - t0) / steps
+        dt = time.perf_counter() - t0
     return {"value": 1.0 / dt, "unit": "crops/s", "cores": cores, "kind": "port",
-            "sample": f"{steps} timed UNet single-step forwards (bs=1, 64x64 latent, fp32 torch CPU oracle, live path) after 1 warm-up"}
+            "sample": "1 timed UNet single-step forward (bs=1, 64x64 latent, fp32 torch CPU oracle, live path)"}
 
 
 def main():
@@ -71,10 +96,11 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus and world > 1:
+    if world > 1 and world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
 
     import torch
+    torch.set_num_threads(_threads())
     dist = None
     if world > 1:
         import torch.distributed as dist
@@ -82,16 +108,77 @@ def main():
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
     from odise_amd.runtime import Context
-    from odise_amd.unet import HipUNet
-    from oracle.sd_unet import UNetModel, config2_inputs, init_synthetic_
-
     ctx = Context(local_rank)
-    # random-init weights of the SD-v1 UNet architecture (no network / checkpoints); identical on every rank
-    model = init_synthetic_(UNetModel(width_div=1), seed=1234).eval()
-    hip = HipUNet(ctx, model.state_dict(), use_graph=not args.no_graph)
-    B = args.crops
-    x, context, cond_emb = config2_inputs(B, 64)
-    dx, dc, de = ctx.to_device(x.numpy()), ctx.to_device(context.numpy()), ctx.to_device(cond_emb.numpy())
+    B = args.images
+
+    if args.stage == "unet":
+        from odise_amd.unet import HipUNet
+        from oracle.sd_unet import UNetModel, config2_inputs, init_synthetic_
+        model = init_synthetic_(UNetModel(width_div=1), seed=1234).eval()
+        hip = HipUNet(ctx, model.state_dict(), use_graph=True)
+        x, context, cond_emb = config2_inputs(B, 64)
+        dx, dc, de = ctx.to_device(x.numpy()), ctx.to_device(context.numpy()), ctx.to_device(cond_emb.numpy())
+        step = lambda: hip.run_nhwc(dx, dc, de, 0)
+        flops_per_unit, unit, metric = UNET_FLOPS_LIVE, "crops/s", "SD-UNet single-step feature extraction crops/sec (stage of panoptic-inference images/sec @1024x1024; UNet MFMA %peak)"
+        workload = (f"BASELINE configs[1]: SD-UNet single-step feature extraction, bs={B} x 512x512 crop (64x64 latent) per GPU, t=0, "
+                    "taps u2/u5/u8/u11; synthetic SD-v1-shaped weights (859.5M params, seed 1234); hipGraph replay")
+        baseline = (lambda: cpu_baseline_unet(model))
+        gather = None
+    else:
+        from odise_amd import distributed as D
+        from odise_amd.pipeline import HipCategoryODISE
+        from oracle import odise_model as om
+        from oracle.backbone import FeatureExtractorBackbone
+        from oracle.ldm_extractor import ImplicitCaptionerExtractor
+        from oracle.m2f import SemSegHead, init_synthetic_
+        S = args.size
+        K, K_TOT = 133, 254   # COCO panoptic: 133 classes, 254 prompt-engineered strings
+        ext = ImplicitCaptionerExtractor()
+        bb = FeatureExtractorBackbone(ext, [512, 512, 2560, 1920, 960, 640, 512, 512])
+        head = init_synthetic_(SemSegHead(num_classes=K))
+        rng = np.random.default_rng(7)
+        sizes = np.ones(K, np.int64)
+        for i in rng.integers(0, K, size=K_TOT - K):   # 254 strings over 133 synonym groups
+            sizes[i] += 1
+        heads = om.OpenVocabHeads(ext.clip, sizes.tolist(), projection_dim=256)
+        state = ext.export_state()
+        state.update({"backbone.feature_projections." + k: v for k, v in bb.feature_projections.state_dict().items()})
+        state.update({"sem_seg_head." + k: v for k, v in head.state_dict().items()})
+        state["category_head.text_proj.weight"] = heads.text_proj.weight.detach()
+        state["category_head.text_proj.bias"] = heads.text_proj.bias.detach()
+        state["category_head.null_embed"] = heads.null_embed.detach()
+        hip = HipCategoryODISE(ctx, state, overlap_threshold=0.8)
+        hip.set_vocabulary(heads.text_embed.numpy(), heads.clip_text_embed.numpy(), sizes.tolist(), heads.category_overlapping_mask.numpy(),
+                           set(range(80)), heads.alpha, heads.beta)
+        del state, bb, head
+        img = np.random.default_rng(rank).random((B, 3, S, S), dtype=np.float32)  # images shard across ranks: each rank has its own
+        d_img = ctx.to_device(img)
+        out_sizes = [(S, S)] * B
+        records = torch.zeros((B, D.record_size(S, S)), dtype=torch.int32, device="cuda" if world > 1 else "cpu")
+
+        hw = S * S
+
+        def step():
+            # with several ranks the panoptic maps are written straight into this rank's slice of the gather buffer
+            pan_out = [records[b].data_ptr() for b in range(B)] if dist is not None else None
+            res = hip.forward_device(d_img, d_img, out_sizes, to_host=False, pan_out=pan_out)
+            if dist is not None:  # the one exchange step of the path: every rank ends up with every image's panoptic record
+                for b, r in enumerate(res):
+                    table = torch.zeros(1 + D.MAX_SEGMENTS * 3, dtype=torch.int32)
+                    info = r["panoptic_seg"][1][: D.MAX_SEGMENTS]
+                    table[0] = len(info)
+                    for i, sgm in enumerate(info):
+                        table[1 + 3 * i: 4 + 3 * i] = torch.tensor([sgm["id"], int(sgm["isthing"]), sgm["category_id"]], dtype=torch.int32)
+                    records[b, hw:] = table.to(records.device)
+                ctx.sync()
+                D.allgather_records(records)
+            return res
+        flops_per_unit, unit, metric = FLOPS_PER_IMAGE_1024 * (S / 1024.0) ** 2, "images/s", "panoptic-inference images/sec @1024x1024"
+        workload = (f"BASELINE configs[2]: full ODISE(label) panoptic inference (CategoryODISE eval forward: 4 crops/image through CLIP+VAE+UNet, "
+                    f"projections, MSDeformAttn pixel decoder, 9-layer masked decoder, MaskCLIP, semantic+panoptic+instance post-processing), "
+                    f"bs={B} x {S}x{S} per GPU, vocabulary {K} classes/{K_TOT} strings; synthetic weights of the real shapes, random text bank")
+        baseline = (lambda: cpu_baseline_full(ext))
+        gather = True
 
     def barrier():
         ctx.sync()
@@ -100,16 +187,15 @@ def main():
             torch.cuda.synchronize()
 
     for _ in range(args.warmup):
-        hip.run_nhwc(dx, dc, de, 0)
+        step()
     barrier()
     t0 = time.perf_counter()
     ctx.timer_start()
     for _ in range(args.steps):
-        hip.run_nhwc(dx, dc, de, 0)
+        step()
     ev_ms = ctx.timer_stop()  # HIP events on the library's stream (synchronises)
     barrier()
     wall = time.perf_counter() - t0
-    macs = hip.last_macs()
 
     if dist is not None:
         tt = torch.tensor([wall, ev_ms], dtype=torch.float64, device="cuda")
@@ -118,49 +204,22 @@ def main():
 
     if rank == 0:
         ms_per_step = wall * 1e3 / args.steps
-        crops_per_s = world * B * args.steps / wall
+        value = world * B * args.steps / wall
         dev_name, cus, _ = ctx.device_info()
         step_ms_ev = ev_ms / args.steps
-        achieved = UNET_FLOPS_LIVE * B / (step_ms_ev * 1e-3) / 1e12  # TFLOP/s per GPU, live (non-dead) work only
+        achieved = flops_per_unit * B / (step_ms_ev * 1e-3) / 1e12  # TFLOP/s per GPU of live algorithmic work
         out = {
-            "metric": "SD-UNet single-step feature extraction crops/sec (hot-path stage of panoptic-inference images/sec @1024x1024; UNet MFMA %peak)",
-            "value": crops_per_s,
-            "unit": "crops/s",
-            "n_gpus": world,
-            "steps": args.steps,
-            "warmup": args.warmup,
-            "ms_per_step": ms_per_step,
-            "higher_is_better": True,
-            "scaling": "weak",
-            "vs_baseline": None,
-            "dtype": "f16",
-            "data": "synthetic",
-            "config": {
-                "workload": f"BASELINE configs[1]: SD-UNet single-step feature extraction, bs={B} x 512x512 crop (64x64 latent) per GPU, "
-                            "t=0, 77x768 context, taps u2/u5/u8/u11; synthetic SD-v1-shaped weights (859.5M params, seed 1234)",
-                "crops_per_step_per_gpu": B,
-                "images_1024_equiv_per_s": crops_per_s / 4.0,
-                "launch": "eager" if args.no_graph else "hipGraph replay",
-                "device": dev_name,
-                "compute_units": cus,
-                "parallelism": f"dp{world} (independent crops, no data-path collective)",
-            },
-            "roofline": {
-                "bound": "mfma",
-                "achieved": achieved,
-                "peak": MFMA_F16_PEAK / 1e12,
-                "unit": "TFLOP/s",
-                "frac": achieved * 1e12 / MFMA_F16_PEAK,
-                "traffic": None,
-                "kernel": "whole UNet step (MFMA implicit-GEMM conv / GEMM / attention kernels; HIP events over the timed region)",
-                "algorithmic_flops_per_crop": UNET_FLOPS_LIVE,
-                "reference_equivalent_flops_per_crop": UNET_FLOPS_REFERENCE,
-                "launched_macs_per_step": macs,
-                "event_ms_per_step": step_ms_ev,
-            },
+            "metric": metric, "value": value, "unit": unit, "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f16", "data": "synthetic",
+            "config": {"workload": workload, "units_per_step_per_gpu": B, "device": dev_name, "compute_units": cus,
+                       "parallelism": f"dp{world} (independent images, one RCCL all-gather of predictions per step)" if gather else f"dp{world}"},
+            "roofline": {"bound": "mfma", "achieved": achieved, "peak": MFMA_F16_PEAK / 1e12, "unit": "TFLOP/s", "frac": achieved * 1e12 / MFMA_F16_PEAK,
+                         "traffic": None,
+                         "kernel": "whole step (dominant kernel family: MFMA implicit-GEMM conv / GEMM gemm_kernel<...>; see profiles/)",
+                         "algorithmic_flops_per_unit": flops_per_unit, "event_ms_per_step": step_ms_ev},
         }
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(model, args.cpu_steps)
+            out["cpu_baseline"] = baseline()
         print(json.dumps(out), flush=True)
     if dist is not None:
         dist.barrier()

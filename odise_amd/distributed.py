@@ -1,0 +1,68 @@
+"""Data-parallel sharding of the inference path: one process per GPU, images are independent units sharded
+contiguously across ranks (detectron2's InferenceSampler convention, odise/data/build.py:145-151), no collective inside the model
+forward, and exactly one exchange step: an all-gather of fixed-size per-image prediction records (RCCL `ncclAllGather` over xGMI when
+the process group is NCCL; gloo on CPU in the tests), replacing detectron2's pickled `comm.gather` at evaluation time.
+
+Record layout per image (all int32 so the gather is one contiguous buffer):
+    panoptic_seg [H, W] | n_segments | segments [MAX_SEGMENTS, 3] = (id, isthing, category_id)
+"""
+from __future__ import annotations
+
+from typing import List, Tuple
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+MAX_SEGMENTS = 100
+
+
+def shard_range(n_items: int, rank: int, world: int) -> Tuple[int, int]:
+    """Contiguous shard [begin, end) of rank (InferenceSampler: shard sizes differ by at most one)."""
+    base, rem = divmod(n_items, world)
+    begin = rank * base + min(rank, rem)
+    return begin, begin + base + (1 if rank < rem else 0)
+
+
+def record_size(h: int, w: int) -> int:
+    return h * w + 1 + MAX_SEGMENTS * 3
+
+
+def pack_record(panoptic_seg, segments_info, out: torch.Tensor) -> None:
+    """Fill one int32 record (a 1-D view of `out`) from a panoptic map (tensor/ndarray [H,W]) and its segments_info list."""
+    hw = out.numel() - 1 - MAX_SEGMENTS * 3
+    seg = torch.as_tensor(panoptic_seg).reshape(-1).to(out.dtype)
+    assert seg.numel() == hw, (seg.numel(), hw)
+    out[:hw] = seg.to(out.device)
+    n = min(len(segments_info), MAX_SEGMENTS)
+    table = torch.zeros(1 + MAX_SEGMENTS * 3, dtype=out.dtype)
+    table[0] = n
+    for i, s in enumerate(segments_info[:n]):
+        table[1 + 3 * i: 4 + 3 * i] = torch.tensor([int(s["id"]), int(bool(s["isthing"])), int(s["category_id"])], dtype=out.dtype)
+    out[hw:] = table.to(out.device)
+
+
+def unpack_record(rec: torch.Tensor, h: int, w: int):
+    rec = rec.cpu()
+    seg = rec[: h * w].reshape(h, w).numpy().astype(np.int32)
+    n = int(rec[h * w])
+    t = rec[h * w + 1: h * w + 1 + 3 * n].reshape(n, 3).tolist()
+    return seg, [{"id": a, "isthing": bool(b), "category_id": c} for a, b, c in t]
+
+
+def allgather_records(local: torch.Tensor) -> torch.Tensor:
+    """local [n_local, record] int32 on the rank's device -> [world * n_max, record] (ranks padded to the largest shard with -1 rows).
+    One collective for the size vector (8 bytes per rank) and one all-gather of the payload."""
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+        return local
+    world = dist.get_world_size()
+    n = torch.tensor([local.shape[0]], dtype=torch.int64, device=local.device)
+    sizes = [torch.zeros_like(n) for _ in range(world)]
+    dist.all_gather(sizes, n)
+    n_max = int(max(int(s) for s in sizes))
+    padded = torch.full((n_max, local.shape[1]), -1, dtype=local.dtype, device=local.device)
+    padded[: local.shape[0]] = local
+    out = torch.empty((world * n_max, local.shape[1]), dtype=local.dtype, device=local.device)
+    dist.all_gather_into_tensor(out, padded)
+    keep = torch.cat([torch.arange(int(s)) + r * n_max for r, s in enumerate(sizes)]).to(local.device)
+    return out[keep]

@@ -66,15 +66,15 @@ class HipODISE:
         return {k: o.numpy() for k, o in zip(("s2", "s3", "s4", "s5"), outs)}
 
     # ---- MaskFormerHead.layers ------------------------------------------------------------------------------------------------
-    def head_device(self, feats: Optional[list], B: int, H4: int, W4: int, cin: int = 512):
+    def head_device(self, feats: Optional[list], B: int, H4: int, W4: int, cin: int = 512, want_outputs: bool = True):
         Q, Cd = self.num_queries, self.hidden_dim
-        pm = self.ctx.empty((B, Q, H4, W4), np.float32)
-        me = self.ctx.empty((B, Q, Cd), np.float32)
-        mp = self.ctx.empty((B, Q, Cd), np.float32)
+        pm = self.ctx.empty((B, Q, H4, W4), np.float32) if want_outputs else None
+        me = self.ctx.empty((B, Q, Cd), np.float32) if want_outputs else None
+        mp = self.ctx.empty((B, Q, Cd), np.float32) if want_outputs else None
         ls = C.c_float()
         arr = (C.c_void_p * 4)(*[f.ptr for f in feats]) if feats is not None else None
-        check(self.ctx.lib.odise_hip_head_forward(self.ctx.h, arr, B, cin, H4, W4, C.c_void_p(pm.ptr), C.c_void_p(me.ptr), C.c_void_p(mp.ptr),
-                                                   C.byref(ls)), "head_forward")
+        p = lambda a: C.c_void_p(a.ptr) if a is not None else None
+        check(self.ctx.lib.odise_hip_head_forward(self.ctx.h, arr, B, cin, H4, W4, p(pm), p(me), p(mp), C.byref(ls)), "head_forward")
         return pm, me, mp, float(ls.value)
 
     def head(self, features: Optional[Dict[str, np.ndarray]] = None, image_hw=None) -> Dict[str, np.ndarray]:
@@ -145,8 +145,10 @@ class HipCategoryODISE(HipODISE):
                                                C.c_void_p(ce.ptr) if ce is not None else None), "classify")
         return (out, ce) if want_clip_embed else out
 
-    def postprocess_image(self, b: int, mask_cls: np.ndarray, pad_hw, img_hw, out_hw) -> dict:
-        """Post-processing of image b (odise.py:336-370) from its mask_cls [Q,K+1] (host) and the device-resident mask logits."""
+    def postprocess_image(self, b: int, mask_cls: np.ndarray, pad_hw, img_hw, out_hw, to_host: bool = True, pan_out=None) -> dict:
+        """Post-processing of image b (odise.py:336-370) from its mask_cls [Q,K+1] (host) and the device-resident mask logits.
+        to_host=False keeps the large results (sem_seg, panoptic map, instance masks) on the device as DeviceArrays, like the
+        reference, whose outputs are device tensors."""
         ctx, lib = self.ctx, self.ctx.lib
         Q, K = self.num_queries, self.num_classes
         oh, ow = out_hw
@@ -165,7 +167,7 @@ class HipCategoryODISE(HipODISE):
                                                p(counts), p(inst)), "postprocess_pixels")
         result = {}
         if self.semantic_on:
-            result["sem_seg"] = sem.numpy()
+            result["sem_seg"] = sem.numpy() if to_host else sem
         if self.panoptic_on:
             cnt = counts.numpy()
             seg_map = np.zeros(Q, np.int32)
@@ -185,10 +187,11 @@ class HipCategoryODISE(HipODISE):
                     current += 1
                     seg_map[q] = current
                     segments_info.append({"id": current, "isthing": bool(isthing), "category_id": pred_class})
-            seg = ctx.empty((oh, ow), np.int32)
+            seg = ctx.empty((oh, ow), np.int32) if pan_out is None else None
             dmap = ctx.to_device(seg_map)
-            check(lib.odise_hip_panoptic_write(ctx.h, p(ids), p(dmap), p(seg), oh * ow), "panoptic_write")
-            result["panoptic_seg"] = (seg.numpy(), segments_info)
+            dst = p(seg) if seg is not None else C.c_void_p(int(pan_out))   # optionally write into a caller-owned buffer (gather slice)
+            check(lib.odise_hip_panoptic_write(ctx.h, p(ids), p(dmap), dst, oh * ow), "panoptic_write")
+            result["panoptic_seg"] = ((seg.numpy() if to_host else seg) if seg is not None else None, segments_info)
         if self.instance_on:
             sc = probs[:, :-1].reshape(-1)                                                  # maskformer_model.py:349-357
             topk = min(self.test_topk_per_image, sc.size)
@@ -205,9 +208,19 @@ class HipCategoryODISE(HipODISE):
                 didx = ctx.to_device(qidx.astype(np.int32))
                 check(lib.odise_hip_instance_masks(ctx.h, b, p(didx), len(qidx), pad_hw[0], pad_hw[1], img_hw[0], img_hw[1], oh, ow, p(masks)),
                       "instance_masks")
-            result["instances"] = {"pred_masks": masks.numpy(), "scores": (s * mask_scores).astype(np.float32), "pred_classes": cls.astype(np.int64),
+            result["instances"] = {"pred_masks": masks.numpy() if to_host else masks, "scores": (s * mask_scores).astype(np.float32), "pred_classes": cls.astype(np.int64),
                                    "query_index": qidx}
         return result
+
+    def forward_device(self, padded: DeviceArray, img01: DeviceArray, out_sizes, to_host: bool = False, pan_out=None) -> list:
+        """Hot path with inputs already resident in HBM: padded [B,3,Hp,Wp] and img01 [B,3,H,W] fp32 in [0,1]."""
+        B, _, Hp, Wp = padded.shape
+        H, W = img01.shape[-2:]
+        self.backbone_device(padded, want_outputs=False)
+        self.head_device(None, B, Hp // 4, Wp // 4, want_outputs=False)
+        mask_cls = self.classify_device(img01).numpy()
+        return [self.postprocess_image(b, mask_cls[b], (Hp, Wp), (H, W), out_sizes[b], to_host=to_host,
+                                       pan_out=pan_out[b] if pan_out is not None else None) for b in range(B)]
 
     def forward(self, batched_inputs) -> list:
         """CategoryODISE.forward, eval branch (odise.py:236-246, 282-372) for a batch of equally sized images."""

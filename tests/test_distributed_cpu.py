@@ -1,0 +1,75 @@
+"""CPU (gloo, world_size 2): the data-parallel sharding and the single prediction all-gather of the inference path."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from odise_amd import distributed as D
+
+
+def test_shard_ranges_cover_everything_contiguously():
+    for n in (0, 1, 7, 8, 9, 100):
+        for world in (1, 2, 3, 8):
+            spans = [D.shard_range(n, r, world) for r in range(world)]
+            assert spans[0][0] == 0 and spans[-1][1] == n
+            assert all(a[1] == b[0] for a, b in zip(spans, spans[1:]))
+            sizes = [e - b for b, e in spans]
+            assert max(sizes) - min(sizes) <= 1
+
+
+def test_record_roundtrip():
+    h, w = 6, 5
+    seg = np.arange(h * w, dtype=np.int32).reshape(h, w) % 4
+    info = [{"id": 1, "isthing": True, "category_id": 17}, {"id": 2, "isthing": False, "category_id": 120}]
+    rec = torch.zeros(D.record_size(h, w), dtype=torch.int32)
+    D.pack_record(seg, info, rec)
+    seg2, info2 = D.unpack_record(rec, h, w)
+    np.testing.assert_array_equal(seg, seg2)
+    assert info == info2
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, n_images, h, w, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    b, e = D.shard_range(n_images, rank, world)
+    local = torch.zeros((e - b, D.record_size(h, w)), dtype=torch.int32)
+    for i, img in enumerate(range(b, e)):   # "prediction" of image `img`: a map filled with img+1 and one segment per image
+        D.pack_record(np.full((h, w), img + 1, np.int32), [{"id": 1, "isthing": bool(img % 2), "category_id": img}], local[i])
+    allrec = D.allgather_records(local)
+    q.put((rank, allrec.clone()))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("n_images", [4, 5])
+def test_allgather_predictions_gloo_world2(n_images):
+    h, w, world = 4, 3, 2
+    port = _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, n_images, h, w, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    results = dict(q.get(timeout=120) for _ in range(world))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for r in range(world):
+        rec = results[r]
+        assert rec.shape == (n_images, D.record_size(h, w))      # every rank holds every image, in global order
+        for img in range(n_images):
+            seg, info = D.unpack_record(rec[img], h, w)
+            assert (seg == img + 1).all()
+            assert info == [{"id": 1, "isthing": bool(img % 2), "category_id": img}]
