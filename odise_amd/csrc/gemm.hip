@@ -41,6 +41,7 @@ struct GemmEpi {
 
 struct ConvGeom {
     int H, W, Cin, KH, KW, stride, pad_t, pad_l, OH, OW, ups;
+    int chunk_major;  // K-tiles walk (Cin chunk outer, tap inner): see prep_tile
 };
 
 struct GemmArgs {
@@ -280,7 +281,20 @@ __global__ void __launch_bounds__(64 * WAVES_M * WAVES_N) gemm_kernel(GemmArgs g
     auto prep_tile = [&](int kt) {
         tk_k = kt * BK + ls * 8;
         tk_ok = tk_k < g.K;
-        if (CONV) {
+        if (CONV && g.cg.chunk_major) {
+            // Cin % 64 == 0: visit the KH*KW taps of one 64-channel chunk back to back.  Consecutive K-tiles then read the
+            // same input pixels shifted by one column (or one row every KW tiles), so the shifted re-reads hit the XCD's L2
+            // instead of coming back from the Infinity Cache after Cin/64 K-tiles of other traffic (4 MiB L2 holds ~4 K-tile
+            // steps of the 32 co-resident blocks).  Only the fp32 summation order changes.
+            const int taps = g.cg.KH * g.cg.KW;
+            const int chunk = kt / taps;
+            const int tap = kt - chunk * taps;
+            tk_c = chunk * BK + ls * 8;
+            tk_ky = tap / g.cg.KW;
+            tk_kx = tap - tk_ky * g.cg.KW;
+            tk_k = tap * g.cg.Cin + tk_c;
+            tk_ok = true;
+        } else if (CONV) {
             tk_ky = tk_kx = tk_c = 0;
             if (tk_ok) {
                 const int tap = tk_k / g.cg.Cin;
@@ -494,6 +508,7 @@ static int launch_gemm_t(odise_hip_ctx* ctx, GemmArgs& g, int batch) {
 }
 
 static int g_gemm_debug = 0;  // see GemmArgs::dbg
+static int g_conv_flags = 0;  // tools only: 1 = tap-major K order even when Cin % 64 == 0
 
 // Tile ids: 0:128x128 1:64x128 2:64x64 (4 waves)  3:256x320 4:256x256 5:256x128 (8 waves)
 static const int kTileBM[6] = {128, 64, 64, 256, 256, 256};
@@ -638,6 +653,7 @@ int conv_forced(odise_hip_ctx* ctx, const odise_conv_desc* d, int force_tile, in
     g.cg.H = d->H; g.cg.W = d->W; g.cg.Cin = d->Cin; g.cg.KH = d->KH; g.cg.KW = d->KW;
     g.cg.stride = d->stride; g.cg.pad_t = d->pad_t; g.cg.pad_l = d->pad_l; g.cg.OH = d->OH; g.cg.OW = d->OW;
     g.cg.ups = d->upsample2x;
+    g.cg.chunk_major = (d->Cin % 64 == 0 && d->KH * d->KW > 1 && !(g_conv_flags & 1)) ? 1 : 0;
     // a 1x1 stride-1 unpadded conv is a plain GEMM over pixels
     if (d->KH == 1 && d->KW == 1 && d->stride == 1 && d->pad_t == 0 && d->pad_l == 0 && !d->upsample2x && d->OH == d->H &&
         d->OW == d->W) {
@@ -649,7 +665,7 @@ int conv_forced(odise_hip_ctx* ctx, const odise_conv_desc* d, int force_tile, in
 
 }  // namespace odise
 
-extern "C" int odise_hip_gemm_debug(int flags) { odise::g_gemm_debug = flags; return 0; }
+extern "C" int odise_hip_gemm_debug(int flags) { odise::g_gemm_debug = flags & 15; odise::g_conv_flags = flags >> 4; return 0; }
 extern "C" int odise_hip_gemm(odise_hip_ctx* ctx, const odise_gemm_desc* d) { return odise::gemm_forced(ctx, d, -1, 0); }
 extern "C" int odise_hip_conv2d(odise_hip_ctx* ctx, const odise_conv_desc* d) { return odise::conv_forced(ctx, d, -1, 0); }
 // test hooks: force a tile shape (0:128x128, 1:64x128, 2:64x64) and/or a split-K factor
