@@ -186,6 +186,69 @@ __device__ __forceinline__ void epi_fast8(const GemmEpi& e, float (&v)[8], int m
     *reinterpret_cast<f16x8*>((f16*)e.C + (int64_t)z * e.strideC + (int64_t)m * e.ldc + n) = t;
 }
 
+// ---- epilogue through LDS: passes of 64 rows (two wave-rows x one 32-row MFMA tile) x BN fp32.  The caller guarantees that every
+// wave is done with the operand tiles (barrier) and that no LDS-DMA is outstanding.
+template <int BM, int BN, int WAVES_M, int WAVES_N>
+__device__ __forceinline__ void gemm_epilogue(const GemmArgs& g, f32x16 (&acc)[BM / WAVES_M / 32][BN / WAVES_N / 32], char* smem, int m0, int n0,
+                                              int z, int zb, bool split) {
+    constexpr int NT = 64 * WAVES_M * WAVES_N;
+    constexpr int WTM = BM / WAVES_M, WTN = BN / WAVES_N;
+    constexpr int TM = WTM / 32, TN = WTN / 32;
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+    const int wm = wave / WAVES_N, wn = wave % WAVES_N;
+    const int hi = lane >> 5, l31 = lane & 31;
+    constexpr int LDS_LD = BN + 4;
+    constexpr int CH = BN / 8;
+    float* stg = reinterpret_cast<float*>(smem);
+#pragma unroll
+    for (int gp = 0; gp < WAVES_M / 2; ++gp) {
+#pragma unroll
+        for (int p = 0; p < TM; ++p) {
+            if (gp > 0 || p > 0) lds_barrier();  // staging reads of the previous pass are done (global stores may still fly)
+            if ((wm >> 1) == gp) {
+#pragma unroll
+                for (int j = 0; j < TN; ++j) {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int row = (wm & 1) * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+                        const int col = wn * WTN + j * 32 + l31;
+                        stg[row * LDS_LD + col] = acc[p][j][r];
+                    }
+                }
+            }
+            lds_barrier();
+            for (int c = tid; c < 64 * CH; c += NT) {
+                const int row = c / CH;
+                const int c8 = c - row * CH;
+                const int m = m0 + (gp * 2 + (row >> 5)) * WTM + p * 32 + (row & 31);
+                const int n = n0 + c8 * 8;
+                if (m < g.M && n < g.N) {
+                    float v[8];
+                    const float4 t0 = *reinterpret_cast<const float4*>(&stg[row * LDS_LD + c8 * 8]);
+                    const float4 t1 = *reinterpret_cast<const float4*>(&stg[row * LDS_LD + c8 * 8 + 4]);
+                    v[0] = t0.x; v[1] = t0.y; v[2] = t0.z; v[3] = t0.w;
+                    v[4] = t1.x; v[5] = t1.y; v[6] = t1.z; v[7] = t1.w;
+                    if (split) {
+                        float* w = g.ws + ((int64_t)z * g.M + m) * g.N + n;
+                        const int nv = (g.N - n) < 8 ? (g.N - n) : 8;
+                        if (nv == 8 && (g.N & 3) == 0) {
+                            *reinterpret_cast<float4*>(w) = t0;
+                            *reinterpret_cast<float4*>(w + 4) = t1;
+                        } else {
+                            for (int i = 0; i < nv; ++i) w[i] = v[i];
+                        }
+                    } else if (!(g.dbg & 8) || v[0] == 12345.678f) {  // dbg 8: ablate the global store + epilogue math
+                        if (g.epi.fast && n + 8 <= g.N) epi_fast8(g.epi, v, m, n, zb);
+                        else epi_store8(g.epi, v, m, n, g.N, zb);
+                    }
+                }
+            }
+        }
+    }
+}
+
 template <int BM, int BN, int WAVES_M, int WAVES_N, bool CONV, bool INTERLEAVE>
 __global__ void __launch_bounds__(64 * WAVES_M * WAVES_N) gemm_kernel(GemmArgs g) {
     constexpr int BK = 64;
@@ -401,55 +464,317 @@ __global__ void __launch_bounds__(64 * WAVES_M * WAVES_N) gemm_kernel(GemmArgs g
     __syncthreads();  // every wave is done with the operand tiles before the staging buffer is reused
     if (g.dbg & 4) return;  // ablation: main loop only
 
-    // ---- epilogue through LDS: passes of 64 rows (two wave-rows x one 32-row MFMA tile) x BN fp32 -------------------
-    constexpr int LDS_LD = BN + 4;
-    constexpr int CH = BN / 8;
-    float* stg = reinterpret_cast<float*>(smem);
+    gemm_epilogue<BM, BN, WAVES_M, WAVES_N>(g, acc, smem, m0, n0, z, zb, split);
+}
+
+template <int N>
+__device__ __forceinline__ void wait_vmcnt() {
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+
+// ---- Ping-pong pipelined variant of the 256 x BN tile (BN = 256 / 320, 8 waves as 4(M) x 2(N), K % 64 == 0) ---------------------
+// The plain kernel above drains every LDS-DMA at each K-tile boundary (vmcnt(0) + barrier) and all 8 waves read fragments,
+// multiply and wait in lockstep: the matrix pipe idles while operands are fetched and vice versa (measured: 22 % of the time is
+// DMA wait, 8 % fragment reads).  Here
+//   * a K-tile is consumed in NP phases of two 32-column N-tiles of each wave (A fragments of the whole K-tile are read in phase
+//     0 and kept in VGPRs, B fragments per phase), so the A rows and the B rows of a stage are released progressively and refilled
+//     with K-tile t+2 while K-tile t+1 is multiplied: 1 to 1.5 K-tiles of LDS-DMA stay in flight ACROSS the barriers, retired by
+//     counted `s_waitcnt vmcnt(N)` (never 0 in steady state);
+//   * the waves form two groups (wm 0-1 / wm 2-3 = the two waves of every SIMD) staggered by one barrier: while one group issues its
+//     16 MFMAs (s_setprio 1), the other reads its next fragments and issues its share of the DMA, then they swap.
+// Every phase is  {ds_read fragments, issue DMA group, vmcnt(allowed), lgkmcnt(0)} barrier {MFMA} barrier.
+// Hazards: (RAW) the vmcnt before barrier A of phase q covers what phase q+1 reads, so both groups have waited for their share and
+// passed a barrier before anyone reads it; (WAR) fragment reads are retired (lgkmcnt(0)) before barrier A, refills of those rows
+// are issued one phase later at the earliest, i.e. after a barrier both groups passed.
+// DMA groups of the tile sequence (per thread: 4 A loads, TN B loads; B piece j = the rows of N-tile j of both wave columns):
+//   NP = 2: (t,0) issues B0..B3 of tile t+1, (t,1) issues A0..A3 of tile t+2
+//   NP = 3: (t,0) issues B2,B3,B4 of tile t+1, (t,1) issues A0,A1,A2 of tile t+2, (t,2) issues A3,B0,B1 of tile t+2
+template <int BN, int PT, bool CONV>
+__global__ void __launch_bounds__(512) gemm_pp_kernel(GemmArgs g) {
+    constexpr int BM = 256, BK = 64, WAVES_M = 4, WAVES_N = 2;
+    constexpr int WTN = BN / WAVES_N;
+    constexpr int TM = 2, TN = WTN / 32;
+    constexpr int NP = (TN + PT - 1) / PT;   // phases per K-tile (PT N-tiles of the wave each)
+    constexpr int NL = 4 + TN;               // LDS-DMA loads per thread per K-tile
+    constexpr int LPP = (NL + NP - 1) / NP;  // loads per phase
+    constexpr int A_BYTES = BM * BK * 2, B_BYTES = BN * BK * 2, STAGE_BYTES = A_BYTES + B_BYTES;
+    static_assert(PT == 1 || PT == 2, "one or two N-tiles per phase");
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 1, wn = wave & 1;
+    const int grp = wave >> 2;  // waves w and w+4 share a SIMD
+    const int hi = lane >> 5, l31 = lane & 31;
+    int bx, by;
+    {
+        const int nbx = gridDim.x, nb = gridDim.x * gridDim.y;
+        const int bid = blockIdx.y * nbx + blockIdx.x;
+        const int q = nb >> 3, r = nb & 7;
+        const int xcd = bid & 7, idx = bid >> 3;
+        const int logical = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+        by = logical / nbx;
+        bx = logical - by * nbx;
+    }
+    const int m0 = by * BM;
+    const int n0 = bx * BN;
+    const int z = blockIdx.z;
+    const bool split = g.splitk > 1;
+    const int zb = split ? 0 : z;
+    const int nk_total = g.K / BK;
+    int kt_begin = 0, kt_end = nk_total;
+    if (split) {
+        kt_begin = z * g.ktiles_per_split;
+        kt_end = kt_begin + g.ktiles_per_split;
+        if (kt_end > nk_total) kt_end = nk_total;
+    }
+    const f16* Ab = g.A + (int64_t)zb * g.strideA;
+    const f16* Wb = g.W + (int64_t)zb * g.strideW;
+
+    // ---- per-lane DMA descriptors: lane fills physical 16-byte slot (lane & 7) of row (8*wave + lane/8) of every 64-row piece
+    // and fetches logical slot ls (XOR swizzle on the source, see gemm_kernel)
+    const int rbase = wave * 8 + (lane >> 3);
+    const int ls = (lane & 7) ^ ((rbase >> 1) & 7);
+    int64_t a_off[4];
+    int a_iy0[4], a_ix0[4];  // conv: top-left input coordinate of the row's window; rows >= M get iy0 far out of range
 #pragma unroll
-    for (int gp = 0; gp < WAVES_M / 2; ++gp) {
-#pragma unroll
-        for (int p = 0; p < TM; ++p) {
-            if (gp > 0 || p > 0) lds_barrier();  // staging reads of the previous pass are done (global stores may still fly)
-            if ((wm >> 1) == gp) {
-#pragma unroll
-                for (int j = 0; j < TN; ++j) {
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) {
-                        const int row = (wm & 1) * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
-                        const int col = wn * WTN + j * 32 + l31;
-                        stg[row * LDS_LD + col] = acc[p][j][r];
-                    }
-                }
-            }
-            lds_barrier();
-            for (int c = tid; c < 64 * CH; c += NT) {
-                const int row = c / CH;
-                const int c8 = c - row * CH;
-                const int m = m0 + (gp * 2 + (row >> 5)) * WTM + p * 32 + (row & 31);
-                const int n = n0 + c8 * 8;
-                if (m < g.M && n < g.N) {
-                    float v[8];
-                    const float4 t0 = *reinterpret_cast<const float4*>(&stg[row * LDS_LD + c8 * 8]);
-                    const float4 t1 = *reinterpret_cast<const float4*>(&stg[row * LDS_LD + c8 * 8 + 4]);
-                    v[0] = t0.x; v[1] = t0.y; v[2] = t0.z; v[3] = t0.w;
-                    v[4] = t1.x; v[5] = t1.y; v[6] = t1.z; v[7] = t1.w;
-                    if (split) {
-                        float* w = g.ws + ((int64_t)z * g.M + m) * g.N + n;
-                        const int nv = (g.N - n) < 8 ? (g.N - n) : 8;
-                        if (nv == 8 && (g.N & 3) == 0) {
-                            *reinterpret_cast<float4*>(w) = t0;
-                            *reinterpret_cast<float4*>(w + 4) = t1;
-                        } else {
-                            for (int i = 0; i < nv; ++i) w[i] = v[i];
-                        }
-                    } else if (!(g.dbg & 8) || v[0] == 12345.678f) {  // dbg 8: ablate the global store + epilogue math
-                        if (g.epi.fast && n + 8 <= g.N) epi_fast8(g.epi, v, m, n, zb);
-                        else epi_store8(g.epi, v, m, n, g.N, zb);
-                    }
-                }
-            }
+    for (int j = 0; j < 4; ++j) {
+        const int m = m0 + rbase + 64 * j;
+        const bool ok = m < g.M;
+        if (CONV) {
+            const int ohw = g.cg.OH * g.cg.OW;
+            const int mm = ok ? m : 0;
+            const int img = mm / ohw;
+            const int rem = mm - img * ohw;
+            const int oy = rem / g.cg.OW;
+            const int ox = rem - oy * g.cg.OW;
+            a_iy0[j] = ok ? oy * g.cg.stride - g.cg.pad_t : -(1 << 28);
+            a_ix0[j] = ox * g.cg.stride - g.cg.pad_l;
+            a_off[j] = ((int64_t)img * g.cg.H * g.cg.W + (int64_t)a_iy0[j] * g.cg.W + a_ix0[j]) * g.cg.Cin + ls * 8;
+        } else {
+            a_iy0[j] = ok ? 0 : -1;
+            a_ix0[j] = 0;
+            a_off[j] = (int64_t)m * g.lda + ls * 8;
         }
     }
+    // B piece j covers rows j*32 + 8*(wave&3) + lane/8 of wave column (wave>>2)
+    const int nb0 = n0 + (wave >> 2) * WTN + (wave & 3) * 8 + (lane >> 3);
+    const int64_t b_off0 = (int64_t)nb0 * g.ldw + ls * 8;
+    const int b_lds0 = ((wave >> 2) * WTN + (wave & 3) * 8) * 128;  // LDS byte offset of this wave's 8 rows inside piece 0
+
+    // K-tile position (wave-uniform, advanced incrementally: no divisions in the loop).  Conv taps are whole 64-channel chunks
+    // (Cin % 64 == 0), walked chunk-major or tap-major (see gemm_kernel::prep_tile).
+    struct TileK {
+        int ky, kx, c0;
+        int64_t a_delta;  // element offset added to a_off
+        int kw;           // element offset inside a weight row
+    };
+    auto finish = [&](TileK& t) {
+        if (CONV) {
+            t.a_delta = ((int64_t)t.ky * g.cg.W + t.kx) * g.cg.Cin + t.c0;
+            t.kw = (t.ky * g.cg.KW + t.kx) * g.cg.Cin + t.c0;
+        } else {
+            t.a_delta = t.c0;
+            t.kw = t.c0;
+        }
+    };
+    auto decode = [&](int kt) {
+        TileK t;
+        t.ky = t.kx = 0;
+        t.c0 = kt * BK;
+        if (CONV) {
+            int tap;
+            if (g.cg.chunk_major) {
+                const int taps = g.cg.KH * g.cg.KW;
+                const int chunk = kt / taps;
+                tap = kt - chunk * taps;
+                t.c0 = chunk * BK;
+            } else {
+                tap = (kt * BK) / g.cg.Cin;
+                t.c0 = kt * BK - tap * g.cg.Cin;
+            }
+            t.ky = tap / g.cg.KW;
+            t.kx = tap - t.ky * g.cg.KW;
+        }
+        finish(t);
+        return t;
+    };
+    auto advance = [&](TileK& t) {
+        if (CONV) {
+            if (g.cg.chunk_major) {
+                if (++t.kx == g.cg.KW) {
+                    t.kx = 0;
+                    if (++t.ky == g.cg.KH) { t.ky = 0; t.c0 += BK; }
+                }
+            } else {
+                t.c0 += BK;
+                if (t.c0 == g.cg.Cin) {
+                    t.c0 = 0;
+                    if (++t.kx == g.cg.KW) { t.kx = 0; ++t.ky; }
+                }
+            }
+        } else {
+            t.c0 += BK;
+        }
+        finish(t);
+    };
+    auto issue_A = [&](int j, int stage, const TileK& t) {
+        bool ok;
+        if (CONV) {
+            const int iy = a_iy0[j] + t.ky, ix = a_ix0[j] + t.kx;
+            ok = (unsigned)iy < (unsigned)g.cg.H && (unsigned)ix < (unsigned)g.cg.W;
+        } else {
+            ok = a_iy0[j] >= 0;
+        }
+        const f16* src = ok ? Ab + a_off[j] + t.a_delta : g.zeros;
+        glds16(src, smem + stage * STAGE_BYTES + (j * 64 + wave * 8) * 128);
+    };
+    auto issue_B = [&](int j, int stage, const TileK& t) {
+        const bool ok = (nb0 + j * 32) < g.N;
+        const f16* src = ok ? Wb + b_off0 + (int64_t)(j * 32) * g.ldw + t.kw : g.zeros;
+        glds16(src, smem + stage * STAGE_BYTES + A_BYTES + b_lds0 + j * 4096);
+    };
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    int koff[4];
+#pragma unroll
+    for (int s = 0; s < 4; ++s) koff[s] = ((s * 2 + hi) ^ ((l31 >> 1) & 7)) << 4;
+    const int a_lane_off = (wm * 64 + l31) * 128;
+    const int b_lane_off = A_BYTES + (wn * WTN + l31) * 128;
+
+    // load l of a K-tile: l < 4 -> A piece l, else B piece l-4; issued in slot l / LPP of the tile (see the schedule above)
+    auto issue = [&](int l, int stage, const TileK& t) {
+        if (l < 4) issue_A(l, stage, t);
+        else issue_B(l - 4, stage, t);
+    };
+    // ---- prologue: all of tile 0, and the slots of tile 1 that the steady state would have issued before phase (0,0)
+    TileK t1 = decode(kt_begin), t2;  // positions of K-tiles kt+1 and kt+2 while tile kt is multiplied
+    if (kt_begin < kt_end) {
+        const TileK t0 = t1;
+        advance(t1);
+#pragma unroll
+        for (int l = 0; l < NL; ++l) issue(l, 0, t0);
+        constexpr int pro1 = (NP - 1) * LPP < NL ? (NP - 1) * LPP : NL;
+        if (kt_begin + 1 < kt_end) {
+#pragma unroll
+            for (int l = 0; l < pro1; ++l) issue(l, 1, t1);
+            wait_vmcnt<NL + pro1 - (4 + PT)>();  // phase (0,0) needs A and the first PT B pieces of tile 0
+        } else {
+            wait_vmcnt<NL - (4 + PT)>();
+        }
+    }
+    t2 = t1;
+    advance(t2);
+    __builtin_amdgcn_s_barrier();
+    if (grp == 1) __builtin_amdgcn_s_barrier();  // stagger: group 1 runs one barrier interval behind group 0
+
+    f16x8 af[TM][4], bf[PT][4];
+    for (int kt = kt_begin; kt < kt_end; ++kt) {
+        const int cur = (kt - kt_begin) & 1;
+        const bool has1 = (kt + 1) < kt_end && !(g.dbg & 1), has2 = (kt + 2) < kt_end && !(g.dbg & 1);  // dbg 1: ablate the DMA
+        const char* fa = smem + cur * STAGE_BYTES + a_lane_off;
+        const char* fb = smem + cur * STAGE_BYTES + b_lane_off;
+        const bool rd = !(g.dbg & 2) || kt == kt_begin;  // dbg 2: ablate the fragment reads
+#pragma unroll
+        for (int p = 0; p < NP; ++p) {
+            const int j0 = PT * p;
+            const int nj = (j0 + PT <= TN) ? PT : (TN - j0);
+            // -------- load segment: fragments of this phase, one slot of DMA, counted wait for what the NEXT phase reads
+            if (p == 0 && rd) {
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int s = 0; s < 4; ++s) af[i][s] = *reinterpret_cast<const f16x8*>(fa + koff[s] + i * 4096);
+            }
+#pragma unroll
+            for (int jj = 0; jj < PT; ++jj)
+                if (jj < nj && rd) {
+#pragma unroll
+                    for (int s = 0; s < 4; ++s) bf[jj][s] = *reinterpret_cast<const f16x8*>(fb + koff[s] + (j0 + jj) * 4096);
+                }
+            // loads through index `need` (counted from A0 of tile kt) must have landed before the next phase reads
+            const int need = (p + 1 < NP) ? 4 + ((p + 2) * PT < TN ? (p + 2) * PT : TN) : NL + 4 + PT;
+            if (p == 0) {
+                if (has1) {
+#pragma unroll
+                    for (int l = 0; l < NL; ++l)
+                        if (l / LPP == NP - 1) issue(l, cur ^ 1, t1);
+                    wait_vmcnt<2 * NL - (4 + (2 * PT < TN ? 2 * PT : TN))>();
+                } else {
+                    wait_vmcnt<0>();
+                }
+            } else {
+                const int issued2 = (p * LPP < NL) ? p * LPP : NL;  // loads of tile kt+2 issued once this phase's slot is out
+                if (has2) {
+#pragma unroll
+                    for (int l = 0; l < NL; ++l)
+                        if (l / LPP == p - 1) issue(l, cur, t2);
+                    switch (2 * NL + issued2 - need) {  // compile-time after unrolling
+                        case 4: wait_vmcnt<4>(); break;
+                        case 5: wait_vmcnt<5>(); break;
+                        case 6: wait_vmcnt<6>(); break;
+                        case 7: wait_vmcnt<7>(); break;
+                        case 8: wait_vmcnt<8>(); break;
+                        case 9: wait_vmcnt<9>(); break;
+                        case 10: wait_vmcnt<10>(); break;
+                        case 11: wait_vmcnt<11>(); break;
+                        case 12: wait_vmcnt<12>(); break;
+                        case 13: wait_vmcnt<13>(); break;
+                        case 14: wait_vmcnt<14>(); break;
+                        case 15: wait_vmcnt<15>(); break;
+                        default: wait_vmcnt<0>(); break;
+                    }
+                } else if (has1) {
+                    switch (2 * NL - need) {
+                        case 1: wait_vmcnt<1>(); break;
+                        case 2: wait_vmcnt<2>(); break;
+                        case 3: wait_vmcnt<3>(); break;
+                        case 4: wait_vmcnt<4>(); break;
+                        case 8: wait_vmcnt<8>(); break;
+                        case 9: wait_vmcnt<9>(); break;
+                        case 10: wait_vmcnt<10>(); break;
+                        case 11: wait_vmcnt<11>(); break;
+                        default: wait_vmcnt<0>(); break;
+                    }
+                } else {
+                    wait_vmcnt<0>();
+                }
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_sched_barrier(0);
+            __builtin_amdgcn_s_barrier();
+            __builtin_amdgcn_sched_barrier(0);
+            // -------- MFMA segment
+            __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+            for (int s = 0; s < 4; ++s)
+#pragma unroll
+                for (int jj = 0; jj < PT; ++jj)
+                    if (jj < nj) {
+#pragma unroll
+                        for (int i = 0; i < TM; ++i)
+                            acc[i][j0 + jj] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[i][s], bf[jj][s], acc[i][j0 + jj], 0, 0, 0);
+                    }
+            __builtin_amdgcn_s_setprio(0);
+            __builtin_amdgcn_sched_barrier(0);
+            __builtin_amdgcn_s_barrier();
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        t1 = t2;
+        advance(t2);
+    }
+    if (grp == 0) __builtin_amdgcn_s_barrier();  // re-align the two groups
+    __syncthreads();
+    if (g.dbg & 4) return;
+    gemm_epilogue<BM, BN, WAVES_M, WAVES_N>(g, acc, smem, m0, n0, z, zb, split);
 }
 
 __global__ void __launch_bounds__(256) splitk_reduce_kernel(const float* __restrict__ ws, int splitk, int M, int N, GemmEpi e) {
@@ -507,8 +832,29 @@ static int launch_gemm_t(odise_hip_ctx* ctx, GemmArgs& g, int batch) {
     return ODISE_OK;
 }
 
+template <int BN, int PT, bool CONV>
+static int launch_gemm_pp(odise_hip_ctx* ctx, GemmArgs& g, int batch) {
+    constexpr int lds = 2 * (256 + BN) * 64 * 2;
+    auto kern = gemm_pp_kernel<BN, PT, CONV>;
+    static bool attr_set = false;  // per instantiation
+    if (!attr_set) {
+        ODISE_CHECK_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+        attr_set = true;
+    }
+    dim3 grid((unsigned)ceil_div(g.N, BN), (unsigned)ceil_div(g.M, 256), (unsigned)(g.splitk > 1 ? g.splitk : batch));
+    hipLaunchKernelGGL(kern, grid, dim3(512), lds, ctx->stream, g);
+    ODISE_CHECK_HIP(hipGetLastError());
+    if (g.splitk > 1) {
+        const int64_t total = (int64_t)g.M * ceil_div(g.N, 8);
+        const int blocks = (int)std::min<int64_t>(ceil_div(total, 256), 2048);
+        hipLaunchKernelGGL(splitk_reduce_kernel, dim3(blocks), dim3(256), 0, ctx->stream, g.ws, g.splitk, g.M, g.N, g.epi);
+        ODISE_CHECK_HIP(hipGetLastError());
+    }
+    return ODISE_OK;
+}
+
 static int g_gemm_debug = 0;  // see GemmArgs::dbg
-static int g_conv_flags = 0;  // tools only: 1 = tap-major K order even when Cin % 64 == 0
+static int g_conv_flags = 0;  // tools only: 1 = tap-major K order even when Cin % 64 == 0, 2 = never use the ping-pong kernel, 4 = one N-tile per phase at BN = 256
 
 // Tile ids: 0:128x128 1:64x128 2:64x64 (4 waves)  3:256x320 4:256x256 5:256x128 (8 waves)
 static const int kTileBM[6] = {128, 64, 64, 256, 256, 256};
@@ -583,6 +929,13 @@ static int launch_gemm(odise_hip_ctx* ctx, GemmArgs& g, int batch, int force_til
                      ? 1 : 0;
     g.zeros = (const f16*)ctx->zeros;
     g.dbg = g_gemm_debug;
+    // the 256-row tiles run the ping-pong pipelined kernel whenever its preconditions hold
+    if ((tile == 3 || tile == 4) && !no_interleave && !(g_conv_flags & 2) && g.K % 64 == 0 &&
+        (!CONV || (g.cg.Cin % 64 == 0 && !g.cg.ups))) {
+        if (tile == 3) return launch_gemm_pp<320, 1, CONV>(ctx, g, batch);
+        if (g_conv_flags & 4) return launch_gemm_pp<256, 1, CONV>(ctx, g, batch);
+        return launch_gemm_pp<256, 2, CONV>(ctx, g, batch);
+    }
     if (no_interleave) {
         if (tile == 3) return launch_gemm_t<256, 320, 4, 2, CONV, false>(ctx, g, batch);
         if (tile == 4) return launch_gemm_t<256, 256, 4, 2, CONV, false>(ctx, g, batch);

@@ -132,8 +132,9 @@ class Context:
 
     def gemm(self, A: DeviceArray, W: DeviceArray, *, bias_n=None, bias_m=None, scale_m=None, residual=None,
              rowgroup_add=None, rows_per_group=0, act=ACT_NONE, geglu=False, alpha=1.0, out_dtype=np.float16,
-             force_tile=-1, force_split=0, out=None) -> DeviceArray:
-        """C[M,N] = epi(alpha * A[M,K] @ W[N,K]^T); 3-D inputs are batched over dim 0."""
+             force_tile=-1, force_split=0, out=None, lda=None) -> DeviceArray:
+        """C[M,N] = epi(alpha * A[M,K] @ W[N,K]^T); 3-D inputs are batched over dim 0.  `lda` overrides the row stride of A
+        (tools: overlapping rows make A cache-resident)."""
         batched = len(A.shape) == 3 or len(W.shape) == 3
         batch = (A.shape[0] if len(A.shape) == 3 else W.shape[0]) if batched else 1
         M, K = A.shape[-2:]
@@ -144,7 +145,7 @@ class Context:
         out = out if out is not None else self.empty(oshape, out_dtype)
         d = GemmDesc()
         d.M, d.N, d.K = M, N, K
-        d.A, d.lda = A.ptr, K
+        d.A, d.lda = A.ptr, (K if lda is None else int(lda))
         d.W, d.ldw = W.ptr, K
         d.C, d.ldc = out.ptr, No
         d.c_dtype = F32 if np.dtype(out_dtype) == np.float32 else F16
