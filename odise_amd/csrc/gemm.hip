@@ -17,6 +17,7 @@
 //   * small-M layers (8x8 / 16x16 latents at batch 1) are weight-streaming bound: split-K over grid.z
 //     with an fp32 workspace and a fused reduce+epilogue kernel keeps >=2 blocks per CU in flight.
 #include "common.h"
+#include <stdlib.h>
 
 namespace odise {
 
@@ -489,22 +490,27 @@ __device__ __forceinline__ void wait_vmcnt() {
 // DMA groups of the tile sequence (per thread: 4 A loads, TN B loads; B piece j = the rows of N-tile j of both wave columns):
 //   NP = 2: (t,0) issues B0..B3 of tile t+1, (t,1) issues A0..A3 of tile t+2
 //   NP = 3: (t,0) issues B2,B3,B4 of tile t+1, (t,1) issues A0,A1,A2 of tile t+2, (t,2) issues A3,B0,B1 of tile t+2
-template <int BN, int PT, bool CONV>
+template <int BM, int BN, int WAVES_N, int PT, bool CONV>
 __global__ void __launch_bounds__(512) gemm_pp_kernel(GemmArgs g) {
-    constexpr int BM = 256, BK = 64, WAVES_M = 4, WAVES_N = 2;
+    constexpr int BK = 64, WAVES_M = 8 / WAVES_N;
     constexpr int WTN = BN / WAVES_N;
     constexpr int TM = 2, TN = WTN / 32;
     constexpr int NP = (TN + PT - 1) / PT;   // phases per K-tile (PT N-tiles of the wave each)
-    constexpr int NL = 4 + TN;               // LDS-DMA loads per thread per K-tile
+    constexpr int JA = BM / 64, JB = BN / 64;  // 64-row DMA pieces (one 16-byte load per thread each)
+    constexpr int TPB = TN / JB;             // N-tiles of a wave covered by one B piece (the piece spans every wave column)
+    constexpr int NL = JA + JB;              // LDS-DMA loads per thread per K-tile
     constexpr int LPP = (NL + NP - 1) / NP;  // loads per phase
     constexpr int A_BYTES = BM * BK * 2, B_BYTES = BN * BK * 2, STAGE_BYTES = A_BYTES + B_BYTES;
     static_assert(PT == 1 || PT == 2, "one or two N-tiles per phase");
+    static_assert(BM / WAVES_M == 64 && WTN % 32 == 0 && TN % JB == 0, "bad tile");
+    // WAR rule of the schedule: B piece j (read in phase j*TPB/PT) is refilled in slot (JA+j)/LPP, i.e. one phase later at the earliest
+    static_assert((JA + JB - 1) / LPP >= ((JB - 1) * TPB) / PT && JA / LPP >= 0, "refill would overtake the fragment reads");
     extern __shared__ __attribute__((aligned(16))) char smem[];
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wm = wave >> 1, wn = wave & 1;
+    const int wm = wave / WAVES_N, wn = wave % WAVES_N;
     const int grp = wave >> 2;  // waves w and w+4 share a SIMD
     const int hi = lane >> 5, l31 = lane & 31;
     int bx, by;
@@ -536,10 +542,10 @@ __global__ void __launch_bounds__(512) gemm_pp_kernel(GemmArgs g) {
     // and fetches logical slot ls (XOR swizzle on the source, see gemm_kernel)
     const int rbase = wave * 8 + (lane >> 3);
     const int ls = (lane & 7) ^ ((rbase >> 1) & 7);
-    int64_t a_off[4];
-    int a_iy0[4], a_ix0[4];  // conv: top-left input coordinate of the row's window; rows >= M get iy0 far out of range
+    int64_t a_off[JA];
+    int a_iy0[JA], a_ix0[JA];  // conv: top-left input coordinate of the row's window; rows >= M get iy0 far out of range
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
+    for (int j = 0; j < JA; ++j) {
         const int m = m0 + rbase + 64 * j;
         const bool ok = m < g.M;
         if (CONV) {
@@ -558,10 +564,13 @@ __global__ void __launch_bounds__(512) gemm_pp_kernel(GemmArgs g) {
             a_off[j] = (int64_t)m * g.lda + ls * 8;
         }
     }
-    // B piece j covers rows j*32 + 8*(wave&3) + lane/8 of wave column (wave>>2)
-    const int nb0 = n0 + (wave >> 2) * WTN + (wave & 3) * 8 + (lane >> 3);
+    // B piece j = rows [j*RB, (j+1)*RB) of EVERY wave column (RB = 64 / WAVES_N), i.e. exactly the rows the waves read for N-tiles
+    // j*TPB .. of theirs; this wave fills 8 of them
+    constexpr int RB = 64 / WAVES_N;
+    const int b_row0 = (WAVES_N == 2) ? (wave >> 2) * WTN + (wave & 3) * 8 : wave * 8;
+    const int nb0 = n0 + b_row0 + (lane >> 3);
     const int64_t b_off0 = (int64_t)nb0 * g.ldw + ls * 8;
-    const int b_lds0 = ((wave >> 2) * WTN + (wave & 3) * 8) * 128;  // LDS byte offset of this wave's 8 rows inside piece 0
+    const int b_lds0 = b_row0 * 128;  // LDS byte offset of this wave's 8 rows inside piece 0
 
     // K-tile position (wave-uniform, advanced incrementally: no divisions in the loop).  Conv taps are whole 64-channel chunks
     // (Cin % 64 == 0), walked chunk-major or tap-major (see gemm_kernel::prep_tile).
@@ -631,9 +640,9 @@ __global__ void __launch_bounds__(512) gemm_pp_kernel(GemmArgs g) {
         glds16(src, smem + stage * STAGE_BYTES + (j * 64 + wave * 8) * 128);
     };
     auto issue_B = [&](int j, int stage, const TileK& t) {
-        const bool ok = (nb0 + j * 32) < g.N;
-        const f16* src = ok ? Wb + b_off0 + (int64_t)(j * 32) * g.ldw + t.kw : g.zeros;
-        glds16(src, smem + stage * STAGE_BYTES + A_BYTES + b_lds0 + j * 4096);
+        const bool ok = (nb0 + j * RB) < g.N;
+        const f16* src = ok ? Wb + b_off0 + (int64_t)(j * RB) * g.ldw + t.kw : g.zeros;
+        glds16(src, smem + stage * STAGE_BYTES + A_BYTES + b_lds0 + j * RB * 128);
     };
 
     f32x16 acc[TM][TN];
@@ -650,11 +659,13 @@ __global__ void __launch_bounds__(512) gemm_pp_kernel(GemmArgs g) {
     const int a_lane_off = (wm * 64 + l31) * 128;
     const int b_lane_off = A_BYTES + (wn * WTN + l31) * 128;
 
-    // load l of a K-tile: l < 4 -> A piece l, else B piece l-4; issued in slot l / LPP of the tile (see the schedule above)
+    // load l of a K-tile: l < JA -> A piece l, else B piece l-JA; issued in slot l / LPP of the tile (see the schedule above)
     auto issue = [&](int l, int stage, const TileK& t) {
-        if (l < 4) issue_A(l, stage, t);
-        else issue_B(l - 4, stage, t);
+        if (l < JA) issue_A(l, stage, t);
+        else issue_B(l - JA, stage, t);
     };
+    // number of loads (from A0 of a tile) that must have landed before its N-tiles [0, nt) can be read
+    auto loads_for_tiles = [](int nt) { return JA + (nt + TPB - 1) / TPB; };
     // ---- prologue: all of tile 0, and the slots of tile 1 that the steady state would have issued before phase (0,0)
     TileK t1 = decode(kt_begin), t2;  // positions of K-tiles kt+1 and kt+2 while tile kt is multiplied
     if (kt_begin < kt_end) {
@@ -666,9 +677,9 @@ __global__ void __launch_bounds__(512) gemm_pp_kernel(GemmArgs g) {
         if (kt_begin + 1 < kt_end) {
 #pragma unroll
             for (int l = 0; l < pro1; ++l) issue(l, 1, t1);
-            wait_vmcnt<NL + pro1 - (4 + PT)>();  // phase (0,0) needs A and the first PT B pieces of tile 0
+            wait_vmcnt<NL + pro1 - (JA + (PT + TPB - 1) / TPB)>();  // phase (0,0) needs A and the first PT N-tiles of B of tile 0
         } else {
-            wait_vmcnt<NL - (4 + PT)>();
+            wait_vmcnt<NL - (JA + (PT + TPB - 1) / TPB)>();
         }
     }
     t2 = t1;
@@ -701,13 +712,13 @@ __global__ void __launch_bounds__(512) gemm_pp_kernel(GemmArgs g) {
                     for (int s = 0; s < 4; ++s) bf[jj][s] = *reinterpret_cast<const f16x8*>(fb + koff[s] + (j0 + jj) * 4096);
                 }
             // loads through index `need` (counted from A0 of tile kt) must have landed before the next phase reads
-            const int need = (p + 1 < NP) ? 4 + ((p + 2) * PT < TN ? (p + 2) * PT : TN) : NL + 4 + PT;
+            const int need = (p + 1 < NP) ? loads_for_tiles((p + 2) * PT < TN ? (p + 2) * PT : TN) : NL + loads_for_tiles(PT);
             if (p == 0) {
                 if (has1) {
 #pragma unroll
                     for (int l = 0; l < NL; ++l)
                         if (l / LPP == NP - 1) issue(l, cur ^ 1, t1);
-                    wait_vmcnt<2 * NL - (4 + (2 * PT < TN ? 2 * PT : TN))>();
+                    wait_vmcnt<2 * NL - (JA + ((2 * PT < TN ? 2 * PT : TN) + TPB - 1) / TPB)>();
                 } else {
                     wait_vmcnt<0>();
                 }
@@ -832,16 +843,16 @@ static int launch_gemm_t(odise_hip_ctx* ctx, GemmArgs& g, int batch) {
     return ODISE_OK;
 }
 
-template <int BN, int PT, bool CONV>
+template <int BM, int BN, int WAVES_N, int PT, bool CONV>
 static int launch_gemm_pp(odise_hip_ctx* ctx, GemmArgs& g, int batch) {
-    constexpr int lds = 2 * (256 + BN) * 64 * 2;
-    auto kern = gemm_pp_kernel<BN, PT, CONV>;
+    constexpr int lds = 2 * (BM + BN) * 64 * 2;
+    auto kern = gemm_pp_kernel<BM, BN, WAVES_N, PT, CONV>;
     static bool attr_set = false;  // per instantiation
     if (!attr_set) {
         ODISE_CHECK_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
         attr_set = true;
     }
-    dim3 grid((unsigned)ceil_div(g.N, BN), (unsigned)ceil_div(g.M, 256), (unsigned)(g.splitk > 1 ? g.splitk : batch));
+    dim3 grid((unsigned)ceil_div(g.N, BN), (unsigned)ceil_div(g.M, BM), (unsigned)(g.splitk > 1 ? g.splitk : batch));
     hipLaunchKernelGGL(kern, grid, dim3(512), lds, ctx->stream, g);
     ODISE_CHECK_HIP(hipGetLastError());
     if (g.splitk > 1) {
@@ -856,9 +867,10 @@ static int launch_gemm_pp(odise_hip_ctx* ctx, GemmArgs& g, int batch) {
 static int g_gemm_debug = 0;  // see GemmArgs::dbg
 static int g_conv_flags = 0;  // tools only: 1 = tap-major K order even when Cin % 64 == 0, 2 = never use the ping-pong kernel, 4 = one N-tile per phase at BN = 256
 
-// Tile ids: 0:128x128 1:64x128 2:64x64 (4 waves)  3:256x320 4:256x256 5:256x128 (8 waves)
-static const int kTileBM[6] = {128, 64, 64, 256, 256, 256};
-static const int kTileBN[6] = {128, 128, 64, 320, 256, 128};
+// Tile ids: 0:128x128 1:64x128 2:64x64 (4 waves)  3:256x320 4:256x256 5:256x128 (8 waves)  6:512x128 (8 waves, ping-pong only)
+static const int kNumTiles = 7;
+static const int kTileBM[kNumTiles] = {128, 64, 64, 256, 256, 256, 512};
+static const int kTileBN[kNumTiles] = {128, 128, 64, 320, 256, 128, 128};
 
 // Tile / split-K selection by a small cost model (times in microseconds, calibrated on MI355X with tools/gemm_bench.py):
 //   t = rounds * (k_tiles_per_split * t_ktile + t_fixed) + t_reduce,   rounds = ceil(blocks * split / resident slots)
@@ -870,15 +882,32 @@ struct TileCost {
     double t_ktile, t_fixed;
     int slots_per_cu;
 };
-static const TileCost kTileCost[6] = {
-    // fitted on MI355X with tools/tile_calib.py (M=131072, N=512|640, K=320 and 1152, all CUs busy)
-    {1.68, 9.5, 2},   // 128x128
-    {1.58, 4.1, 3},   // 64x128
-    {1.28, 2.4, 4},   // 64x64
-    {3.04, 29.0, 1},  // 256x320
-    {2.58, 22.0, 1},  // 256x256
-    {1.75, 10.6, 1},  // 256x128
+static const TileCost kTileCost[kNumTiles] = {
+    // fitted on MI355X with tools/tile_calib.py (M = 131072, N = 512 | 640, K = 320 / 1152 / 4096, all CUs busy)
+    {1.45, 6.0, 2},   // 128x128
+    {1.25, 3.5, 3},   // 64x128
+    {1.06, 2.6, 4},   // 64x64
+    {2.65, 15.0, 1},  // 256x320 (plain kernel: K % 64 != 0, ragged conv channels, fused upsample)
+    {2.10, 15.0, 1},  // 256x256 (plain kernel)
+    {1.42, 6.0, 1},   // 256x128
+    {2.25, 12.0, 1},  // 512x128 (ping-pong kernel only)
 };
+// the 256-row tiles as run by the ping-pong kernel (K % 64 == 0; conv: Cin % 64 == 0, no fused upsample)
+static const TileCost kTileCostPP[2] = {
+    {2.55, 16.0, 1},  // 256x320
+    {2.10, 12.0, 1},  // 256x256
+};
+// previous fit (before the lean epilogue / ping-pong kernel), kept selectable for A/B runs: ODISE_GEMM_FLAGS=8
+static const TileCost kTileCostOld[kNumTiles] = {{1.68, 9.5, 2}, {1.58, 4.1, 3}, {1.28, 2.4, 4}, {3.04, 29.0, 1},
+                                                 {2.58, 22.0, 1}, {1.75, 10.6, 1}, {2.25, 12.0, 1}};
+static int env_gemm_flags() {
+    static int v = -1;
+    if (v < 0) {
+        const char* e = getenv("ODISE_GEMM_FLAGS");  // developer switch: same bits as odise_hip_gemm_debug(flags) >> 4
+        v = e ? atoi(e) : 0;
+    }
+    return v;
+}
 
 template <bool CONV>
 static int launch_gemm(odise_hip_ctx* ctx, GemmArgs& g, int batch, int force_tile, int force_split) {
@@ -889,14 +918,18 @@ static int launch_gemm(odise_hip_ctx* ctx, GemmArgs& g, int batch, int force_til
     if (no_interleave) force_tile -= 16;
     int tile = 2, best_split = 1;
     double best = 1e30;
-    for (int t = 0; t < 6; ++t) {
-        if (force_tile >= 0 && force_tile <= 5 && t != force_tile) continue;
+    const int flags = g_conv_flags | env_gemm_flags();
+    const bool pp_ok = !no_interleave && !(flags & 2) && g.K % 64 == 0 && (!CONV || (g.cg.Cin % 64 == 0 && !g.cg.ups));
+    for (int t = 0; t < kNumTiles; ++t) {
+        if (force_tile >= 0 && force_tile < kNumTiles && t != force_tile) continue;
+        if (t == 6 && (!pp_ok || (flags & 16))) continue;
+        const TileCost& tc = (flags & 8) ? kTileCostOld[t] : (pp_ok && (t == 3 || t == 4)) ? kTileCostPP[t - 3] : kTileCost[t];
         if (force_tile < 0) {
             if (kTileBM[t] > 64 && g.M <= kTileBM[t] / 2) continue;            // mostly-empty row tiles
             if (kTileBN[t] > 64 && g.N <= kTileBN[t] / 2 && t != 2) continue;  // mostly-empty column tiles
         }
         const int64_t nb = blocks(t);
-        const int64_t slots = cus * kTileCost[t].slots_per_cu;
+        const int64_t slots = cus * tc.slots_per_cu;
         const int max_split = (batch == 1) ? std::max(1, std::min(nk / 2, 32)) : 1;
         for (int sp = 1; sp <= max_split; ++sp) {
             if (force_split > 0 && sp != std::min(force_split, std::max(1, nk))) continue;
@@ -907,12 +940,12 @@ static int launch_gemm(odise_hip_ctx* ctx, GemmArgs& g, int batch, int force_til
             // so the main-loop term is a throughput term; the prologue/epilogue term is paid once per residency round
             const double rounds = (double)ceil_div(nb * eff_sp, slots);
             const double blocks_eff = std::max((double)(nb * eff_sp), 0.45 * (double)slots);
-            double t_us = blocks_eff * per * kTileCost[t].t_ktile / (double)slots + rounds * kTileCost[t].t_fixed;
+            double t_us = blocks_eff * per * tc.t_ktile / (double)slots + rounds * tc.t_fixed;
             if (eff_sp > 1) t_us += 4.0 + ((2.0 * eff_sp * 4.0 + 2.0) * (double)g.M * g.N) / 2.5e6;  // bytes / (2.5 TB/s) in us
             if (t_us < best) { best = t_us; tile = t; best_split = eff_sp; }
         }
     }
-    if (force_tile >= 0 && force_tile <= 5) tile = force_tile;
+    if (force_tile >= 0 && force_tile < kNumTiles && !(force_tile == 6 && !pp_ok)) tile = force_tile;
     g.splitk = 1;
     g.ktiles_per_split = nk;
     if (force_split > 0 && batch == 1) best_split = std::min(force_split, nk);
@@ -930,11 +963,11 @@ static int launch_gemm(odise_hip_ctx* ctx, GemmArgs& g, int batch, int force_til
     g.zeros = (const f16*)ctx->zeros;
     g.dbg = g_gemm_debug;
     // the 256-row tiles run the ping-pong pipelined kernel whenever its preconditions hold
-    if ((tile == 3 || tile == 4) && !no_interleave && !(g_conv_flags & 2) && g.K % 64 == 0 &&
-        (!CONV || (g.cg.Cin % 64 == 0 && !g.cg.ups))) {
-        if (tile == 3) return launch_gemm_pp<320, 1, CONV>(ctx, g, batch);
-        if (g_conv_flags & 4) return launch_gemm_pp<256, 1, CONV>(ctx, g, batch);
-        return launch_gemm_pp<256, 2, CONV>(ctx, g, batch);
+    if ((tile == 3 || tile == 4 || tile == 6) && pp_ok) {
+        if (tile == 6) return launch_gemm_pp<512, 128, 1, 2, CONV>(ctx, g, batch);
+        if (tile == 3) return launch_gemm_pp<256, 320, 2, 1, CONV>(ctx, g, batch);
+        if (flags & 4) return launch_gemm_pp<256, 256, 2, 1, CONV>(ctx, g, batch);
+        return launch_gemm_pp<256, 256, 2, 2, CONV>(ctx, g, batch);
     }
     if (no_interleave) {
         if (tile == 3) return launch_gemm_t<256, 320, 4, 2, CONV, false>(ctx, g, batch);
@@ -1006,7 +1039,10 @@ int conv_forced(odise_hip_ctx* ctx, const odise_conv_desc* d, int force_tile, in
     g.cg.H = d->H; g.cg.W = d->W; g.cg.Cin = d->Cin; g.cg.KH = d->KH; g.cg.KW = d->KW;
     g.cg.stride = d->stride; g.cg.pad_t = d->pad_t; g.cg.pad_l = d->pad_l; g.cg.OH = d->OH; g.cg.OW = d->OW;
     g.cg.ups = d->upsample2x;
-    g.cg.chunk_major = (d->Cin % 64 == 0 && d->KH * d->KW > 1 && !(g_conv_flags & 1)) ? 1 : 0;
+    // chunk-major K order pays when the input stays in the 256 MiB Infinity Cache (shifted tap re-reads hit L2: +4..10 % on the
+    // 64x64 / 32x32 latents); a streamed input prefers tap-major (whole 1-2 KiB pixel vectors in DRAM-page order: +10 % at 128^2+)
+    const int64_t in_bytes = (int64_t)d->N * d->H * d->W * d->Cin * 2;
+    g.cg.chunk_major = (d->Cin % 64 == 0 && d->KH * d->KW > 1 && in_bytes <= (128ll << 20) && !((g_conv_flags | env_gemm_flags()) & 1)) ? 1 : 0;
     // a 1x1 stride-1 unpadded conv is a plain GEMM over pixels
     if (d->KH == 1 && d->KW == 1 && d->stride == 1 && d->pad_t == 0 && d->pad_l == 0 && !d->upsample2x && d->OH == d->H &&
         d->OW == d->W) {
