@@ -28,6 +28,8 @@ struct AttnArgs {
     f16* O; int64_t ldo, strideO;
     const uint8_t* mask; int64_t ldmask, strideMask;
     float scale_log2e;
+    int nsplit;   // > 1: keys are split over `nsplit` blocks per (query block, head, batch); partial results go to `part`
+    float* part;  // [B, H, nsplit, Lq, D + 2] fp32: unnormalised O^T rows, running max (log2 domain), running sum
 };
 
 template <int DPAD>
@@ -44,7 +46,9 @@ __global__ void __launch_bounds__(256) attn_kernel(AttnArgs a) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int hi = lane >> 5, l31 = lane & 31;
     const int b = blockIdx.z, h = blockIdx.y;
-    const int q = blockIdx.x * 128 + wave * 32 + l31;  // this lane's query
+    const int split = a.nsplit > 1 ? blockIdx.x % a.nsplit : 0;
+    const int qblock = a.nsplit > 1 ? blockIdx.x / a.nsplit : blockIdx.x;
+    const int q = qblock * 128 + wave * 32 + l31;  // this lane's query
     const bool qok = q < a.Lq;
     const int D = a.D;
 
@@ -71,7 +75,13 @@ __global__ void __launch_bounds__(256) attn_kernel(AttnArgs a) {
     float m_run = -INFINITY, l_run = 0.f;
 
     const int ntiles = (a.Lk + 63) / 64;
-    for (int kt = 0; kt < ntiles; ++kt) {
+    int kt_begin = 0, kt_end = ntiles;
+    if (a.nsplit > 1) {
+        const int per = (ntiles + a.nsplit - 1) / a.nsplit;
+        kt_begin = split * per;
+        kt_end = min(ntiles, kt_begin + per);
+    }
+    for (int kt = kt_begin; kt < kt_end; ++kt) {
         const int kv0 = kt * 64;
         __syncthreads();  // previous tile fully consumed
         // ---- stage K tile: 64 keys x DPAD ----
@@ -175,8 +185,29 @@ __global__ void __launch_bounds__(256) attn_kernel(AttnArgs a) {
         }
     }
 
-    // ---- epilogue: normalise and store O[q][h*D + d] ----
     const float l_tot = l_run + __shfl_xor(l_run, 32);
+    if (a.nsplit > 1) {
+        // ---- split-KV: hand the unnormalised partial to attn_combine_kernel ----
+        if (qok) {
+            float* P = a.part + ((((int64_t)b * a.H + h) * a.nsplit + split) * a.Lq + q) * (D + 2);
+#pragma unroll
+            for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const int d0 = dt * 32 + 8 * g + 4 * hi;
+                    if (d0 < D) {
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) P[d0 + i] = ot[dt][4 * g + i];
+                    }
+                }
+            if (hi == 0) {
+                P[D] = m_run;
+                P[D + 1] = l_tot;
+            }
+        }
+        return;
+    }
+    // ---- epilogue: normalise and store O[q][h*D + d] ----
     const float inv = l_tot > 0.f ? 1.f / l_tot : 0.f;
     if (qok) {
         f16* Ob = a.O + (int64_t)b * a.strideO + (int64_t)q * a.ldo + (int64_t)h * D;
@@ -196,13 +227,65 @@ __global__ void __launch_bounds__(256) attn_kernel(AttnArgs a) {
     }
 }
 
+// O[q] = sum_s O_s 2^(m_s - M) / sum_s l_s 2^(m_s - M): one thread per (row, 4 channels)
+__global__ void __launch_bounds__(256) attn_combine_kernel(AttnArgs a) {
+    const int D = a.D, D4 = D >> 2;
+    const int64_t total = (int64_t)a.B * a.H * a.Lq * D4;
+    const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= total) return;
+    const int d0 = (int)(idx % D4) * 4;
+    const int64_t row = idx / D4;  // (b*H + h)*Lq + q
+    const int q = (int)(row % a.Lq);
+    const int64_t bh = row / a.Lq;
+    const int h = (int)(bh % a.H), b = (int)(bh / a.H);
+    const float* P = a.part + ((bh * a.nsplit) * a.Lq + q) * (D + 2);
+    const int64_t sstride = (int64_t)a.Lq * (D + 2);
+    float M = -INFINITY;
+    for (int s = 0; s < a.nsplit; ++s) M = fmaxf(M, P[s * sstride + D]);
+    float o[4] = {0.f, 0.f, 0.f, 0.f}, L = 0.f;
+    if (M > -INFINITY) {
+        for (int s = 0; s < a.nsplit; ++s) {
+            const float* Ps = P + s * sstride;
+            const float w = exp2f(Ps[D] - M);  // m_s = -inf -> 0
+            L += Ps[D + 1] * w;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) o[i] += Ps[d0 + i] * w;
+        }
+    }
+    const float inv = L > 0.f ? 1.f / L : 0.f;
+    f16x4 r;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) r[i] = (f16)(o[i] * inv);
+    *reinterpret_cast<f16x4*>(a.O + (int64_t)b * a.strideO + (int64_t)q * a.ldo + (int64_t)h * D + d0) = r;
+}
+
 template <int DPAD>
-static int launch_attn(odise_hip_ctx* ctx, const AttnArgs& a) {
+static int launch_attn(odise_hip_ctx* ctx, AttnArgs& a) {
     constexpr int DT = (DPAD + 31) / 32;
     const size_t lds = 64 * (DPAD + 8) * 2 + (size_t)DT * 32 * 68 * 2;
-    dim3 grid((unsigned)ceil_div(a.Lq, 128), (unsigned)a.H, (unsigned)a.B);
+    // few queries against many keys (masked cross-attention of the mask decoder: 100 queries x up to 16384 keys): split the keys
+    // over blocks until the CUs are covered twice, then fold the partials
+    const int64_t qblocks = ceil_div(a.Lq, 128), base = qblocks * a.H * a.B;
+    const int ntiles = (int)ceil_div(a.Lk, 64);
+    a.nsplit = 1;
+    a.part = nullptr;
+    if (base < ctx->cu_count && ntiles >= 8 && a.D % 4 == 0) {
+        int ns = (int)std::min<int64_t>(ceil_div(2 * (int64_t)ctx->cu_count, base), ntiles / 4);
+        while (ns > 1 && (size_t)a.B * a.H * ns * a.Lq * (a.D + 2) * sizeof(float) > ctx->ws_bytes) --ns;
+        if (ns > 1) {
+            const int per = (int)ceil_div(ntiles, ns);
+            a.nsplit = (int)ceil_div(ntiles, per);  // no empty splits
+            a.part = (float*)ctx->ws;
+        }
+    }
+    dim3 grid((unsigned)(qblocks * a.nsplit), (unsigned)a.H, (unsigned)a.B);
     hipLaunchKernelGGL((attn_kernel<DPAD>), grid, dim3(256), lds, ctx->stream, a);
     ODISE_CHECK_HIP(hipGetLastError());
+    if (a.nsplit > 1) {
+        const int64_t total = (int64_t)a.B * a.H * a.Lq * (a.D / 4);
+        hipLaunchKernelGGL(attn_combine_kernel, dim3((unsigned)ceil_div(total, 256)), dim3(256), 0, ctx->stream, a);
+        ODISE_CHECK_HIP(hipGetLastError());
+    }
     return ODISE_OK;
 }
 

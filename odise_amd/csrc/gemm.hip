@@ -936,12 +936,15 @@ static int launch_gemm(odise_hip_ctx* ctx, GemmArgs& g, int batch, int force_til
             if (sp > 1 && (size_t)sp * g.M * g.N * sizeof(float) > ctx->ws_bytes) break;
             const int per = (int)ceil_div(nk, sp);
             const int eff_sp = (int)ceil_div(nk, per);
-            // operand delivery is chip-bound: per-block K-tile time shrinks (down to ~0.45x) when fewer blocks are resident,
-            // so the main-loop term is a throughput term; the prologue/epilogue term is paid once per residency round
-            const double rounds = (double)ceil_div(nb * eff_sp, slots);
-            const double blocks_eff = std::max((double)(nb * eff_sp), 0.45 * (double)slots);
-            double t_us = blocks_eff * per * tc.t_ktile / (double)slots + rounds * tc.t_fixed;
-            if (eff_sp > 1) t_us += 4.0 + ((2.0 * eff_sp * 4.0 + 2.0) * (double)g.M * g.N) / 2.5e6;  // bytes / (2.5 TB/s) in us
+            // Full residency rounds run at the calibrated K-tile time; the last (or only) partial round still costs most of a
+            // block's time: an under-filled chip delivers operands only a little faster per block (measured with
+            // tools/shape_sweep.py: ~0.8x at 60 % fill), so idle CUs are better bought back with split-K than left idle.
+            const int64_t nblk = nb * eff_sp;
+            const int64_t rounds = ceil_div(nblk, slots);
+            const double fill_last = (double)(nblk - (rounds - 1) * slots) / (double)slots;
+            double t_us = per * tc.t_ktile * ((double)(rounds - 1) + 0.55 + 0.45 * fill_last) + (double)rounds * tc.t_fixed;
+            // split-K partials: write + read fp32 per split, mostly Infinity-Cache resident at these sizes
+            if (eff_sp > 1) t_us += 4.0 + ((2.0 * eff_sp * 4.0 + 2.0) * (double)g.M * g.N) / 6.0e6;
             if (t_us < best) { best = t_us; tile = t; best_split = eff_sp; }
         }
     }

@@ -34,7 +34,22 @@ __global__ void __launch_bounds__(256) gn_partial_kernel(const f16* __restrict__
 #pragma unroll
             for (int i = 0; i < 8; ++i) s[i] = q[i] = 0.f;
             const f16* xb = x + ((int64_t)n * HW) * C + v * 8;
-            for (int p = p_begin + pl; p < p_end; p += PL) {
+            int p = p_begin + pl;
+            // four independent 16-byte loads in flight per lane (the accumulation chain is short; the loop is latency-bound otherwise)
+            for (; p + 3 * PL < p_end; p += 4 * PL) {
+                f16x8 t[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) t[u] = *reinterpret_cast<const f16x8*>(xb + (int64_t)(p + u * PL) * C);
+#pragma unroll
+                for (int u = 0; u < 4; ++u)
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) {
+                        const float a = (float)t[u][i];
+                        s[i] += a;
+                        q[i] += a * a;
+                    }
+            }
+            for (; p < p_end; p += PL) {
                 const f16x8 t = *reinterpret_cast<const f16x8*>(xb + (int64_t)p * C);
 #pragma unroll
                 for (int i = 0; i < 8; ++i) {
@@ -65,74 +80,105 @@ __global__ void __launch_bounds__(256) gn_partial_kernel(const f16* __restrict__
     }
 }
 
-// grid (blocks_per_image, N); block 256
-__global__ void __launch_bounds__(256) gn_apply_kernel(const f16* __restrict__ x, f16* __restrict__ y,
-                                                      const float* __restrict__ partial, const float* __restrict__ gamma,
-                                                      const float* __restrict__ beta, int HW, int C, int G, int nchunks,
-                                                      float eps, int act, const f16* __restrict__ residual,
-                                                      const f16* __restrict__ accum) {
-    extern __shared__ __attribute__((aligned(16))) float sss[];  // scale[C], shift[C], mean[G], rstd[G], red[2*256]
-    float* scale = sss;
-    float* shift = sss + C;
-    float* mean = sss + 2 * C;
-    float* rstd = mean + G;
-    double* red = reinterpret_cast<double*>(rstd + G + ((2 * C + 2 * G) & 1));  // 8-byte aligned
-    const int n = blockIdx.y, tid = threadIdx.x;
+// grid (N); block 256: folds the chunk partials of one image in a fixed order (fp64) -> stats[n][g] = (mean, rstd)
+__global__ void __launch_bounds__(256) gn_finalize_kernel(const float* __restrict__ partial, float* __restrict__ stats, int HW, int C, int G,
+                                                         int nchunks, float eps) {
+    __shared__ double red[2 * 256];
+    const int n = blockIdx.x, tid = threadIdx.x;
     const int cpg = C / G;
-    // fold the partials: lane (g = tid % G, sub = tid / G) sums chunks sub, sub+nsub, ...; then a fixed-order fold over sub
+    // lane (g = tid % G, sub = tid / G) sums chunks sub, sub+nsub, ...; then a fixed-order fold over sub
     const int nsub = 256 / G;
-    {
-        const int gI = tid % G, sub = tid / G;
-        double s = 0.0, q = 0.0;
-        if (sub < nsub) {
-            for (int ch = sub; ch < nchunks; ch += nsub) {
-                const float* o = partial + (((int64_t)n * nchunks + ch) * G + gI) * 2;
-                s += (double)o[0];
-                q += (double)o[1];
-            }
+    const int gI = tid % G, sub = tid / G;
+    double s = 0.0, q = 0.0;
+    if (sub < nsub) {
+        for (int ch = sub; ch < nchunks; ch += nsub) {
+            const float* o = partial + (((int64_t)n * nchunks + ch) * G + gI) * 2;
+            s += (double)o[0];
+            q += (double)o[1];
         }
-        red[2 * tid] = s;
-        red[2 * tid + 1] = q;
     }
+    red[2 * tid] = s;
+    red[2 * tid + 1] = q;
     __syncthreads();
     if (tid < G) {
-        double s = 0.0, q = 0.0;
-        for (int sub = 0; sub < nsub; ++sub) {
-            s += red[2 * (sub * G + tid)];
-            q += red[2 * (sub * G + tid) + 1];
+        s = q = 0.0;
+        for (int u = 0; u < nsub; ++u) {
+            s += red[2 * (u * G + tid)];
+            q += red[2 * (u * G + tid) + 1];
         }
         const double cnt = (double)HW * cpg;
         const double mu = s / cnt;
         double var = q / cnt - mu * mu;
         if (var < 0.0) var = 0.0;
-        mean[tid] = (float)mu;
-        rstd[tid] = (float)(1.0 / sqrt(var + (double)eps));
+        stats[((int64_t)n * G + tid) * 2] = (float)mu;
+        stats[((int64_t)n * G + tid) * 2 + 1] = (float)(1.0 / sqrt(var + (double)eps));
     }
-    __syncthreads();
+}
+
+// grid (blocks_per_image, N); block 256; every thread normalises up to four 16-byte vectors (all loads issued first)
+__global__ void __launch_bounds__(256) gn_apply_kernel(const f16* __restrict__ x, f16* __restrict__ y,
+                                                      const float* __restrict__ stats, const float* __restrict__ gamma,
+                                                      const float* __restrict__ beta, int HW, int C, int G,
+                                                      int act, const f16* __restrict__ residual,
+                                                      const f16* __restrict__ accum) {
+    extern __shared__ __attribute__((aligned(16))) float sss[];  // scale[C], shift[C]
+    float* scale = sss;
+    float* shift = sss + C;
+    const int n = blockIdx.y, tid = threadIdx.x;
+    const int cpg = C / G;
     for (int c = tid; c < C; c += blockDim.x) {
         const int gI = c / cpg;
-        const float sc = rstd[gI] * (gamma ? gamma[c] : 1.f);
+        const float mu = stats[((int64_t)n * G + gI) * 2], rs = stats[((int64_t)n * G + gI) * 2 + 1];
+        const float sc = rs * (gamma ? gamma[c] : 1.f);
         scale[c] = sc;
-        shift[c] = (beta ? beta[c] : 0.f) - mean[gI] * sc;
+        shift[c] = (beta ? beta[c] : 0.f) - mu * sc;
     }
     __syncthreads();
+    // stream: 32-bit vector indices (HW * C / 8 < 2^31, checked by the launcher); four vectors per thread per sweep, loads first
     const int C8 = C >> 3;
-    const int64_t total = (int64_t)HW * C8;
+    const int total = HW * C8;
     const f16* xb = x + (int64_t)n * HW * C;
     f16* yb = y + (int64_t)n * HW * C;
-    for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + tid; idx < total; idx += (int64_t)gridDim.x * blockDim.x) {
-        const int c0 = (int)(idx % C8) * 8;
-        const f16x8 v = *reinterpret_cast<const f16x8*>(xb + idx * 8);
-        f16x8 r = {0, 0, 0, 0, 0, 0, 0, 0}, a = {0, 0, 0, 0, 0, 0, 0, 0};
-        if (residual) r = *reinterpret_cast<const f16x8*>(residual + (int64_t)n * HW * C + idx * 8);
-        if (accum) a = *reinterpret_cast<const f16x8*>(accum + (int64_t)n * HW * C + idx * 8);
-        f16x8 o;
+    const f16* rb = residual ? residual + (int64_t)n * HW * C : nullptr;
+    const f16* ab = accum ? accum + (int64_t)n * HW * C : nullptr;
+    const int stride = gridDim.x * blockDim.x;
+    for (int base = blockIdx.x * blockDim.x + tid; base < total; base += 4 * stride) {
+        f16x8 v[4], r[4], a[4];
 #pragma unroll
-        for (int i = 0; i < 8; ++i) {
-            const float t = (float)v[i] * scale[c0 + i] + shift[c0 + i] + (float)r[i];   // y = act(gn(x) + residual) + accum
-            o[i] = (f16)(act_apply(t, act) + (float)a[i]);
+        for (int u = 0; u < 4; ++u) {
+            const int idx = base + u * stride;
+            const f16x8 z = {0, 0, 0, 0, 0, 0, 0, 0};
+            v[u] = r[u] = a[u] = z;
+            if (idx < total) {
+                v[u] = *reinterpret_cast<const f16x8*>(xb + (int64_t)idx * 8);
+                if (rb) r[u] = *reinterpret_cast<const f16x8*>(rb + (int64_t)idx * 8);
+                if (ab) a[u] = *reinterpret_cast<const f16x8*>(ab + (int64_t)idx * 8);
+            }
         }
-        *reinterpret_cast<f16x8*>(yb + idx * 8) = o;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int idx = base + u * stride;
+            if (idx >= total) break;
+            const int c0 = (idx % C8) * 8;
+            const float4 s0 = *reinterpret_cast<const float4*>(scale + c0), s1 = *reinterpret_cast<const float4*>(scale + c0 + 4);
+            const float4 h0 = *reinterpret_cast<const float4*>(shift + c0), h1 = *reinterpret_cast<const float4*>(shift + c0 + 4);
+            const float sc[8] = {s0.x, s0.y, s0.z, s0.w, s1.x, s1.y, s1.z, s1.w};
+            const float sh[8] = {h0.x, h0.y, h0.z, h0.w, h1.x, h1.y, h1.z, h1.w};
+            float t[8];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) t[i] = (float)v[u][i] * sc[i] + sh[i] + (float)r[u][i];  // y = act(gn(x) + residual) + accum
+            if (act == ODISE_ACT_SILU) {
+#pragma unroll
+                for (int i = 0; i < 8; ++i) t[i] = t[i] / (1.0f + __expf(-t[i]));
+            } else if (act != ODISE_ACT_NONE) {
+#pragma unroll
+                for (int i = 0; i < 8; ++i) t[i] = act_apply(t[i], act);
+            }
+            f16x8 o;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) o[i] = (f16)(t[i] + (float)a[u][i]);
+            *reinterpret_cast<f16x8*>(yb + (int64_t)idx * 8) = o;
+        }
     }
 }
 
@@ -242,23 +288,25 @@ extern "C" int odise_hip_group_norm_ex(odise_hip_ctx* ctx, const void* x, void* 
     const int VW = V < 256 ? V : 256;
     const int PL = 256 / VW;
     // chunking: ~2 blocks per CU over the batch, every pixel lane gets at least ~2 pixels, at most 512 chunks per image
-    int64_t want = std::max<int64_t>(1, (int64_t)ctx->cu_count * 2 / N);
-    int64_t maxc = std::max<int64_t>(1, HW / (2 * PL));
-    int nchunks = (int)std::min<int64_t>(std::min<int64_t>(want, maxc), 128);
+    ODISE_REQUIRE((int64_t)HW * (C / 8) < (1ll << 31) - (1 << 24), "group_norm: image too large");
+    int64_t want = std::max<int64_t>(1, (int64_t)ctx->cu_count * 8 / N);
+    int64_t maxc = std::max<int64_t>(1, HW / (4 * PL));
+    int nchunks = (int)std::min<int64_t>(std::min<int64_t>(want, maxc), 256);
     const int ppc = (int)ceil_div(HW, nchunks);
     nchunks = (int)ceil_div(HW, ppc);
-    const size_t pbytes = (size_t)N * nchunks * groups * 2 * sizeof(float);
+    const size_t pbytes = ((size_t)N * nchunks * groups * 2 + (size_t)N * groups * 2) * sizeof(float);
     ODISE_REQUIRE(pbytes <= ctx->ws_bytes, "group_norm: workspace too small");
     float* partial = (float*)ctx->ws;
+    float* stats = partial + (size_t)N * nchunks * groups * 2;
     hipLaunchKernelGGL(gn_partial_kernel, dim3(nchunks, N), dim3(256), 2 * (size_t)PL * C * sizeof(float), ctx->stream, (const f16*)x,
                        partial, HW, C, groups, ppc);
     ODISE_CHECK_HIP(hipGetLastError());
+    hipLaunchKernelGGL(gn_finalize_kernel, dim3(N), dim3(256), 0, ctx->stream, partial, stats, HW, C, groups, nchunks, eps);
+    ODISE_CHECK_HIP(hipGetLastError());
     const int64_t total = (int64_t)HW * (C / 8);
-    int bpi = (int)std::min<int64_t>(ceil_div(total, 256 * 2), std::max<int64_t>(1, (int64_t)ctx->cu_count * 4 / N));
-    bpi = std::max(1, bpi);
-    const size_t lds = (2 * (size_t)C + 2 * groups + 2) * sizeof(float) + 2 * 256 * sizeof(double);
-    hipLaunchKernelGGL(gn_apply_kernel, dim3(bpi, N), dim3(256), lds, ctx->stream, (const f16*)x, (f16*)y, partial, gamma, beta, HW, C,
-                       groups, nchunks, eps, act, (const f16*)residual, (const f16*)accum);
+    const int bpi = (int)std::max<int64_t>(1, ceil_div(total, 256 * 4));  // four vectors per thread
+    hipLaunchKernelGGL(gn_apply_kernel, dim3(bpi, N), dim3(256), 2 * (size_t)C * sizeof(float), ctx->stream, (const f16*)x, (f16*)y, stats, gamma,
+                       beta, HW, C, groups, act, (const f16*)residual, (const f16*)accum);
     ODISE_CHECK_HIP(hipGetLastError());
     return ODISE_OK;
 }
