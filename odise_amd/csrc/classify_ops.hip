@@ -269,12 +269,16 @@ __global__ void __launch_bounds__(256) column_stats_kernel(const f16* __restrict
         partial[(int64_t)blockIdx.x * 2 * Qpad + i] = a;
     }
 }
-__global__ void column_fold_kernel(const float* __restrict__ partial, float* __restrict__ out, int nblocks, int n) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+// one wavefront per output column: lanes stride over the block partials, then a fixed-order butterfly (deterministic)
+__global__ void __launch_bounds__(256) column_fold_kernel(const float* __restrict__ partial, float* __restrict__ out, int nblocks, int n) {
+    const int i = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
     if (i >= n) return;
     double a = 0.0;
-    for (int b = 0; b < nblocks; ++b) a += (double)partial[(int64_t)b * n + i];
-    out[i] = (float)a;
+    for (int b = lane; b < nblocks; b += 64) a += (double)partial[(int64_t)b * n + i];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) a += __shfl_xor(a, o);
+    if (lane == 0) out[i] = (float)a;
 }
 
 // seg[p] = map[q] where ids[p] = q | flag and the pixel is inside mask q (flag) ; 0 otherwise  (maskformer_model.py:321-333)
@@ -341,7 +345,7 @@ int launch_column_stats(odise_hip_ctx* ctx, const f16* S, float* partial, float*
     const int nb = (int)ceil_div(npix, ppb);
     hipLaunchKernelGGL(column_stats_kernel, dim3(nb), dim3(256), (size_t)PL * 2 * Qpad * sizeof(float), ctx->stream, S, partial, npix, Qpad, ppb);
     ODISE_CHECK_HIP(hipGetLastError());
-    hipLaunchKernelGGL(column_fold_kernel, dim3((unsigned)ceil_div(2 * Qpad, 256)), dim3(256), 0, ctx->stream, partial, out2, nb, 2 * Qpad);
+    hipLaunchKernelGGL(column_fold_kernel, dim3((unsigned)ceil_div(2 * Qpad, 4)), dim3(256), 0, ctx->stream, partial, out2, nb, 2 * Qpad);
     ODISE_CHECK_HIP(hipGetLastError());
     return ODISE_OK;
 }

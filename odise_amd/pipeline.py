@@ -124,6 +124,7 @@ class HipCategoryODISE(HipODISE):
         self.test_topk_per_image, self.size_divisibility = test_topk_per_image, size_divisibility
         self.num_classes = 0
         self.thing_ids = set()
+        self._pool = {}
 
     def set_vocabulary(self, cat_text, clip_text, group_sizes, overlap, thing_ids, alpha=0.3, beta=0.7):
         """cat_text / clip_text: [K_tot, dim] CLIP text embeddings of the category_head / clip_head prompt sets."""
@@ -145,72 +146,125 @@ class HipCategoryODISE(HipODISE):
                                                C.c_void_p(ce.ptr) if ce is not None else None), "classify")
         return (out, ce) if want_clip_embed else out
 
+    def _buf(self, tag: str, shape, dtype) -> DeviceArray:
+        """Pooled device buffer: post-processing outputs are hundreds of MB per image; allocating them per call costs more than
+        the kernels that fill them (hipMalloc / hipFree synchronise the device)."""
+        shape = tuple(int(x) for x in shape)
+        key = (tag, np.dtype(dtype).str)
+        need = int(np.prod(shape, dtype=np.int64)) * np.dtype(dtype).itemsize
+        cur = self._pool.get(key)
+        if cur is None or cur.nbytes < need:
+            cur = self.ctx.empty((max(need, 16),), np.uint8)
+            self._pool[key] = cur
+        return cur.view(shape, dtype)
+
     def postprocess_image(self, b: int, mask_cls: np.ndarray, pad_hw, img_hw, out_hw, to_host: bool = True, pan_out=None) -> dict:
-        """Post-processing of image b (odise.py:336-370) from its mask_cls [Q,K+1] (host) and the device-resident mask logits.
-        to_host=False keeps the large results (sem_seg, panoptic map, instance masks) on the device as DeviceArrays, like the
-        reference, whose outputs are device tensors."""
+        """Post-processing of image b alone (see postprocess_batch)."""
+        return self.postprocess_batch({b: mask_cls}, pad_hw, img_hw, {b: out_hw}, to_host=to_host,
+                                      pan_out={b: pan_out} if pan_out is not None else None)[0]
+
+    def postprocess_batch(self, mask_cls, pad_hw, img_hw, out_sizes, to_host: bool = True, pan_out=None) -> list:
+        """Post-processing (odise.py:336-370) of the images in `mask_cls` ({b: [Q,K+1]} or an array [B,Q,K+1], host) from the
+        device-resident mask logits.  The work is staged ACROSS images - every host decision (kept queries, panoptic segment
+        ids, instance top-k) is taken for the whole batch between two rounds of kernel launches - so a step has two device
+        synchronisations instead of three per image.  to_host=False keeps the large results (sem_seg, panoptic map, instance
+        masks) on the device, like the reference, whose outputs are device tensors; they live in pooled buffers that the next
+        call reuses."""
         ctx, lib = self.ctx, self.ctx.lib
         Q, K = self.num_queries, self.num_classes
-        oh, ow = out_hw
-        probs = _softmax(mask_cls.astype(np.float32))
-        scores, labels = probs.max(-1), probs.argmax(-1)
-        keep = (labels != K) & (scores > self.object_mask_threshold)                       # maskformer_model.py:290
-        kscore = ctx.to_device(np.where(keep, scores, -1.0).astype(np.float32))
-        semT = ctx.to_device(np.ascontiguousarray(probs[:, :-1].T)) if self.semantic_on else None
-        sem = ctx.empty((K, oh, ow), np.float32) if self.semantic_on else None
-        ids = ctx.empty((oh * ow,), np.int32)
-        counts = ctx.empty((3, Q), np.int32)
+        items = list(mask_cls.items()) if isinstance(mask_cls, dict) else list(enumerate(mask_cls))
+        sizes = out_sizes if isinstance(out_sizes, dict) else dict(enumerate(out_sizes))
+        n = len(items)
         qpad = (Q + 7) // 8 * 8
-        inst = ctx.empty((2, qpad), np.float32) if self.instance_on else None
         p = lambda a: C.c_void_p(a.ptr) if a is not None else None
-        check(lib.odise_hip_postprocess_pixels(ctx.h, b, p(kscore), p(semT), K, pad_hw[0], pad_hw[1], img_hw[0], img_hw[1], oh, ow, p(sem), p(ids),
-                                               p(counts), p(inst)), "postprocess_pixels")
-        result = {}
-        if self.semantic_on:
-            result["sem_seg"] = sem.numpy() if to_host else sem
-        if self.panoptic_on:
-            cnt = counts.numpy()
-            seg_map = np.zeros(Q, np.int32)
-            segments_info, stuff_memory, current = [], {}, 0
-            for q in np.nonzero(keep)[0]:                                                   # kept queries in order (maskformer_model.py:312-340)
-                pred_class = int(labels[q])
-                isthing = pred_class in self.thing_ids
-                mask_area, original_area, inter = int(cnt[0, q]), int(cnt[1, q]), int(cnt[2, q])
-                if mask_area > 0 and original_area > 0 and inter > 0:
-                    if mask_area / original_area < self.overlap_threshold:
-                        continue
-                    if not isthing:
-                        if pred_class in stuff_memory:
-                            seg_map[q] = stuff_memory[pred_class]
-                            continue
-                        stuff_memory[pred_class] = current + 1
-                    current += 1
-                    seg_map[q] = current
-                    segments_info.append({"id": current, "isthing": bool(isthing), "category_id": pred_class})
-            seg = ctx.empty((oh, ow), np.int32) if pan_out is None else None
-            dmap = ctx.to_device(seg_map)
-            dst = p(seg) if seg is not None else C.c_void_p(int(pan_out))   # optionally write into a caller-owned buffer (gather slice)
-            check(lib.odise_hip_panoptic_write(ctx.h, p(ids), p(dmap), dst, oh * ow), "panoptic_write")
-            result["panoptic_seg"] = ((seg.numpy() if to_host else seg) if seg is not None else None, segments_info)
-        if self.instance_on:
-            sc = probs[:, :-1].reshape(-1)                                                  # maskformer_model.py:349-357
-            topk = min(self.test_topk_per_image, sc.size)
-            top = np.argpartition(-sc, topk - 1)[:topk]
-            top = top[np.argsort(-sc[top], kind="stable")]
-            cls, qidx, s = top % K, top // K, sc[top]
+        # ---- stage A (host): class probabilities, kept queries; one upload for the batch
+        probs = [_softmax(np.asarray(mc, np.float32)) for _, mc in items]
+        scores = [pr.max(-1) for pr in probs]
+        labels = [pr.argmax(-1) for pr in probs]
+        keep = [(lb != K) & (sc > self.object_mask_threshold) for lb, sc in zip(labels, scores)]   # maskformer_model.py:290
+        up = np.zeros((n, Q + K * Q), np.float32)
+        for i in range(n):
+            up[i, :Q] = np.where(keep[i], scores[i], -1.0)
+            if self.semantic_on:
+                up[i, Q:] = np.ascontiguousarray(probs[i][:, :-1].T).reshape(-1)
+        dup = self._buf("post_in", up.shape, np.float32).copy_from(up)
+        dcnt = self._buf("post_counts", (n, 3 * Q + 2 * qpad), np.float32)   # [3,Q] int32 counters + [2,qpad] fp32 instance stats
+        row = (3 * Q + 2 * qpad) * 4
+        sems, idss = [], []
+        # ---- stage B (device): per-pixel pass of every image
+        for i, (b, _) in enumerate(items):
+            oh, ow = sizes[b]
+            kscore = dup.view((Q,), np.float32, i * up.shape[1] * 4)
+            semT = dup.view((K, Q), np.float32, (i * up.shape[1] + Q) * 4) if self.semantic_on else None
+            sem = self._buf(f"sem{i}", (K, oh, ow), np.float32) if self.semantic_on else None
+            ids = self._buf(f"ids{i}", (oh * ow,), np.int32)
+            counts = dcnt.view((3, Q), np.int32, i * row)
+            inst = dcnt.view((2, qpad), np.float32, i * row + 3 * Q * 4) if self.instance_on else None
+            check(lib.odise_hip_postprocess_pixels(ctx.h, b, p(kscore), p(semT), K, pad_hw[0], pad_hw[1], img_hw[0], img_hw[1], oh, ow, p(sem),
+                                                   p(ids), p(counts), p(inst)), "postprocess_pixels")
+            sems.append(sem)
+            idss.append(ids)
+        # ---- stage C: one read-back (synchronises), host decisions for the batch
+        raw = dcnt.numpy()
+        results = [dict() for _ in range(n)]
+        maps = np.zeros((n, Q + self.test_topk_per_image), np.int32)   # [seg_map | instance query indices]
+        inst_sel = []
+        for i, (b, _) in enumerate(items):
             if self.panoptic_on:
-                thing = np.array([int(c) in self.thing_ids for c in cls], bool)
-                cls, qidx, s = cls[thing], qidx[thing], s[thing]
-            st = inst.numpy()
-            mask_scores = st[0, qidx] / (st[1, qidx] + 1e-6)
-            masks = ctx.empty((len(qidx), oh, ow), np.float32)
-            if len(qidx):
-                didx = ctx.to_device(qidx.astype(np.int32))
-                check(lib.odise_hip_instance_masks(ctx.h, b, p(didx), len(qidx), pad_hw[0], pad_hw[1], img_hw[0], img_hw[1], oh, ow, p(masks)),
-                      "instance_masks")
-            result["instances"] = {"pred_masks": masks.numpy() if to_host else masks, "scores": (s * mask_scores).astype(np.float32), "pred_classes": cls.astype(np.int64),
-                                   "query_index": qidx}
-        return result
+                cnt = raw[i, :3 * Q].view(np.int32).reshape(3, Q)
+                segments_info, stuff_memory, current = [], {}, 0
+                for q in np.nonzero(keep[i])[0]:                                            # kept queries in order (maskformer_model.py:312-340)
+                    pred_class = int(labels[i][q])
+                    isthing = pred_class in self.thing_ids
+                    mask_area, original_area, inter = int(cnt[0, q]), int(cnt[1, q]), int(cnt[2, q])
+                    if mask_area > 0 and original_area > 0 and inter > 0:
+                        if mask_area / original_area < self.overlap_threshold:
+                            continue
+                        if not isthing:
+                            if pred_class in stuff_memory:
+                                maps[i, q] = stuff_memory[pred_class]
+                                continue
+                            stuff_memory[pred_class] = current + 1
+                        current += 1
+                        maps[i, q] = current
+                        segments_info.append({"id": current, "isthing": bool(isthing), "category_id": pred_class})
+                results[i]["panoptic_seg"] = (None, segments_info)
+            if self.instance_on:
+                sc = probs[i][:, :-1].reshape(-1)                                           # maskformer_model.py:349-357
+                topk = min(self.test_topk_per_image, sc.size)
+                top = np.argpartition(-sc, topk - 1)[:topk]
+                top = top[np.argsort(-sc[top], kind="stable")]
+                cls, qidx, s = top % K, top // K, sc[top]
+                if self.panoptic_on:
+                    thing = np.array([int(c) in self.thing_ids for c in cls], bool)
+                    cls, qidx, s = cls[thing], qidx[thing], s[thing]
+                st = raw[i, 3 * Q:].reshape(2, qpad)
+                mask_scores = st[0, qidx] / (st[1, qidx] + 1e-6)
+                maps[i, Q:Q + len(qidx)] = qidx
+                inst_sel.append((cls, qidx, s, mask_scores))
+        dmaps = self._buf("post_maps", maps.shape, np.int32).copy_from(maps)
+        # ---- stage D (device): panoptic map and instance masks of every image
+        for i, (b, _) in enumerate(items):
+            oh, ow = sizes[b]
+            if self.panoptic_on:
+                ext = pan_out[b] if pan_out is not None and pan_out[b] is not None else None
+                seg = self._buf(f"seg{i}", (oh, ow), np.int32) if ext is None else None
+                dst = p(seg) if seg is not None else C.c_void_p(int(ext))   # optionally write into a caller-owned buffer (gather slice)
+                dmap = dmaps.view((Q,), np.int32, i * maps.shape[1] * 4)
+                check(lib.odise_hip_panoptic_write(ctx.h, p(idss[i]), p(dmap), dst, oh * ow), "panoptic_write")
+                results[i]["panoptic_seg"] = ((seg.numpy() if to_host else seg) if seg is not None else None, results[i]["panoptic_seg"][1])
+            if self.semantic_on:
+                results[i]["sem_seg"] = sems[i].numpy() if to_host else sems[i]
+            if self.instance_on:
+                cls, qidx, s, mask_scores = inst_sel[i]
+                masks = self._buf(f"masks{i}", (max(len(qidx), 1), oh, ow), np.float32).view((len(qidx), oh, ow))
+                if len(qidx):
+                    didx = dmaps.view((len(qidx),), np.int32, (i * maps.shape[1] + Q) * 4)
+                    check(lib.odise_hip_instance_masks(ctx.h, b, p(didx), len(qidx), pad_hw[0], pad_hw[1], img_hw[0], img_hw[1], oh, ow, p(masks)),
+                          "instance_masks")
+                results[i]["instances"] = {"pred_masks": masks.numpy() if to_host else masks, "scores": (s * mask_scores).astype(np.float32),
+                                           "pred_classes": cls.astype(np.int64), "query_index": qidx}
+        return results
 
     def forward_device(self, padded: DeviceArray, img01: DeviceArray, out_sizes, to_host: bool = False, pan_out=None) -> list:
         """Hot path with inputs already resident in HBM: padded [B,3,Hp,Wp] and img01 [B,3,H,W] fp32 in [0,1]."""
@@ -219,8 +273,8 @@ class HipCategoryODISE(HipODISE):
         self.backbone_device(padded, want_outputs=False)
         self.head_device(None, B, Hp // 4, Wp // 4, want_outputs=False)
         mask_cls = self.classify_device(img01).numpy()
-        return [self.postprocess_image(b, mask_cls[b], (Hp, Wp), (H, W), out_sizes[b], to_host=to_host,
-                                       pan_out=pan_out[b] if pan_out is not None else None) for b in range(B)]
+        return self.postprocess_batch(mask_cls, (Hp, Wp), (H, W), out_sizes, to_host=to_host,
+                                      pan_out=dict(enumerate(pan_out)) if pan_out is not None else None)
 
     def forward(self, batched_inputs) -> list:
         """CategoryODISE.forward, eval branch (odise.py:236-246, 282-372) for a batch of equally sized images."""
@@ -242,8 +296,5 @@ class HipCategoryODISE(HipODISE):
         self.backbone_device(dpad, want_outputs=False)
         self.head_device(None, B, Hp // 4, Wp // 4)
         mask_cls = self.classify_device(self.ctx.to_device(img01)).numpy()
-        outs = []
-        for b, x in enumerate(batched_inputs):
-            oh, ow = int(x.get("height", H)), int(x.get("width", W))
-            outs.append(self.postprocess_image(b, mask_cls[b], (Hp, Wp), (H, W), (oh, ow)))
-        return outs
+        sizes = [(int(x.get("height", H)), int(x.get("width", W))) for x in batched_inputs]
+        return self.postprocess_batch(mask_cls, (Hp, Wp), (H, W), sizes)

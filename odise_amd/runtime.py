@@ -30,6 +30,19 @@ class DeviceArray:
         self.ptr = p.value
         self._owned = True
 
+    def view(self, shape, dtype=None, offset_bytes: int = 0) -> "DeviceArray":
+        """Non-owning array over (a slice of) this buffer; keeps the owner alive."""
+        v = DeviceArray.__new__(DeviceArray)
+        v.ctx = self.ctx
+        v.shape = tuple(int(x) for x in shape)
+        v.dtype = np.dtype(dtype if dtype is not None else self.dtype)
+        v.nbytes = int(np.prod(v.shape, dtype=np.int64)) * v.dtype.itemsize
+        assert offset_bytes >= 0 and offset_bytes + v.nbytes <= self.nbytes, "view out of range"
+        v.ptr = self.ptr + offset_bytes
+        v._owned = False
+        v._base = self
+        return v
+
     def free(self):
         if self._owned and self.ptr and self.ctx.h:
             self.ctx.lib.odise_hip_free(self.ctx.h, C.c_void_p(self.ptr))
