@@ -11,7 +11,7 @@ import os
 import re
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "lib", "libodise_hip.so")
+LIB_PATH = os.environ.get("ODISE_HIP_LIB") or os.path.join(HERE, "lib", "libodise_hip.so")  # env: developer A/B builds
 HEADER_PATH = os.path.join(HERE, "..", "include", "odise_hip.h")
 
 F16, F32 = 0, 1

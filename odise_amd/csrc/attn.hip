@@ -124,43 +124,56 @@ __global__ void __launch_bounds__(256) attn_kernel(AttnArgs a) {
             }
         }
         // ---- scale, mask, online softmax (this lane: one query, 32 of the 64 keys) ----
+        // At d_head 40..64 this section, not the MFMAs, bounds the kernel (4096^2 scores per head: ~8 VALU slots each against
+        // 2 x 16 MFMA cycles per 32x32 tile), so the common case - no mask, tile fully inside Lk - runs a lean path: row max on
+        // the raw scores, one FMA (scale and max subtraction) + one v_exp_f32 per score.
+        const bool general = (Mb != nullptr) || (kv0 + 64 > a.Lk);  // wave-uniform
         float mx = -INFINITY;
+        if (general) {
 #pragma unroll
-        for (int t = 0; t < 2; ++t) {
+            for (int t = 0; t < 2; ++t) {
 #pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                const int kbase = kv0 + t * 32 + 8 * g + 4 * hi;  // keys kbase .. kbase+3  <-> regs 4g..4g+3
-                uint32_t mbits = 0;
-                if (Mb && kbase < a.Lk) mbits = *reinterpret_cast<const uint32_t*>(Mb + kbase);
+                for (int g = 0; g < 4; ++g) {
+                    const int kbase = kv0 + t * 32 + 8 * g + 4 * hi;  // keys kbase .. kbase+3  <-> regs 4g..4g+3
+                    uint32_t mbits = 0;
+                    if (Mb && kbase < a.Lk) mbits = *reinterpret_cast<const uint32_t*>(Mb + kbase);
 #pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    float s = st[t][4 * g + i] * a.scale_log2e;
-                    const bool dead = (kbase + i >= a.Lk) || ((mbits >> (8 * i)) & 0xff);
-                    s = dead ? -INFINITY : s;
-                    st[t][4 * g + i] = s;
-                    mx = fmaxf(mx, s);
+                    for (int i = 0; i < 4; ++i) {
+                        float s = st[t][4 * g + i];
+                        const bool dead = (kbase + i >= a.Lk) || ((mbits >> (8 * i)) & 0xff);
+                        s = dead ? -INFINITY : s;
+                        st[t][4 * g + i] = s;
+                        mx = fmaxf(mx, s);
+                    }
                 }
             }
+        } else {
+#pragma unroll
+            for (int t = 0; t < 2; ++t)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) mx = fmaxf(mx, st[t][r]);
         }
-        mx = fmaxf(mx, __shfl_xor(mx, 32));
+        mx = fmaxf(mx, __shfl_xor(mx, 32)) * a.scale_log2e;  // scale > 0: max commutes with the scaling (-inf stays -inf)
         const float m_new = fmaxf(m_run, mx);
         const float m_safe = (m_new == -INFINITY) ? 0.f : m_new;
-        const float alpha = exp2f(m_run - m_safe);  // m_run = -inf -> 0
+        const float alpha = __builtin_amdgcn_exp2f(m_run - m_safe);  // m_run = -inf -> 0
         float psum = 0.f;
 #pragma unroll
         for (int t = 0; t < 2; ++t)
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const float p = exp2f(st[t][r] - m_safe);
+                const float p = __builtin_amdgcn_exp2f(fmaf(st[t][r], a.scale_log2e, -m_safe));  // masked: fma(-inf) = -inf -> 0
                 st[t][r] = p;
                 psum += p;
             }
         l_run = l_run * alpha + psum;
         m_run = m_new;
+        if (__builtin_amdgcn_ballot_w64(alpha != 1.0f) != 0) {  // the running max settles after a few tiles: skip the rescale then
 #pragma unroll
-        for (int t = 0; t < DT; ++t)
+            for (int t = 0; t < DT; ++t)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) ot[t][r] *= alpha;
+                for (int r = 0; r < 16; ++r) ot[t][r] *= alpha;
+        }
 
         // ---- O^T += V^T P^T : per (key tile t, half-step s2) one MFMA per d tile ----
 #pragma unroll
@@ -295,6 +308,7 @@ extern "C" int odise_hip_attention(odise_hip_ctx* ctx, const odise_attn_desc* d)
     using namespace odise;
     ODISE_REQUIRE(ctx && d, "attention: null argument");
     ODISE_REQUIRE(d->B >= 0 && d->H >= 1 && d->Lq >= 0 && d->Lk >= 1 && d->D >= 8, "attention: bad dims");
+    ODISE_REQUIRE(d->scale > 0.f, "attention: scale must be positive");
     ODISE_REQUIRE(d->D % 8 == 0 && d->D <= 160, "attention: head dim %d must be a multiple of 8 and <= 160", d->D);
     if (d->B == 0 || d->Lq == 0) return ODISE_OK;
     ODISE_REQUIRE(d->Q && d->K && d->Vt && d->O, "attention: null device pointer");

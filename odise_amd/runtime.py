@@ -233,12 +233,12 @@ class Context:
         return y
 
     def attention(self, Q: DeviceArray, K: DeviceArray, Vt: DeviceArray, heads: int, scale: float,
-                  mask: Optional[DeviceArray] = None, Lk: Optional[int] = None) -> DeviceArray:
+                  mask: Optional[DeviceArray] = None, Lk: Optional[int] = None, out: Optional[DeviceArray] = None) -> DeviceArray:
         """Q [B,Lq,H*D], K [B,Lk,H*D], Vt [B,H*D,ldvt] (transposed V) -> O [B,Lq,H*D] (all f16)."""
         B, Lq, HD = Q.shape
         Lk = Lk if Lk is not None else K.shape[1]
         D = HD // heads
-        O = self.empty((B, Lq, HD), np.float16)
+        O = out if out is not None else self.empty((B, Lq, HD), np.float16)
         d = AttnDesc()
         d.B, d.H, d.Lq, d.Lk, d.D = B, heads, Lq, Lk, D
         d.Q, d.ldq, d.strideQ = Q.ptr, HD, Lq * HD
