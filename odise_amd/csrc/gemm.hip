@@ -37,7 +37,7 @@ struct GemmEpi {
     int geglu;
     float alpha;
     int64_t strideC, strideR;
-    int fast;  // 1: fp16 output, 16-byte aligned rows, no GEGLU / scale_m / bias_m / rowgroup_add -> epi_fast8 for full chunks
+    int fast;  // 1: every vector access of a full 8-column chunk is aligned -> epi_fast8 (set by launch_gemm)
 };
 
 struct ConvGeom {
@@ -163,11 +163,39 @@ __device__ __forceinline__ void epi_fast8(const GemmEpi& e, float (&v)[8], int m
         const float4 b1 = *reinterpret_cast<const float4*>(e.bias_n + n + 4);
         b[0] = b0.x; b[1] = b0.y; b[2] = b0.z; b[3] = b0.w; b[4] = b1.x; b[5] = b1.y; b[6] = b1.z; b[7] = b1.w;
     }
-    f16x8 r = {0, 0, 0, 0, 0, 0, 0, 0};
-    if (e.residual) r = *reinterpret_cast<const f16x8*>(e.residual + (int64_t)z * e.strideR + (int64_t)m * e.ldr + n);
-    const float alpha = e.alpha;
+    if (e.rowgroup_add) {  // per-image vector (time embedding): one row-group index per 8 outputs
+        const float* rg = e.rowgroup_add + (int64_t)((unsigned)m / (unsigned)e.rows_per_group) * e.ldg + n;
+        const float4 r0 = *reinterpret_cast<const float4*>(rg);
+        const float4 r1 = *reinterpret_cast<const float4*>(rg + 4);
+        b[0] += r0.x; b[1] += r0.y; b[2] += r0.z; b[3] += r0.w; b[4] += r1.x; b[5] += r1.y; b[6] += r1.z; b[7] += r1.w;
+    }
+    float alpha = e.alpha;
+    if (e.scale_m) alpha *= e.scale_m[m];
+    if (e.bias_m) {
+        const float bm = e.bias_m[m];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) b[i] += bm;
+    }
 #pragma unroll
     for (int i = 0; i < 8; ++i) v[i] = v[i] * alpha + b[i];
+    if (e.geglu) {
+        // columns are (a, gate) pairs; the output has N/2 columns (no activation / residual on this path)
+        float o[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) o[i] = v[2 * i] * gelu_exact(v[2 * i + 1]);
+        const int64_t off = (int64_t)z * e.strideC + (int64_t)m * e.ldc + (n >> 1);
+        if (e.c_dtype == ODISE_F16) {
+            f16x4 t;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) t[i] = (f16)o[i];
+            *reinterpret_cast<f16x4*>((f16*)e.C + off) = t;
+        } else {
+            *reinterpret_cast<float4*>((float*)e.C + off) = make_float4(o[0], o[1], o[2], o[3]);
+        }
+        return;
+    }
+    f16x8 r = {0, 0, 0, 0, 0, 0, 0, 0};
+    if (e.residual) r = *reinterpret_cast<const f16x8*>(e.residual + (int64_t)z * e.strideR + (int64_t)m * e.ldr + n);
     if (e.act == ODISE_ACT_SILU) {
 #pragma unroll
         for (int i = 0; i < 8; ++i) v[i] = v[i] / (1.0f + __expf(-v[i]));
@@ -181,10 +209,17 @@ __device__ __forceinline__ void epi_fast8(const GemmEpi& e, float (&v)[8], int m
 #pragma unroll
         for (int i = 0; i < 8; ++i) v[i] = gelu_exact(v[i]);
     }
-    f16x8 t;
+    const int64_t off = (int64_t)z * e.strideC + (int64_t)m * e.ldc + n;
+    if (e.c_dtype == ODISE_F16) {
+        f16x8 t;
 #pragma unroll
-    for (int i = 0; i < 8; ++i) t[i] = (f16)(v[i] + (float)r[i]);
-    *reinterpret_cast<f16x8*>((f16*)e.C + (int64_t)z * e.strideC + (int64_t)m * e.ldc + n) = t;
+        for (int i = 0; i < 8; ++i) t[i] = (f16)(v[i] + (float)r[i]);
+        *reinterpret_cast<f16x8*>((f16*)e.C + off) = t;
+    } else {
+        float* c = (float*)e.C + off;
+        *reinterpret_cast<float4*>(c) = make_float4(v[0] + (float)r[0], v[1] + (float)r[1], v[2] + (float)r[2], v[3] + (float)r[3]);
+        *reinterpret_cast<float4*>(c + 4) = make_float4(v[4] + (float)r[4], v[5] + (float)r[5], v[6] + (float)r[6], v[7] + (float)r[7]);
+    }
 }
 
 // ---- epilogue through LDS: passes of 64 rows (two wave-rows x one 32-row MFMA tile) x BN fp32.  The caller guarantees that every
@@ -957,12 +992,26 @@ static int launch_gemm(odise_hip_ctx* ctx, GemmArgs& g, int batch, int force_til
         g.splitk = (int)ceil_div(nk, g.ktiles_per_split);
         ODISE_REQUIRE((size_t)g.splitk * g.M * g.N * sizeof(float) <= ctx->ws_bytes, "gemm: split-K workspace too small");
     }
+    if (flags & 32) {  // ODISE_GEMM_FLAGS=32: log every launch (tools/shape_log.py aggregates)
+        fprintf(stderr, "GEMMLOG conv=%d M=%d N=%d K=%d batch=%d cin=%d kh=%d h=%d w=%d stride=%d ups=%d tile=%d split=%d pp=%d\n", (int)CONV, g.M, g.N,
+                g.K, batch, g.cg.Cin, g.cg.KH, g.cg.H, g.cg.W, g.cg.stride, g.cg.ups, tile, best_split, (int)pp_ok);
+    }
     g.ws = (float*)ctx->ws;
-    g.epi.fast = (g.epi.c_dtype == ODISE_F16 && !g.epi.geglu && !g.epi.scale_m && !g.epi.bias_m && !g.epi.rowgroup_add && (g.epi.ldc % 8) == 0 &&
-                  (((uintptr_t)g.epi.C & 15) == 0) && (g.epi.strideC % 8) == 0 &&
-                  (!g.epi.residual || ((g.epi.ldr % 8) == 0 && (g.epi.strideR % 8) == 0 && ((uintptr_t)g.epi.residual & 15) == 0)) &&
-                  (!g.epi.bias_n || ((uintptr_t)g.epi.bias_n & 15) == 0))
-                     ? 1 : 0;
+    {
+        // epi_fast8 preconditions: every vector access of a full 8-column chunk is naturally aligned
+        const GemmEpi& e = g.epi;
+        const int esz = e.c_dtype == ODISE_F16 ? 2 : 4;
+        const int out_vec = (e.geglu ? 4 : 8) * esz;  // bytes stored per chunk
+        auto aligned = [](const void* p, int64_t ld_elems, int64_t stride_elems, int elem, int bytes) {
+            return ((uintptr_t)p % bytes) == 0 && (ld_elems * elem) % bytes == 0 && (stride_elems * elem) % bytes == 0;
+        };
+        bool ok = aligned(e.C, e.ldc, e.strideC, esz, out_vec);
+        ok = ok && (!e.residual || (!e.geglu && aligned(e.residual, e.ldr, e.strideR, 2, 16)));
+        ok = ok && (!e.bias_n || ((uintptr_t)e.bias_n & 15) == 0);
+        ok = ok && (!e.rowgroup_add || (((uintptr_t)e.rowgroup_add & 15) == 0 && e.ldg % 4 == 0));
+        ok = ok && (!e.geglu || e.act == ODISE_ACT_NONE);
+        g.epi.fast = ok ? 1 : 0;
+    }
     g.zeros = (const f16*)ctx->zeros;
     g.dbg = g_gemm_debug;
     // the 256-row tiles run the ping-pong pipelined kernel whenever its preconditions hold
