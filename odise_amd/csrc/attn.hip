@@ -81,21 +81,26 @@ __global__ void __launch_bounds__(256) attn_kernel(AttnArgs a) {
         kt_begin = split * per;
         kt_end = min(ntiles, kt_begin + per);
     }
-    for (int kt = kt_begin; kt < kt_end; ++kt) {
+    // K / V^T tiles are fetched one tile ahead into registers (the loads of tile kt+1 fly while tile kt is multiplied) and written
+    // to LDS after the barrier that retires the previous tile's reads
+    constexpr int NKR = (64 * KSLOTS + 255) / 256;  // 16-byte K slots per thread
+    constexpr int NVR = DT;                         // 16-byte V^T slots per thread (DT*32 rows x 8 slots / 256 threads)
+    f16x8 kreg[NKR], vreg[NVR];
+    auto fetch = [&](int kt) {
         const int kv0 = kt * 64;
-        __syncthreads();  // previous tile fully consumed
-        // ---- stage K tile: 64 keys x DPAD ----
-        for (int c = tid; c < 64 * KSLOTS; c += 256) {
+#pragma unroll
+        for (int u = 0; u < NKR; ++u) {
+            const int c = tid + u * 256;
             const int key = c / KSLOTS, sl = c - key * KSLOTS;
-            f16x8 v = zero8;
-            if (kv0 + key < a.Lk && sl * 8 < D) v = *reinterpret_cast<const f16x8*>(Kb + (int64_t)(kv0 + key) * a.ldk + sl * 8);
-            *reinterpret_cast<f16x8*>(Ks + key * KROW + sl * 8) = v;
+            kreg[u] = zero8;
+            if (c < 64 * KSLOTS && kv0 + key < a.Lk && sl * 8 < D) kreg[u] = *reinterpret_cast<const f16x8*>(Kb + (int64_t)(kv0 + key) * a.ldk + sl * 8);
         }
-        // ---- stage V^T tile: DT*32 rows (d) x 64 keys ----
-        for (int c = tid; c < DT * 32 * 8; c += 256) {
+#pragma unroll
+        for (int u = 0; u < NVR; ++u) {
+            const int c = tid + u * 256;
             const int d = c >> 3, sl = c & 7;
-            f16x8 v = zero8;
             const int k0 = kv0 + sl * 8;
+            f16x8 v = zero8;
             if (d < D && k0 < a.Lk) {
                 v = *reinterpret_cast<const f16x8*>(Vb + (int64_t)d * a.ldvt + k0);
                 if (k0 + 8 > a.Lk) {
@@ -104,12 +109,34 @@ __global__ void __launch_bounds__(256) attn_kernel(AttnArgs a) {
                         if (k0 + i >= a.Lk) v[i] = (f16)0.f;
                 }
             }
+            vreg[u] = v;
+        }
+    };
+    auto stage = [&]() {
+#pragma unroll
+        for (int u = 0; u < NKR; ++u) {
+            const int c = tid + u * 256;
+            const int key = c / KSLOTS, sl = c - key * KSLOTS;
+            if (c < 64 * KSLOTS) *reinterpret_cast<f16x8*>(Ks + key * KROW + sl * 8) = kreg[u];
+        }
+#pragma unroll
+        for (int u = 0; u < NVR; ++u) {
+            const int c = tid + u * 256;
+            const int d = c >> 3, sl = c & 7;
             // V^T row stride is 136 B: write as two 8-byte halves (8-byte aligned)
+            const f16x8 v = vreg[u];
             f16x4 lo4 = {v[0], v[1], v[2], v[3]}, hi4 = {v[4], v[5], v[6], v[7]};
             *reinterpret_cast<f16x4*>(Vs + d * VROW + sl * 8) = lo4;
             *reinterpret_cast<f16x4*>(Vs + d * VROW + sl * 8 + 4) = hi4;
         }
+    };
+    if (kt_begin < kt_end) fetch(kt_begin);
+    for (int kt = kt_begin; kt < kt_end; ++kt) {
+        const int kv0 = kt * 64;
+        __syncthreads();  // previous tile fully consumed
+        stage();
         __syncthreads();
+        if (kt + 1 < kt_end) fetch(kt + 1);
 
         // ---- S^T = K Q^T for two 32-key tiles ----
         f32x16 st[2];

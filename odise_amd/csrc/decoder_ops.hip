@@ -101,33 +101,70 @@ struct MsdaPrep {
 
 // off [R, M*L*P*2] f32, aw [R, M*L*P] f32 (R = B*Lq rows; query q = r % Lq) -> loc [R,M,L,P,2], w [R,M,L,P]
 // reference point of query q = centre of its own cell at its own level, identical for every sampled level (valid ratios 1)
+// LC, PC: compile-time levels / points (0, 0 = runtime values from g: generic, arrays spill to scratch)
+template <int LC, int PC>
 __global__ void __launch_bounds__(256) msda_prepare_kernel(const float* __restrict__ off, const float* __restrict__ aw, float* __restrict__ loc,
                                                           float* __restrict__ w, int Lq, int64_t rows_heads, MsdaPrep g) {
+    constexpr bool FIXED = LC > 0;
+    constexpr int NE = FIXED ? LC * PC : 32;
     for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < rows_heads; idx += (int64_t)gridDim.x * blockDim.x) {
+        const int L = FIXED ? LC : g.L, P = FIXED ? PC : g.P;
         const int64_t r = idx / g.M;
         const int q = (int)(r % Lq);
         int lvl = 0;
-        for (int l = 1; l < g.L; ++l)
+        for (int l = 1; l < L; ++l)
             if (q >= g.start[l]) lvl = l;
         const int local = q - g.start[lvl];
         const float ref_y = ((float)(local / g.W[lvl]) + 0.5f) / (float)g.H[lvl];
         const float ref_x = ((float)(local % g.W[lvl]) + 0.5f) / (float)g.W[lvl];
-        const int LP = g.L * g.P;
+        const int LP = L * P;
         const float* a = aw + idx * LP;
-        float mx = -INFINITY;
-        for (int i = 0; i < LP; ++i) mx = fmaxf(mx, a[i]);
-        float e[32];
-        float sum = 0.f;
-        for (int i = 0; i < LP; ++i) { e[i] = expf(a[i] - mx); sum += e[i]; }
-        const float inv = 1.f / sum;
         const float* o = off + idx * LP * 2;
-        for (int l = 0; l < g.L; ++l)
-            for (int p = 0; p < g.P; ++p) {
-                const int i = l * g.P + p;
-                w[idx * LP + i] = e[i] * inv;
-                loc[(idx * LP + i) * 2 + 0] = ref_x + o[2 * i + 0] / (float)g.W[l];
-                loc[(idx * LP + i) * 2 + 1] = ref_y + o[2 * i + 1] / (float)g.H[l];
+        float e[NE], ov[2 * NE];
+        if (FIXED && (NE & 3) == 0) {
+            // a lane's 4*LP + 8*LP bytes are contiguous and 16-byte aligned: vector loads (scalar ones waste 3/4 of every request)
+#pragma unroll
+            for (int i = 0; i < NE; i += 4) {
+                const float4 t = *reinterpret_cast<const float4*>(a + i);
+                e[i] = t.x; e[i + 1] = t.y; e[i + 2] = t.z; e[i + 3] = t.w;
             }
+#pragma unroll
+            for (int i = 0; i < 2 * NE; i += 4) {
+                const float4 t = *reinterpret_cast<const float4*>(o + i);
+                ov[i] = t.x; ov[i + 1] = t.y; ov[i + 2] = t.z; ov[i + 3] = t.w;
+            }
+        } else {
+            for (int i = 0; i < LP; ++i) e[i] = a[i];
+            for (int i = 0; i < 2 * LP; ++i) ov[i] = o[i];
+        }
+        float mx = -INFINITY;
+#pragma unroll
+        for (int i = 0; i < NE; ++i)
+            if (i < LP) mx = fmaxf(mx, e[i]);
+        float sum = 0.f;
+#pragma unroll
+        for (int i = 0; i < NE; ++i)
+            if (i < LP) { e[i] = expf(e[i] - mx); sum += e[i]; }
+        const float inv = 1.f / sum;
+#pragma unroll
+        for (int i = 0; i < NE; ++i)
+            if (i < LP) {
+                const int l = i / P;
+                e[i] *= inv;
+                ov[2 * i + 0] = ref_x + ov[2 * i + 0] / (float)g.W[l];
+                ov[2 * i + 1] = ref_y + ov[2 * i + 1] / (float)g.H[l];
+            }
+        float* wo = w + idx * LP;
+        float* lo = loc + idx * LP * 2;
+        if (FIXED && (NE & 3) == 0) {
+#pragma unroll
+            for (int i = 0; i < NE; i += 4) *reinterpret_cast<float4*>(wo + i) = make_float4(e[i], e[i + 1], e[i + 2], e[i + 3]);
+#pragma unroll
+            for (int i = 0; i < 2 * NE; i += 4) *reinterpret_cast<float4*>(lo + i) = make_float4(ov[i], ov[i + 1], ov[i + 2], ov[i + 3]);
+        } else {
+            for (int i = 0; i < LP; ++i) wo[i] = e[i];
+            for (int i = 0; i < 2 * LP; ++i) lo[i] = ov[i];
+        }
     }
 }
 
@@ -264,7 +301,8 @@ int launch_msda_prepare(odise_hip_ctx* ctx, const float* off, const float* aw, f
     g.L = L; g.P = P; g.M = M;
     for (int l = 0; l < L; ++l) { g.H[l] = Hs[l]; g.W[l] = Ws[l]; g.start[l] = starts[l]; }
     const int64_t rh = (int64_t)B * Lq * M;
-    hipLaunchKernelGGL(msda_prepare_kernel, dim3(g1(rh)), dim3(256), 0, ctx->stream, off, aw, loc, w, Lq, rh, g);
+    if (L == 3 && P == 4) hipLaunchKernelGGL((msda_prepare_kernel<3, 4>), dim3(g1(rh)), dim3(256), 0, ctx->stream, off, aw, loc, w, Lq, rh, g);
+    else hipLaunchKernelGGL((msda_prepare_kernel<0, 0>), dim3(g1(rh)), dim3(256), 0, ctx->stream, off, aw, loc, w, Lq, rh, g);
     ODISE_CHECK_HIP(hipGetLastError());
     return ODISE_OK;
 }
