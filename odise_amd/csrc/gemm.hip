@@ -222,14 +222,40 @@ __device__ __forceinline__ void epi_fast8(const GemmEpi& e, float (&v)[8], int m
     }
 }
 
-// ---- epilogue through LDS: passes of 64 rows (two wave-rows x one 32-row MFMA tile) x BN fp32.  The caller guarantees that every
-// wave is done with the operand tiles (barrier) and that no LDS-DMA is outstanding.
-template <int BM, int BN, int WAVES_M, int WAVES_N>
+// ---- epilogue through LDS (fp32 staging) in passes of WG wave-rows = WG * (BM / WAVES_M) rows x BN columns: the waves of those
+// rows dump their accumulators, then ALL threads read 8 consecutive columns per lane, apply the epilogue and store 16 bytes.
+// WG is as large as the kernel's LDS allows (epi_wave_rows): fewer passes = fewer barriers and more waves staging at once.
+// The caller guarantees that every wave is done with the operand tiles (barrier) and that no LDS-DMA is outstanding.
+// LDS requested by the two kernel families: the operand stages, stretched (when that keeps the blocks-per-CU count) so that the
+// epilogue can stage more wave-rows per pass
+constexpr int plain_lds_bytes(int BM, int BN, int WAVES_M) {
+    const int stage = (BM + BN) * 64 * 2 * 2;
+    const int all_rows = BM * (BN + 4) * 4;  // the whole tile staged in one pass
+    // 4-wave tiles share a CU: only stretch while the resident block count (160 KiB / LDS) is unchanged
+    return (all_rows > stage && (160 * 1024) / all_rows == (160 * 1024) / stage) ? all_rows : stage;
+}
+constexpr int pp_lds_bytes(int BM, int BN, int WAVES_M) {
+    const int stage = (BM + BN) * 64 * 2 * 2;
+    const int half_rows = (BM / 2) * (BN + 4) * 4;  // one block per CU anyway: stage half the tile per pass when it fits
+    return (half_rows > stage && half_rows <= 160 * 1024) ? half_rows : stage;
+}
+constexpr int epi_wave_rows(int BM, int BN, int WAVES_M, int lds_bytes) {
+    const int per_row = (BM / WAVES_M) * (BN + 4) * 4;
+    int wg = lds_bytes / per_row;
+    if (wg < 1) wg = 1;
+    if (wg > WAVES_M) wg = WAVES_M;
+    while (WAVES_M % wg) --wg;
+    return wg;
+}
+constexpr int epi_lds_bytes(int BM, int BN, int WAVES_M, int WG) { return WG * (BM / WAVES_M) * (BN + 4) * 4; }
+
+template <int BM, int BN, int WAVES_M, int WAVES_N, int WG>
 __device__ __forceinline__ void gemm_epilogue(const GemmArgs& g, f32x16 (&acc)[BM / WAVES_M / 32][BN / WAVES_N / 32], char* smem, int m0, int n0,
                                               int z, int zb, bool split) {
     constexpr int NT = 64 * WAVES_M * WAVES_N;
     constexpr int WTM = BM / WAVES_M, WTN = BN / WAVES_N;
     constexpr int TM = WTM / 32, TN = WTN / 32;
+    constexpr int ROWS = WG * WTM;  // rows per pass
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = tid >> 6;
@@ -239,46 +265,45 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& g, f32x16 (&acc)[B
     constexpr int CH = BN / 8;
     float* stg = reinterpret_cast<float*>(smem);
 #pragma unroll
-    for (int gp = 0; gp < WAVES_M / 2; ++gp) {
+    for (int gp = 0; gp < WAVES_M / WG; ++gp) {
+        if (gp > 0) lds_barrier();  // staging reads of the previous pass are done (global stores may still fly)
+        if (wm / WG == gp) {
 #pragma unroll
-        for (int p = 0; p < TM; ++p) {
-            if (gp > 0 || p > 0) lds_barrier();  // staging reads of the previous pass are done (global stores may still fly)
-            if ((wm >> 1) == gp) {
+            for (int p = 0; p < TM; ++p)
 #pragma unroll
                 for (int j = 0; j < TN; ++j) {
 #pragma unroll
                     for (int r = 0; r < 16; ++r) {
-                        const int row = (wm & 1) * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+                        const int row = (wm % WG) * WTM + p * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
                         const int col = wn * WTN + j * 32 + l31;
                         stg[row * LDS_LD + col] = acc[p][j][r];
                     }
                 }
-            }
-            lds_barrier();
-            for (int c = tid; c < 64 * CH; c += NT) {
-                const int row = c / CH;
-                const int c8 = c - row * CH;
-                const int m = m0 + (gp * 2 + (row >> 5)) * WTM + p * 32 + (row & 31);
-                const int n = n0 + c8 * 8;
-                if (m < g.M && n < g.N) {
-                    float v[8];
-                    const float4 t0 = *reinterpret_cast<const float4*>(&stg[row * LDS_LD + c8 * 8]);
-                    const float4 t1 = *reinterpret_cast<const float4*>(&stg[row * LDS_LD + c8 * 8 + 4]);
-                    v[0] = t0.x; v[1] = t0.y; v[2] = t0.z; v[3] = t0.w;
-                    v[4] = t1.x; v[5] = t1.y; v[6] = t1.z; v[7] = t1.w;
-                    if (split) {
-                        float* w = g.ws + ((int64_t)z * g.M + m) * g.N + n;
-                        const int nv = (g.N - n) < 8 ? (g.N - n) : 8;
-                        if (nv == 8 && (g.N & 3) == 0) {
-                            *reinterpret_cast<float4*>(w) = t0;
-                            *reinterpret_cast<float4*>(w + 4) = t1;
-                        } else {
-                            for (int i = 0; i < nv; ++i) w[i] = v[i];
-                        }
-                    } else if (!(g.dbg & 8) || v[0] == 12345.678f) {  // dbg 8: ablate the global store + epilogue math
-                        if (g.epi.fast && n + 8 <= g.N) epi_fast8(g.epi, v, m, n, zb);
-                        else epi_store8(g.epi, v, m, n, g.N, zb);
+        }
+        lds_barrier();
+        for (int c = tid; c < ROWS * CH; c += NT) {
+            const int row = c / CH;
+            const int c8 = c - row * CH;
+            const int m = m0 + gp * ROWS + row;
+            const int n = n0 + c8 * 8;
+            if (m < g.M && n < g.N) {
+                float v[8];
+                const float4 t0 = *reinterpret_cast<const float4*>(&stg[row * LDS_LD + c8 * 8]);
+                const float4 t1 = *reinterpret_cast<const float4*>(&stg[row * LDS_LD + c8 * 8 + 4]);
+                v[0] = t0.x; v[1] = t0.y; v[2] = t0.z; v[3] = t0.w;
+                v[4] = t1.x; v[5] = t1.y; v[6] = t1.z; v[7] = t1.w;
+                if (split) {
+                    float* w = g.ws + ((int64_t)z * g.M + m) * g.N + n;
+                    const int nv = (g.N - n) < 8 ? (g.N - n) : 8;
+                    if (nv == 8 && (g.N & 3) == 0) {
+                        *reinterpret_cast<float4*>(w) = t0;
+                        *reinterpret_cast<float4*>(w + 4) = t1;
+                    } else {
+                        for (int i = 0; i < nv; ++i) w[i] = v[i];
                     }
+                } else if (!(g.dbg & 8) || v[0] == 12345.678f) {  // dbg 8: ablate the global store + epilogue math
+                    if (g.epi.fast && n + 8 <= g.N) epi_fast8(g.epi, v, m, n, zb);
+                    else epi_store8(g.epi, v, m, n, g.N, zb);
                 }
             }
         }
@@ -500,7 +525,7 @@ __global__ void __launch_bounds__(64 * WAVES_M * WAVES_N) gemm_kernel(GemmArgs g
     __syncthreads();  // every wave is done with the operand tiles before the staging buffer is reused
     if (g.dbg & 4) return;  // ablation: main loop only
 
-    gemm_epilogue<BM, BN, WAVES_M, WAVES_N>(g, acc, smem, m0, n0, z, zb, split);
+    gemm_epilogue<BM, BN, WAVES_M, WAVES_N, epi_wave_rows(BM, BN, WAVES_M, plain_lds_bytes(BM, BN, WAVES_M))>(g, acc, smem, m0, n0, z, zb, split);
 }
 
 template <int N>
@@ -820,7 +845,7 @@ __global__ void __launch_bounds__(512) gemm_pp_kernel(GemmArgs g) {
     if (grp == 0) __builtin_amdgcn_s_barrier();  // re-align the two groups
     __syncthreads();
     if (g.dbg & 4) return;
-    gemm_epilogue<BM, BN, WAVES_M, WAVES_N>(g, acc, smem, m0, n0, z, zb, split);
+    gemm_epilogue<BM, BN, WAVES_M, WAVES_N, epi_wave_rows(BM, BN, WAVES_M, pp_lds_bytes(BM, BN, WAVES_M))>(g, acc, smem, m0, n0, z, zb, split);
 }
 
 __global__ void __launch_bounds__(256) splitk_reduce_kernel(const float* __restrict__ ws, int splitk, int M, int N, GemmEpi e) {
@@ -855,9 +880,8 @@ __global__ void __launch_bounds__(256) splitk_reduce_kernel(const float* __restr
 template <int BM, int BN, int WAVES_M, int WAVES_N, bool CONV, bool INTERLEAVE = true>
 static int launch_gemm_t(odise_hip_ctx* ctx, GemmArgs& g, int batch) {
     constexpr int NT = 64 * WAVES_M * WAVES_N;
-    constexpr int stage = (BM + BN) * 64 * 2 * 2;
-    constexpr int epi = 64 * (BN + 4) * 4;
-    constexpr int lds = stage > epi ? stage : epi;
+    constexpr int lds = plain_lds_bytes(BM, BN, WAVES_M);
+    static_assert(epi_lds_bytes(BM, BN, WAVES_M, epi_wave_rows(BM, BN, WAVES_M, lds)) <= lds, "epilogue staging exceeds the LDS request");
     auto kern = gemm_kernel<BM, BN, WAVES_M, WAVES_N, CONV, INTERLEAVE>;
     if (lds > 65536) {
         static bool attr_set = false;  // per instantiation
@@ -880,7 +904,8 @@ static int launch_gemm_t(odise_hip_ctx* ctx, GemmArgs& g, int batch) {
 
 template <int BM, int BN, int WAVES_N, int PT, bool CONV>
 static int launch_gemm_pp(odise_hip_ctx* ctx, GemmArgs& g, int batch) {
-    constexpr int lds = 2 * (BM + BN) * 64 * 2;
+    constexpr int lds = pp_lds_bytes(BM, BN, 8 / WAVES_N);
+    static_assert(epi_lds_bytes(BM, BN, 8 / WAVES_N, epi_wave_rows(BM, BN, 8 / WAVES_N, lds)) <= lds, "epilogue staging exceeds the LDS request");
     auto kern = gemm_pp_kernel<BM, BN, WAVES_N, PT, CONV>;
     static bool attr_set = false;  // per instantiation
     if (!attr_set) {
