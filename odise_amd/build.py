@@ -47,6 +47,9 @@ def build(verbose: bool = True, force: bool = False) -> str:
     hm = _headers_mtime()
     flags = ["-O3", "-std=c++17", "-fPIC", f"--offload-arch={ARCH}", 
              "-Wno-unused-result", "-x", "hip"]
+    # per-source extras.  attn.hip: MFMA results are consumed by VALU code every tile (softmax, rescale), so keep them in VGPRs -
+    # the default AGPR form costs a v_accvgpr_read/write per element (128 VALU slots per tile) and a wave of occupancy.
+    extra = {"attn.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form"]}
     jobs = []
     objs = []
     for src in _sources():
@@ -58,7 +61,7 @@ def build(verbose: bool = True, force: bool = False) -> str:
 
     def _compile(job):
         sp, op = job
-        cmd = [hipcc, *flags, "-c", sp, "-o", op]
+        cmd = [hipcc, *flags, *extra.get(os.path.basename(sp), []), "-c", sp, "-o", op]
         if verbose:
             print("[odise_amd.build]", " ".join(cmd), flush=True)
         r = subprocess.run(cmd, capture_output=True, text=True)

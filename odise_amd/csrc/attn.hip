@@ -184,15 +184,22 @@ __global__ void __launch_bounds__(256) attn_kernel(AttnArgs a) {
         const float m_new = fmaxf(m_run, mx);
         const float m_safe = (m_new == -INFINITY) ? 0.f : m_new;
         const float alpha = __builtin_amdgcn_exp2f(m_run - m_safe);  // m_run = -inf -> 0
-        float psum = 0.f;
+        // two scores per VALU op where a packed form exists (v_pk_fma_f32, v_pk_add_f32); v_exp_f32 has none
+        typedef float f32x2 __attribute__((ext_vector_type(2)));
+        const f32x2 sc2 = {a.scale_log2e, a.scale_log2e}, nm2 = {-m_safe, -m_safe};
+        f32x2 ps2 = {0.f, 0.f};
 #pragma unroll
         for (int t = 0; t < 2; ++t)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const float p = __builtin_amdgcn_exp2f(fmaf(st[t][r], a.scale_log2e, -m_safe));  // masked: fma(-inf) = -inf -> 0
-                st[t][r] = p;
-                psum += p;
+            for (int r = 0; r < 16; r += 2) {
+                const f32x2 x = {st[t][r], st[t][r + 1]};
+                const f32x2 y = __builtin_elementwise_fma(x, sc2, nm2);  // masked: fma(-inf) = -inf -> p = 0
+                const f32x2 p = {__builtin_amdgcn_exp2f(y[0]), __builtin_amdgcn_exp2f(y[1])};
+                st[t][r] = p[0];
+                st[t][r + 1] = p[1];
+                ps2 += p;
             }
+        const float psum = ps2[0] + ps2[1];
         l_run = l_run * alpha + psum;
         m_run = m_new;
         if (__builtin_amdgcn_ballot_w64(alpha != 1.0f) != 0) {  // the running max settles after a few tiles: skip the rescale then
