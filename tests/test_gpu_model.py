@@ -110,3 +110,19 @@ def test_classification_stage(models, ctx):
     print("class prob max abs err", np.abs(p_got - p_ref).max(), "argmax agreement", (p_got.argmax(-1) == p_ref.argmax(-1)).mean())
     assert np.abs(p_got - p_ref).max() < 2e-2
     assert (p_got.argmax(-1) == p_ref.argmax(-1)).mean() >= 0.95
+
+
+def test_postprocess_x4_kernel_matches_generic(models, monkeypatch):
+    """The x4-upsampling specialisation of the per-pixel pass (output size = image size) must reproduce the generic kernel bit for bit,
+    including ragged widths (ow % 4 != 0) and the clamped border taps."""
+    bb, head, heads, hip = models
+    img = _image_u8(500, 502, seed=11)
+    monkeypatch.delenv("ODISE_POST_GENERIC", raising=False)
+    fast = hip.forward([{"image": img}])[0]
+    monkeypatch.setenv("ODISE_POST_GENERIC", "1")
+    gen = hip.forward([{"image": img}])[0]
+    np.testing.assert_array_equal(fast["panoptic_seg"][0], gen["panoptic_seg"][0])
+    assert fast["panoptic_seg"][1] == gen["panoptic_seg"][1]
+    np.testing.assert_array_equal(fast["sem_seg"], gen["sem_seg"])
+    np.testing.assert_array_equal(fast["instances"]["pred_masks"], gen["instances"]["pred_masks"])
+    np.testing.assert_array_equal(fast["instances"]["scores"], gen["instances"]["scores"])
