@@ -381,6 +381,33 @@ __global__ void __launch_bounds__(256) instance_masks_kernel(const f16* __restri
     out[(int64_t)n * npix + p] = v > 0.f ? 1.f : 0.f;
 }
 
+// x4 specialisation of instance_masks_kernel (same tap pattern as postprocess_pixels_x4_kernel): a thread writes the 4 pixels of a
+// cell column as one 16-byte store
+__global__ void __launch_bounds__(256) instance_masks_x4_kernel(const f16* __restrict__ logits, const int* __restrict__ idx,
+                                                               float* __restrict__ out, PostGeom g) {
+    const int n = blockIdx.y;
+    const int cw = g.ow >> 2;  // ow % 4 == 0 on this path
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= g.oh * cw) return;
+    const int oy = t / cw, cx = t - oy * cw;
+    const int cy = oy >> 2, ky = oy & 3;
+    const int ra = max(ky < 2 ? cy - 1 : cy, 0), rb = min(ky < 2 ? cy : cy + 1, g.h4 - 1);
+    const float ty = ky == 0 ? 0.625f : ky == 1 ? 0.875f : ky == 2 ? 0.125f : 0.375f;
+    const int cl = max(cx - 1, 0), cr = min(cx + 1, g.w4 - 1);
+    const f16* lr = logits + (int64_t)idx[n] * g.h4 * g.w4;
+    const float al = (float)lr[ra * g.w4 + cl], ac = (float)lr[ra * g.w4 + cx], ar = (float)lr[ra * g.w4 + cr];
+    const float bl = (float)lr[rb * g.w4 + cl], bc = (float)lr[rb * g.w4 + cx], br = (float)lr[rb * g.w4 + cr];
+    float o[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const float tx = k == 0 ? 0.625f : k == 1 ? 0.875f : k == 2 ? 0.125f : 0.375f;
+        const float v00 = k < 2 ? al : ac, v01 = k < 2 ? ac : ar, v10 = k < 2 ? bl : bc, v11 = k < 2 ? bc : br;
+        const float top = v00 + tx * (v01 - v00), bot = v10 + tx * (v11 - v10);
+        o[k] = (top + ty * (bot - top)) > 0.f ? 1.f : 0.f;
+    }
+    *reinterpret_cast<float4*>(out + (int64_t)n * g.oh * g.ow + (int64_t)oy * g.ow + 4 * cx) = make_float4(o[0], o[1], o[2], o[3]);
+}
+
 // ---- launchers -------------------------------------------------------------------------------------------------------
 int launch_resize_bilinear_norm(odise_hip_ctx* ctx, const float* x, f16* y, int B, int H, int W, int S) {
     dim3 grid((unsigned)ceil_div(S * S, 256), (unsigned)B);
@@ -442,6 +469,13 @@ int launch_panoptic_write(odise_hip_ctx* ctx, const int* ids, const int* map, in
 }
 int launch_instance_masks(odise_hip_ctx* ctx, const f16* logits, const int* idx, float* out, int n, const PostGeom& g) {
     if (n == 0) return ODISE_OK;
+    if (g.oh == g.ih && g.ow == g.iw && g.ph == 4 * g.h4 && g.pw == 4 * g.w4 && g.ow % 4 == 0 && ((uintptr_t)out & 15) == 0 &&
+        !getenv("ODISE_POST_GENERIC")) {
+        dim3 grid4((unsigned)ceil_div(g.oh * (g.ow / 4), 256), (unsigned)n);
+        hipLaunchKernelGGL(instance_masks_x4_kernel, grid4, dim3(256), 0, ctx->stream, logits, idx, out, g);
+        ODISE_CHECK_HIP(hipGetLastError());
+        return ODISE_OK;
+    }
     dim3 grid((unsigned)ceil_div(g.oh * g.ow, 256), (unsigned)n);
     hipLaunchKernelGGL(instance_masks_kernel, grid, dim3(256), 0, ctx->stream, logits, idx, out, g);
     ODISE_CHECK_HIP(hipGetLastError());

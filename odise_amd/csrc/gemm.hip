@@ -43,6 +43,7 @@ struct GemmEpi {
 struct ConvGeom {
     int H, W, Cin, KH, KW, stride, pad_t, pad_l, OH, OW, ups;
     int chunk_major;  // K-tiles walk (Cin chunk outer, tap inner): see prep_tile
+    int halo_tx, halo_ty;  // conv3_halo_kernel: 16x16 output patches per image row / column (0 = not a halo launch)
 };
 
 struct GemmArgs {
@@ -239,6 +240,11 @@ constexpr int pp_lds_bytes(int BM, int BN, int WAVES_M) {
     const int half_rows = (BM / 2) * (BN + 4) * 4;  // one block per CU anyway: stage half the tile per pass when it fits
     return (half_rows > stage && half_rows <= 160 * 1024) ? half_rows : stage;
 }
+constexpr int halo_lds_bytes(int BN) {
+    const int layout = 2 * BN * 64 * 2 + 2 * (41 + 1) * 1024;  // two B stages + two halo buffers (41 groups + a dummy one)
+    const int epi = 128 * (BN + 4) * 4;                        // two wave-rows per epilogue pass
+    return layout > epi ? layout : epi;
+}
 constexpr int epi_wave_rows(int BM, int BN, int WAVES_M, int lds_bytes) {
     const int per_row = (BM / WAVES_M) * (BN + 4) * 4;
     int wg = lds_bytes / per_row;
@@ -249,7 +255,7 @@ constexpr int epi_wave_rows(int BM, int BN, int WAVES_M, int lds_bytes) {
 }
 constexpr int epi_lds_bytes(int BM, int BN, int WAVES_M, int WG) { return WG * (BM / WAVES_M) * (BN + 4) * 4; }
 
-template <int BM, int BN, int WAVES_M, int WAVES_N, int WG>
+template <int BM, int BN, int WAVES_M, int WAVES_N, int WG, bool HALO = false>
 __device__ __forceinline__ void gemm_epilogue(const GemmArgs& g, f32x16 (&acc)[BM / WAVES_M / 32][BN / WAVES_N / 32], char* smem, int m0, int n0,
                                               int z, int zb, bool split) {
     constexpr int NT = 64 * WAVES_M * WAVES_N;
@@ -284,7 +290,16 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& g, f32x16 (&acc)[B
         for (int c = tid; c < ROWS * CH; c += NT) {
             const int row = c / CH;
             const int c8 = c - row * CH;
-            const int m = m0 + gp * ROWS + row;
+            int m = m0 + gp * ROWS + row;
+            if (HALO) {
+                // block tile row -> pixel of the block's 16x16 output patch (m0 / BM = patch index: image, patch row, patch column)
+                const int rt = gp * ROWS + row;
+                const int patch = m0 / BM;
+                const int per_img = g.cg.halo_tx * g.cg.halo_ty;
+                const int img = patch / per_img, pr = patch - img * per_img;
+                const int oy = (pr / g.cg.halo_tx) * 16 + (rt >> 4), ox = (pr % g.cg.halo_tx) * 16 + (rt & 15);
+                m = (oy < g.cg.OH && ox < g.cg.OW) ? (img * g.cg.OH + oy) * g.cg.OW + ox : g.M;
+            }
             const int n = n0 + c8 * 8;
             if (m < g.M && n < g.N) {
                 float v[8];
@@ -848,6 +863,238 @@ __global__ void __launch_bounds__(512) gemm_pp_kernel(GemmArgs g) {
     gemm_epilogue<BM, BN, WAVES_M, WAVES_N, epi_wave_rows(BM, BN, WAVES_M, pp_lds_bytes(BM, BN, WAVES_M))>(g, acc, smem, m0, n0, z, zb, split);
 }
 
+
+// ---- 3x3 / stride 1 / pad 1 convolution with the A operand reused from an LDS-resident input patch ("halo") ------------------------
+// The im2col view re-fetches every input pixel 9 times (once per tap) through the LDS-DMA path, which is what bounds the ping-pong
+// kernel on the 3x3 layers (ablation: 23 % of the loop is operand delivery).  Here a block owns a 16x16 OUTPUT patch of one image:
+// per 64-channel chunk it fetches the 18x18 input patch once (41 KB instead of 9 x 32 KB) and the nine K-tiles of the chunk read
+// their A fragments from it at the tap's pixel offset; only the weights stream per K-tile.  Same ping-pong phase structure, MFMA
+// order and fp32 summation order (chunk-major) as gemm_pp_kernel, so results are identical to it.
+//   LDS: [B stage 0][B stage 1][halo 0][halo 1]; halo pixel hp (row-major 18x18) at hp*128 B, 16-byte slots XOR-swizzled with
+//   (halo column >> 1) & 7 on the DMA source and on the fragment reads: a ds_read_b128 lane group covers 8 columns of one patch row
+//   and the 8 complementary columns of the next, i.e. 16 consecutive columns = 16 distinct 16-byte units (keying on the pixel index
+//   instead costs +3.7 LDS cycles per A read: measured SQ_LDS_BANK_CONFLICT 20x).  DMA groups of 8 pixels (1 KiB per wave-instruction): 41 real groups + dummy ones so that every wave
+//   issues the same H = 6 loads per chunk (uniform vmcnt accounting).
+// Schedule per K-tile t (LB = B loads per thread per phase): (t,0) issues [halo of the NEXT chunk when t opens a chunk] and the
+// second half of B(t+1); (t,1) issues the first half of B(t+2).  Split-K ranges are whole chunks.
+template <int BN, int PT>
+__global__ void __launch_bounds__(512) conv3_halo_kernel(GemmArgs g) {
+    constexpr int BM = 256, BK = 64, WAVES_N = 2, WAVES_M = 4;
+    constexpr int WTN = BN / WAVES_N;
+    constexpr int TM = 2, TN = WTN / 32;
+    constexpr int NP = 2;
+    constexpr int JB = BN / 64;       // B loads per thread per K-tile
+    constexpr int LB = JB / 2;        // per phase
+    constexpr int RB = 32;            // rows of a B piece per wave column
+    constexpr int HW_ = 18, HPIX = HW_ * HW_;
+    constexpr int HGROUPS = (HPIX + 7) / 8;  // 41 real 8-pixel groups
+    constexpr int H = 6;                     // halo loads per thread per chunk (48 groups over 8 waves; groups >= HGROUPS are dummies)
+    constexpr int B_BYTES = BN * BK * 2;
+    constexpr int HALO_BYTES = (HGROUPS + 1) * 1024;  // + one dummy group
+    constexpr int HALO0 = 2 * B_BYTES;
+    static_assert(TN == PT * NP && JB == 2 * LB, "two phases of PT N-tiles, one B piece per N-tile");
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave / WAVES_N, wn = wave % WAVES_N;
+    const int grp = wave >> 2;
+    const int hi = lane >> 5, l31 = lane & 31;
+    int bx, by;
+    {
+        const int nbx = gridDim.x, nb = gridDim.x * gridDim.y;
+        const int bid = blockIdx.y * nbx + blockIdx.x;
+        const int q = nb >> 3, r = nb & 7;
+        const int xcd = bid & 7, idx = bid >> 3;
+        const int logical = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+        by = logical / nbx;
+        bx = logical - by * nbx;
+    }
+    const int m0 = by * BM;  // patch index * 256 (the epilogue maps tile rows to pixels)
+    const int n0 = bx * BN;
+    const int z = blockIdx.z;
+    const bool split = g.splitk > 1;
+    const int zb = 0;
+    const int nk_total = g.K / BK;
+    int kt_begin = 0, kt_end = nk_total;
+    if (split) {
+        kt_begin = z * g.ktiles_per_split;  // a multiple of 9: whole chunks
+        kt_end = kt_begin + g.ktiles_per_split;
+        if (kt_end > nk_total) kt_end = nk_total;
+    }
+    const f16* Ab = g.A;
+    const f16* Wb = g.W;
+    const int per_img = g.cg.halo_tx * g.cg.halo_ty;
+    const int img = by / per_img, pr = by - img * per_img;
+    const int py0 = (pr / g.cg.halo_tx) * 16 - 1, px0 = (pr % g.cg.halo_tx) * 16 - 1;  // input coordinate of halo pixel (0,0)
+
+    // ---- halo DMA descriptors: load h of this wave fills group h*8 + wave; lane -> pixel 8*group + lane/8, physical slot lane & 7
+    int64_t h_off[H];  // element offset of the lane's 16 bytes for chunk 0, or -1 (out of the image / dummy -> zero line)
+#pragma unroll
+    for (int h = 0; h < H; ++h) {
+        const int group = h * 8 + wave;
+        const int hp = group * 8 + (lane >> 3);
+        h_off[h] = -1;
+        if (group < HGROUPS && hp < HPIX) {
+            const int hy = hp / HW_, hx = hp - hy * HW_;
+            const int iy = py0 + hy, ix = px0 + hx;
+            if ((unsigned)iy < (unsigned)g.cg.H && (unsigned)ix < (unsigned)g.cg.W)
+                h_off[h] = (((int64_t)img * g.cg.H + iy) * g.cg.W + ix) * g.cg.Cin + (((lane & 7) ^ ((hx >> 1) & 7)) << 3);
+        }
+    }
+    auto issue_halo = [&](int chunk) {
+        char* dst = smem + HALO0 + (chunk & 1) * HALO_BYTES;
+#pragma unroll
+        for (int h = 0; h < H; ++h) {
+            const int group = h * 8 + wave;
+            const f16* src = h_off[h] >= 0 ? Ab + h_off[h] + chunk * BK : g.zeros;
+            glds16(src, dst + (group < HGROUPS ? group : HGROUPS) * 1024);
+        }
+    };
+    // ---- B (weight) DMA: piece j = rows [32j, 32j+32) of both wave columns
+    const int rbase = wave * 8 + (lane >> 3);
+    const int ls = (lane & 7) ^ ((rbase >> 1) & 7);
+    const int b_row0 = (wave >> 2) * WTN + (wave & 3) * 8;
+    const int nb0 = n0 + b_row0 + (lane >> 3);
+    const int64_t b_off0 = (int64_t)nb0 * g.ldw + ls * 8;
+    const int b_lds0 = b_row0 * 128;
+    auto issue_B = [&](int j, int stage, int kw) {
+        const bool ok = (nb0 + j * RB) < g.N;
+        const f16* src = ok ? Wb + b_off0 + (int64_t)(j * RB) * g.ldw + kw : g.zeros;
+        glds16(src, smem + stage * B_BYTES + b_lds0 + j * RB * 128);
+    };
+    // K-tile position: chunk-major (tap inner).  kw = element offset inside a weight row [Cout][ky][kx][Cin]
+    struct TileK {
+        int ky, kx, chunk, kw;
+    };
+    auto finish = [&](TileK& t) { t.kw = (t.ky * 3 + t.kx) * g.cg.Cin + t.chunk * BK; };
+    auto advance = [&](TileK& t) {
+        if (++t.kx == 3) {
+            t.kx = 0;
+            if (++t.ky == 3) { t.ky = 0; ++t.chunk; }
+        }
+        finish(t);
+    };
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    int koff[4];
+#pragma unroll
+    for (int s = 0; s < 4; ++s) koff[s] = ((s * 2 + hi) ^ ((l31 >> 1) & 7)) << 4;
+    const int b_lane_off = (wn * WTN + l31) * 128;
+    const int a_pix0 = (wm * 4 + (l31 >> 4)) * HW_ + (l31 & 15);  // halo pixel of this lane's row of A tile i = 0 at tap (0,0); tile 1: +2 rows
+
+    // ---- prologue: halo of the first chunk, B of tile 0, first half of B of tile 1
+    TileK t0;
+    t0.ky = t0.kx = 0;
+    t0.chunk = kt_begin / 9;
+    finish(t0);
+    TileK t1 = t0, t2;
+    if (kt_begin < kt_end) {
+        advance(t1);
+        issue_halo(t0.chunk);
+#pragma unroll
+        for (int j = 0; j < JB; ++j) issue_B(j, 0, t0.kw);
+        if (kt_begin + 1 < kt_end) {
+#pragma unroll
+            for (int j = 0; j < LB; ++j) issue_B(j, 1, t1.kw);
+            wait_vmcnt<2 * LB>();  // phase (0,0) needs the halo and the first half of B(0); its second half and B(1) may fly
+        } else {
+            wait_vmcnt<LB>();
+        }
+    }
+    t2 = t1;
+    advance(t2);
+    __builtin_amdgcn_s_barrier();
+    if (grp == 1) __builtin_amdgcn_s_barrier();  // stagger: group 1 runs one barrier interval behind group 0
+
+    TileK tc = t0;  // position of the K-tile being multiplied
+    f16x8 af[TM][4], bf[PT][4];
+    for (int kt = kt_begin; kt < kt_end; ++kt) {
+        const int cur = (kt - kt_begin) & 1;
+        const bool has1 = (kt + 1) < kt_end, has2 = (kt + 2) < kt_end;
+        const bool opens = tc.ky == 0 && tc.kx == 0;                       // first tap of a chunk
+        const bool halo_next = opens && (kt + 9) < kt_end;                 // the next chunk is inside this block's K range
+        const char* fb = smem + cur * B_BYTES + b_lane_off;
+#pragma unroll
+        for (int p = 0; p < NP; ++p) {
+            const int j0 = PT * p;
+            // -------- load segment
+            if (p == 0) {
+                const char* ha = smem + HALO0 + (tc.chunk & 1) * HALO_BYTES;
+                const int pix = a_pix0 + tc.ky * HW_ + tc.kx;
+                const int key = (((l31 & 15) + tc.kx) >> 1) & 7;  // swizzle key = halo COLUMN / 2 (see the header)
+#pragma unroll
+                for (int i = 0; i < TM; ++i) {
+                    const int hp = pix + i * 2 * HW_;
+#pragma unroll
+                    for (int s = 0; s < 4; ++s)
+                        af[i][s] = *reinterpret_cast<const f16x8*>(ha + hp * 128 + (((s * 2 + hi) ^ key) << 4));
+                }
+            }
+#pragma unroll
+            for (int jj = 0; jj < PT; ++jj) {
+#pragma unroll
+                for (int s = 0; s < 4; ++s) bf[jj][s] = *reinterpret_cast<const f16x8*>(fb + koff[s] + (j0 + jj) * 4096);
+            }
+            if (p == 0) {
+                // halo first (older than this phase's B loads), then the second half of B(t+1)
+                if (halo_next) issue_halo(tc.chunk + 1);
+                if (has1) {
+#pragma unroll
+                    for (int j = LB; j < JB; ++j) issue_B(j, cur ^ 1, t1.kw);
+                }
+                // next phase reads the second half of B(t): younger loads = first + second half of B(t+1) [+ halo]
+                if (halo_next) { if (has1) wait_vmcnt<2 * LB + H>(); else wait_vmcnt<H>(); }
+                else { if (has1) wait_vmcnt<2 * LB>(); else wait_vmcnt<0>(); }
+            } else {
+                if (has2) {
+#pragma unroll
+                    for (int j = 0; j < LB; ++j) issue_B(j, cur, t2.kw);
+                }
+                // next phase, (t+1,0), reads the first half of B(t+1) (and a halo fetched a whole chunk ago): younger loads = [halo
+                // issued in (t,0)], second half of B(t+1), first half of B(t+2)
+                if (halo_next) {
+                    if (has2) wait_vmcnt<2 * LB + H>(); else if (has1) wait_vmcnt<LB + H>(); else wait_vmcnt<H>();
+                } else {
+                    if (has2) wait_vmcnt<2 * LB>(); else if (has1) wait_vmcnt<LB>(); else wait_vmcnt<0>();
+                }
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_sched_barrier(0);
+            __builtin_amdgcn_s_barrier();
+            __builtin_amdgcn_sched_barrier(0);
+            // -------- MFMA segment
+            __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+            for (int s = 0; s < 4; ++s)
+#pragma unroll
+                for (int jj = 0; jj < PT; ++jj)
+#pragma unroll
+                    for (int i = 0; i < TM; ++i)
+                        acc[i][j0 + jj] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[i][s], bf[jj][s], acc[i][j0 + jj], 0, 0, 0);
+            __builtin_amdgcn_s_setprio(0);
+            __builtin_amdgcn_sched_barrier(0);
+            __builtin_amdgcn_s_barrier();
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        tc = t1;
+        t1 = t2;
+        advance(t2);
+    }
+    if (grp == 0) __builtin_amdgcn_s_barrier();  // re-align the two groups
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    gemm_epilogue<BM, BN, WAVES_M, WAVES_N, epi_wave_rows(BM, BN, WAVES_M, halo_lds_bytes(BN)), true>(g, acc, smem, m0, n0, z, zb, split);
+}
+
 __global__ void __launch_bounds__(256) splitk_reduce_kernel(const float* __restrict__ ws, int splitk, int M, int N, GemmEpi e) {
     const int CH = (N + 7) / 8;
     const int64_t total = (int64_t)M * CH;
@@ -924,13 +1171,37 @@ static int launch_gemm_pp(odise_hip_ctx* ctx, GemmArgs& g, int batch) {
     return ODISE_OK;
 }
 
+template <int BN, int PT>
+static int launch_conv3_halo(odise_hip_ctx* ctx, GemmArgs& g) {
+    constexpr int lds = halo_lds_bytes(BN);
+    static_assert(epi_lds_bytes(256, BN, 4, epi_wave_rows(256, BN, 4, lds)) <= lds, "epilogue staging exceeds the LDS request");
+    auto kern = conv3_halo_kernel<BN, PT>;
+    static bool attr_set = false;  // per instantiation
+    if (!attr_set) {
+        ODISE_CHECK_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+        attr_set = true;
+    }
+    const int n_img = g.M / (g.cg.OH * g.cg.OW);
+    dim3 grid((unsigned)ceil_div(g.N, BN), (unsigned)(n_img * g.cg.halo_tx * g.cg.halo_ty), (unsigned)(g.splitk > 1 ? g.splitk : 1));
+    hipLaunchKernelGGL(kern, grid, dim3(512), lds, ctx->stream, g);
+    ODISE_CHECK_HIP(hipGetLastError());
+    if (g.splitk > 1) {
+        const int64_t total = (int64_t)g.M * ceil_div(g.N, 8);
+        const int blocks = (int)std::min<int64_t>(ceil_div(total, 256), 2048);
+        hipLaunchKernelGGL(splitk_reduce_kernel, dim3(blocks), dim3(256), 0, ctx->stream, g.ws, g.splitk, g.M, g.N, g.epi);
+        ODISE_CHECK_HIP(hipGetLastError());
+    }
+    return ODISE_OK;
+}
+
 static int g_gemm_debug = 0;  // see GemmArgs::dbg
 static int g_conv_flags = 0;  // tools only: 1 = tap-major K order even when Cin % 64 == 0, 2 = never use the ping-pong kernel, 4 = one N-tile per phase at BN = 256
 
 // Tile ids: 0:128x128 1:64x128 2:64x64 (4 waves)  3:256x320 4:256x256 5:256x128 (8 waves)  6:512x128 (8 waves, ping-pong only)
-static const int kNumTiles = 7;
-static const int kTileBM[kNumTiles] = {128, 64, 64, 256, 256, 256, 512};
-static const int kTileBN[kNumTiles] = {128, 128, 64, 320, 256, 128, 128};
+//           7: 16x16-pixel patch x 256 channels, 8: 16x16-pixel patch x 128 channels (conv3_halo_kernel: 3x3 / stride 1 / pad 1 only)
+static const int kNumTiles = 9;
+static const int kTileBM[kNumTiles] = {128, 64, 64, 256, 256, 256, 512, 256, 256};
+static const int kTileBN[kNumTiles] = {128, 128, 64, 320, 256, 128, 128, 256, 128};
 
 // Tile / split-K selection by a small cost model (times in microseconds, calibrated on MI355X with tools/gemm_bench.py):
 //   t = rounds * (k_tiles_per_split * t_ktile + t_fixed) + t_reduce,   rounds = ceil(blocks * split / resident slots)
@@ -951,6 +1222,8 @@ static const TileCost kTileCost[kNumTiles] = {
     {2.10, 15.0, 1},  // 256x256 (plain kernel)
     {1.42, 6.0, 1},   // 256x128
     {2.25, 12.0, 1},  // 512x128 (ping-pong kernel only)
+    {1.92, 12.0, 1},  // halo 256 pixels x 256 channels (measured 7 % under the im2col ping-pong tile on the 512-channel VAE layers)
+    {1.32, 10.0, 1},  // halo 256 pixels x 128 channels (wins over 512x128 when that tile cannot fill the CUs)
 };
 // the 256-row tiles as run by the ping-pong kernel (K % 64 == 0; conv: Cin % 64 == 0, no fused upsample)
 static const TileCost kTileCostPP[2] = {
@@ -958,8 +1231,8 @@ static const TileCost kTileCostPP[2] = {
     {2.10, 12.0, 1},  // 256x256
 };
 // previous fit (before the lean epilogue / ping-pong kernel), kept selectable for A/B runs: ODISE_GEMM_FLAGS=8
-static const TileCost kTileCostOld[kNumTiles] = {{1.68, 9.5, 2}, {1.58, 4.1, 3}, {1.28, 2.4, 4}, {3.04, 29.0, 1},
-                                                 {2.58, 22.0, 1}, {1.75, 10.6, 1}, {2.25, 12.0, 1}};
+static const TileCost kTileCostOld[kNumTiles] = {{1.68, 9.5, 2}, {1.58, 4.1, 3}, {1.28, 2.4, 4}, {3.04, 29.0, 1}, {2.58, 22.0, 1},
+                                                 {1.75, 10.6, 1}, {2.25, 12.0, 1}, {1.92, 12.0, 1}, {1.32, 10.0, 1}};
 static int env_gemm_flags() {
     static int v = -1;
     if (v < 0) {
@@ -972,8 +1245,20 @@ static int env_gemm_flags() {
 template <bool CONV>
 static int launch_gemm(odise_hip_ctx* ctx, GemmArgs& g, int batch, int force_tile, int force_split) {
     const int64_t cus = ctx->cu_count;
-    auto blocks = [&](int t) { return ceil_div(g.M, kTileBM[t]) * ceil_div(g.N, kTileBN[t]) * (int64_t)batch; };
     const int nk = (int)ceil_div(g.K, 64);
+    // the halo kernel owns 16x16 output patches: 3x3 / stride 1 / pad 1 convs over whole 64-channel chunks
+    bool halo_ok = false;
+    int64_t halo_patches = 0;
+    if (CONV) {
+        halo_ok = g.cg.KH == 3 && g.cg.KW == 3 && g.cg.stride == 1 && g.cg.pad_t == 1 && g.cg.pad_l == 1 && !g.cg.ups && g.cg.Cin % 64 == 0 &&
+                  g.cg.OH == g.cg.H && g.cg.OW == g.cg.W && batch == 1;
+        g.cg.halo_tx = (int)ceil_div(g.cg.OW, 16);
+        g.cg.halo_ty = (int)ceil_div(g.cg.OH, 16);
+        halo_patches = (int64_t)(g.M / (g.cg.OH * g.cg.OW)) * g.cg.halo_tx * g.cg.halo_ty;
+    }
+    auto blocks = [&](int t) {
+        return (t >= 7 ? halo_patches : ceil_div(g.M, kTileBM[t])) * ceil_div(g.N, kTileBN[t]) * (int64_t)batch;
+    };
     const bool no_interleave = force_tile >= 16;  // test hook: tile + 16 selects the non-interleaved issue order
     if (no_interleave) force_tile -= 16;
     int tile = 2, best_split = 1;
@@ -983,6 +1268,7 @@ static int launch_gemm(odise_hip_ctx* ctx, GemmArgs& g, int batch, int force_til
     for (int t = 0; t < kNumTiles; ++t) {
         if (force_tile >= 0 && force_tile < kNumTiles && t != force_tile) continue;
         if (t == 6 && (!pp_ok || (flags & 16))) continue;
+        if (t >= 7 && (!halo_ok || !pp_ok || (flags & 64))) continue;  // ODISE_GEMM_FLAGS=64: never use the halo kernel
         const TileCost& tc = (flags & 8) ? kTileCostOld[t] : (pp_ok && (t == 3 || t == 4)) ? kTileCostPP[t - 3] : kTileCost[t];
         if (force_tile < 0) {
             if (kTileBM[t] > 64 && g.M <= kTileBM[t] / 2) continue;            // mostly-empty row tiles
@@ -994,7 +1280,8 @@ static int launch_gemm(odise_hip_ctx* ctx, GemmArgs& g, int batch, int force_til
         for (int sp = 1; sp <= max_split; ++sp) {
             if (force_split > 0 && sp != std::min(force_split, std::max(1, nk))) continue;
             if (sp > 1 && (size_t)sp * g.M * g.N * sizeof(float) > ctx->ws_bytes) break;
-            const int per = (int)ceil_div(nk, sp);
+            // the halo kernel splits K in whole 64-channel chunks (9 K-tiles each)
+            const int per = t >= 7 ? (int)ceil_div(nk / 9, sp) * 9 : (int)ceil_div(nk, sp);
             const int eff_sp = (int)ceil_div(nk, per);
             // Full residency rounds run at the calibrated K-tile time; the last (or only) partial round still costs most of a
             // block's time: an under-filled chip delivers operands only a little faster per block (measured with
@@ -1008,12 +1295,12 @@ static int launch_gemm(odise_hip_ctx* ctx, GemmArgs& g, int batch, int force_til
             if (t_us < best) { best = t_us; tile = t; best_split = eff_sp; }
         }
     }
-    if (force_tile >= 0 && force_tile < kNumTiles && !(force_tile == 6 && !pp_ok)) tile = force_tile;
+    if (force_tile >= 0 && force_tile < kNumTiles && !(force_tile == 6 && !pp_ok) && !(force_tile >= 7 && !(halo_ok && pp_ok))) tile = force_tile;
     g.splitk = 1;
     g.ktiles_per_split = nk;
     if (force_split > 0 && batch == 1) best_split = std::min(force_split, nk);
     if (best_split > 1 && batch == 1) {
-        g.ktiles_per_split = (int)ceil_div(nk, best_split);
+        g.ktiles_per_split = tile >= 7 ? (int)ceil_div(nk / 9, best_split) * 9 : (int)ceil_div(nk, best_split);
         g.splitk = (int)ceil_div(nk, g.ktiles_per_split);
         ODISE_REQUIRE((size_t)g.splitk * g.M * g.N * sizeof(float) <= ctx->ws_bytes, "gemm: split-K workspace too small");
     }
@@ -1040,6 +1327,11 @@ static int launch_gemm(odise_hip_ctx* ctx, GemmArgs& g, int batch, int force_til
     g.zeros = (const f16*)ctx->zeros;
     g.dbg = g_gemm_debug;
     // the 256-row tiles run the ping-pong pipelined kernel whenever its preconditions hold
+    if (tile >= 7) {
+        g.cg.chunk_major = 1;
+        return tile == 7 ? launch_conv3_halo<256, 2>(ctx, g) : launch_conv3_halo<128, 1>(ctx, g);
+    }
+    g.cg.halo_tx = g.cg.halo_ty = 0;
     if ((tile == 3 || tile == 4 || tile == 6) && pp_ok) {
         if (tile == 6) return launch_gemm_pp<512, 128, 1, 2, CONV>(ctx, g, batch);
         if (tile == 3) return launch_gemm_pp<256, 320, 2, 1, CONV>(ctx, g, batch);

@@ -112,11 +112,12 @@ def test_classification_stage(models, ctx):
     assert (p_got.argmax(-1) == p_ref.argmax(-1)).mean() >= 0.95
 
 
-def test_postprocess_x4_kernel_matches_generic(models, monkeypatch):
-    """The x4-upsampling specialisation of the per-pixel pass (output size = image size) must reproduce the generic kernel bit for bit,
-    including ragged widths (ow % 4 != 0) and the clamped border taps."""
+@pytest.mark.parametrize("h,w", [(500, 502), (512, 512)])
+def test_postprocess_x4_kernel_matches_generic(models, monkeypatch, h, w):
+    """The x4-upsampling specialisations of the per-pixel pass and of the instance masks (output size = image size) must reproduce
+    the generic kernels bit for bit, including ragged widths (ow % 4 != 0) and the clamped border taps."""
     bb, head, heads, hip = models
-    img = _image_u8(500, 502, seed=11)
+    img = _image_u8(h, w, seed=11)
     monkeypatch.delenv("ODISE_POST_GENERIC", raising=False)
     fast = hip.forward([{"image": img}])[0]
     monkeypatch.setenv("ODISE_POST_GENERIC", "1")
