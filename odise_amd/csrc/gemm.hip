@@ -565,7 +565,7 @@ __device__ __forceinline__ void wait_vmcnt() {
 // DMA groups of the tile sequence (per thread: 4 A loads, TN B loads; B piece j = the rows of N-tile j of both wave columns):
 //   NP = 2: (t,0) issues B0..B3 of tile t+1, (t,1) issues A0..A3 of tile t+2
 //   NP = 3: (t,0) issues B2,B3,B4 of tile t+1, (t,1) issues A0,A1,A2 of tile t+2, (t,2) issues A3,B0,B1 of tile t+2
-template <int BM, int BN, int WAVES_N, int PT, bool CONV>
+template <int BM, int BN, int WAVES_N, int PT, bool CONV, int V = 0>  // V: tuning variants (bit 0: DMA issued before the fragment reads, bit 1: no s_setprio)
 __global__ void __launch_bounds__(512) gemm_pp_kernel(GemmArgs g) {
     constexpr int BK = 64, WAVES_M = 8 / WAVES_N;
     constexpr int WTN = BN / WAVES_N;
@@ -774,18 +774,21 @@ __global__ void __launch_bounds__(512) gemm_pp_kernel(GemmArgs g) {
             const int j0 = PT * p;
             const int nj = (j0 + PT <= TN) ? PT : (TN - j0);
             // -------- load segment: fragments of this phase, one slot of DMA, counted wait for what the NEXT phase reads
-            if (p == 0 && rd) {
+            auto read_frags = [&]() {
+                if (p == 0 && rd) {
 #pragma unroll
-                for (int i = 0; i < TM; ++i)
+                    for (int i = 0; i < TM; ++i)
 #pragma unroll
-                    for (int s = 0; s < 4; ++s) af[i][s] = *reinterpret_cast<const f16x8*>(fa + koff[s] + i * 4096);
-            }
-#pragma unroll
-            for (int jj = 0; jj < PT; ++jj)
-                if (jj < nj && rd) {
-#pragma unroll
-                    for (int s = 0; s < 4; ++s) bf[jj][s] = *reinterpret_cast<const f16x8*>(fb + koff[s] + (j0 + jj) * 4096);
+                        for (int s = 0; s < 4; ++s) af[i][s] = *reinterpret_cast<const f16x8*>(fa + koff[s] + i * 4096);
                 }
+#pragma unroll
+                for (int jj = 0; jj < PT; ++jj)
+                    if (jj < nj && rd) {
+#pragma unroll
+                        for (int s = 0; s < 4; ++s) bf[jj][s] = *reinterpret_cast<const f16x8*>(fb + koff[s] + (j0 + jj) * 4096);
+                    }
+            };
+            if (!(V & 1)) read_frags();
             // loads through index `need` (counted from A0 of tile kt) must have landed before the next phase reads
             const int need = (p + 1 < NP) ? loads_for_tiles((p + 2) * PT < TN ? (p + 2) * PT : TN) : NL + loads_for_tiles(PT);
             if (p == 0) {
@@ -834,12 +837,16 @@ __global__ void __launch_bounds__(512) gemm_pp_kernel(GemmArgs g) {
                     wait_vmcnt<0>();
                 }
             }
+            if (V & 1) {
+                __builtin_amdgcn_sched_barrier(0);
+                read_frags();
+            }
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             __builtin_amdgcn_sched_barrier(0);
             __builtin_amdgcn_s_barrier();
             __builtin_amdgcn_sched_barrier(0);
             // -------- MFMA segment
-            __builtin_amdgcn_s_setprio(1);
+            if (!(V & 2)) __builtin_amdgcn_s_setprio(1);
 #pragma unroll
             for (int s = 0; s < 4; ++s)
 #pragma unroll
@@ -849,7 +856,7 @@ __global__ void __launch_bounds__(512) gemm_pp_kernel(GemmArgs g) {
                         for (int i = 0; i < TM; ++i)
                             acc[i][j0 + jj] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[i][s], bf[jj][s], acc[i][j0 + jj], 0, 0, 0);
                     }
-            __builtin_amdgcn_s_setprio(0);
+            if (!(V & 2)) __builtin_amdgcn_s_setprio(0);
             __builtin_amdgcn_sched_barrier(0);
             __builtin_amdgcn_s_barrier();
             __builtin_amdgcn_sched_barrier(0);
@@ -863,6 +870,322 @@ __global__ void __launch_bounds__(512) gemm_pp_kernel(GemmArgs g) {
     gemm_epilogue<BM, BN, WAVES_M, WAVES_N, epi_wave_rows(BM, BN, WAVES_M, pp_lds_bytes(BM, BN, WAVES_M))>(g, acc, smem, m0, n0, z, zb, split);
 }
 
+
+// ---- Ping-pong kernel, second generation: fragment reads moved into the MFMA segment -----------------------------------------------
+// PMC of gemm_pp_kernel (SQ_WAVE_CYCLES vs MFMA cycles): a barrier interval lasts ~950 cycles for 512 cycles of MFMA - the critical
+// path is the OTHER group's load segment (16 ds_read_b128, their latency, then 4 LDS-DMA issues).  Here every k-step of the MFMA
+// segment is followed by the ds_reads that refill exactly the fragment registers it just consumed with the NEXT phase's data, so the
+// reads fly under the remaining MFMAs and the load segment shrinks to {DMA issue, counted vmcnt, lgkmcnt(0)}.
+//   * RAW: the reads of phase q+1 are issued after barrier A(q); the vmcnt at the end of load segment q-1 therefore covers what phase
+//     q+1 reads (one phase further ahead than gemm_pp_kernel), for both groups before a barrier the reader has passed.
+//   * WAR: those reads are retired by the lgkmcnt(0) of load segment q+1 before barrier A(q+1); the refill of their rows is issued in
+//     load segment q+2 at the earliest (slot = read phase + 1 of the tile two K-tiles ahead).
+//   * DMA slots of tile T (phases of tile T-2, slot NP = phase 0 of tile T-1): B piece read in phase r -> slot r+1; A pieces spread
+//     over slots 1..NP-1.  The allowed-outstanding counts are computed by pp2_allowed() from this table.
+namespace pp2 {
+constexpr int read_phase(int l, int JA, int TPB, int PT) { return l < JA ? 0 : ((l - JA) * TPB) / PT; }
+constexpr int slot(int l, int JA, int NP, int TPB, int PT) {
+    return l < JA ? (NP >= 3 ? 1 + (l * (NP - 1)) / JA : 1) : read_phase(l, JA, TPB, PT) + 1;
+}
+// loads issued up to and including phase p of the current tile (tiles 0 = current, 1, 2 = next ones; nf = how many of those exist)
+// that come after the last load phase p+2 needs -> s_waitcnt vmcnt(that)
+constexpr int allowed(int p, int nf, int JA, int JB, int NP, int TPB, int PT) {
+    const int NL = JA + JB;
+    const int np = p + 2, Tn = np / NP, pn = np % NP;
+    // key = (tile * (NP + 1) + slot) * 64 + l  (issue order)
+    int last = -1;
+    for (int T = 0; T <= Tn && T <= nf; ++T)
+        for (int l = 0; l < NL; ++l)
+            if (T < Tn || read_phase(l, JA, TPB, PT) <= pn) {
+                const int key = (T * (NP + 1) + slot(l, JA, NP, TPB, PT)) * 64 + l;
+                if (key > last) last = key;
+            }
+    int cnt = 0;
+    for (int T = 0; T <= 2 && T <= nf; ++T)
+        for (int l = 0; l < NL; ++l) {
+            const int sl = slot(l, JA, NP, TPB, PT);
+            const int time = (T - 2) * NP + sl;  // relative to phase 0 of the current tile
+            const int key = (T * (NP + 1) + sl) * 64 + l;
+            if (time <= p && key > last) ++cnt;
+        }
+    return cnt;
+}
+template <int NF, int JA, int JB, int NP, int TPB, int PT>
+__device__ __forceinline__ void wait_phase(int p) {  // p is a compile-time constant after unrolling: the switch folds
+    switch (p) {
+        case 0: wait_vmcnt<allowed(0, NF, JA, JB, NP, TPB, PT)>(); break;
+        case 1: wait_vmcnt<allowed(1, NF, JA, JB, NP, TPB, PT)>(); break;
+        case 2: wait_vmcnt<allowed(NP > 2 ? 2 : 0, NF, JA, JB, NP, TPB, PT)>(); break;
+        case 3: wait_vmcnt<allowed(NP > 3 ? 3 : 0, NF, JA, JB, NP, TPB, PT)>(); break;
+        default: wait_vmcnt<allowed(NP > 4 ? 4 : 0, NF, JA, JB, NP, TPB, PT)>(); break;
+    }
+}
+}  // namespace pp2
+
+template <int BM, int BN, int WAVES_N, int PT, bool CONV>
+__global__ void __launch_bounds__(512) gemm_pp2_kernel(GemmArgs g) {
+    constexpr int BK = 64, WAVES_M = 8 / WAVES_N;
+    constexpr int WTN = BN / WAVES_N;
+    constexpr int TM = 2, TN = WTN / 32;
+    constexpr int NP = (TN + PT - 1) / PT;   // phases per K-tile (PT N-tiles of the wave each)
+    constexpr int JA = BM / 64, JB = BN / 64;  // 64-row DMA pieces (one 16-byte load per thread each)
+    constexpr int TPB = TN / JB;             // N-tiles of a wave covered by one B piece (the piece spans every wave column)
+    constexpr int NL = JA + JB;              // LDS-DMA loads per thread per K-tile
+    constexpr int A_BYTES = BM * BK * 2, B_BYTES = BN * BK * 2, STAGE_BYTES = A_BYTES + B_BYTES;
+    static_assert(PT == 1 || PT == 2, "one or two N-tiles per phase");
+    static_assert(BM / WAVES_M == 64 && WTN % 32 == 0 && TN % JB == 0, "bad tile");
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave / WAVES_N, wn = wave % WAVES_N;
+    const int grp = wave >> 2;  // waves w and w+4 share a SIMD
+    const int hi = lane >> 5, l31 = lane & 31;
+    int bx, by;
+    {
+        const int nbx = gridDim.x, nb = gridDim.x * gridDim.y;
+        const int bid = blockIdx.y * nbx + blockIdx.x;
+        const int q = nb >> 3, r = nb & 7;
+        const int xcd = bid & 7, idx = bid >> 3;
+        const int logical = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+        by = logical / nbx;
+        bx = logical - by * nbx;
+    }
+    const int m0 = by * BM;
+    const int n0 = bx * BN;
+    const int z = blockIdx.z;
+    const bool split = g.splitk > 1;
+    const int zb = split ? 0 : z;
+    const int nk_total = g.K / BK;
+    int kt_begin = 0, kt_end = nk_total;
+    if (split) {
+        kt_begin = z * g.ktiles_per_split;
+        kt_end = kt_begin + g.ktiles_per_split;
+        if (kt_end > nk_total) kt_end = nk_total;
+    }
+    const f16* Ab = g.A + (int64_t)zb * g.strideA;
+    const f16* Wb = g.W + (int64_t)zb * g.strideW;
+
+    // ---- per-lane DMA descriptors: lane fills physical 16-byte slot (lane & 7) of row (8*wave + lane/8) of every 64-row piece
+    // and fetches logical slot ls (XOR swizzle on the source, see gemm_kernel)
+    const int rbase = wave * 8 + (lane >> 3);
+    const int ls = (lane & 7) ^ ((rbase >> 1) & 7);
+    int64_t a_off[JA];
+    int a_iy0[JA], a_ix0[JA];  // conv: top-left input coordinate of the row's window; rows >= M get iy0 far out of range
+#pragma unroll
+    for (int j = 0; j < JA; ++j) {
+        const int m = m0 + rbase + 64 * j;
+        const bool ok = m < g.M;
+        if (CONV) {
+            const int ohw = g.cg.OH * g.cg.OW;
+            const int mm = ok ? m : 0;
+            const int img = mm / ohw;
+            const int rem = mm - img * ohw;
+            const int oy = rem / g.cg.OW;
+            const int ox = rem - oy * g.cg.OW;
+            a_iy0[j] = ok ? oy * g.cg.stride - g.cg.pad_t : -(1 << 28);
+            a_ix0[j] = ox * g.cg.stride - g.cg.pad_l;
+            a_off[j] = ((int64_t)img * g.cg.H * g.cg.W + (int64_t)a_iy0[j] * g.cg.W + a_ix0[j]) * g.cg.Cin + ls * 8;
+        } else {
+            a_iy0[j] = ok ? 0 : -1;
+            a_ix0[j] = 0;
+            a_off[j] = (int64_t)m * g.lda + ls * 8;
+        }
+    }
+    // B piece j = rows [j*RB, (j+1)*RB) of EVERY wave column (RB = 64 / WAVES_N), i.e. exactly the rows the waves read for N-tiles
+    // j*TPB .. of theirs; this wave fills 8 of them
+    constexpr int RB = 64 / WAVES_N;
+    const int b_row0 = (WAVES_N == 2) ? (wave >> 2) * WTN + (wave & 3) * 8 : wave * 8;
+    const int nb0 = n0 + b_row0 + (lane >> 3);
+    const int64_t b_off0 = (int64_t)nb0 * g.ldw + ls * 8;
+    const int b_lds0 = b_row0 * 128;  // LDS byte offset of this wave's 8 rows inside piece 0
+
+    // K-tile position (wave-uniform, advanced incrementally: no divisions in the loop).  Conv taps are whole 64-channel chunks
+    // (Cin % 64 == 0), walked chunk-major or tap-major (see gemm_kernel::prep_tile).
+    struct TileK {
+        int ky, kx, c0;
+        int64_t a_delta;  // element offset added to a_off
+        int kw;           // element offset inside a weight row
+    };
+    auto finish = [&](TileK& t) {
+        if (CONV) {
+            t.a_delta = ((int64_t)t.ky * g.cg.W + t.kx) * g.cg.Cin + t.c0;
+            t.kw = (t.ky * g.cg.KW + t.kx) * g.cg.Cin + t.c0;
+        } else {
+            t.a_delta = t.c0;
+            t.kw = t.c0;
+        }
+    };
+    auto decode = [&](int kt) {
+        TileK t;
+        t.ky = t.kx = 0;
+        t.c0 = kt * BK;
+        if (CONV) {
+            int tap;
+            if (g.cg.chunk_major) {
+                const int taps = g.cg.KH * g.cg.KW;
+                const int chunk = kt / taps;
+                tap = kt - chunk * taps;
+                t.c0 = chunk * BK;
+            } else {
+                tap = (kt * BK) / g.cg.Cin;
+                t.c0 = kt * BK - tap * g.cg.Cin;
+            }
+            t.ky = tap / g.cg.KW;
+            t.kx = tap - t.ky * g.cg.KW;
+        }
+        finish(t);
+        return t;
+    };
+    auto advance = [&](TileK& t) {
+        if (CONV) {
+            if (g.cg.chunk_major) {
+                if (++t.kx == g.cg.KW) {
+                    t.kx = 0;
+                    if (++t.ky == g.cg.KH) { t.ky = 0; t.c0 += BK; }
+                }
+            } else {
+                t.c0 += BK;
+                if (t.c0 == g.cg.Cin) {
+                    t.c0 = 0;
+                    if (++t.kx == g.cg.KW) { t.kx = 0; ++t.ky; }
+                }
+            }
+        } else {
+            t.c0 += BK;
+        }
+        finish(t);
+    };
+    auto issue_A = [&](int j, int stage, const TileK& t) {
+        bool ok;
+        if (CONV) {
+            const int iy = a_iy0[j] + t.ky, ix = a_ix0[j] + t.kx;
+            ok = (unsigned)iy < (unsigned)g.cg.H && (unsigned)ix < (unsigned)g.cg.W;
+        } else {
+            ok = a_iy0[j] >= 0;
+        }
+        const f16* src = ok ? Ab + a_off[j] + t.a_delta : g.zeros;
+        glds16(src, smem + stage * STAGE_BYTES + (j * 64 + wave * 8) * 128);
+    };
+    auto issue_B = [&](int j, int stage, const TileK& t) {
+        const bool ok = (nb0 + j * RB) < g.N;
+        const f16* src = ok ? Wb + b_off0 + (int64_t)(j * RB) * g.ldw + t.kw : g.zeros;
+        glds16(src, smem + stage * STAGE_BYTES + A_BYTES + b_lds0 + j * RB * 128);
+    };
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    int koff[4];
+#pragma unroll
+    for (int s = 0; s < 4; ++s) koff[s] = ((s * 2 + hi) ^ ((l31 >> 1) & 7)) << 4;
+    const int a_lane_off = (wm * 64 + l31) * 128;
+    const int b_lane_off = A_BYTES + (wn * WTN + l31) * 128;
+
+    // issue every load of tile T whose slot is `sl` (program order = ascending l)
+    auto issue_slot = [&](int sl, int stage, const TileK& t) {
+#pragma unroll
+        for (int l = 0; l < NL; ++l)
+            if (pp2::slot(l, JA, NP, TPB, PT) == sl) {
+                if (l < JA) issue_A(l, stage, t);
+                else issue_B(l - JA, stage, t);
+            }
+    };
+    constexpr int pro1 = []() { int c = 0; for (int l = 0; l < JA + JB; ++l) c += pp2::slot(l, JA, NP, TPB, PT) < NP ? 1 : 0; return c; }();
+    // ---- prologue: all of tile 0, the slots of tile 1 that precede phase (0,0); tile 0 must have landed before the first fragment reads
+    TileK t1 = decode(kt_begin), t2;
+    if (kt_begin < kt_end) {
+        const TileK t0 = t1;
+        advance(t1);
+#pragma unroll
+        for (int sl = 1; sl <= NP; ++sl) issue_slot(sl, 0, t0);
+        if (kt_begin + 1 < kt_end) {
+#pragma unroll
+            for (int sl = 1; sl < NP; ++sl) issue_slot(sl, 1, t1);
+            wait_vmcnt<pro1>();
+        } else {
+            wait_vmcnt<0>();
+        }
+    }
+    t2 = t1;
+    advance(t2);
+    __builtin_amdgcn_s_barrier();
+    f16x8 af[TM][4], bf[PT][4];
+    // fragments of phase (0,0)
+    {
+        const char* fa = smem + a_lane_off;
+        const char* fb = smem + b_lane_off;
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+#pragma unroll
+            for (int i = 0; i < TM; ++i) af[i][s] = *reinterpret_cast<const f16x8*>(fa + koff[s] + i * 4096);
+#pragma unroll
+            for (int jj = 0; jj < PT; ++jj) bf[jj][s] = *reinterpret_cast<const f16x8*>(fb + koff[s] + jj * 4096);
+        }
+    }
+    if (grp == 1) __builtin_amdgcn_s_barrier();  // stagger: group 1 runs one barrier interval behind group 0
+
+    for (int kt = kt_begin; kt < kt_end; ++kt) {
+        const int cur = (kt - kt_begin) & 1;
+        const bool has1 = (kt + 1) < kt_end, has2 = (kt + 2) < kt_end;
+#pragma unroll
+        for (int p = 0; p < NP; ++p) {
+            const int j0 = PT * p;
+            // -------- load segment: one slot of DMA, counted wait for what phase q+2 reads, retire the reads issued in the last MFMA segment
+            if (p == 0) {
+                if (has1) issue_slot(NP, cur ^ 1, t1);
+            } else {
+                if (has2) issue_slot(p, cur, t2);
+            }
+            if (has2) pp2::wait_phase<2, JA, JB, NP, TPB, PT>(p);
+            else if (has1) pp2::wait_phase<1, JA, JB, NP, TPB, PT>(p);
+            else pp2::wait_phase<0, JA, JB, NP, TPB, PT>(p);
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_sched_barrier(0);
+            __builtin_amdgcn_s_barrier();
+            __builtin_amdgcn_sched_barrier(0);
+            // -------- MFMA segment; after each k-step its fragment registers are refilled with the next phase's data
+            const bool next_in_tile = (p + 1 < NP);
+            const bool have_next = next_in_tile || has1;
+            const char* nfa = smem + (cur ^ 1) * STAGE_BYTES + a_lane_off;                                   // A of tile kt+1
+            const char* nfb = smem + (next_in_tile ? cur : (cur ^ 1)) * STAGE_BYTES + b_lane_off + (next_in_tile ? (j0 + PT) * 4096 : 0);
+            __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+            for (int s = 0; s < 4; ++s) {
+#pragma unroll
+                for (int jj = 0; jj < PT; ++jj)
+#pragma unroll
+                    for (int i = 0; i < TM; ++i)
+                        acc[i][j0 + jj] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[i][s], bf[jj][s], acc[i][j0 + jj], 0, 0, 0);
+                if (have_next) {
+                    if (!next_in_tile) {
+#pragma unroll
+                        for (int i = 0; i < TM; ++i) af[i][s] = *reinterpret_cast<const f16x8*>(nfa + koff[s] + i * 4096);
+                    }
+#pragma unroll
+                    for (int jj = 0; jj < PT; ++jj) bf[jj][s] = *reinterpret_cast<const f16x8*>(nfb + koff[s] + jj * 4096);
+                }
+            }
+            __builtin_amdgcn_s_setprio(0);
+            __builtin_amdgcn_sched_barrier(0);
+            __builtin_amdgcn_s_barrier();
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        t1 = t2;
+        advance(t2);
+    }
+    if (grp == 0) __builtin_amdgcn_s_barrier();  // re-align the two groups
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (g.dbg & 4) return;
+    gemm_epilogue<BM, BN, WAVES_M, WAVES_N, epi_wave_rows(BM, BN, WAVES_M, pp_lds_bytes(BM, BN, WAVES_M))>(g, acc, smem, m0, n0, z, zb, split);
+}
 
 // ---- 3x3 / stride 1 / pad 1 convolution with the A operand reused from an LDS-resident input patch ("halo") ------------------------
 // The im2col view re-fetches every input pixel 9 times (once per tap) through the LDS-DMA path, which is what bounds the ping-pong
@@ -991,7 +1314,15 @@ __global__ void __launch_bounds__(512) conv3_halo_kernel(GemmArgs g) {
     const int b_lane_off = (wn * WTN + l31) * 128;
     const int a_pix0 = (wm * 4 + (l31 >> 4)) * HW_ + (l31 & 15);  // halo pixel of this lane's row of A tile i = 0 at tap (0,0); tile 1: +2 rows
 
-    // ---- prologue: halo of the first chunk, B of tile 0, first half of B of tile 1
+    // A fragments of the K-tile at position t (chunk, tap) for k-step s, from the chunk's halo buffer
+    auto read_a = [&](const TileK& t, int s, f16x8 (&dst)[TM][4]) {
+        const char* ha = smem + HALO0 + (t.chunk & 1) * HALO_BYTES;
+        const int pix = a_pix0 + t.ky * HW_ + t.kx;
+        const int key = (((l31 & 15) + t.kx) >> 1) & 7;  // swizzle key = halo COLUMN / 2 (see the header)
+#pragma unroll
+        for (int i = 0; i < TM; ++i) dst[i][s] = *reinterpret_cast<const f16x8*>(ha + (pix + i * 2 * HW_) * 128 + (((s * 2 + hi) ^ key) << 4));
+    };
+    // ---- prologue: halo of the first chunk, B of tile 0, first half of B of tile 1; everything of tile 0 lands before the first reads
     TileK t0;
     t0.ky = t0.kx = 0;
     t0.chunk = kt_begin / 9;
@@ -1005,81 +1336,79 @@ __global__ void __launch_bounds__(512) conv3_halo_kernel(GemmArgs g) {
         if (kt_begin + 1 < kt_end) {
 #pragma unroll
             for (int j = 0; j < LB; ++j) issue_B(j, 1, t1.kw);
-            wait_vmcnt<2 * LB>();  // phase (0,0) needs the halo and the first half of B(0); its second half and B(1) may fly
-        } else {
             wait_vmcnt<LB>();
+        } else {
+            wait_vmcnt<0>();
         }
     }
     t2 = t1;
     advance(t2);
     __builtin_amdgcn_s_barrier();
-    if (grp == 1) __builtin_amdgcn_s_barrier();  // stagger: group 1 runs one barrier interval behind group 0
-
     TileK tc = t0;  // position of the K-tile being multiplied
     f16x8 af[TM][4], bf[PT][4];
+    {   // fragments of phase (0,0)
+        const char* fb = smem + b_lane_off;
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            read_a(tc, s, af);
+#pragma unroll
+            for (int jj = 0; jj < PT; ++jj) bf[jj][s] = *reinterpret_cast<const f16x8*>(fb + koff[s] + jj * 4096);
+        }
+    }
+    if (grp == 1) __builtin_amdgcn_s_barrier();  // stagger: group 1 runs one barrier interval behind group 0
+
+    // Fragment reads live in the MFMA segment (see gemm_pp2_kernel): after k-step s its registers are refilled with the next phase's
+    // data, so the counted waits cover what phase q+2 reads.  (t,0) issues the second half of B(t+1) and then [the halo of the next
+    // chunk when t opens a chunk]; (t,1) issues the first half of B(t+2).
     for (int kt = kt_begin; kt < kt_end; ++kt) {
         const int cur = (kt - kt_begin) & 1;
         const bool has1 = (kt + 1) < kt_end, has2 = (kt + 2) < kt_end;
         const bool opens = tc.ky == 0 && tc.kx == 0;                       // first tap of a chunk
         const bool halo_next = opens && (kt + 9) < kt_end;                 // the next chunk is inside this block's K range
-        const char* fb = smem + cur * B_BYTES + b_lane_off;
 #pragma unroll
         for (int p = 0; p < NP; ++p) {
             const int j0 = PT * p;
             // -------- load segment
             if (p == 0) {
-                const char* ha = smem + HALO0 + (tc.chunk & 1) * HALO_BYTES;
-                const int pix = a_pix0 + tc.ky * HW_ + tc.kx;
-                const int key = (((l31 & 15) + tc.kx) >> 1) & 7;  // swizzle key = halo COLUMN / 2 (see the header)
-#pragma unroll
-                for (int i = 0; i < TM; ++i) {
-                    const int hp = pix + i * 2 * HW_;
-#pragma unroll
-                    for (int s = 0; s < 4; ++s)
-                        af[i][s] = *reinterpret_cast<const f16x8*>(ha + hp * 128 + (((s * 2 + hi) ^ key) << 4));
-                }
-            }
-#pragma unroll
-            for (int jj = 0; jj < PT; ++jj) {
-#pragma unroll
-                for (int s = 0; s < 4; ++s) bf[jj][s] = *reinterpret_cast<const f16x8*>(fb + koff[s] + (j0 + jj) * 4096);
-            }
-            if (p == 0) {
-                // halo first (older than this phase's B loads), then the second half of B(t+1)
-                if (halo_next) issue_halo(tc.chunk + 1);
                 if (has1) {
 #pragma unroll
                     for (int j = LB; j < JB; ++j) issue_B(j, cur ^ 1, t1.kw);
                 }
-                // next phase reads the second half of B(t): younger loads = first + second half of B(t+1) [+ halo]
-                if (halo_next) { if (has1) wait_vmcnt<2 * LB + H>(); else wait_vmcnt<H>(); }
-                else { if (has1) wait_vmcnt<2 * LB>(); else wait_vmcnt<0>(); }
+                if (halo_next) issue_halo(tc.chunk + 1);
+                // phase (t+1,0) reads the first half of B(t+1) and a halo fetched a chunk ago: younger = this segment's loads
+                if (halo_next) { if (has1) wait_vmcnt<LB + H>(); else wait_vmcnt<H>(); }
+                else { if (has1) wait_vmcnt<LB>(); else wait_vmcnt<0>(); }
             } else {
                 if (has2) {
 #pragma unroll
                     for (int j = 0; j < LB; ++j) issue_B(j, cur, t2.kw);
                 }
-                // next phase, (t+1,0), reads the first half of B(t+1) (and a halo fetched a whole chunk ago): younger loads = [halo
-                // issued in (t,0)], second half of B(t+1), first half of B(t+2)
-                if (halo_next) {
-                    if (has2) wait_vmcnt<2 * LB + H>(); else if (has1) wait_vmcnt<LB + H>(); else wait_vmcnt<H>();
-                } else {
-                    if (has2) wait_vmcnt<2 * LB>(); else if (has1) wait_vmcnt<LB>(); else wait_vmcnt<0>();
-                }
+                // phase (t+1,1) reads the second half of B(t+1) (issued in (t,0) BEFORE the halo): younger = [halo], first half of B(t+2)
+                if (halo_next) { if (has2) wait_vmcnt<LB + H>(); else wait_vmcnt<H>(); }
+                else { if (has2) wait_vmcnt<LB>(); else wait_vmcnt<0>(); }
             }
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             __builtin_amdgcn_sched_barrier(0);
             __builtin_amdgcn_s_barrier();
             __builtin_amdgcn_sched_barrier(0);
-            // -------- MFMA segment
+            // -------- MFMA segment with the next phase's fragment reads
+            const bool next_in_tile = (p + 1 < NP);
+            const bool have_next = next_in_tile || has1;
+            const char* nfb = smem + (next_in_tile ? cur : (cur ^ 1)) * B_BYTES + b_lane_off + (next_in_tile ? (j0 + PT) * 4096 : 0);
             __builtin_amdgcn_s_setprio(1);
 #pragma unroll
-            for (int s = 0; s < 4; ++s)
+            for (int s = 0; s < 4; ++s) {
 #pragma unroll
                 for (int jj = 0; jj < PT; ++jj)
 #pragma unroll
                     for (int i = 0; i < TM; ++i)
                         acc[i][j0 + jj] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[i][s], bf[jj][s], acc[i][j0 + jj], 0, 0, 0);
+                if (have_next) {
+                    if (!next_in_tile) read_a(t1, s, af);
+#pragma unroll
+                    for (int jj = 0; jj < PT; ++jj) bf[jj][s] = *reinterpret_cast<const f16x8*>(nfb + koff[s] + jj * 4096);
+                }
+            }
             __builtin_amdgcn_s_setprio(0);
             __builtin_amdgcn_sched_barrier(0);
             __builtin_amdgcn_s_barrier();
@@ -1090,7 +1419,7 @@ __global__ void __launch_bounds__(512) conv3_halo_kernel(GemmArgs g) {
         advance(t2);
     }
     if (grp == 0) __builtin_amdgcn_s_barrier();  // re-align the two groups
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
     __syncthreads();
     gemm_epilogue<BM, BN, WAVES_M, WAVES_N, epi_wave_rows(BM, BN, WAVES_M, halo_lds_bytes(BN)), true>(g, acc, smem, m0, n0, z, zb, split);
 }
@@ -1149,11 +1478,33 @@ static int launch_gemm_t(odise_hip_ctx* ctx, GemmArgs& g, int batch) {
     return ODISE_OK;
 }
 
-template <int BM, int BN, int WAVES_N, int PT, bool CONV>
+template <int BM, int BN, int WAVES_N, int PT, bool CONV, int V = 0>
 static int launch_gemm_pp(odise_hip_ctx* ctx, GemmArgs& g, int batch) {
     constexpr int lds = pp_lds_bytes(BM, BN, 8 / WAVES_N);
     static_assert(epi_lds_bytes(BM, BN, 8 / WAVES_N, epi_wave_rows(BM, BN, 8 / WAVES_N, lds)) <= lds, "epilogue staging exceeds the LDS request");
-    auto kern = gemm_pp_kernel<BM, BN, WAVES_N, PT, CONV>;
+    auto kern = gemm_pp_kernel<BM, BN, WAVES_N, PT, CONV, V>;
+    static bool attr_set = false;  // per instantiation
+    if (!attr_set) {
+        ODISE_CHECK_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+        attr_set = true;
+    }
+    dim3 grid((unsigned)ceil_div(g.N, BN), (unsigned)ceil_div(g.M, BM), (unsigned)(g.splitk > 1 ? g.splitk : batch));
+    hipLaunchKernelGGL(kern, grid, dim3(512), lds, ctx->stream, g);
+    ODISE_CHECK_HIP(hipGetLastError());
+    if (g.splitk > 1) {
+        const int64_t total = (int64_t)g.M * ceil_div(g.N, 8);
+        const int blocks = (int)std::min<int64_t>(ceil_div(total, 256), 2048);
+        hipLaunchKernelGGL(splitk_reduce_kernel, dim3(blocks), dim3(256), 0, ctx->stream, g.ws, g.splitk, g.M, g.N, g.epi);
+        ODISE_CHECK_HIP(hipGetLastError());
+    }
+    return ODISE_OK;
+}
+
+template <int BM, int BN, int WAVES_N, int PT, bool CONV>
+static int launch_gemm_pp2(odise_hip_ctx* ctx, GemmArgs& g, int batch) {
+    static_assert((BN / WAVES_N / 32) % PT == 0, "whole phases");
+    constexpr int lds = pp_lds_bytes(BM, BN, 8 / WAVES_N);
+    auto kern = gemm_pp2_kernel<BM, BN, WAVES_N, PT, CONV>;
     static bool attr_set = false;  // per instantiation
     if (!attr_set) {
         ODISE_CHECK_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
@@ -1332,10 +1683,26 @@ static int launch_gemm(odise_hip_ctx* ctx, GemmArgs& g, int batch, int force_til
         return tile == 7 ? launch_conv3_halo<256, 2>(ctx, g) : launch_conv3_halo<128, 1>(ctx, g);
     }
     g.cg.halo_tx = g.cg.halo_ty = 0;
+    // second-generation ping-pong kernel (fragment reads under the MFMAs): measured +3..18 % on the implicit-GEMM convs and on
+    // dense problems that do not fill the chip twice; the large dense GEMMs keep the first generation (-5..12 % there).
+    // ODISE_GEMM_FLAGS: 512 forces it, 1024 forbids it.
+    const bool pp2_auto = !(flags & 1024) && ((CONV && tile != 6) || (!CONV && blocks(tile) * (g.splitk > 1 ? g.splitk : 1) <= 2 * cus));
+    if ((tile == 3 || tile == 4 || tile == 6) && pp_ok && ((flags & 512) || pp2_auto)) {
+        if (tile == 6) return launch_gemm_pp2<512, 128, 1, 2, CONV>(ctx, g, batch);
+        if (tile == 3) return launch_gemm_pp2<256, 320, 2, 1, CONV>(ctx, g, batch);
+        return launch_gemm_pp2<256, 256, 2, 2, CONV>(ctx, g, batch);
+    }
     if ((tile == 3 || tile == 4 || tile == 6) && pp_ok) {
         if (tile == 6) return launch_gemm_pp<512, 128, 1, 2, CONV>(ctx, g, batch);
         if (tile == 3) return launch_gemm_pp<256, 320, 2, 1, CONV>(ctx, g, batch);
         if (flags & 4) return launch_gemm_pp<256, 256, 2, 1, CONV>(ctx, g, batch);
+        if ((flags >> 7) & 3) {  // tuning variants of the 256x256 tile (tools/pp_variants.py)
+            switch ((flags >> 7) & 3) {
+                case 1: return launch_gemm_pp<256, 256, 2, 2, CONV, 1>(ctx, g, batch);
+                case 2: return launch_gemm_pp<256, 256, 2, 2, CONV, 2>(ctx, g, batch);
+                default: return launch_gemm_pp<256, 256, 2, 2, CONV, 3>(ctx, g, batch);
+            }
+        }
         return launch_gemm_pp<256, 256, 2, 2, CONV>(ctx, g, batch);
     }
     if (no_interleave) {

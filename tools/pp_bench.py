@@ -39,9 +39,9 @@ def bench(variants, fn, flop, label, it=10, rounds=3):
         print(f"{label} {name:8s}: {best[name]*1e3:8.1f} us {flop/(best[name]*1e-3)/1e12:7.1f} TF/s   max|d|={np.abs(outs[name]-ref).max():.3g}", flush=True)
 
 
-NO_PP, PT1 = 2 << 4, 4 << 4
-variants = [("plain", NO_PP), ("pp", 0)] + ([("pp-pt1", PT1)] if tile == 4 else [])
-bn = 320 if tile == 3 else 256
+NO_PP, PT1, PP2, NO_HALO = 2 << 4, 4 << 4, 512 << 4, 64 << 4
+variants = [("pp", NO_HALO), ("pp2", PP2 | NO_HALO)]
+bn = 320 if tile == 3 else 128 if tile == 6 else 256
 for (M, N, K) in [(65536, 2 * bn, 4096), (65536, 2 * bn, 320), (65536, 2 * bn, 640), (65536, 4 * bn, 1024), (4096, 4 * bn, 4096), (16384, bn, 8192), (1000, bn + 8, 192)]:
     A, W, O = rand((M, K)), rand((N, K), K ** -0.5), ctx.empty((M, N), np.float16)
     bench(variants, lambda: ctx.gemm(A, W, force_tile=tile, out=O), 2.0 * M * N * K, f"gemm M={M} N={N} K={K} tile {tile}")
