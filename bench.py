@@ -54,23 +54,21 @@ def _threads():
 
 
 def cpu_baseline_full(ext):
-    """Oracle restatement (kind='port') on the host cores.  Bounded sample: ONE 512x512 crop through the feature extractor
-    (CLIP + VAE encoder + UNet + truncated VAE decoder = 2.86 of the 3.13 TFLOP a crop costs end to end, i.e. 92 % of an image's
-    work); images/s is extrapolated as crops/s / 4 and therefore an upper bound of the CPU rate."""
+    """Oracle restatement (kind='port') on the host cores.  Bounded sample: the 4 crops of ONE 1024x1024 image through the feature
+    extractor (CLIP + VAE encoder + UNet + truncated VAE decoder = 2.86 of the 3.13 TFLOP a crop costs end to end, i.e. 92 % of an
+    image's work), one warm-up pass and one timed pass (~10-20 s of CPU work); images/s = 1 / pass time, an upper bound of the CPU rate."""
     import torch
     cores = _threads()
     torch.set_num_threads(cores)
-    img = torch.rand(1, 3, 512, 512, generator=torch.Generator().manual_seed(0))
-    t0 = time.perf_counter()
-    ext(img)
-    dt = time.perf_counter() - t0
-    if dt < 8.0:  # fast host: take a second, warm sample
+    img = torch.rand(4, 3, 512, 512, generator=torch.Generator().manual_seed(0))
+    with torch.no_grad():
+        ext(img[:1])  # warm-up (allocator, thread pool)
         t0 = time.perf_counter()
         ext(img)
         dt = time.perf_counter() - t0
-    return {"value": 1.0 / dt / 4.0, "unit": "images/s", "cores": cores, "kind": "port",
-            "sample": "1 timed 512x512 crop through the fp32 torch CPU oracle of LdmImplicitCaptionerExtractor (92% of a 1024^2 image's "
-                      "work is 4 such crops); images/s = crops/s / 4, heads and post-processing excluded"}
+    return {"value": 1.0 / dt, "unit": "images/s", "cores": cores, "kind": "port",
+            "sample": "the 4 crops (512x512) of one 1024x1024 image through the fp32 torch CPU oracle of LdmImplicitCaptionerExtractor "
+                      "(92% of an image's work), 1 timed pass after a 1-crop warm-up; heads and post-processing excluded"}
 
 
 def cpu_baseline_unet(model):
@@ -89,6 +87,37 @@ def cpu_baseline_unet(model):
         dt = time.perf_counter() - t0
     return {"value": 1.0 / dt, "unit": "crops/s", "cores": cores, "kind": "port",
             "sample": "1 timed UNet single-step forward (bs=1, 64x64 latent, fp32 torch CPU oracle, live path)"}
+
+
+def dominant_kernel(ctx):
+    """The kernel with the largest share of the step (profiles/): conv3_halo_kernel<256,2> on the VAE 512->512 3x3 convolutions at
+    128x128 for the 16 crops of a 4-image step (7 launches per step, 18 % of the step's FLOPs).  Timed live with HIP events on the
+    library's stream; algorithmic FLOPs per launch = 2 * pixels * Cout * 9 * Cin.  `traffic` = HBM bytes per launch from the PMC
+    passes of the same launch (tools/one_conv.py under rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, FETCH doubled as the guide's gfx950
+    correction prescribes), recorded in profiles/r01_dominant_conv_traffic.json; null when that file is absent."""
+    n, hw, cin, cout = 16, 128, 512, 512
+    rng = np.random.default_rng(0)
+    X = ctx.to_device(rng.standard_normal((n, hw, hw, cin), dtype=np.float32).astype(np.float16))
+    Wt = ctx.to_device((rng.standard_normal((cout, 3, 3, cin), dtype=np.float32) * (9 * cin) ** -0.5).astype(np.float16))
+    O = ctx.empty((n, hw, hw, cout), np.float16)
+    for _ in range(3):
+        ctx.conv2d(X, Wt, out=O)
+    ctx.sync()
+    ctx.timer_start()
+    it = 10
+    for _ in range(it):
+        ctx.conv2d(X, Wt, out=O)
+    us = ctx.timer_stop() / it * 1e3
+    flops = 2.0 * n * hw * hw * cout * 9 * cin
+    traffic = None
+    tp = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_dominant_conv_traffic.json")
+    if os.path.exists(tp):
+        with open(tp) as f:
+            traffic = json.load(f).get("hbm_bytes_per_launch")
+    for a in (X, Wt, O):
+        a.free()
+    return {"kernel": "conv3_halo_kernel<256,2> (3x3 conv 512->512 @128x128, 16 crops)", "launch_us": us, "flops": flops,
+            "achieved": flops / (us * 1e-6) / 1e12, "traffic": traffic, "launches_per_step": 7}
 
 
 def main():
@@ -202,6 +231,7 @@ def main():
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         wall, ev_ms = float(tt[0]), float(tt[1])
 
+    dom = dominant_kernel(ctx) if (rank == 0 and args.stage == "full") else None
     if rank == 0:
         ms_per_step = wall * 1e3 / args.steps
         value = world * B * args.steps / wall
@@ -215,9 +245,16 @@ def main():
                        "parallelism": f"dp{world} (independent images, one RCCL all-gather of predictions per step)" if gather else f"dp{world}"},
             "roofline": {"bound": "mfma", "achieved": achieved, "peak": MFMA_F16_PEAK / 1e12, "unit": "TFLOP/s", "frac": achieved * 1e12 / MFMA_F16_PEAK,
                          "traffic": None,
-                         "kernel": "whole step (dominant kernel family: MFMA implicit-GEMM conv / GEMM gemm_kernel<...>; see profiles/)",
+                         "kernel": "whole step (all kernels; per-kernel times in profiles/)",
                          "algorithmic_flops_per_unit": flops_per_unit, "event_ms_per_step": step_ms_ev},
         }
+        if dom is not None:
+            # the contract's roofline object describes the DOMINANT kernel; the whole-step figure moves to step_* keys
+            out["roofline"] = {"bound": "mfma", "achieved": dom["achieved"], "peak": MFMA_F16_PEAK / 1e12, "unit": "TFLOP/s",
+                               "frac": dom["achieved"] * 1e12 / MFMA_F16_PEAK, "traffic": dom["traffic"], "kernel": dom["kernel"],
+                               "launch_us": dom["launch_us"], "algorithmic_flops_per_launch": dom["flops"], "launches_per_step": dom["launches_per_step"],
+                               "step_achieved": achieved, "step_frac": achieved * 1e12 / MFMA_F16_PEAK,
+                               "algorithmic_flops_per_unit": flops_per_unit, "event_ms_per_step": step_ms_ev}
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = baseline()
         print(json.dumps(out), flush=True)
