@@ -6,16 +6,18 @@
 // These are the dense conv / im2col and Linear GEMMs of the SD-v1 UNet ResBlock / SpatialTransformer
 // (ldm.py:469-491 -> ldm UNetModel), the VAE, CLIP and Mask2Former heads.
 //
-// CDNA4 mapping: 256 threads = 4 wavefronts (2x2), v_mfma_f32_32x32x16_f16, fp32 accumulate.
-//   * block tile BMxBNx64; A and W tiles staged global->VGPR->LDS (register prefetch of tile t+1 is in
-//     flight while tile t is multiplied; one barrier per K-tile; LDS double-buffered).
-//   * LDS rows are 128 B (64 halves); 16-byte slots are XOR-swizzled with (row>>1)&7 so that the
-//     16-lane groups of ds_read_b128 hit 16 distinct slots of the 256-B bank row (conflict-free),
-//     and the 8-lane groups of ds_write_b128 write one full 128-B row.
-//   * epilogue goes through LDS (fp32) so that bias / time-embedding broadcast / activation / GEGLU /
-//     residual run on 8 consecutive output channels per lane and stores are 16-byte coalesced.
-//   * small-M layers (8x8 / 16x16 latents at batch 1) are weight-streaming bound: split-K over grid.z
-//     with an fp32 workspace and a fused reduce+epilogue kernel keeps >=2 blocks per CU in flight.
+// CDNA4 mapping (v_mfma_f32_32x32x16_f16, fp32 accumulate, block tile BM x BN x 64):
+//   * gemm_kernel      - 4- or 8-wave tiles 64x64 .. 256x320; A and W tiles go global -> LDS by LDS-DMA (global_load_lds_dwordx4),
+//                        double-buffered, one barrier per K-tile; small / ragged problems, split-K over grid.z.
+//   * gemm_pp_kernel   - 256x256 / 256x320 / 512x128 tiles, 8 waves in two groups staggered by a barrier (one multiplies while the
+//                        other feeds), DMA in flight across barriers with counted vmcnt.
+//   * gemm_pp2_kernel  - same, with the next phase's fragment reads issued under the MFMAs.
+//   * conv3_halo_kernel- 3x3 convs: A fragments come from an LDS-resident 18x18 input patch fetched once per 64-channel chunk.
+//   LDS rows are 128 B (64 halves); 16-byte slots are XOR-swizzled (applied to the DMA source address, the LDS image of a DMA
+//   instruction being lane-linear) so that the 16-lane groups of ds_read_b128 hit 16 distinct slots of the 256-B bank row.
+//   The epilogue goes through LDS (fp32) so that bias / time-embedding broadcast / activation / GEGLU / residual run on 8 consecutive
+//   output channels per lane and stores are 16-byte coalesced.  Tile, split-K and kernel generation are chosen by launch_gemm's
+//   cost model.  Every variant keeps the same fp32 summation order: results are bit-identical across kernels for a given K order.
 #include "common.h"
 #include <stdlib.h>
 
