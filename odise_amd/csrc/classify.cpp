@@ -18,6 +18,7 @@ namespace odise {
 
 struct ClassifyModel {
     bool built = false;
+    bool caption = false;  // CaptionODISE: word_head.text_proj, no null embedding, learned binary class head (odise.py:545-569)
     LinW text_proj;
     const HostTensor* null_host = nullptr;
     std::vector<float> null_embed;
@@ -49,14 +50,22 @@ static int classify_build(odise_hip_ctx* ctx) {
     classify_destroy(ms);
     ClassifyModel* c = new ClassifyModel();
     ms->classify = c;
-    Packer pk{ctx, ms, "category_head.", ""};
+    // CategoryODISE: category_head.{text_proj, null_embed} (odise.py:1236-1241); CaptionODISE: word_head.text_proj only (odise.py:1040-1060)
+    Packer pcat{ctx, ms, "category_head.", ""};
+    Packer pword{ctx, ms, "word_head.", ""};
+    c->caption = pcat.find("text_proj.weight") == nullptr && pword.find("text_proj.weight") != nullptr;
+    Packer& pk = c->caption ? pword : pcat;
     ODISE_TRY(pk.linear("text_proj", c->text_proj));
-    const HostTensor* ne = pk.find("null_embed");
-    if (!ne || ne->numel() != c->text_proj.in) {
-        set_error("classify: bad or missing category_head.null_embed");
-        return ODISE_ERR_STATE;
+    if (c->caption) {
+        c->null_embed.assign((size_t)c->text_proj.in, 0.f);  // the null row of the bank is unused in this variant
+    } else {
+        const HostTensor* ne = pk.find("null_embed");
+        if (!ne || ne->numel() != c->text_proj.in) {
+            set_error("classify: bad or missing category_head.null_embed");
+            return ODISE_ERR_STATE;
+        }
+        c->null_embed = ne->data;
     }
-    c->null_embed = ne->data;
     c->dim = c->text_proj.in;
     c->pdim = c->text_proj.out;
     c->built = true;
@@ -175,7 +184,12 @@ extern "C" int odise_hip_classify(odise_hip_ctx* ctx, const float* image, int B,
     d.C = L2; d.ldc = c->Ktot; d.c_dtype = ODISE_F32; d.alpha = 1.f; d.batch = 1;
     ODISE_TRY(ex.gemm(d));
     // ---- ensemble + null merge -----------------------------------------------------------------------------------------------
-    ODISE_TRY(launch_classify_rows(ctx, L1, L2, c->seg, c->ovl, mask_cls, MQ, c->K, c->Ktot, ho.logit_scale, 100.0f, c->alpha, c->beta));
+    if (c->caption && !ho.class_logits) {
+        set_error("classify: word_head weights were loaded but the decoder has no class_embed (not a CaptionODISE checkpoint)");
+        return ODISE_ERR_STATE;
+    }
+    ODISE_TRY(launch_classify_rows(ctx, L1, L2, c->seg, c->ovl, c->caption ? ho.class_logits : nullptr, mask_cls, MQ, c->K, c->Ktot,
+                                   ho.logit_scale, 100.0f, c->alpha, c->beta));
     ms->arena.release(mk);
     return ODISE_OK;
 }

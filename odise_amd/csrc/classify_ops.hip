@@ -97,9 +97,11 @@ __global__ void __launch_bounds__(256) l2_normalize_kernel(const TIn* __restrict
 
 // one block per (b,q) row.  L1 [rows, K1tot+1] cosines vs the category text bank (+ null as last column); L2 [rows, K2tot] cosines
 // vs the MaskCLIP text bank; seg [K+1] group offsets (shared by both banks); ovl [K]; out [rows, K+1] log-probabilities.
+// binary (optional) [rows, 2]: learned (object, no-object) logits of CaptionODISE's class_embed - when given the no-object probability
+// is softmax(binary)[1] (odise.py:559-565) instead of the null-text probability of CategoryODISE (odise.py:313-314).
 __global__ void __launch_bounds__(256) classify_rows_kernel(const float* __restrict__ L1, const float* __restrict__ L2, const int* __restrict__ seg,
-                                                           const int* __restrict__ ovl, float* __restrict__ out, int K, int Ktot, float ls1,
-                                                           float ls2, float alpha, float beta) {
+                                                           const int* __restrict__ ovl, const float* __restrict__ binary, float* __restrict__ out,
+                                                           int K, int Ktot, float ls1, float ls2, float alpha, float beta) {
     extern __shared__ float sm[];  // a[K], b[K], open[K], red[8]
     float* a = sm;
     float* bq = sm + K;
@@ -155,9 +157,13 @@ __global__ void __launch_bounds__(256) classify_rows_kernel(const float* __restr
     float so = 0.f;
     for (int k = tid; k < K; k += blockDim.x) so += expf(op[k] - mo);
     so = block_sum(so);
-    // null probability from softmax over [a, null] (odise.py:313-314)
+    // null probability from softmax over [a, null] (odise.py:313-314), or the learned binary head of the caption variant
     const float mn = fmaxf(ma, nul);
-    const float pn = expf(nul - mn) / (sa * expf(ma - mn) + expf(nul - mn));
+    float pn = expf(nul - mn) / (sa * expf(ma - mn) + expf(nul - mn));
+    if (binary) {
+        const float b0 = binary[row * 2], b1 = binary[row * 2 + 1], mb2 = fmaxf(b0, b1);
+        pn = expf(b1 - mb2) / (expf(b0 - mb2) + expf(b1 - mb2));
+    }
     float* orow = out + row * (K + 1);
     for (int k = tid; k < K; k += blockDim.x) orow[k] = logf(expf(op[k] - mo) / so * (1.f - pn) + 1e-8f);
     if (tid == 0) orow[K] = logf(pn + 1e-8f);
@@ -431,9 +437,9 @@ int launch_l2_normalize_f32(odise_hip_ctx* ctx, const float* x, f16* y, int64_t 
     ODISE_CHECK_HIP(hipGetLastError());
     return ODISE_OK;
 }
-int launch_classify_rows(odise_hip_ctx* ctx, const float* L1, const float* L2, const int* seg, const int* ovl, float* out, int64_t rows, int K,
+int launch_classify_rows(odise_hip_ctx* ctx, const float* L1, const float* L2, const int* seg, const int* ovl, const float* binary, float* out, int64_t rows, int K,
                          int Ktot, float ls1, float ls2, float alpha, float beta) {
-    hipLaunchKernelGGL(classify_rows_kernel, dim3((unsigned)rows), dim3(256), (3 * (size_t)K + 8) * sizeof(float), ctx->stream, L1, L2, seg, ovl, out,
+    hipLaunchKernelGGL(classify_rows_kernel, dim3((unsigned)rows), dim3(256), (3 * (size_t)K + 8) * sizeof(float), ctx->stream, L1, L2, seg, ovl, binary, out,
                        K, Ktot, ls1, ls2, alpha, beta);
     ODISE_CHECK_HIP(hipGetLastError());
     return ODISE_OK;

@@ -178,7 +178,7 @@ int launch_maskclip_token_mask(odise_hip_ctx* ctx, const f16* logits, uint8_t* o
                                int64_t ldm);
 int launch_l2_normalize_f16(odise_hip_ctx* ctx, const f16* x, f16* y, int64_t rows, int C);
 int launch_l2_normalize_f32(odise_hip_ctx* ctx, const float* x, f16* y, int64_t rows, int C);
-int launch_classify_rows(odise_hip_ctx* ctx, const float* L1, const float* L2, const int* seg, const int* ovl, float* out, int64_t rows, int K,
+int launch_classify_rows(odise_hip_ctx* ctx, const float* L1, const float* L2, const int* seg, const int* ovl, const float* binary, float* out, int64_t rows, int K,
                          int Ktot, float ls1, float ls2, float alpha, float beta);
 int launch_postprocess_pixels(odise_hip_ctx* ctx, const f16* logits, const float* kscore, f16* S, int* ids, int* counts, const PostGeom& g);
 int launch_column_stats(odise_hip_ctx* ctx, const f16* S, float* partial, float* out2, int npix, int Qpad);
@@ -190,6 +190,7 @@ struct HeadOutputs {
     const f16* mask_embed;   // [B, Q, C]
     int B, Q, C, h4, w4;
     float logit_scale;
+    const float* class_logits;  // [B, Q, 2] learned (object, no-object) logits of the caption variant's class_embed, or nullptr
 };
 int head_outputs(ModelStore* ms, HeadOutputs* out);
 

@@ -71,6 +71,9 @@ struct MaskGenModel {
     f16* pred_masks = nullptr;   // [B, Q, H4*W4] logits
     f16* mask_embed = nullptr;   // [B, Q, C]
     f16* mask_pooled = nullptr;  // [B, Q, C]
+    bool has_class_embed = false;  // CaptionODISE: learned Linear(C, 2) on the decoder output (mask2former_transformer_decoder.py:333)
+    LinW class_embed;
+    float* class_logits = nullptr;  // [B, Q, 2] of the final prediction head
     int out_B = 0, out_h = 0, out_w = 0;
     double last_macs = 0.0;
 };
@@ -195,6 +198,14 @@ static int maskgen_build_head(odise_hip_ctx* ctx) {
         return ODISE_ERR_STATE;
     }
     ODISE_TRY(pd.norm("decoder_norm", g->decoder_norm));
+    g->has_class_embed = pd.find("class_embed.weight") != nullptr;
+    if (g->has_class_embed) {
+        ODISE_TRY(pd.linear("class_embed", g->class_embed));
+        if (g->class_embed.out != 2) {
+            set_error("decoder: class_embed must have 2 outputs (object / no-object), found %d", g->class_embed.out);
+            return ODISE_ERR_STATE;
+        }
+    }
     const HostTensor* qf = pd.find("query_feat.weight");
     if (!qf || qf->shape.size() != 2 || qf->shape[1] != C) {
         set_error("decoder: bad or missing query_feat.weight");
@@ -566,6 +577,19 @@ static int head_forward(odise_hip_ctx* ctx, const Act feats[4]) {
         ODISE_TRY(ex.layer_norm(tq, out, MQ, L.ffn_norm, 1e-5f));
         ODISE_TRY(prediction_heads(i + 1 < nl ? (i + 1) % 3 : -1));
     }
+    // ---- learned (object, no-object) logits of the final prediction head: outputs_class = class_embed(decoder_output), odise.py:734
+    g->class_logits = nullptr;
+    if (g->has_class_embed) {
+        float* cl = (float*)ex.alloc_bytes((size_t)MQ * 2 * 4);
+        if (!cl) return ODISE_ERR_NOMEM;
+        odise_gemm_desc d;
+        memset(&d, 0, sizeof(d));
+        d.M = (int)MQ; d.N = 2; d.K = C;
+        d.A = dn; d.lda = C; d.W = g->class_embed.w; d.ldw = C;
+        d.C = cl; d.ldc = 2; d.c_dtype = ODISE_F32; d.bias_n = g->class_embed.b; d.alpha = 1.f; d.batch = 1;
+        ODISE_TRY(ex.gemm(d));
+        g->class_logits = cl;
+    }
     // ---- PooledMaskEmbed on the final prediction (odise.py:984-1015) ------------------------------------------------------------
     ODISE_TRY(launch_mask_binarize_f16(ctx, masks, m01, inv, MQ, (int)HW4));
     for (int b = 0; b < B; ++b) {
@@ -597,6 +621,7 @@ int head_outputs(ModelStore* ms, HeadOutputs* out) {
     out->pred_masks = g->pred_masks; out->mask_embed = g->mask_embed;
     out->B = g->out_B; out->Q = g->Q; out->C = g->C; out->h4 = g->out_h; out->w4 = g->out_w;
     out->logit_scale = g->logit_scale;
+    out->class_logits = g->class_logits;
     return ODISE_OK;
 }
 

@@ -104,12 +104,14 @@ class HipCategoryODISE(HipODISE):
     (list of {"image": uint8/float CHW, "height", "width"}) and returns the reference's output format (list of dicts with
     "sem_seg" [K,h,w] fp32, "panoptic_seg" (int32 [h,w], segments_info), "instances" {pred_masks, scores, pred_classes})."""
 
+    HEAD_KEYS = ("category_head.text_proj.weight", "category_head.text_proj.bias", "category_head.null_embed")
+
     def __init__(self, ctx: Context, state, semantic_on=True, panoptic_on=True, instance_on=True, object_mask_threshold=0.0,
                  overlap_threshold=0.8, test_topk_per_image=100, size_divisibility=64):
         super().__init__(ctx, {k: v for k, v in state.items()})
         # category_head weights are loaded through the same store: re-register them (the store was cleared after build)
         n = 0
-        for key in ("category_head.text_proj.weight", "category_head.text_proj.bias", "category_head.null_embed"):
+        for key in self.HEAD_KEYS:
             val = state[key]
             if hasattr(val, "detach"):
                 val = val.detach().cpu().numpy()
@@ -298,3 +300,13 @@ class HipCategoryODISE(HipODISE):
         mask_cls = self.classify_device(self.ctx.to_device(img01)).numpy()
         sizes = [(int(x.get("height", H)), int(x.get("width", W))) for x in batched_inputs]
         return self.postprocess_batch(mask_cls, (Hp, Wp), (H, W), sizes)
+
+
+class HipCaptionODISE(HipCategoryODISE):
+    """CaptionODISE's eval forward (odise.py:545-619): identical to the label model up to the classification stage, where the
+    no-object probability comes from the decoder's learned 2-way `class_embed` (object / no-object) instead of the null text
+    embedding, and the word bank is projected by `word_head.text_proj` (WordEmbed.forward eval, odise.py:1206-1216; prompt "photo",
+    configs/common/models/mask_generator_with_caption.py:57-63).  The library switches on the presence of `word_head.*` /
+    `sem_seg_head.predictor.class_embed.*` in the state; `set_vocabulary(cat_text=<word bank>, ...)` is unchanged."""
+
+    HEAD_KEYS = ("word_head.text_proj.weight", "word_head.text_proj.bias")

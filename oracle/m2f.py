@@ -230,9 +230,14 @@ class PooledMaskEmbed(nn.Module):
 
 
 class MaskedTransformerDecoder(nn.Module):
-    def __init__(self, hidden_dim=256, num_queries=100, nheads=8, dim_feedforward=2048, dec_layers=9, mask_dim=256, num_classes=133):
+    def __init__(self, hidden_dim=256, num_queries=100, nheads=8, dim_feedforward=2048, dec_layers=9, mask_dim=256, num_classes=133,
+                 learned_class_embed=False):
         super().__init__()
         self.num_heads, self.num_layers, self.num_feature_levels, self.num_classes = nheads, dec_layers, 3, num_classes
+        # CaptionODISE keeps Mask2Former's own nn.Linear(hidden_dim, num_classes + 1) with num_classes = 1 (object / no-object,
+        # mask2former_transformer_decoder.py:333, configs/common/models/mask_generator_with_caption.py:4); CategoryODISE replaces it
+        # with the parameter-free PseudoClassEmbed
+        self.class_embed = nn.Linear(hidden_dim, num_classes + 1) if learned_class_embed else None
         self.hidden_dim = hidden_dim
         self.transformer_self_attention_layers = nn.ModuleList(SelfAttentionLayer(hidden_dim, nheads) for _ in range(dec_layers))
         self.transformer_cross_attention_layers = nn.ModuleList(CrossAttentionLayer(hidden_dim, nheads) for _ in range(dec_layers))
@@ -246,8 +251,11 @@ class MaskedTransformerDecoder(nn.Module):
 
     def forward_prediction_heads(self, output, mask_features, attn_mask_target_size):                             # odise.py:729-776
         decoder_output = self.decoder_norm(output).transpose(0, 1)
-        fg = torch.ones((*decoder_output.shape[:-1], self.num_classes))
-        outputs_class = torch.cat([fg, torch.zeros((*decoder_output.shape[:-1], 1))], dim=-1)                     # PseudoClassEmbed :910-920
+        if self.class_embed is not None:
+            outputs_class = self.class_embed(decoder_output)                                                      # :734
+        else:
+            fg = torch.ones((*decoder_output.shape[:-1], self.num_classes))
+            outputs_class = torch.cat([fg, torch.zeros((*decoder_output.shape[:-1], 1))], dim=-1)                 # PseudoClassEmbed :910-920
         mask_embed = self.mask_embed(decoder_output)
         outputs_mask = torch.einsum("bqc,bchw->bqhw", mask_embed, mask_features)
         extra = self.post_mask_embed(decoder_output, mask_embed, mask_features, outputs_class, outputs_mask)
@@ -282,14 +290,14 @@ class MaskedTransformerDecoder(nn.Module):
 class SemSegHead(nn.Module):
     """MaskFormerHead.layers (M2F/modeling/meta_arch/mask_former_head.py:118-132): pixel decoder -> predictor."""
 
-    def __init__(self, num_classes=133, in_channels=512, small=False):
+    def __init__(self, num_classes=133, in_channels=512, small=False, learned_class_embed=False):
         super().__init__()
         if small:
             self.pixel_decoder = PixelDecoder(in_channels, conv_dim=64, mask_dim=64, enc_layers=2, d_ffn=128, nheads=8)
-            self.predictor = MaskedTransformerDecoder(64, 20, 8, 128, 3, 64, num_classes)
+            self.predictor = MaskedTransformerDecoder(64, 20, 8, 128, 3, 64, num_classes, learned_class_embed=learned_class_embed)
         else:
             self.pixel_decoder = PixelDecoder(in_channels)
-            self.predictor = MaskedTransformerDecoder(num_classes=num_classes)
+            self.predictor = MaskedTransformerDecoder(num_classes=num_classes, learned_class_embed=learned_class_embed)
 
     @torch.no_grad()
     def forward(self, features):

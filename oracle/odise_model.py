@@ -204,6 +204,32 @@ class OpenVocabHeads(nn.Module):
         return merge_with_null(pred_logits, pred_open_logits)
 
 
+def caption_pred_open_logits(mask_embed, text_embed, logit_scale, group_sizes):
+    """CaptionODISE.cal_pred_open_logits (odise.py:432-449): cosine logits against the projected word bank, max over synonyms."""
+    me = F.normalize(mask_embed, dim=-1)
+    te = F.normalize(text_embed, dim=-1)
+    return ensemble_logits_with_labels(logit_scale * (me @ te.t()), group_sizes)
+
+
+def caption_merge(pred_logits2, pred_open_logits):
+    """CaptionODISE.forward eval branch (odise.py:557-569): learned (object, no-object) logits gate the open-vocabulary distribution."""
+    binary = F.softmax(pred_logits2, dim=-1)
+    probs = F.softmax(pred_open_logits, dim=-1)
+    return torch.log(torch.cat([probs * binary[..., 0:1], binary[..., 1:2]], dim=-1) + 1e-8)
+
+
+@torch.no_grad()
+def caption_classify(heads: "OpenVocabHeads", outputs, images01):
+    """The classification part of CaptionODISE's eval forward: WordEmbed.forward eval (odise.py:1206-1216: text_proj of the test
+    word bank, no null embedding), cal_pred_open_logits, PoolingCLIPHead, merge with the binary class head."""
+    text_embed = heads.text_proj(heads.text_embed)
+    open_logits = caption_pred_open_logits(outputs["mask_embed"], text_embed, outputs["logit_scale"], heads.group_sizes)
+    clip_embed = mask_clip_embed(heads.clip, images01, outputs["pred_masks"])
+    clip_logits = mask_clip_pred_logits(clip_embed, heads.clip_text_embed, heads.group_sizes)
+    open_logits = pooling_clip_head(open_logits, clip_logits, heads.category_overlapping_mask, heads.alpha, heads.beta)
+    return caption_merge(outputs["pred_logits"], open_logits)
+
+
 @torch.no_grad()
 def postprocess(mask_cls_results, pred_masks, padded_hw, image_sizes, out_sizes, num_classes, thing_ids, overlap_threshold=0.8,
                 topk=100) -> List[dict]:

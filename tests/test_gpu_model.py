@@ -127,3 +127,42 @@ def test_postprocess_x4_kernel_matches_generic(models, monkeypatch, h, w):
     np.testing.assert_array_equal(fast["sem_seg"], gen["sem_seg"])
     np.testing.assert_array_equal(fast["instances"]["pred_masks"], gen["instances"]["pred_masks"])
     np.testing.assert_array_equal(fast["instances"]["scores"], gen["instances"]["scores"])
+
+
+def test_caption_variant_matches_oracle(ctx):
+    """CaptionODISE eval forward (odise.py:545-619): learned (object, no-object) class head + word bank without a null embedding."""
+    from odise_amd.pipeline import HipCaptionODISE
+    ext = ImplicitCaptionerExtractor(**SMALL)
+    bb = FeatureExtractorBackbone(ext, [128, 128, 512, 384, 192, 128, 128, 128])
+    head = init_synthetic_(SemSegHead(small=True, num_classes=1, learned_class_embed=True), seed=778)
+    heads = om.OpenVocabHeads(ext.clip, GROUPS, projection_dim=64)
+    state = ext.export_state()
+    state.update({"backbone.feature_projections." + k: v for k, v in bb.feature_projections.state_dict().items()})
+    state.update({"sem_seg_head." + k: v for k, v in head.state_dict().items()})
+    assert "sem_seg_head.predictor.class_embed.weight" in state
+    state["word_head.text_proj.weight"] = heads.text_proj.weight.detach()
+    state["word_head.text_proj.bias"] = heads.text_proj.bias.detach()
+    hip = HipCaptionODISE(ctx, state, overlap_threshold=0.0)
+    hip.set_vocabulary(heads.text_embed.numpy(), heads.clip_text_embed.numpy(), GROUPS, heads.category_overlapping_mask.numpy(), THINGS,
+                       heads.alpha, heads.beta)
+    img = _image_u8(512, 512, seed=33)
+    imgf = img.float()[None] / 255.0
+    outputs = head(bb(imgf))
+    assert outputs["pred_logits"].shape[-1] == 2
+    ref_cls = om.caption_classify(heads, outputs, imgf)
+    ref = om.postprocess(ref_cls, outputs["pred_masks"], (512, 512), [(512, 512)], [(512, 512)], len(GROUPS), THINGS, 0.0)[0]
+    # classification stage
+    img01 = imgf.numpy()
+    hip.backbone_device(ctx.to_device(img01), want_outputs=False)
+    hip.head_device(None, 1, 128, 128)
+    got_cls = hip.classify_device(ctx.to_device(img01)).numpy()
+    p_ref, p_got = np.exp(ref_cls.numpy()), np.exp(got_cls)
+    print("caption class prob max abs err", np.abs(p_got - p_ref).max(), "no-object prob range", p_ref[..., -1].min(), p_ref[..., -1].max())
+    assert np.abs(p_got - p_ref).max() < 2e-2
+    # whole forward
+    got = hip.forward([{"image": img}])[0]
+    pan_ref, info_ref = ref["panoptic_seg"]
+    pan, info = got["panoptic_seg"]
+    agree = (pan == pan_ref.numpy()).mean()
+    print("segments", info, "ref", info_ref, "agreement", agree)
+    assert info == info_ref and agree > 0.995
