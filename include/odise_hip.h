@@ -232,6 +232,20 @@ int odise_hip_panoptic_write(odise_hip_ctx* ctx, const int* ids, const int* map,
 int odise_hip_instance_masks(odise_hip_ctx* ctx, int b, const int* idx, int n, int pad_h, int pad_w, int img_h, int img_w, int out_h,
                              int out_w, float* out);
 
+/* ---- input resize and evaluator reductions of the eval loop --------------------------------------------
+ * Replaces, on device buffers: detectron2 T.ResizeShortestEdge -> PIL.Image.resize(BILINEAR) of the DatasetMapper
+ * (configs/common/data/pano_open_d2_eval.py:74-107) and the per-pixel parts of the evaluators configured there
+ * (odise/evaluation/d2_evaluator.py:49 COCOPanopticEvaluator -> panopticapi pq_compute_single_core, :63 SemSegEvaluator.process). */
+/* src uint8 [H,W,C] -> dst uint8 [OH,OW,C], bit-identical to Pillow's 8-bit bilinear resampler (horizontal pass, then vertical) */
+int odise_hip_resize_bilinear_u8(odise_hip_ctx* ctx, const void* src, int H, int W, int C, void* dst, int OH, int OW);
+/* dst fp32 [C,H,W] = scale * src uint8 [H,W,C] */
+int odise_hip_u8_hwc_to_f32_chw(odise_hip_ctx* ctx, const void* src, float* dst, int H, int W, int C, float scale);
+/* conf int64 [(K+1)*(K+1)] += count of (argmax_k sem_seg[k,p], gt[p]); gt outside [0,K] (ignore label) counts in column K.
+ * The caller zeroes conf before the first image and sums it across ranks (all-gather / all-reduce of (K+1)^2 int64). */
+int odise_hip_semantic_confusion(odise_hip_ctx* ctx, const float* sem_seg, const int* gt, int K, int npix, int64_t* conf);
+/* hist int32 [na*nb] += count of (a[p], b[p]) pairs with 0 <= a < na, 0 <= b < nb (segment-index co-occurrence of PQ matching) */
+int odise_hip_pair_histogram(odise_hip_ctx* ctx, const int* a, const int* b, int npix, int na, int nb, int* hist);
+
 #ifdef __cplusplus
 }
 #endif

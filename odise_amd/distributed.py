@@ -66,3 +66,15 @@ def allgather_records(local: torch.Tensor) -> torch.Tensor:
     dist.all_gather_into_tensor(out, padded)
     keep = torch.cat([torch.arange(int(s)) + r * n_max for r, s in enumerate(sizes)]).to(local.device)
     return out[keep]
+
+
+def sum_confusion(conf: torch.Tensor) -> torch.Tensor:
+    """Semantic evaluation's exchange step: every rank accumulates an int64 [(K+1),(K+1)] confusion matrix over its image shard
+    (odise_hip_semantic_confusion); one all-reduce(SUM) of (K+1)^2 counters replaces detectron2's pickled gather of per-image
+    predictions (SemSegEvaluator.evaluate, odise/evaluation/d2_evaluator.py:63).  Integer sums: the result is independent of the
+    rank count and order."""
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+        return conf
+    out = conf.clone()
+    dist.all_reduce(out, op=dist.ReduceOp.SUM)
+    return out

@@ -281,6 +281,37 @@ class Context:
         check(self.lib.odise_hip_mask_pooling(self.h, _p(x), _p(mask), _p(out), B, Cc, Q, H * W), "mask_pooling")
         return out
 
+    # ---- eval-loop helpers (include/odise_hip.h, last section) ---------------------------------------------------------------------
+    def resize_bilinear_u8(self, img: DeviceArray, out_h: int, out_w: int) -> DeviceArray:
+        """uint8 [H,W,C] -> uint8 [out_h,out_w,C], bit-identical to PIL.Image.resize((out_w, out_h), BILINEAR)."""
+        H, W, Cc = img.shape
+        assert img.dtype == np.uint8
+        out = self.empty((out_h, out_w, Cc), np.uint8)
+        check(self.lib.odise_hip_resize_bilinear_u8(self.h, _p(img), H, W, Cc, _p(out), int(out_h), int(out_w)), "resize_bilinear_u8")
+        return out
+
+    def u8_hwc_to_f32_chw(self, img: DeviceArray, scale: float = 1.0) -> DeviceArray:
+        H, W, Cc = img.shape
+        out = self.empty((Cc, H, W), np.float32)
+        check(self.lib.odise_hip_u8_hwc_to_f32_chw(self.h, _p(img), _p(out), H, W, Cc, C.c_float(scale)), "u8_hwc_to_f32_chw")
+        return out
+
+    def semantic_confusion(self, sem_seg: DeviceArray, gt: DeviceArray, conf: Optional[DeviceArray] = None) -> DeviceArray:
+        """sem_seg f32 [K,H,W], gt int32 [H,W] (ignore label already mapped outside [0,K)) -> int64 [(K+1),(K+1)] accumulated into conf."""
+        K = sem_seg.shape[0]
+        npix = int(np.prod(sem_seg.shape[1:]))
+        if conf is None:
+            conf = self.zeros((K + 1, K + 1), np.int64)
+        check(self.lib.odise_hip_semantic_confusion(self.h, _p(sem_seg), _p(gt), K, npix, _p(conf)), "semantic_confusion")
+        return conf
+
+    def pair_histogram(self, a: DeviceArray, b: DeviceArray, na: int, nb: int, hist: Optional[DeviceArray] = None) -> DeviceArray:
+        npix = int(np.prod(a.shape))
+        if hist is None:
+            hist = self.zeros((na, nb), np.int32)
+        check(self.lib.odise_hip_pair_histogram(self.h, _p(a), _p(b), npix, int(na), int(nb), _p(hist)), "pair_histogram")
+        return hist
+
 
 _default: Optional[Context] = None
 

@@ -73,3 +73,38 @@ def test_allgather_predictions_gloo_world2(n_images):
             seg, info = D.unpack_record(rec[img], h, w)
             assert (seg == img + 1).all()
             assert info == [{"id": 1, "isthing": bool(img % 2), "category_id": img}]
+
+
+def _conf_worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from oracle.eval_ops import semantic_confusion
+    K, n_images = 4, 5
+    b, e = D.shard_range(n_images, rank, world)
+    conf = torch.zeros((K + 1, K + 1), dtype=torch.int64)
+    for img in range(b, e):
+        rng = np.random.default_rng(img)
+        conf += torch.from_numpy(semantic_confusion(rng.standard_normal((K, 6, 7)).astype(np.float32), rng.integers(0, K, (6, 7))))
+    q.put((rank, D.sum_confusion(conf).clone()))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_confusion_matrix_allreduce_gloo_world2():
+    from oracle.eval_ops import semantic_confusion
+    world, port = 2, _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_conf_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    results = dict(q.get(timeout=120) for _ in range(world))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    ref = np.zeros((5, 5), np.int64)
+    for img in range(5):
+        rng = np.random.default_rng(img)
+        ref += semantic_confusion(rng.standard_normal((4, 6, 7)).astype(np.float32), rng.integers(0, 4, (6, 7)))
+    for r in range(world):
+        np.testing.assert_array_equal(results[r].numpy(), ref)
