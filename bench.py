@@ -38,7 +38,7 @@ def parse():
     p.add_argument("--gpus", type=int, default=1)
     p.add_argument("--steps", type=int, default=5)
     p.add_argument("--warmup", type=int, default=2)
-    p.add_argument("--images", type=int, default=4, help="images (or 512^2 crops with --stage unet) per step per GPU")
+    p.add_argument("--images", type=int, default=None, help="images per step per GPU (default 4 = configs[2]); with --stage unet: 512^2 crops (default 1 = configs[1])")
     p.add_argument("--size", type=int, default=1024)
     p.add_argument("--stage", choices=["full", "unet"], default="full")
     p.add_argument("--no-cpu-baseline", action="store_true")
@@ -138,7 +138,7 @@ def main():
 
     from odise_amd.runtime import Context
     ctx = Context(local_rank)
-    B = args.images
+    B = args.images if args.images is not None else (4 if args.stage == "full" else 1)
 
     if args.stage == "unet":
         from odise_amd.unet import HipUNet

@@ -14,11 +14,11 @@ def timeit(fn, it=6, rounds=2):
         for _ in range(it): fn()
         best = min(best, ctx.timer_stop() / it)
     return best * 1e3
-TILES = ["128x128", "64x128", "64x64", "256x320", "256x256", "256x128", "512x128"]
+TILES = ["128x128", "64x128", "64x64", "256x320", "256x256", "256x128", "512x128", "halo256", "halo128"]
 def sweep(label, fn, splits=(1, 2, 3, 4, 6, 8)):
     auto = timeit(lambda: fn(-1, 0))
     res = []
-    for t in range(7):
+    for t in range(9):
         for sp in splits:
             try:
                 res.append((timeit(lambda: fn(t, sp)), t, sp))
