@@ -1,4 +1,6 @@
 // engine.cpp — weight store, packer and launch helpers (see engine.h).
+#include <stdlib.h>
+
 #include "engine.h"
 
 #include <string.h>
@@ -163,7 +165,17 @@ int Exec::conv(const Act& x, const ConvW& w, Act& y, int stride, int pad, bool u
     d.per_image_add_ld = pia_ld;
     d.act = act;
     ms->macs += (double)x.n * oh * ow * w.cout * w.k * w.k * w.cin;
+    y.gn_blocks = 0;
+    if (y.gn_part && !getenv("ODISE_NO_GN_FUSION")) return conv_forced(ctx, &d, -1, 0, y.gn_part, &y.gn_blocks);
     return odise_hip_conv2d(ctx, &d);
+}
+
+int Exec::alloc_gn_stats(Act& a) {
+    // at most one row block per 64 output pixels (the smallest tile) -> [n][blocks][c][2] fp32
+    const int64_t blocks = ceil_div((int64_t)a.h * a.w, 64);
+    a.gn_part = (float*)alloc_bytes((size_t)a.n * blocks * a.c * 2 * sizeof(float));
+    a.gn_blocks = 0;
+    return a.gn_part ? ODISE_OK : ODISE_ERR_NOMEM;
 }
 
 int Exec::linear(const f16* x, int64_t M, const LinW& w, f16* y, int act, const f16* residual, bool geglu) {
@@ -181,6 +193,8 @@ int Exec::linear(const f16* x, int64_t M, const LinW& w, f16* y, int act, const 
 
 int Exec::group_norm(const Act& x, const NormW& w, Act& y, float eps, int act) {
     if (!y.p) ODISE_TRY(alloc(y, x.n, x.h, x.w, x.c));
+    if (x.gn_part && x.gn_blocks > 0)  // the conv that wrote x already reduced it per channel and row block
+        return group_norm_from_colpart(ctx, x.p, y.p, w.g, w.b, x.n, x.h * x.w, x.c, 32, eps, act, x.gn_part, x.gn_blocks);
     return odise_hip_group_norm(ctx, x.p, y.p, w.g, w.b, x.n, x.h * x.w, x.c, 32, eps, act);
 }
 

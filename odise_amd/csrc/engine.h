@@ -49,6 +49,11 @@ struct Arena {
 struct Act {  // NHWC fp16 activation
     f16* p = nullptr;
     int n = 0, h = 0, w = 0, c = 0;
+    // GroupNorm statistics fused into the conv that produces this tensor (gemm.hip GemmEpi::gn_stats): per-channel (sum, sumsq) of
+    // every row block, [n][gn_blocks][c][2] fp32.  gn_part = buffer (Exec::alloc_gn_stats), gn_blocks = row blocks per image once a
+    // conv has filled it (0 = not available: Exec::group_norm runs its own statistics pass)
+    float* gn_part = nullptr;
+    int gn_blocks = 0;
     int64_t pixels() const { return (int64_t)n * h * w; }
     int64_t elems() const { return pixels() * c; }
 };
@@ -104,6 +109,7 @@ struct Exec {
     odise_hip_ctx* ctx;
     ModelStore* ms;
     int alloc(Act& a, int n, int h, int w, int c);
+    int alloc_gn_stats(Act& a);  // reserve the statistics buffer of an (already shaped) activation that a conv is about to write
     void* alloc_bytes(size_t bytes);
 
     int conv(const Act& x, const ConvW& w, Act& y, int stride = 1, int pad = -1, bool upsample = false, const Act* residual = nullptr,
@@ -193,5 +199,10 @@ struct HeadOutputs {
     const float* class_logits;  // [B, Q, 2] learned (object, no-object) logits of the caption variant's class_embed, or nullptr
 };
 int head_outputs(ModelStore* ms, HeadOutputs* out);
+
+// gemm.hip / norm.hip internals used by Exec
+int conv_forced(odise_hip_ctx* ctx, const odise_conv_desc* d, int force_tile, int force_split, float* gn_stats, int* stats_blocks);
+int group_norm_from_colpart(odise_hip_ctx* ctx, const void* x, void* y, const float* gamma, const float* beta, int N, int HW, int C, int groups,
+                            float eps, int act, const float* colpart, int nblk);
 
 }  // namespace odise

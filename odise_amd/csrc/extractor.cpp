@@ -282,10 +282,15 @@ static int extractor_build(odise_hip_ctx* ctx) {
 
 // ---------------------------------------------------------------------------------------------------------------
 static int run_vae_res(Exec& ex, const VaeRes& w, const Act& x, Act& out) {
+    // both convs feed a GroupNorm (conv1 -> norm2 here, conv2 (+ skip) -> norm1 of the next block / norm_out): their epilogues
+    // reduce the statistics, saving one HBM pass over tensors of up to 1 GB
     ODISE_TRY(ex.alloc(out, x.n, x.h, x.w, w.c1.cout));
+    ODISE_TRY(ex.alloc_gn_stats(out));
     const size_t mk = ex.ms->arena.mark();
     Act t1, h, t2, sk;
     ODISE_TRY(ex.group_norm(x, w.n1, t1, 1e-6f, ODISE_ACT_SILU));
+    ODISE_TRY(ex.alloc(h, x.n, x.h, x.w, w.c1.cout));
+    ODISE_TRY(ex.alloc_gn_stats(h));
     ODISE_TRY(ex.conv(t1, w.c1, h, 1, 1));
     ODISE_TRY(ex.group_norm(h, w.n2, t2, 1e-6f, ODISE_ACT_SILU));
     const Act* resid = &x;

@@ -40,6 +40,8 @@ struct GemmEpi {
     float alpha;
     int64_t strideC, strideR;
     int fast;  // 1: every vector access of a full 8-column chunk is aligned -> epi_fast8 (set by launch_gemm)
+    float* gn_stats;  // optional [row blocks][N][2]: per-channel (sum, sum of squares) of the block's fp16 outputs (GroupNorm statistics
+                      // fused into the producing conv; set by launch_gemm only when the chosen kernel supports it)
 };
 
 struct ConvGeom {
@@ -61,6 +63,7 @@ struct GemmArgs {
     float* ws;
     const f16* zeros;  // >= 16 zero bytes (source of padded / out-of-range operand slots)
     int dbg;           // ablation switches (tools only): 1 = no operand DMA after the first tile, 2 = no fragment reads after the first
+    int stats_blocks;  // out: row blocks per image of the fused GroupNorm statistics (0 = not produced, epi.gn_stats was cleared)
 };
 
 // Workgroup barrier that only orders LDS traffic.  `__syncthreads()` also drains the vector-memory counter, i.e. it waits for
@@ -157,7 +160,7 @@ __device__ __forceinline__ void epi_store8(const GemmEpi& e, float (&v)[8], int 
 // Lean epilogue for the common case (all 8 columns in range, 16-byte aligned rows, fp16 output, no GEGLU / per-row terms):
 // every load is issued before the arithmetic, no per-element branches.  The generic epi_store8 above costs ~300 instructions per
 // 8 outputs and made the epilogue instruction-bound (61 of 89 us on a 65536x640x320 GEMM).
-__device__ __forceinline__ void epi_fast8(const GemmEpi& e, float (&v)[8], int m, int n, int z) {
+__device__ __forceinline__ void epi_fast8(const GemmEpi& e, float (&v)[8], int m, int n, int z, float* rounded = nullptr) {
     float b[8];
 #pragma unroll
     for (int i = 0; i < 8; ++i) b[i] = 0.f;
@@ -218,6 +221,10 @@ __device__ __forceinline__ void epi_fast8(const GemmEpi& e, float (&v)[8], int m
 #pragma unroll
         for (int i = 0; i < 8; ++i) t[i] = (f16)(v[i] + (float)r[i]);
         *reinterpret_cast<f16x8*>((f16*)e.C + off) = t;
+        if (rounded) {
+#pragma unroll
+            for (int i = 0; i < 8; ++i) rounded[i] = (float)t[i];
+        }
     } else {
         float* c = (float*)e.C + off;
         *reinterpret_cast<float4*>(c) = make_float4(v[0] + (float)r[0], v[1] + (float)r[1], v[2] + (float)r[2], v[3] + (float)r[3]);
@@ -257,7 +264,7 @@ constexpr int epi_wave_rows(int BM, int BN, int WAVES_M, int lds_bytes) {
 }
 constexpr int epi_lds_bytes(int BM, int BN, int WAVES_M, int WG) { return WG * (BM / WAVES_M) * (BN + 4) * 4; }
 
-template <int BM, int BN, int WAVES_M, int WAVES_N, int WG, bool HALO = false>
+template <int BM, int BN, int WAVES_M, int WAVES_N, int WG, bool HALO = false, bool STATS = false>
 __device__ __forceinline__ void gemm_epilogue(const GemmArgs& g, f32x16 (&acc)[BM / WAVES_M / 32][BN / WAVES_N / 32], char* smem, int m0, int n0,
                                               int z, int zb, bool split) {
     constexpr int NT = 64 * WAVES_M * WAVES_N;
@@ -272,6 +279,13 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& g, f32x16 (&acc)[B
     constexpr int LDS_LD = BN + 4;
     constexpr int CH = BN / 8;
     float* stg = reinterpret_cast<float*>(smem);
+    // fused GroupNorm statistics: with NT % CH == 0 a thread keeps the same 8 columns over the whole loop, so it accumulates their
+    // (sum, sum of squares) over its rows in registers; the block folds the NT / CH row lanes in LDS in a fixed order afterwards
+    // (STATS is only instantiated for the conv kernels that feed GroupNorms: the 16 accumulators cost registers in a 128-accumulator epilogue)
+    const bool stats = STATS && (NT % CH == 0) && g.epi.gn_stats != nullptr && !split;
+    float s8[8], q8[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) s8[i] = q8[i] = 0.f;
 #pragma unroll
     for (int gp = 0; gp < WAVES_M / WG; ++gp) {
         if (gp > 0) lds_barrier();  // staging reads of the previous pass are done (global stores may still fly)
@@ -319,9 +333,40 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& g, f32x16 (&acc)[B
                         for (int i = 0; i < nv; ++i) w[i] = v[i];
                     }
                 } else if (!(g.dbg & 8) || v[0] == 12345.678f) {  // dbg 8: ablate the global store + epilogue math
-                    if (g.epi.fast && n + 8 <= g.N) epi_fast8(g.epi, v, m, n, zb);
-                    else epi_store8(g.epi, v, m, n, g.N, zb);
+                    if (g.epi.fast && n + 8 <= g.N) {
+                        if (stats) {
+                            float r8[8];
+                            epi_fast8(g.epi, v, m, n, zb, r8);
+#pragma unroll
+                            for (int i = 0; i < 8; ++i) { s8[i] += r8[i]; q8[i] += r8[i] * r8[i]; }
+                        } else {
+                            epi_fast8(g.epi, v, m, n, zb);
+                        }
+                    } else {
+                        epi_store8(g.epi, v, m, n, g.N, zb);
+                    }
                 }
+            }
+        }
+    }
+    if (stats) {
+        constexpr int RL = NT / CH;  // row lanes per column chunk
+        lds_barrier();                // the last pass is done with the staging buffer
+        float* red = reinterpret_cast<float*>(smem);  // [RL][BN][2]
+        const int c8 = tid % CH, rl = tid / CH;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            red[((rl * BN) + c8 * 8 + i) * 2 + 0] = s8[i];
+            red[((rl * BN) + c8 * 8 + i) * 2 + 1] = q8[i];
+        }
+        lds_barrier();
+        for (int c = tid; c < BN; c += NT) {
+            float a = 0.f, b = 0.f;
+            for (int r = 0; r < RL; ++r) { a += red[(r * BN + c) * 2]; b += red[(r * BN + c) * 2 + 1]; }
+            if (n0 + c < g.N) {
+                float* o = g.epi.gn_stats + ((int64_t)(m0 / BM) * g.N + n0 + c) * 2;
+                o[0] = a;
+                o[1] = b;
             }
         }
     }
@@ -869,7 +914,7 @@ __global__ void __launch_bounds__(512) gemm_pp_kernel(GemmArgs g) {
     if (grp == 0) __builtin_amdgcn_s_barrier();  // re-align the two groups
     __syncthreads();
     if (g.dbg & 4) return;
-    gemm_epilogue<BM, BN, WAVES_M, WAVES_N, epi_wave_rows(BM, BN, WAVES_M, pp_lds_bytes(BM, BN, WAVES_M))>(g, acc, smem, m0, n0, z, zb, split);
+    gemm_epilogue<BM, BN, WAVES_M, WAVES_N, epi_wave_rows(BM, BN, WAVES_M, pp_lds_bytes(BM, BN, WAVES_M)), false, (CONV && BM == 512)>(g, acc, smem, m0, n0, z, zb, split);
 }
 
 
@@ -1186,7 +1231,7 @@ __global__ void __launch_bounds__(512) gemm_pp2_kernel(GemmArgs g) {
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
     __syncthreads();
     if (g.dbg & 4) return;
-    gemm_epilogue<BM, BN, WAVES_M, WAVES_N, epi_wave_rows(BM, BN, WAVES_M, pp_lds_bytes(BM, BN, WAVES_M))>(g, acc, smem, m0, n0, z, zb, split);
+    gemm_epilogue<BM, BN, WAVES_M, WAVES_N, epi_wave_rows(BM, BN, WAVES_M, pp_lds_bytes(BM, BN, WAVES_M)), false, CONV>(g, acc, smem, m0, n0, z, zb, split);
 }
 
 // ---- 3x3 / stride 1 / pad 1 convolution with the A operand reused from an LDS-resident input patch ("halo") ------------------------
@@ -1423,7 +1468,7 @@ __global__ void __launch_bounds__(512) conv3_halo_kernel(GemmArgs g) {
     if (grp == 0) __builtin_amdgcn_s_barrier();  // re-align the two groups
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
     __syncthreads();
-    gemm_epilogue<BM, BN, WAVES_M, WAVES_N, epi_wave_rows(BM, BN, WAVES_M, halo_lds_bytes(BN)), true>(g, acc, smem, m0, n0, z, zb, split);
+    gemm_epilogue<BM, BN, WAVES_M, WAVES_N, epi_wave_rows(BM, BN, WAVES_M, halo_lds_bytes(BN)), true, true>(g, acc, smem, m0, n0, z, zb, split);
 }
 
 __global__ void __launch_bounds__(256) splitk_reduce_kernel(const float* __restrict__ ws, int splitk, int M, int N, GemmEpi e) {
@@ -1677,6 +1722,19 @@ static int launch_gemm(odise_hip_ctx* ctx, GemmArgs& g, int batch, int force_til
         ok = ok && (!e.geglu || e.act == ODISE_ACT_NONE);
         g.epi.fast = ok ? 1 : 0;
     }
+    g.stats_blocks = 0;
+    if (g.epi.gn_stats) {
+        // fused GroupNorm statistics need: the lean epilogue on whole 8-column chunks, no split-K (the reduce kernel would own the
+        // epilogue), a column-chunk count that divides the thread count, and row blocks that never straddle two images
+        const int ohw = CONV ? g.cg.OH * g.cg.OW : 0;
+        // kernels instantiated with the statistics epilogue: halo tiles, pp2 conv (256x256) and the 512x128 conv tile
+        const bool pp2_used = (tile == 4) && pp_ok && ((flags & 512) || (!(flags & 1024) && CONV));
+        bool ok = CONV && g.splitk == 1 && g.epi.fast && g.N % 8 == 0 && (tile >= 7 || (tile == 6 && pp_ok && !(flags & 512)) || pp2_used);
+        if (ok && tile >= 7) g.stats_blocks = g.cg.halo_tx * g.cg.halo_ty;
+        else if (ok && ohw % kTileBM[tile] == 0) g.stats_blocks = ohw / kTileBM[tile];
+        else ok = false;
+        if (!ok) { g.epi.gn_stats = nullptr; g.stats_blocks = 0; }
+    }
     g.zeros = (const f16*)ctx->zeros;
     g.dbg = g_gemm_debug;
     // the 256-row tiles run the ping-pong pipelined kernel whenever its preconditions hold
@@ -1723,7 +1781,7 @@ static int launch_gemm(odise_hip_ctx* ctx, GemmArgs& g, int batch, int force_til
 }
 
 int gemm_forced(odise_hip_ctx* ctx, const odise_gemm_desc* d, int force_tile, int force_split);
-int conv_forced(odise_hip_ctx* ctx, const odise_conv_desc* d, int force_tile, int force_split);
+int conv_forced(odise_hip_ctx* ctx, const odise_conv_desc* d, int force_tile, int force_split, float* gn_stats = nullptr, int* stats_blocks = nullptr);
 
 int gemm_forced(odise_hip_ctx* ctx, const odise_gemm_desc* d, int force_tile, int force_split) {
     ODISE_REQUIRE(ctx && d, "gemm: null argument");
@@ -1749,11 +1807,12 @@ int gemm_forced(odise_hip_ctx* ctx, const odise_gemm_desc* d, int force_tile, in
     g.epi.ldg = d->ldg > 0 ? d->ldg : d->N;
     g.epi.act = d->act; g.epi.geglu = d->geglu; g.epi.alpha = d->alpha;
     g.epi.strideC = d->strideC; g.epi.strideR = d->strideR;
+    g.epi.gn_stats = nullptr;
     g.cg = ConvGeom{};
     return launch_gemm<false>(ctx, g, batch, force_tile, force_split);
 }
 
-int conv_forced(odise_hip_ctx* ctx, const odise_conv_desc* d, int force_tile, int force_split) {
+int conv_forced(odise_hip_ctx* ctx, const odise_conv_desc* d, int force_tile, int force_split, float* gn_stats, int* stats_blocks) {
     ODISE_REQUIRE(ctx && d, "conv2d: null argument");
     ODISE_REQUIRE(d->N >= 0 && d->H > 0 && d->W > 0 && d->Cin > 0 && d->Cout > 0, "conv2d: bad dims");
     ODISE_REQUIRE(d->Cin % 8 == 0, "conv2d: Cin=%d must be a multiple of 8 (pad the input channels)", d->Cin);
@@ -1774,6 +1833,8 @@ int conv_forced(odise_hip_ctx* ctx, const odise_conv_desc* d, int force_tile, in
     g.epi.ldg = d->per_image_add_ld > 0 ? d->per_image_add_ld : d->Cout;
     g.epi.act = d->act; g.epi.geglu = 0; g.epi.alpha = 1.0f;
     g.epi.strideC = 0; g.epi.strideR = 0;
+    g.epi.gn_stats = gn_stats;
+    if (stats_blocks) *stats_blocks = 0;
     g.cg.H = d->H; g.cg.W = d->W; g.cg.Cin = d->Cin; g.cg.KH = d->KH; g.cg.KW = d->KW;
     g.cg.stride = d->stride; g.cg.pad_t = d->pad_t; g.cg.pad_l = d->pad_l; g.cg.OH = d->OH; g.cg.OW = d->OW;
     g.cg.ups = d->upsample2x;
@@ -1785,9 +1846,11 @@ int conv_forced(odise_hip_ctx* ctx, const odise_conv_desc* d, int force_tile, in
     if (d->KH == 1 && d->KW == 1 && d->stride == 1 && d->pad_t == 0 && d->pad_l == 0 && !d->upsample2x && d->OH == d->H &&
         d->OW == d->W) {
         g.lda = d->Cin;
-        return launch_gemm<false>(ctx, g, 1, force_tile, force_split);
+        return launch_gemm<false>(ctx, g, 1, force_tile, force_split);  // (statistics fusion is declined there: *stats_blocks stays 0)
     }
-    return launch_gemm<true>(ctx, g, 1, force_tile, force_split);
+    const int rc = launch_gemm<true>(ctx, g, 1, force_tile, force_split);
+    if (stats_blocks) *stats_blocks = (rc == ODISE_OK) ? g.stats_blocks : 0;
+    return rc;
 }
 
 }  // namespace odise

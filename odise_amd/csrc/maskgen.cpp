@@ -153,6 +153,7 @@ static int maskgen_build_head(odise_hip_ctx* ctx) {
     g->C = g->in_proj[0].cout;
     const int C = g->C;
     ODISE_TRY(pk.vec_f32("transformer.level_embed", &g->enc_level_embed, 3 * C));
+    g->enc_pos_key = 0;  // PE + level_embed table is derived from these weights: a rebuilt head must not reuse the previous model's
     g->enc_layers.clear();
     for (int i = 0;; ++i) {
         const std::string k = "transformer.encoder.layers." + std::to_string(i);

@@ -115,6 +115,44 @@ __global__ void __launch_bounds__(256) gn_finalize_kernel(const float* __restric
     }
 }
 
+// grid (N); block 256: statistics fused into the producing conv's epilogue arrive as per-channel (sum, sumsq) of every row block:
+// colpart [N][nblk][C][2].  Lane (g = tid % G, sub = tid / G) folds blocks sub, sub + nsub, ... over its group's channels in fp64,
+// then a fixed-order fold over sub -> stats[n][g] = (mean, rstd)
+__global__ void __launch_bounds__(256) gn_finalize_cols_kernel(const float* __restrict__ colpart, float* __restrict__ stats, int HW, int C, int G,
+                                                              int nblk, float eps) {
+    __shared__ double red[2 * 256];
+    const int n = blockIdx.x, tid = threadIdx.x;
+    const int cpg = C / G;
+    const int nsub = 256 / G;
+    const int gI = tid % G, sub = tid / G;
+    double s = 0.0, q = 0.0;
+    if (sub < nsub) {
+        for (int b = sub; b < nblk; b += nsub) {
+            const float* o = colpart + (((int64_t)n * nblk + b) * C + (int64_t)gI * cpg) * 2;
+            for (int c = 0; c < cpg; ++c) {
+                s += (double)o[2 * c];
+                q += (double)o[2 * c + 1];
+            }
+        }
+    }
+    red[2 * tid] = s;
+    red[2 * tid + 1] = q;
+    __syncthreads();
+    if (tid < G) {
+        s = q = 0.0;
+        for (int u = 0; u < nsub; ++u) {
+            s += red[2 * (u * G + tid)];
+            q += red[2 * (u * G + tid) + 1];
+        }
+        const double cnt = (double)HW * cpg;
+        const double mu = s / cnt;
+        double var = q / cnt - mu * mu;
+        if (var < 0.0) var = 0.0;
+        stats[((int64_t)n * G + tid) * 2] = (float)mu;
+        stats[((int64_t)n * G + tid) * 2 + 1] = (float)(1.0 / sqrt(var + (double)eps));
+    }
+}
+
 // grid (blocks_per_image, N); block 256; every thread normalises up to four 16-byte vectors (all loads issued first)
 __global__ void __launch_bounds__(256) gn_apply_kernel(const f16* __restrict__ x, f16* __restrict__ y,
                                                       const float* __restrict__ stats, const float* __restrict__ gamma,
@@ -310,6 +348,26 @@ extern "C" int odise_hip_group_norm_ex(odise_hip_ctx* ctx, const void* x, void* 
     ODISE_CHECK_HIP(hipGetLastError());
     return ODISE_OK;
 }
+
+// GroupNorm whose statistics were produced by the conv that wrote x (gemm.hip: GemmEpi::gn_stats): finalize + apply only
+namespace odise {
+int group_norm_from_colpart(odise_hip_ctx* ctx, const void* x, void* y, const float* gamma, const float* beta, int N, int HW, int C, int groups,
+                            float eps, int act, const float* colpart, int nblk) {
+    ODISE_REQUIRE(ctx && x && y && colpart && nblk > 0, "group_norm: null argument");
+    ODISE_REQUIRE(C % groups == 0 && C % 8 == 0 && C <= GN_MAX_C && groups <= 256, "group_norm: bad channel / group count");
+    ODISE_REQUIRE((int64_t)HW * (C / 8) < (1ll << 31) - (1 << 24), "group_norm: image too large");
+    ODISE_REQUIRE((size_t)N * groups * 2 * sizeof(float) <= ctx->ws_bytes, "group_norm: workspace too small");
+    float* stats = (float*)ctx->ws;
+    hipLaunchKernelGGL(gn_finalize_cols_kernel, dim3(N), dim3(256), 0, ctx->stream, colpart, stats, HW, C, groups, nblk, eps);
+    ODISE_CHECK_HIP(hipGetLastError());
+    const int64_t total = (int64_t)HW * (C / 8);
+    const int bpi = (int)std::max<int64_t>(1, ceil_div(total, 256 * 4));
+    hipLaunchKernelGGL(gn_apply_kernel, dim3(bpi, N), dim3(256), 2 * (size_t)C * sizeof(float), ctx->stream, (const f16*)x, (f16*)y, stats, gamma,
+                       beta, HW, C, groups, act, (const f16*)nullptr, (const f16*)nullptr);
+    ODISE_CHECK_HIP(hipGetLastError());
+    return ODISE_OK;
+}
+}  // namespace odise
 
 extern "C" int odise_hip_layer_norm(odise_hip_ctx* ctx, const void* x, void* y, const float* gamma, const float* beta,
                                     int rows, int C, float eps) {
