@@ -53,13 +53,15 @@ def _threads():
     return max(1, min(avail, 16))  # torch's intra-op pool stops scaling (and thrashes) far below a 256-thread host
 
 
-def cpu_baseline_full(ext):
+def cpu_baseline_full():
     """Oracle restatement (kind='port') on the host cores.  Bounded sample: the 4 crops of ONE 1024x1024 image through the feature
     extractor (CLIP + VAE encoder + UNet + truncated VAE decoder = 2.86 of the 3.13 TFLOP a crop costs end to end, i.e. 92 % of an
     image's work), one warm-up pass and one timed pass (~10-20 s of CPU work); images/s = 1 / pass time, an upper bound of the CPU rate."""
     import torch
+    from oracle.ldm_extractor import ImplicitCaptionerExtractor
     cores = _threads()
     torch.set_num_threads(cores)
+    ext = ImplicitCaptionerExtractor()
     img = torch.rand(4, 3, 512, 512, generator=torch.Generator().manual_seed(0))
     with torch.no_grad():
         ext(img[:1])  # warm-up (allocator, thread pool)
@@ -71,9 +73,10 @@ def cpu_baseline_full(ext):
                       "(92% of an image's work), 1 timed pass after a 1-crop warm-up; heads and post-processing excluded"}
 
 
-def cpu_baseline_unet(model):
+def cpu_baseline_unet():
     import torch
-    from oracle.sd_unet import config2_inputs, unet_forward
+    from oracle.sd_unet import UNetModel, config2_inputs, init_synthetic_, unet_forward
+    model = init_synthetic_(UNetModel(width_div=1), seed=1234).eval()
     cores = _threads()
     torch.set_num_threads(cores)
     x, context, cond_emb = config2_inputs(1, 64)
@@ -140,46 +143,33 @@ def main():
     ctx = Context(local_rank)
     B = args.images if args.images is not None else (4 if args.stage == "full" else 1)
 
+    # Weights: random tensors of the real architecture's shapes (odise_amd/synthetic.py; no checkpoints, no network).  The oracle is
+    # imported only by the cpu_baseline leg below.
+    from odise_amd.synthetic import synthetic_state, synthetic_vocabulary
     if args.stage == "unet":
         from odise_amd.unet import HipUNet
-        from oracle.sd_unet import UNetModel, config2_inputs, init_synthetic_
-        model = init_synthetic_(UNetModel(width_div=1), seed=1234).eval()
-        hip = HipUNet(ctx, model.state_dict(), use_graph=True)
-        x, context, cond_emb = config2_inputs(B, 64)
-        dx, dc, de = ctx.to_device(x.numpy()), ctx.to_device(context.numpy()), ctx.to_device(cond_emb.numpy())
+        hip = HipUNet(ctx, synthetic_state(["model.diffusion_model."], strip="model.diffusion_model."), use_graph=True)
+        r = np.random.default_rng(1)
+        x = r.standard_normal((B, 4, 64, 64), dtype=np.float32)                                   # x_t
+        context = (r.standard_normal((1, 77, 768), dtype=np.float32) + 0.1 * r.standard_normal((B, 77, 768), dtype=np.float32))
+        cond_emb = 0.02 * r.standard_normal((B, 1280), dtype=np.float32)                          # implicit-captioner time-embedding term
+        dx, dc, de = ctx.to_device(x), ctx.to_device(context.astype(np.float32)), ctx.to_device(cond_emb.astype(np.float32))
         step = lambda: hip.run_nhwc(dx, dc, de, 0)
         flops_per_unit, unit, metric = UNET_FLOPS_LIVE, "crops/s", "SD-UNet single-step feature extraction crops/sec (stage of panoptic-inference images/sec @1024x1024; UNet MFMA %peak)"
         workload = (f"BASELINE configs[1]: SD-UNet single-step feature extraction, bs={B} x 512x512 crop (64x64 latent) per GPU, t=0, "
-                    "taps u2/u5/u8/u11; synthetic SD-v1-shaped weights (859.5M params, seed 1234); hipGraph replay")
-        baseline = (lambda: cpu_baseline_unet(model))
+                    "taps u2/u5/u8/u11; synthetic SD-v1-shaped weights (859.5M params); hipGraph replay")
+        baseline = cpu_baseline_unet
         gather = None
     else:
         from odise_amd import distributed as D
         from odise_amd.pipeline import HipCategoryODISE
-        from oracle import odise_model as om
-        from oracle.backbone import FeatureExtractorBackbone
-        from oracle.ldm_extractor import ImplicitCaptionerExtractor
-        from oracle.m2f import SemSegHead, init_synthetic_
         S = args.size
         K, K_TOT = 133, 254   # COCO panoptic: 133 classes, 254 prompt-engineered strings
-        ext = ImplicitCaptionerExtractor()
-        bb = FeatureExtractorBackbone(ext, [512, 512, 2560, 1920, 960, 640, 512, 512])
-        head = init_synthetic_(SemSegHead(num_classes=K))
-        rng = np.random.default_rng(7)
-        sizes = np.ones(K, np.int64)
-        for i in rng.integers(0, K, size=K_TOT - K):   # 254 strings over 133 synonym groups
-            sizes[i] += 1
-        heads = om.OpenVocabHeads(ext.clip, sizes.tolist(), projection_dim=256)
-        state = ext.export_state()
-        state.update({"backbone.feature_projections." + k: v for k, v in bb.feature_projections.state_dict().items()})
-        state.update({"sem_seg_head." + k: v for k, v in head.state_dict().items()})
-        state["category_head.text_proj.weight"] = heads.text_proj.weight.detach()
-        state["category_head.text_proj.bias"] = heads.text_proj.bias.detach()
-        state["category_head.null_embed"] = heads.null_embed.detach()
+        state = synthetic_state()
         hip = HipCategoryODISE(ctx, state, overlap_threshold=0.8)
-        hip.set_vocabulary(heads.text_embed.numpy(), heads.clip_text_embed.numpy(), sizes.tolist(), heads.category_overlapping_mask.numpy(),
-                           set(range(80)), heads.alpha, heads.beta)
-        del state, bb, head
+        cat, clp, sizes, overlap = synthetic_vocabulary(K, K_TOT, 768)
+        hip.set_vocabulary(cat, clp, sizes, overlap, set(range(80)), 0.3, 0.7)
+        del state
         img = np.random.default_rng(rank).random((B, 3, S, S), dtype=np.float32)  # images shard across ranks: each rank has its own
         d_img = ctx.to_device(img)
         out_sizes = [(S, S)] * B
@@ -206,7 +196,7 @@ def main():
         workload = (f"BASELINE configs[2]: full ODISE(label) panoptic inference (CategoryODISE eval forward: 4 crops/image through CLIP+VAE+UNet, "
                     f"projections, MSDeformAttn pixel decoder, 9-layer masked decoder, MaskCLIP, semantic+panoptic+instance post-processing), "
                     f"bs={B} x {S}x{S} per GPU, vocabulary {K} classes/{K_TOT} strings; synthetic weights of the real shapes, random text bank")
-        baseline = (lambda: cpu_baseline_full(ext))
+        baseline = cpu_baseline_full
         gather = True
 
     def barrier():
