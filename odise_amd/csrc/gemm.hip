@@ -612,8 +612,9 @@ __device__ __forceinline__ void wait_vmcnt() {
 // DMA groups of the tile sequence (per thread: 4 A loads, TN B loads; B piece j = the rows of N-tile j of both wave columns):
 //   NP = 2: (t,0) issues B0..B3 of tile t+1, (t,1) issues A0..A3 of tile t+2
 //   NP = 3: (t,0) issues B2,B3,B4 of tile t+1, (t,1) issues A0,A1,A2 of tile t+2, (t,2) issues A3,B0,B1 of tile t+2
-template <int BM, int BN, int WAVES_N, int PT, bool CONV, int V = 0>  // V: tuning variants (bit 0: DMA issued before the fragment reads, bit 1: no s_setprio)
+template <int BM, int BN, int WAVES_N, int PT, bool CONV>
 __global__ void __launch_bounds__(512) gemm_pp_kernel(GemmArgs g) {
+    // (measured and rejected: issuing the DMA before the fragment reads -17 %, dropping s_setprio +-1 %)
     constexpr int BK = 64, WAVES_M = 8 / WAVES_N;
     constexpr int WTN = BN / WAVES_N;
     constexpr int TM = 2, TN = WTN / 32;
@@ -835,7 +836,7 @@ __global__ void __launch_bounds__(512) gemm_pp_kernel(GemmArgs g) {
                         for (int s = 0; s < 4; ++s) bf[jj][s] = *reinterpret_cast<const f16x8*>(fb + koff[s] + (j0 + jj) * 4096);
                     }
             };
-            if (!(V & 1)) read_frags();
+            read_frags();
             // loads through index `need` (counted from A0 of tile kt) must have landed before the next phase reads
             const int need = (p + 1 < NP) ? loads_for_tiles((p + 2) * PT < TN ? (p + 2) * PT : TN) : NL + loads_for_tiles(PT);
             if (p == 0) {
@@ -884,16 +885,12 @@ __global__ void __launch_bounds__(512) gemm_pp_kernel(GemmArgs g) {
                     wait_vmcnt<0>();
                 }
             }
-            if (V & 1) {
-                __builtin_amdgcn_sched_barrier(0);
-                read_frags();
-            }
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             __builtin_amdgcn_sched_barrier(0);
             __builtin_amdgcn_s_barrier();
             __builtin_amdgcn_sched_barrier(0);
             // -------- MFMA segment
-            if (!(V & 2)) __builtin_amdgcn_s_setprio(1);
+            __builtin_amdgcn_s_setprio(1);
 #pragma unroll
             for (int s = 0; s < 4; ++s)
 #pragma unroll
@@ -903,7 +900,7 @@ __global__ void __launch_bounds__(512) gemm_pp_kernel(GemmArgs g) {
                         for (int i = 0; i < TM; ++i)
                             acc[i][j0 + jj] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[i][s], bf[jj][s], acc[i][j0 + jj], 0, 0, 0);
                     }
-            if (!(V & 2)) __builtin_amdgcn_s_setprio(0);
+            __builtin_amdgcn_s_setprio(0);
             __builtin_amdgcn_sched_barrier(0);
             __builtin_amdgcn_s_barrier();
             __builtin_amdgcn_sched_barrier(0);
@@ -1525,11 +1522,11 @@ static int launch_gemm_t(odise_hip_ctx* ctx, GemmArgs& g, int batch) {
     return ODISE_OK;
 }
 
-template <int BM, int BN, int WAVES_N, int PT, bool CONV, int V = 0>
+template <int BM, int BN, int WAVES_N, int PT, bool CONV>
 static int launch_gemm_pp(odise_hip_ctx* ctx, GemmArgs& g, int batch) {
     constexpr int lds = pp_lds_bytes(BM, BN, 8 / WAVES_N);
     static_assert(epi_lds_bytes(BM, BN, 8 / WAVES_N, epi_wave_rows(BM, BN, 8 / WAVES_N, lds)) <= lds, "epilogue staging exceeds the LDS request");
-    auto kern = gemm_pp_kernel<BM, BN, WAVES_N, PT, CONV, V>;
+    auto kern = gemm_pp_kernel<BM, BN, WAVES_N, PT, CONV>;
     static bool attr_set = false;  // per instantiation
     if (!attr_set) {
         ODISE_CHECK_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
@@ -1756,13 +1753,6 @@ static int launch_gemm(odise_hip_ctx* ctx, GemmArgs& g, int batch, int force_til
         if (tile == 6) return launch_gemm_pp<512, 128, 1, 2, CONV>(ctx, g, batch);
         if (tile == 3) return launch_gemm_pp<256, 320, 2, 1, CONV>(ctx, g, batch);
         if (flags & 4) return launch_gemm_pp<256, 256, 2, 1, CONV>(ctx, g, batch);
-        if ((flags >> 7) & 3) {  // tuning variants of the 256x256 tile (tools/pp_variants.py)
-            switch ((flags >> 7) & 3) {
-                case 1: return launch_gemm_pp<256, 256, 2, 2, CONV, 1>(ctx, g, batch);
-                case 2: return launch_gemm_pp<256, 256, 2, 2, CONV, 2>(ctx, g, batch);
-                default: return launch_gemm_pp<256, 256, 2, 2, CONV, 3>(ctx, g, batch);
-            }
-        }
         return launch_gemm_pp<256, 256, 2, 2, CONV>(ctx, g, batch);
     }
     if (no_interleave) {
