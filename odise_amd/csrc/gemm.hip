@@ -1231,6 +1231,10 @@ __global__ void __launch_bounds__(512) gemm_pp2_kernel(GemmArgs g) {
     gemm_epilogue<BM, BN, WAVES_M, WAVES_N, epi_wave_rows(BM, BN, WAVES_M, pp_lds_bytes(BM, BN, WAVES_M)), false, CONV>(g, acc, smem, m0, n0, z, zb, split);
 }
 
+// (A third structure - every wave free-running through the four k-steps with register double-buffered fragments and ONE barrier per
+// K-tile, i.e. the classic software-pipelined GEMM - was built and measured too: bit-identical results, 5-12 % SLOWER than the
+// ping-pong kernels on the large shapes (898 vs 1012 TFLOP/s at 65536x512x4096), so the barrier count is not what bounds them.)
+
 // ---- 3x3 / stride 1 / pad 1 convolution with the A operand reused from an LDS-resident input patch ("halo") ------------------------
 // The im2col view re-fetches every input pixel 9 times (once per tap) through the LDS-DMA path, which is what bounds the ping-pong
 // kernel on the 3x3 layers (ablation: 23 % of the loop is operand delivery).  Here a block owns a 16x16 OUTPUT patch of one image:

@@ -40,7 +40,7 @@ def bench(variants, fn, flop, label, it=10, rounds=3):
 
 
 NO_PP, PT1, PP2, NO_HALO = 2 << 4, 4 << 4, 512 << 4, 64 << 4
-variants = [("pp", NO_HALO), ("pp2", PP2 | NO_HALO)]
+variants = [("pp", NO_HALO | (1024 << 4)), ("pp2", PP2 | NO_HALO)]
 bn = 320 if tile == 3 else 128 if tile == 6 else 256
 for (M, N, K) in [(65536, 2 * bn, 4096), (65536, 2 * bn, 320), (65536, 2 * bn, 640), (65536, 4 * bn, 1024), (4096, 4 * bn, 4096), (16384, bn, 8192), (1000, bn + 8, 192)]:
     A, W, O = rand((M, K)), rand((N, K), K ** -0.5), ctx.empty((M, N), np.float16)
