@@ -126,6 +126,9 @@ class HipCategoryODISE(HipODISE):
         self.test_topk_per_image, self.size_divisibility = test_topk_per_image, size_divisibility
         self.num_classes = 0
         self.thing_ids = set()
+        self.metadata, self.test_labels = None, None
+        self._alpha, self._beta = 0.3, 0.7
+        self._banks, self._vocab_cache = None, {}
         self._pool = {}
 
     def set_vocabulary(self, cat_text, clip_text, group_sizes, overlap, thing_ids, alpha=0.3, beta=0.7):
@@ -139,6 +142,63 @@ class HipCategoryODISE(HipODISE):
                                                      C.c_float(alpha), C.c_float(beta)), "set_vocabulary")
         self.num_classes = len(gs)
         self.thing_ids = set(int(t) for t in thing_ids)
+        self._alpha, self._beta = float(alpha), float(beta)
+        self._banks, self.test_labels = (cat, clp, gs, ov), None           # banks handed over directly: no label strings known
+
+    # ---- open-vocabulary state (OpenPanopticInference's protocol, odise/modeling/wrapper/pano_wrapper.py:20-70) ------------------
+    def attach_text(self, tokenizer, text_encoder, train_labels=None, clip_text_encoder=None):
+        """Give the model what `load_open_state_dict` needs to turn label lists into text banks on the device
+        (odise_amd.tokenizer.SimpleTokenizer, odise_amd.text.HipTextEncoder; `train_labels` decide the seen/unseen ensemble weights)."""
+        self._tokenizer, self._text_encoder, self._clip_text_encoder = tokenizer, text_encoder, clip_text_encoder
+        self._train_labels = train_labels
+        self._vocab_cache = {}
+
+    def set_labels(self, labels, thing_ids=None, metadata=None):
+        """Vocabulary from label strings (needs `attach_text`): what building the reference model with `labels=` / `metadata=` does."""
+        st = {"category_head.test_labels": labels}
+        if metadata is not None:
+            st["metadata"] = metadata
+        if thing_ids is not None:
+            st["thing_ids"] = thing_ids
+        self.load_open_state_dict(st)
+
+    def open_state_dict(self) -> dict:
+        """The inference-time switches the reference collects from its module tree (odise.py:1249-1262, 1440-1466,
+        maskformer_model.py test-time attributes): a flat dict with the reference's key suffixes."""
+        return {"category_head.test_labels": self.test_labels, "clip_head.test_labels": self.test_labels, "category_head.text_banks": self._banks,
+                "metadata": self.metadata, "thing_ids": set(self.thing_ids), "sem_seg_head.num_classes": self.num_classes, "semantic_on": self.semantic_on,
+                "instance_on": self.instance_on, "panoptic_on": self.panoptic_on, "test_topk_per_image": self.test_topk_per_image}
+
+    def load_open_state_dict(self, state: dict) -> None:
+        labels, banks = None, None
+        for k, v in state.items():
+            if k.endswith("test_labels"):
+                labels = v
+            elif k.endswith("text_banks"):
+                banks = v
+            elif k.endswith("thing_ids"):
+                self.thing_ids = set(v)
+            elif k.endswith("metadata"):
+                self.metadata = v
+            elif k.endswith(("semantic_on", "instance_on", "panoptic_on", "test_topk_per_image")):
+                setattr(self, k.rsplit(".", 1)[-1], v)
+        if state.get("metadata") is not None:
+            md = self.metadata
+            ids = md["thing_ids"] if isinstance(md, dict) else (getattr(md, "thing_ids", None) or
+                                                                  list(getattr(md, "thing_dataset_id_to_contiguous_id", {}).values()))
+            self.thing_ids = set(int(i) for i in ids)
+        if labels is None and banks is not None:
+            if banks is not self._banks:                                   # restore banks that were set without label strings
+                self.set_vocabulary(*banks, self.thing_ids, self._alpha, self._beta)
+        elif labels is not None and [list(l) for l in labels] != self.test_labels:
+            from .checkpoint import build_vocabulary
+            key = tuple(tuple(l) for l in labels)
+            if key not in self._vocab_cache:                               # the reference caches text embeddings per label tuple (odise.py:1281-1288)
+                self._vocab_cache[key] = build_vocabulary(labels, self._tokenizer, self._text_encoder, train_labels=self._train_labels,
+                                                          clip_text_encoder=self._clip_text_encoder)
+            cat, clp, sizes, overlap = self._vocab_cache[key]
+            self.set_vocabulary(cat, clp, sizes, overlap, self.thing_ids, self._alpha, self._beta)
+            self.test_labels = [list(l) for l in labels]
 
     def classify_device(self, image01: DeviceArray, want_clip_embed=False):
         B, _, H, W = image01.shape
@@ -310,3 +370,42 @@ class HipCaptionODISE(HipCategoryODISE):
     `sem_seg_head.predictor.class_embed.*` in the state; `set_vocabulary(cat_text=<word bank>, ...)` is unchanged."""
 
     HEAD_KEYS = ("word_head.text_proj.weight", "word_head.text_proj.bias")
+
+
+class HipOpenPanopticInference:
+    """OpenPanopticInference (odise/modeling/wrapper/pano_wrapper.py:13-70): run the wrapped model with another vocabulary / metadata /
+    task switches and restore its own afterwards.  `model` must have been given a tokenizer and a text encoder (`attach_text`)."""
+
+    def __init__(self, model: HipCategoryODISE, labels, metadata=None, semantic_on=True, instance_on=True, panoptic_on=True,
+                 test_topk_per_image=100):
+        self.model, self.labels, self.metadata = model, labels, metadata
+        self.open_state_dict = {}
+        for k in model.open_state_dict():
+            if k.endswith("test_labels"):
+                self.open_state_dict[k] = labels
+            elif k.endswith("metadata"):
+                self.open_state_dict[k] = metadata
+            elif k.endswith("num_classes"):
+                self.open_state_dict[k] = len(labels)
+            elif k.endswith("semantic_on"):
+                self.open_state_dict[k] = semantic_on
+            elif k.endswith("instance_on"):
+                self.open_state_dict[k] = instance_on
+            elif k.endswith("panoptic_on"):
+                self.open_state_dict[k] = panoptic_on
+            elif k.endswith("test_topk_per_image"):
+                self.open_state_dict[k] = test_topk_per_image
+
+    @property
+    def num_classes(self):
+        return len(self.labels)
+
+    def forward(self, batched_inputs):
+        saved = self.model.open_state_dict()
+        self.model.load_open_state_dict(self.open_state_dict)
+        try:
+            return self.model.forward(batched_inputs)
+        finally:
+            self.model.load_open_state_dict(saved)
+
+    __call__ = forward

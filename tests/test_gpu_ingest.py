@@ -8,7 +8,7 @@ import pytest
 import torch
 
 from odise_amd import checkpoint as ck
-from odise_amd.pipeline import HipCategoryODISE
+from odise_amd.pipeline import HipCategoryODISE, HipOpenPanopticInference
 from odise_amd.text import HipTextEncoder
 from odise_amd.tokenizer import SimpleTokenizer
 from oracle import odise_model as om
@@ -105,3 +105,20 @@ def test_ingested_checkpoints_and_device_vocabulary_match_oracle(ctx):
     assert info == info_ref and agree > 0.995
     sem_ref = ref["sem_seg"].numpy()
     assert np.abs(got["sem_seg"] - sem_ref).max() / np.abs(sem_ref).max() < 2e-2
+    # ---- OpenPanopticInference (pano_wrapper.py:20-70): another label set for one call, the model's own vocabulary afterwards
+    train = [["sky"], ["car", "truck"], ["dog"]]
+    hip.attach_text(tok, enc, train_labels=train)
+    labels2, things2 = LABELS[:5], {0, 3}
+    wrap = HipOpenPanopticInference(hip, labels2, metadata={"thing_ids": sorted(things2)}, instance_on=False)
+    got2 = wrap([{"image": img}])[0]
+    assert "instances" not in got2 and got2["sem_seg"].shape[0] == len(labels2)
+    after = hip.forward([{"image": img}])[0]
+    np.testing.assert_array_equal(after["panoptic_seg"][0], pan)
+    np.testing.assert_array_equal(after["sem_seg"], got["sem_seg"])
+    assert "instances" in after
+    cat2, clp2, sizes2, ov2 = ck.build_vocabulary(labels2, tok, enc, train_labels=train)
+    hip.set_vocabulary(cat2, clp2, sizes2, ov2, things2, heads.alpha, heads.beta)
+    hip.instance_on = False
+    exp2 = hip.forward([{"image": img}])[0]
+    np.testing.assert_array_equal(got2["panoptic_seg"][0], exp2["panoptic_seg"][0])
+    np.testing.assert_array_equal(got2["sem_seg"], exp2["sem_seg"])
