@@ -39,7 +39,8 @@ enum {
     ODISE_ERR_ARG = -1,      /* bad argument (shape/alignment/dtype) */
     ODISE_ERR_HIP = -2,      /* a HIP runtime call failed           */
     ODISE_ERR_STATE = -3,    /* missing weights / wrong call order  */
-    ODISE_ERR_NOMEM = -4     /* workspace / arena exhausted         */
+    ODISE_ERR_NOMEM = -4,    /* workspace / arena exhausted         */
+    ODISE_ERR_UNSUPPORTED = -5 /* a valid input this library does not handle (e.g. progressive JPEG) */
 };
 
 /* ---- context / plumbing ------------------------------------------------------------ */
@@ -240,11 +241,38 @@ int odise_hip_instance_masks(odise_hip_ctx* ctx, int b, const int* idx, int n, i
 int odise_hip_resize_bilinear_u8(odise_hip_ctx* ctx, const void* src, int H, int W, int C, void* dst, int OH, int OW);
 /* dst fp32 [C,H,W] = scale * src uint8 [H,W,C] */
 int odise_hip_u8_hwc_to_f32_chw(odise_hip_ctx* ctx, const void* src, float* dst, int H, int W, int C, float scale);
+/* dst fp32 [C,Hp,Wp] = the same, zero padded at the bottom / right (detectron2 ImageList.from_tensors(images, size_divisibility),
+ * odise.py:240) */
+int odise_hip_u8_hwc_to_f32_chw_padded(odise_hip_ctx* ctx, const void* src, float* dst, int H, int W, int C, int Hp, int Wp, float scale);
 /* conf int64 [(K+1)*(K+1)] += count of (argmax_k sem_seg[k,p], gt[p]); gt outside [0,K] (ignore label) counts in column K.
  * The caller zeroes conf before the first image and sums it across ranks (all-gather / all-reduce of (K+1)^2 int64). */
 int odise_hip_semantic_confusion(odise_hip_ctx* ctx, const float* sem_seg, const int* gt, int K, int npix, int64_t* conf);
 /* hist int32 [na*nb] += count of (a[p], b[p]) pairs with 0 <= a < na, 0 <= b < nb (segment-index co-occurrence of PQ matching) */
 int odise_hip_pair_histogram(odise_hip_ctx* ctx, const int* a, const int* b, int npix, int na, int nb, int* hist);
+
+/* ---- JPEG input -------------------------------------------------------------------------------------------
+ * Replaces detectron2 `read_image(file, "RGB")` = PIL.Image.open -> EXIF transpose -> convert("RGB") of the DatasetMapper
+ * (configs/common/data/pano_open_d2_eval.py:74-107; demo/demo.py:399) for baseline JPEG files, bit-identical to Pillow /
+ * libjpeg-turbo defaults (islow IDCT, fancy upsampling).  Huffman decoding runs on the host, everything per-sample on the device.
+ * 8-bit SOF0/SOF1, one interleaved scan, grey or YCbCr with luma sampling 1x1 / 2x1 / 2x2; anything else: ODISE_ERR_UNSUPPORTED. */
+typedef struct odise_jpeg_info {
+    int32_t width, height;        /* coded size (before the EXIF orientation is applied) */
+    int32_t components;           /* 1 (grey) or 3 (YCbCr) */
+    int32_t h_samp, v_samp;       /* luma sampling factors */
+    int32_t orientation;          /* EXIF tag 0x0112, 1..8 (1 when absent) */
+    int32_t restart_interval;     /* MCUs, 0 = none */
+    int32_t blocks_x[3], blocks_y[3]; /* 8x8-block grid of every component (padded to whole MCUs) */
+    int64_t coef_count;           /* int16 coefficients of all components */
+} odise_jpeg_info;
+/* host only: parse the headers of a JPEG byte stream */
+int odise_hip_jpeg_info(const void* data, int64_t len, odise_jpeg_info* info);
+/* host only: entropy-decode into coefs int16 [coef_count] (component after component, [blocks_y][blocks_x][64], natural order,
+ * not dequantised); qtables (optional) uint16 [components*64] receives every component's quantisation table in natural order */
+int odise_hip_jpeg_entropy_decode(const void* data, int64_t len, int16_t* coefs, int64_t capacity, uint16_t* qtables);
+/* data: host bytes of the file.  dst_rgb: device uint8 [out_h,out_w,3] (capacity in bytes); the decoded size is returned in
+ * out_h / out_w (height and width swap for EXIF orientations 5..8 when apply_orientation != 0).  Asynchronous on the context's stream. */
+int odise_hip_jpeg_decode(odise_hip_ctx* ctx, const void* data, int64_t len, void* dst_rgb, int64_t dst_capacity, int apply_orientation,
+                          int* out_h, int* out_w);
 
 #ifdef __cplusplus
 }

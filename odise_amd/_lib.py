@@ -60,6 +60,17 @@ class AttnDesc(C.Structure):
     ]
 
 
+class JpegInfo(C.Structure):
+    """odise_jpeg_info (include/odise_hip.h)."""
+    _fields_ = [("width", C.c_int32), ("height", C.c_int32), ("components", C.c_int32), ("h_samp", C.c_int32), ("v_samp", C.c_int32),
+                ("orientation", C.c_int32), ("restart_interval", C.c_int32), ("blocks_x", C.c_int32 * 3), ("blocks_y", C.c_int32 * 3),
+                ("coef_count", C.c_int64)]
+
+
+class UnsupportedInput(RuntimeError):
+    """ODISE_ERR_UNSUPPORTED: a valid input the library does not handle (e.g. a progressive JPEG); nothing was computed."""
+
+
 def header_symbols() -> list[str]:
     """Every function name declared in include/odise_hip.h."""
     with open(HEADER_PATH) as f:
@@ -95,4 +106,6 @@ def load() -> C.CDLL:
 def check(rc: int, what: str = "") -> None:
     if rc != 0:
         msg = load().odise_hip_last_error().decode("utf-8", "replace")
+        if rc == -5:
+            raise UnsupportedInput(f"libodise_hip {what}: {msg}")
         raise RuntimeError(f"libodise_hip {what} failed (code {rc}): {msg}")

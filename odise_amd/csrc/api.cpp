@@ -54,6 +54,7 @@ extern "C" int odise_hip_destroy(odise_hip_ctx* ctx) {
     hipSetDevice(ctx->device);
     hipStreamSynchronize(ctx->stream);
     models_destroy(ctx);
+    odise::jpeg_release(ctx);
     if (ctx->ws) hipFree(ctx->ws);
     if (ctx->zeros) hipFree(ctx->zeros);
     if (ctx->ev0) hipEventDestroy(ctx->ev0);

@@ -63,4 +63,14 @@ struct odise_hip_ctx {
     void* zeros = nullptr;  // 256 zero bytes
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     void* models = nullptr;  // odise::ModelStore* (weights + unet), see unet.cpp
+    // jpeg.hip: pinned host staging for entropy-decoded coefficients, device coefficients + planes, upload-complete event
+    void* jpeg_host = nullptr;
+    size_t jpeg_host_bytes = 0;
+    void* jpeg_dev = nullptr;
+    size_t jpeg_dev_bytes = 0;
+    hipEvent_t jpeg_ev = nullptr;
 };
+
+namespace odise {
+void jpeg_release(odise_hip_ctx* ctx);
+}

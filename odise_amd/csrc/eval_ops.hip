@@ -109,6 +109,18 @@ __global__ void __launch_bounds__(256) u8_hwc_to_f32_chw_kernel(const uint8_t* _
     dst[idx] = (float)src[(int64_t)p * C + c] * scale;
 }
 
+// dst [C,Hp,Wp]: the image in the top-left corner, zeros elsewhere (ImageList.from_tensors)
+__global__ void __launch_bounds__(256) u8_hwc_to_f32_chw_pad_kernel(const uint8_t* __restrict__ src, float* __restrict__ dst, int H, int W, int C,
+                                                                   int Hp, int Wp, float scale) {
+    const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t plane = (int64_t)Hp * Wp;
+    if (idx >= plane * C) return;
+    const int c = (int)(idx / plane);
+    const int64_t p = idx - c * plane;
+    const int y = (int)(p / Wp), x = (int)(p - (int64_t)y * Wp);
+    dst[idx] = (y < H && x < W) ? (float)src[((int64_t)y * W + x) * C + c] * scale : 0.f;
+}
+
 // per pixel: first-maximum argmax over K planes (torch.argmax semantics for distinct values; ties -> lowest class), count (pred, gt)
 __global__ void __launch_bounds__(256) semantic_confusion_kernel(const float* __restrict__ sem, const int* __restrict__ gt, int K, int npix,
                                                                 unsigned long long* __restrict__ conf) {
@@ -220,6 +232,15 @@ extern "C" int odise_hip_u8_hwc_to_f32_chw(odise_hip_ctx* ctx, const void* src, 
     ODISE_REQUIRE(ctx && src && dst && H > 0 && W > 0 && C > 0, "u8_hwc_to_f32_chw: bad argument");
     const int64_t total = (int64_t)H * W * C;
     hipLaunchKernelGGL(u8_hwc_to_f32_chw_kernel, dim3((unsigned)ceil_div(total, 256)), dim3(256), 0, ctx->stream, (const uint8_t*)src, dst, H * W, C, scale);
+    ODISE_CHECK_HIP(hipGetLastError());
+    return ODISE_OK;
+}
+
+extern "C" int odise_hip_u8_hwc_to_f32_chw_padded(odise_hip_ctx* ctx, const void* src, float* dst, int H, int W, int C, int Hp, int Wp, float scale) {
+    ODISE_REQUIRE(ctx && src && dst && H > 0 && W > 0 && C > 0 && Hp >= H && Wp >= W, "u8_hwc_to_f32_chw_padded: bad argument");
+    const int64_t total = (int64_t)Hp * Wp * C;
+    hipLaunchKernelGGL(u8_hwc_to_f32_chw_pad_kernel, dim3((unsigned)ceil_div(total, 256)), dim3(256), 0, ctx->stream, (const uint8_t*)src, dst, H, W, C,
+                       Hp, Wp, scale);
     ODISE_CHECK_HIP(hipGetLastError());
     return ODISE_OK;
 }

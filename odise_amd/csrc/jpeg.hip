@@ -1,0 +1,585 @@
+// jpeg.hip — baseline JPEG decoding for the input side of the eval loop.
+//
+// The reference reads every image with detectron2 `read_image(file, "RGB")` (DatasetMapper of
+// configs/common/data/pano_open_d2_eval.py:74-107, demo/demo.py:399) = Pillow on libjpeg-turbo with its defaults: JDCT_ISLOW, fancy
+// chroma upsampling, JFIF YCbCr -> RGB, then the EXIF transpose.  Here the serial part (marker parsing, Huffman entropy decoding) runs
+// on the host straight into a pinned staging buffer, and everything per-sample runs on the device, bit-identical to libjpeg:
+//   jpeg_idct_kernel   dequantisation + the LL&M "islow" integer IDCT (CONST_BITS 13, PASS1_BITS 2): 8 lanes per 8x8 block - a lane
+//                      owns a column in pass 1 and a row in pass 2, the 8x8 int32 workspace is exchanged through LDS
+//   jpeg_color_kernel  triangle-filter ("fancy") h2v1 / h2v2 chroma upsampling evaluated per output pixel from the decoded planes,
+//                      the 16-bit fixed-point YCbCr -> RGB conversion, the EXIF orientation as an index map, packed RGB store
+// Scope: 8-bit SOF0 / SOF1 Huffman files with one interleaved scan, grey or YCbCr, luma sampling 1x1 / 2x1 / 2x2 and 1x1 chroma -
+// progressive, arithmetic-coded, CMYK and RGB-coded files return ODISE_ERR_UNSUPPORTED (the caller decides what to do with them;
+// there is no CPU decode path in this library).  The input bytes are untrusted: every read is bounds-checked, truncated entropy data
+// decodes as zero bits like libjpeg does.
+#include <string.h>
+
+#include <vector>
+
+#include "common.h"
+
+namespace odise {
+
+static const uint8_t kZigzag[64] = {0,  1,  8,  16, 9,  2,  3,  10, 17, 24, 32, 25, 18, 11, 4,  5,  12, 19, 26, 33, 40, 48,
+                                    41, 34, 27, 20, 13, 6,  7,  14, 21, 28, 35, 42, 49, 56, 57, 50, 43, 36, 29, 22, 15, 23,
+                                    30, 37, 44, 51, 58, 59, 52, 45, 38, 31, 39, 46, 53, 60, 61, 54, 47, 55, 62, 63};
+
+struct HuffTable {
+    bool present = false;
+    uint8_t look_bits[512];  // 9-bit lookahead: code length (0 = longer than 9 bits)
+    uint8_t look_sym[512];
+    int32_t maxcode[18];     // largest code of each length (-1 = none); [17] is a sentinel that always matches
+    int32_t valoff[17];      // symbol index = code + valoff[length]
+    uint8_t vals[256];
+};
+
+static bool build_table(const uint8_t* counts, const uint8_t* symbols, int nsym, HuffTable& t) {
+    memset(t.look_bits, 0, sizeof(t.look_bits));
+    memcpy(t.vals, symbols, nsym);
+    int code = 0, k = 0;
+    for (int len = 1; len <= 16; ++len) {
+        t.valoff[len] = k - code;
+        const int n = counts[len - 1];
+        if (code + n > (1 << len)) return false;  // over-subscribed
+        if (len <= 9) {
+            for (int i = 0; i < n; ++i) {
+                const int first = (code + i) << (9 - len);
+                for (int f = 0; f < (1 << (9 - len)); ++f) {
+                    t.look_bits[first + f] = (uint8_t)len;
+                    t.look_sym[first + f] = symbols[k + i];
+                }
+            }
+        }
+        code += n;
+        k += n;
+        t.maxcode[len] = n ? code - 1 : -1;
+        code <<= 1;
+    }
+    t.maxcode[17] = 0x7fffffff;
+    t.present = true;
+    return true;
+}
+
+struct JpegHeader {
+    int width = 0, height = 0, ncomp = 0;
+    int id[3] = {0, 0, 0}, h[3] = {1, 1, 1}, v[3] = {1, 1, 1}, tq[3] = {0, 0, 0}, td[3] = {0, 0, 0}, ta[3] = {0, 0, 0};
+    int hmax = 1, vmax = 1, mcus_x = 0, mcus_y = 0;
+    int bx[3] = {0, 0, 0}, by[3] = {0, 0, 0};  // component block grids (padded to whole MCUs)
+    int64_t coef_off[3] = {0, 0, 0}, coef_count = 0;
+    int restart = 0, orientation = 1, adobe = -1;
+    bool jfif = false, have_sof = false;
+    bool qt_ok[4] = {false, false, false, false};
+    uint16_t qt[4][64];
+    HuffTable dc[4], ac[4];
+    int64_t data_start = 0;
+};
+
+static int exif_orientation(const uint8_t* t, int64_t n) {
+    if (n < 8) return 1;
+    bool le;
+    if (t[0] == 'I' && t[1] == 'I') le = true;
+    else if (t[0] == 'M' && t[1] == 'M') le = false;
+    else return 1;
+    auto u16 = [&](int64_t o) -> int { return le ? (t[o] | (t[o + 1] << 8)) : ((t[o] << 8) | t[o + 1]); };
+    auto u32 = [&](int64_t o) -> int64_t {
+        return le ? ((int64_t)t[o] | ((int64_t)t[o + 1] << 8) | ((int64_t)t[o + 2] << 16) | ((int64_t)t[o + 3] << 24))
+                  : (((int64_t)t[o] << 24) | ((int64_t)t[o + 1] << 16) | ((int64_t)t[o + 2] << 8) | (int64_t)t[o + 3]);
+    };
+    const int64_t ifd = u32(4);
+    if (ifd + 2 > n) return 1;
+    const int cnt = u16(ifd);
+    for (int i = 0; i < cnt; ++i) {
+        const int64_t o = ifd + 2 + 12 * (int64_t)i;
+        if (o + 12 > n) break;
+        if (u16(o) == 0x0112) {
+            const int val = u16(o + 8);
+            return (val >= 1 && val <= 8) ? val : 1;
+        }
+    }
+    return 1;
+}
+
+#define JPEG_FAIL(code, ...)        \
+    do {                            \
+        set_error(__VA_ARGS__);     \
+        return code;                \
+    } while (0)
+
+// Marker segments up to and including the first SOS header; validates what the decoder relies on.
+static int parse_header(const uint8_t* d, int64_t len, JpegHeader& H) {
+    if (!d || len < 4 || d[0] != 0xFF || d[1] != 0xD8) JPEG_FAIL(ODISE_ERR_ARG, "jpeg: not a JPEG stream (no SOI)");
+    int64_t p = 2;
+    for (;;) {
+        while (p < len && d[p] != 0xFF) ++p;
+        while (p < len && d[p] == 0xFF) ++p;
+        if (p >= len) JPEG_FAIL(ODISE_ERR_ARG, "jpeg: truncated before the scan");
+        const int m = d[p++];
+        if (m == 0xD8 || m == 0x01 || (m >= 0xD0 && m <= 0xD7)) continue;
+        if (m == 0xD9) JPEG_FAIL(ODISE_ERR_ARG, "jpeg: EOI before any scan");
+        if (p + 2 > len) JPEG_FAIL(ODISE_ERR_ARG, "jpeg: truncated marker segment");
+        const int L = (d[p] << 8) | d[p + 1];
+        if (L < 2 || p + L > len) JPEG_FAIL(ODISE_ERR_ARG, "jpeg: bad marker segment length");
+        const uint8_t* s = d + p + 2;
+        const int n = L - 2;
+        p += L;
+        if (m == 0xDB) {
+            int q = 0;
+            while (q < n) {
+                const int pq = s[q] >> 4, tq = s[q] & 15;
+                const int bytes = pq ? 128 : 64;
+                if (tq > 3 || pq > 1 || q + 1 + bytes > n) JPEG_FAIL(ODISE_ERR_ARG, "jpeg: bad DQT");
+                for (int i = 0; i < 64; ++i) H.qt[tq][kZigzag[i]] = pq ? (uint16_t)((s[q + 1 + 2 * i] << 8) | s[q + 2 + 2 * i]) : s[q + 1 + i];
+                H.qt_ok[tq] = true;
+                q += 1 + bytes;
+            }
+        } else if (m == 0xC0 || m == 0xC1) {
+            if (H.have_sof || n < 6) JPEG_FAIL(ODISE_ERR_ARG, "jpeg: bad SOF");
+            if (s[0] != 8) JPEG_FAIL(ODISE_ERR_UNSUPPORTED, "jpeg: %d-bit samples are not supported", (int)s[0]);
+            H.height = (s[1] << 8) | s[2];
+            H.width = (s[3] << 8) | s[4];
+            H.ncomp = s[5];
+            if (H.ncomp != 1 && H.ncomp != 3) JPEG_FAIL(ODISE_ERR_UNSUPPORTED, "jpeg: %d components (CMYK / YCCK) are not supported", H.ncomp);
+            if (n < 6 + 3 * H.ncomp || H.width == 0 || H.height == 0) JPEG_FAIL(ODISE_ERR_ARG, "jpeg: bad SOF");
+            for (int i = 0; i < H.ncomp; ++i) {
+                H.id[i] = s[6 + 3 * i];
+                H.h[i] = s[7 + 3 * i] >> 4;
+                H.v[i] = s[7 + 3 * i] & 15;
+                H.tq[i] = s[8 + 3 * i];
+                if (H.tq[i] > 3 || H.h[i] < 1 || H.v[i] < 1 || H.h[i] > 4 || H.v[i] > 4) JPEG_FAIL(ODISE_ERR_ARG, "jpeg: bad component spec");
+            }
+            H.have_sof = true;
+        } else if (m == 0xC2 || m == 0xC3 || (m >= 0xC5 && m <= 0xC7) || (m >= 0xC9 && m <= 0xCB) || (m >= 0xCD && m <= 0xCF)) {
+            JPEG_FAIL(ODISE_ERR_UNSUPPORTED, "jpeg: SOF marker 0x%02x (progressive / lossless / arithmetic coding) is not supported", m);
+        } else if (m == 0xC4) {
+            int q = 0;
+            while (q < n) {
+                if (q + 17 > n) JPEG_FAIL(ODISE_ERR_ARG, "jpeg: bad DHT");
+                const int tc = s[q] >> 4, th = s[q] & 15;
+                int total = 0;
+                for (int i = 0; i < 16; ++i) total += s[q + 1 + i];
+                if (tc > 1 || th > 3 || total > 256 || q + 17 + total > n) JPEG_FAIL(ODISE_ERR_ARG, "jpeg: bad DHT");
+                if (!build_table(s + q + 1, s + q + 17, total, tc ? H.ac[th] : H.dc[th])) JPEG_FAIL(ODISE_ERR_ARG, "jpeg: bad Huffman table");
+                q += 17 + total;
+            }
+        } else if (m == 0xDD) {
+            if (n < 2) JPEG_FAIL(ODISE_ERR_ARG, "jpeg: bad DRI");
+            H.restart = (s[0] << 8) | s[1];
+        } else if (m == 0xE0 && n >= 5 && memcmp(s, "JFIF\0", 5) == 0) {
+            H.jfif = true;
+        } else if (m == 0xEE && n >= 12 && memcmp(s, "Adobe", 5) == 0) {
+            H.adobe = s[11];
+        } else if (m == 0xE1 && n >= 6 && memcmp(s, "Exif\0\0", 6) == 0) {
+            H.orientation = exif_orientation(s + 6, n - 6);
+        } else if (m == 0xDA) {
+            if (!H.have_sof) JPEG_FAIL(ODISE_ERR_ARG, "jpeg: SOS before SOF");
+            if (n < 1 || s[0] != H.ncomp || n < 1 + 2 * H.ncomp + 3) JPEG_FAIL(ODISE_ERR_UNSUPPORTED, "jpeg: multi-scan files are not supported");
+            for (int i = 0; i < H.ncomp; ++i) {
+                if (s[1 + 2 * i] != H.id[i]) JPEG_FAIL(ODISE_ERR_UNSUPPORTED, "jpeg: scan component order differs from the frame");
+                H.td[i] = s[2 + 2 * i] >> 4;
+                H.ta[i] = s[2 + 2 * i] & 15;
+                if (H.td[i] > 3 || H.ta[i] > 3 || !H.dc[H.td[i]].present || !H.ac[H.ta[i]].present) JPEG_FAIL(ODISE_ERR_ARG, "jpeg: scan refers to a missing Huffman table");
+                if (!H.qt_ok[H.tq[i]]) JPEG_FAIL(ODISE_ERR_ARG, "jpeg: component refers to a missing quantisation table");
+            }
+            H.data_start = p;
+            break;
+        }
+    }
+    if (H.ncomp == 3) {
+        const bool rgb_ids = H.id[0] == 'R' && H.id[1] == 'G' && H.id[2] == 'B';
+        if (H.adobe == 0 || (!H.jfif && H.adobe < 0 && rgb_ids)) JPEG_FAIL(ODISE_ERR_UNSUPPORTED, "jpeg: RGB-coded files are not supported");
+        const bool luma_ok = (H.h[0] == 1 && H.v[0] == 1) || (H.h[0] == 2 && H.v[0] == 1) || (H.h[0] == 2 && H.v[0] == 2);
+        if (!luma_ok || H.h[1] != 1 || H.v[1] != 1 || H.h[2] != 1 || H.v[2] != 1)
+            JPEG_FAIL(ODISE_ERR_UNSUPPORTED, "jpeg: sampling factors %dx%d,%dx%d,%dx%d are not supported", H.h[0], H.v[0], H.h[1], H.v[1], H.h[2], H.v[2]);
+    } else {
+        H.h[0] = H.v[0] = 1;  // a single-component scan is never interleaved
+    }
+    H.hmax = H.h[0];
+    H.vmax = H.v[0];
+    H.mcus_x = (H.width + 8 * H.hmax - 1) / (8 * H.hmax);
+    H.mcus_y = (H.height + 8 * H.vmax - 1) / (8 * H.vmax);
+    int64_t off = 0;
+    for (int c = 0; c < H.ncomp; ++c) {
+        H.bx[c] = H.mcus_x * H.h[c];
+        H.by[c] = H.mcus_y * H.v[c];
+        H.coef_off[c] = off;
+        off += (int64_t)H.bx[c] * H.by[c] * 64;
+    }
+    H.coef_count = off;
+    return ODISE_OK;
+}
+
+// Bit reader over the entropy-coded segment: removes the FF00 stuffing, stops at the first marker and then supplies zero bits.
+struct BitReader {
+    const uint8_t* p;
+    const uint8_t* end;
+    uint64_t acc = 0;
+    int n = 0;
+    bool marker = false;
+    inline void fill() {
+        while (n <= 56) {
+            unsigned b = 0;
+            if (!marker && p < end) {
+                b = *p++;
+                if (b == 0xFF) {
+                    const unsigned c = p < end ? *p : 0xD9u;
+                    if (c == 0) ++p;
+                    else { marker = true; --p; b = 0; }
+                }
+            }
+            acc = (acc << 8) | b;
+            n += 8;
+        }
+    }
+    inline unsigned peek(int k) const { return (unsigned)((acc >> (n - k)) & ((1u << k) - 1)); }
+    inline unsigned take(int k) { n -= k; return (unsigned)((acc >> n) & ((1u << k) - 1)); }
+    inline int symbol(const HuffTable& t) {  // needs >= 16 valid bits
+        const unsigned look = peek(9);
+        const int nb = t.look_bits[look];
+        if (nb) { n -= nb; return t.look_sym[look]; }
+        for (int len = 10; len <= 16; ++len) {
+            const int code = (int)peek(len);
+            if (code <= t.maxcode[len]) { n -= len; return t.vals[(code + t.valoff[len]) & 255]; }
+        }
+        n -= 16;
+        return -1;  // not a code of this table (corrupt data)
+    }
+    // skip to just after the next RSTn (or stay at any other marker / the end)
+    inline void restart() {
+        acc = 0;
+        n = 0;
+        marker = false;
+        while (p + 1 < end && !(p[0] == 0xFF && p[1] >= 0xD0 && p[1] <= 0xD7)) {
+            if (p[0] == 0xFF && p[1] != 0 && p[1] != 0xFF) { marker = true; return; }  // some other marker: the data ends here
+            ++p;
+        }
+        if (p + 1 < end) p += 2;
+        else p = end;
+    }
+};
+
+static inline int extend(unsigned v, int s) { return (s && v < (1u << (s - 1))) ? (int)v - (1 << s) + 1 : (int)v; }
+
+// coefs: H.coef_count int16, zero-filled by the caller; natural (row-major) order inside a block, not dequantised
+static void entropy_decode(const uint8_t* d, int64_t len, const JpegHeader& H, int16_t* coefs) {
+    BitReader br;
+    br.p = d + H.data_start;
+    br.end = d + len;
+    int pred[3] = {0, 0, 0};
+    const int nm = H.mcus_x * H.mcus_y;
+    int until_restart = H.restart;
+    for (int mcu = 0; mcu < nm; ++mcu) {
+        if (H.restart) {
+            if (until_restart == 0) {
+                br.restart();
+                pred[0] = pred[1] = pred[2] = 0;
+                until_restart = H.restart;
+            }
+            --until_restart;
+        }
+        const int my = mcu / H.mcus_x, mx = mcu - my * H.mcus_x;
+        for (int c = 0; c < H.ncomp; ++c) {
+            const HuffTable& dct = H.dc[H.td[c]];
+            const HuffTable& act = H.ac[H.ta[c]];
+            for (int v = 0; v < H.v[c]; ++v)
+                for (int h = 0; h < H.h[c]; ++h) {
+                    int16_t* blk = coefs + H.coef_off[c] + ((int64_t)(my * H.v[c] + v) * H.bx[c] + (mx * H.h[c] + h)) * 64;
+                    br.fill();
+                    int s = br.symbol(dct);
+                    if (s < 0 || s > 16) s = 0;
+                    pred[c] += extend(s ? br.take(s) : 0u, s);
+                    blk[0] = (int16_t)pred[c];
+                    for (int k = 1; k < 64;) {
+                        br.fill();
+                        const int rs = br.symbol(act);
+                        if (rs < 0) break;
+                        const int r = rs >> 4;
+                        s = rs & 15;
+                        if (s == 0) {
+                            if (r != 15) break;  // EOB
+                            k += 16;
+                            continue;
+                        }
+                        k += r;
+                        if (k > 63) break;  // corrupt data
+                        blk[kZigzag[k]] = (int16_t)extend(br.take(s), s);
+                        ++k;
+                    }
+                }
+        }
+    }
+}
+
+// ---- device side -----------------------------------------------------------------------------------------------------------------
+struct JpegPlanes {
+    int ncomp;
+    int bx[3], by[3];        // block grids
+    int64_t coef_off[3];     // int16 elements
+    int64_t plane_off[3];    // bytes
+    int64_t first_block[3];  // running block index of the component's first block
+    int64_t blocks;
+    uint16_t qt[3][64];
+};
+
+__device__ __forceinline__ void idct8(const int (&r)[8], int (&o)[8]) {
+    // jidctint.c: even part
+    int z2 = r[2], z3 = r[6];
+    int z1 = (z2 + z3) * 4433;
+    const int tmp2 = z1 - z3 * 15137;
+    const int tmp3 = z1 + z2 * 6270;
+    const int tmp0 = (r[0] + r[4]) << 13;
+    const int tmp1 = (r[0] - r[4]) << 13;
+    const int tmp10 = tmp0 + tmp3, tmp13 = tmp0 - tmp3, tmp11 = tmp1 + tmp2, tmp12 = tmp1 - tmp2;
+    // odd part
+    int t0 = r[7], t1 = r[5], t2 = r[3], t3 = r[1];
+    z1 = t0 + t3;
+    z2 = t1 + t2;
+    z3 = t0 + t2;
+    int z4 = t1 + t3;
+    const int z5 = (z3 + z4) * 9633;
+    t0 *= 2446;
+    t1 *= 16819;
+    t2 *= 25172;
+    t3 *= 12299;
+    z1 *= -7373;
+    z2 *= -20995;
+    z3 = z3 * -16069 + z5;
+    z4 = z4 * -3196 + z5;
+    t0 += z1 + z3;
+    t1 += z2 + z4;
+    t2 += z2 + z3;
+    t3 += z1 + z4;
+    o[0] = tmp10 + t3;
+    o[7] = tmp10 - t3;
+    o[1] = tmp11 + t2;
+    o[6] = tmp11 - t2;
+    o[2] = tmp12 + t1;
+    o[5] = tmp12 - t1;
+    o[3] = tmp13 + t0;
+    o[4] = tmp13 - t0;
+}
+
+__global__ void __launch_bounds__(256) jpeg_idct_kernel(const int16_t* __restrict__ coefs, uint8_t* __restrict__ planes, JpegPlanes P) {
+    __shared__ int ws[32][8][9];  // [block in the workgroup][row][col], padded
+    const int tid = threadIdx.x, lb = tid >> 3, c8 = tid & 7;
+    const int64_t blk = (int64_t)blockIdx.x * 32 + lb;
+    const bool live = blk < P.blocks;
+    int comp = 0;
+    if (P.ncomp == 3) comp = blk >= P.first_block[2] ? 2 : (blk >= P.first_block[1] ? 1 : 0);
+    const int64_t bi = blk - P.first_block[comp];
+    int r[8], o[8];
+    if (live) {
+        const int16_t* cb = coefs + P.coef_off[comp] + bi * 64;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) r[k] = (int)cb[k * 8 + c8] * (int)P.qt[comp][k * 8 + c8];  // pass 1: this lane's column
+        idct8(r, o);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) ws[lb][k][c8] = (o[k] + (1 << 10)) >> 11;
+    }
+    __syncthreads();
+    if (live) {
+#pragma unroll
+        for (int k = 0; k < 8; ++k) r[k] = ws[lb][c8][k];  // pass 2: this lane's row
+        idct8(r, o);
+        const int byi = (int)(bi / P.bx[comp]), bxi = (int)(bi - (int64_t)byi * P.bx[comp]);
+        uint32_t lo = 0, hi = 0;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            int val = ((o[k] + (1 << 17)) >> 18) + 128;
+            val = val < 0 ? 0 : (val > 255 ? 255 : val);
+            if (k < 4) lo |= (uint32_t)val << (8 * k);
+            else hi |= (uint32_t)val << (8 * (k - 4));
+        }
+        uint8_t* dst = planes + P.plane_off[comp] + ((int64_t)(byi * 8 + c8) * P.bx[comp] + bxi) * 8;
+        *reinterpret_cast<uint2*>(dst) = make_uint2(lo, hi);
+    }
+}
+
+struct JpegColor {
+    int W, H;            // coded image size
+    int OW, OH;          // output size (after the orientation)
+    int orientation;
+    int ncomp, hx, vx;   // chroma expansion factors (1 | 2)
+    int dw, dh;          // real chroma samples
+    int pitch[3];
+    int64_t plane_off[3];
+};
+
+__device__ __forceinline__ int chroma_at(const uint8_t* __restrict__ p, int pitch, int dw, int dh, int hx, int vx, int x, int y) {
+    if (hx == 1) return p[(int64_t)y * pitch + x];
+    const int cx = x >> 1;
+    if (dw <= 2) return p[(int64_t)(vx == 2 ? (y >> 1) : y) * pitch + cx];  // jdsample.c: plain replication for narrow components
+    const int nb = (x & 1) ? (cx + 1 < dw ? cx + 1 : cx) : (cx > 0 ? cx - 1 : 0);  // the further column (clamped: reproduces the edge rules)
+    if (vx == 1) {
+        const uint8_t* row = p + (int64_t)y * pitch;
+        return (3 * row[cx] + row[nb] + ((x & 1) ? 2 : 1)) >> 2;
+    }
+    const int cy = y >> 1;
+    const int fy = (y & 1) ? (cy + 1 < dh ? cy + 1 : cy) : (cy > 0 ? cy - 1 : 0);
+    const uint8_t* rn = p + (int64_t)cy * pitch;
+    const uint8_t* rf = p + (int64_t)fy * pitch;
+    const int s_this = 3 * rn[cx] + rf[cx], s_nb = 3 * rn[nb] + rf[nb];
+    return (3 * s_this + s_nb + ((x & 1) ? 7 : 8)) >> 4;
+}
+
+__global__ void __launch_bounds__(256) jpeg_color_kernel(const uint8_t* __restrict__ planes, uint8_t* __restrict__ out, JpegColor G) {
+    const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= (int64_t)G.OW * G.OH) return;
+    const int oy = (int)(idx / G.OW), ox = (int)(idx - (int64_t)oy * G.OW);
+    int x = ox, y = oy;
+    switch (G.orientation) {  // PIL.ImageOps.exif_transpose as an index map
+        case 2: x = G.W - 1 - ox; break;
+        case 3: x = G.W - 1 - ox; y = G.H - 1 - oy; break;
+        case 4: y = G.H - 1 - oy; break;
+        case 5: x = oy; y = ox; break;
+        case 6: x = oy; y = G.H - 1 - ox; break;
+        case 7: x = G.W - 1 - oy; y = G.H - 1 - ox; break;
+        case 8: x = G.W - 1 - oy; y = ox; break;
+        default: break;
+    }
+    const int Y = planes[G.plane_off[0] + (int64_t)y * G.pitch[0] + x];
+    int R = Y, Gc = Y, B = Y;
+    if (G.ncomp == 3) {
+        const int cb = chroma_at(planes + G.plane_off[1], G.pitch[1], G.dw, G.dh, G.hx, G.vx, x, y) - 128;
+        const int cr = chroma_at(planes + G.plane_off[2], G.pitch[2], G.dw, G.dh, G.hx, G.vx, x, y) - 128;
+        R = Y + ((91881 * cr + 32768) >> 16);                       // jdcolor.c build_ycc_rgb_table
+        Gc = Y + ((-22554 * cb + 32768 - 46802 * cr) >> 16);
+        B = Y + ((116130 * cb + 32768) >> 16);
+        R = R < 0 ? 0 : (R > 255 ? 255 : R);
+        Gc = Gc < 0 ? 0 : (Gc > 255 ? 255 : Gc);
+        B = B < 0 ? 0 : (B > 255 ? 255 : B);
+    }
+    uint8_t* o = out + idx * 3;
+    o[0] = (uint8_t)R;
+    o[1] = (uint8_t)Gc;
+    o[2] = (uint8_t)B;
+}
+
+static void fill_info(const JpegHeader& H, odise_jpeg_info* info) {
+    info->width = H.width;
+    info->height = H.height;
+    info->components = H.ncomp;
+    info->h_samp = H.hmax;
+    info->v_samp = H.vmax;
+    info->orientation = H.orientation;
+    info->restart_interval = H.restart;
+    for (int c = 0; c < 3; ++c) {
+        info->blocks_x[c] = c < H.ncomp ? H.bx[c] : 0;
+        info->blocks_y[c] = c < H.ncomp ? H.by[c] : 0;
+    }
+    info->coef_count = H.coef_count;
+}
+
+void jpeg_release(odise_hip_ctx* ctx) {
+    if (ctx->jpeg_host) (void)hipHostFree(ctx->jpeg_host);
+    if (ctx->jpeg_dev) (void)hipFree(ctx->jpeg_dev);
+    if (ctx->jpeg_ev) (void)hipEventDestroy(ctx->jpeg_ev);
+    ctx->jpeg_host = ctx->jpeg_dev = nullptr;
+    ctx->jpeg_host_bytes = ctx->jpeg_dev_bytes = 0;
+    ctx->jpeg_ev = nullptr;
+}
+
+}  // namespace odise
+
+using namespace odise;
+
+extern "C" int odise_hip_jpeg_info(const void* data, int64_t len, odise_jpeg_info* info) {
+    ODISE_REQUIRE(data && info && len > 0, "jpeg_info: null argument");
+    std::vector<JpegHeader> hv(1);  // the header holds eight Huffman tables: keep it off the stack
+    const int rc = parse_header((const uint8_t*)data, len, hv[0]);
+    if (rc != ODISE_OK) return rc;
+    fill_info(hv[0], info);
+    return ODISE_OK;
+}
+
+extern "C" int odise_hip_jpeg_entropy_decode(const void* data, int64_t len, int16_t* coefs, int64_t capacity, uint16_t* qtables) {
+    ODISE_REQUIRE(data && coefs && len > 0, "jpeg_entropy_decode: null argument");
+    std::vector<JpegHeader> hv(1);
+    JpegHeader& H = hv[0];
+    const int rc = parse_header((const uint8_t*)data, len, H);
+    if (rc != ODISE_OK) return rc;
+    ODISE_REQUIRE(capacity >= H.coef_count, "jpeg_entropy_decode: coefficient buffer too small (%lld < %lld)", (long long)capacity, (long long)H.coef_count);
+    memset(coefs, 0, (size_t)H.coef_count * sizeof(int16_t));
+    entropy_decode((const uint8_t*)data, len, H, coefs);
+    if (qtables)
+        for (int c = 0; c < H.ncomp; ++c) memcpy(qtables + 64 * c, H.qt[H.tq[c]], 64 * sizeof(uint16_t));
+    return ODISE_OK;
+}
+
+extern "C" int odise_hip_jpeg_decode(odise_hip_ctx* ctx, const void* data, int64_t len, void* dst_rgb, int64_t dst_capacity, int apply_orientation,
+                                     int* out_h, int* out_w) {
+    ODISE_REQUIRE(ctx && data && dst_rgb && len > 0, "jpeg_decode: null argument");
+    std::vector<JpegHeader> hv(1);
+    JpegHeader& H = hv[0];
+    int rc = parse_header((const uint8_t*)data, len, H);
+    if (rc != ODISE_OK) return rc;
+    const int orient = apply_orientation ? H.orientation : 1;
+    const bool swap = orient >= 5;
+    const int OH = swap ? H.width : H.height, OW = swap ? H.height : H.width;
+    if (out_h) *out_h = OH;
+    if (out_w) *out_w = OW;
+    ODISE_REQUIRE(dst_capacity >= (int64_t)OH * OW * 3, "jpeg_decode: output buffer too small for %dx%d RGB", OH, OW);
+    ODISE_CHECK_HIP(hipSetDevice(ctx->device));
+    // ---- staging: pinned host coefficients (reused once the previous image's upload has finished), device coefficients + planes
+    const size_t coef_bytes = (size_t)H.coef_count * sizeof(int16_t);
+    JpegPlanes P;
+    JpegColor G;
+    P.ncomp = G.ncomp = H.ncomp;
+    int64_t poff = (int64_t)round_up((int64_t)coef_bytes, 256), nblk = 0;
+    for (int c = 0; c < 3; ++c) {
+        const bool on = c < H.ncomp;
+        P.bx[c] = on ? H.bx[c] : 0;
+        P.by[c] = on ? H.by[c] : 0;
+        P.coef_off[c] = on ? H.coef_off[c] : 0;
+        P.plane_off[c] = G.plane_off[c] = poff;
+        P.first_block[c] = nblk;
+        G.pitch[c] = P.bx[c] * 8;
+        if (on) {
+            memcpy(P.qt[c], H.qt[H.tq[c]], sizeof(P.qt[c]));
+            poff += (int64_t)round_up((int64_t)P.bx[c] * P.by[c] * 64, 256);
+            nblk += (int64_t)P.bx[c] * P.by[c];
+        } else {
+            memset(P.qt[c], 0, sizeof(P.qt[c]));
+        }
+    }
+    P.blocks = nblk;
+    if (!ctx->jpeg_ev) ODISE_CHECK_HIP(hipEventCreateWithFlags(&ctx->jpeg_ev, hipEventDisableTiming));
+    else ODISE_CHECK_HIP(hipEventSynchronize(ctx->jpeg_ev));
+    if (ctx->jpeg_host_bytes < coef_bytes) {
+        if (ctx->jpeg_host) (void)hipHostFree(ctx->jpeg_host);
+        ctx->jpeg_host = nullptr;
+        ctx->jpeg_host_bytes = 0;
+        const size_t want = coef_bytes + coef_bytes / 4;
+        if (hipHostMalloc(&ctx->jpeg_host, want, hipHostMallocDefault) != hipSuccess) { set_error("jpeg_decode: cannot pin %zu bytes", want); return ODISE_ERR_NOMEM; }
+        ctx->jpeg_host_bytes = want;
+    }
+    if (ctx->jpeg_dev_bytes < (size_t)poff) {
+        ODISE_CHECK_HIP(hipStreamSynchronize(ctx->stream));
+        if (ctx->jpeg_dev) (void)hipFree(ctx->jpeg_dev);
+        ctx->jpeg_dev = nullptr;
+        ctx->jpeg_dev_bytes = 0;
+        const size_t want = (size_t)poff + (size_t)poff / 4;
+        if (hipMalloc(&ctx->jpeg_dev, want) != hipSuccess) { set_error("jpeg_decode: out of device memory (%zu bytes)", want); return ODISE_ERR_NOMEM; }
+        ctx->jpeg_dev_bytes = want;
+    }
+    int16_t* hc = (int16_t*)ctx->jpeg_host;
+    memset(hc, 0, coef_bytes);
+    entropy_decode((const uint8_t*)data, len, H, hc);
+    ODISE_CHECK_HIP(hipMemcpyAsync(ctx->jpeg_dev, hc, coef_bytes, hipMemcpyHostToDevice, ctx->stream));
+    ODISE_CHECK_HIP(hipEventRecord(ctx->jpeg_ev, ctx->stream));
+    uint8_t* dev = (uint8_t*)ctx->jpeg_dev;
+    hipLaunchKernelGGL(jpeg_idct_kernel, dim3((unsigned)ceil_div(nblk, 32)), dim3(256), 0, ctx->stream, (const int16_t*)dev, dev, P);
+    ODISE_CHECK_HIP(hipGetLastError());
+    G.W = H.width;
+    G.H = H.height;
+    G.OW = OW;
+    G.OH = OH;
+    G.orientation = orient;
+    G.hx = H.hmax;  // chroma is 1x1: its expansion factors are the luma sampling factors
+    G.vx = H.vmax;
+    G.dw = (H.width + H.hmax - 1) / H.hmax;
+    G.dh = (H.height + H.vmax - 1) / H.vmax;
+    const int64_t npix = (int64_t)OW * OH;
+    hipLaunchKernelGGL(jpeg_color_kernel, dim3((unsigned)ceil_div(npix, 256)), dim3(256), 0, ctx->stream, (const uint8_t*)dev, (uint8_t*)dst_rgb, G);
+    ODISE_CHECK_HIP(hipGetLastError());
+    return ODISE_OK;
+}

@@ -339,7 +339,10 @@ class HipCategoryODISE(HipODISE):
                                       pan_out=dict(enumerate(pan_out)) if pan_out is not None else None)
 
     def forward(self, batched_inputs) -> list:
-        """CategoryODISE.forward, eval branch (odise.py:236-246, 282-372) for a batch of equally sized images."""
+        """CategoryODISE.forward, eval branch (odise.py:236-246, 282-372) for a batch of equally sized images.  "image" is a CHW uint8 /
+        float array on the host (values 0..255), or a DeviceArray uint8 [H,W,3] already in HBM (odise_amd.ingest.HipDatasetMapper)."""
+        if isinstance(batched_inputs[0]["image"], DeviceArray):
+            return self._forward_resident(batched_inputs)
         imgs = []
         for x in batched_inputs:
             im = x["image"]
@@ -360,6 +363,22 @@ class HipCategoryODISE(HipODISE):
         mask_cls = self.classify_device(self.ctx.to_device(img01)).numpy()
         sizes = [(int(x.get("height", H)), int(x.get("width", W))) for x in batched_inputs]
         return self.postprocess_batch(mask_cls, (Hp, Wp), (H, W), sizes)
+
+
+    def _forward_resident(self, batched_inputs) -> list:
+        ims = [x["image"] for x in batched_inputs]
+        H, W = ims[0].shape[:2]
+        assert all(i.dtype == np.uint8 and i.shape == (H, W, 3) for i in ims), "device images: uint8 [H,W,3] of one size"
+        d = self.size_divisibility
+        Hp, Wp, B = (H + d - 1) // d * d, (W + d - 1) // d * d, len(ims)
+        padded = self._buf("in_padded", (B, 3, Hp, Wp), np.float32)
+        img01 = padded if (Hp, Wp) == (H, W) else self._buf("in_img01", (B, 3, H, W), np.float32)
+        for b, im in enumerate(ims):                                      # (x - 0) / 255 and ImageList.from_tensors(images, 64), on the device
+            self.ctx.u8_hwc_to_f32_chw_padded(im, Hp, Wp, 1.0 / 255.0, out=padded.view((3, Hp, Wp), offset_bytes=b * 3 * Hp * Wp * 4))
+            if img01 is not padded:
+                self.ctx.u8_hwc_to_f32_chw_padded(im, H, W, 1.0 / 255.0, out=img01.view((3, H, W), offset_bytes=b * 3 * H * W * 4))
+        sizes = [(int(x.get("height", H)), int(x.get("width", W))) for x in batched_inputs]
+        return self.forward_device(padded, img01, sizes, to_host=True)
 
 
 class HipCaptionODISE(HipCategoryODISE):

@@ -296,6 +296,15 @@ class Context:
         check(self.lib.odise_hip_u8_hwc_to_f32_chw(self.h, _p(img), _p(out), H, W, Cc, C.c_float(scale)), "u8_hwc_to_f32_chw")
         return out
 
+    def u8_hwc_to_f32_chw_padded(self, img: DeviceArray, Hp: int, Wp: int, scale: float = 1.0, out: Optional[DeviceArray] = None) -> DeviceArray:
+        """uint8 [H,W,C] -> fp32 [C,Hp,Wp] with the image in the top-left corner and zeros elsewhere (ImageList.from_tensors)."""
+        H, W, Cc = img.shape
+        if out is None:
+            out = self.empty((Cc, Hp, Wp), np.float32)
+        assert out.nbytes == Cc * Hp * Wp * 4
+        check(self.lib.odise_hip_u8_hwc_to_f32_chw_padded(self.h, _p(img), _p(out), H, W, Cc, int(Hp), int(Wp), C.c_float(scale)), "u8_hwc_to_f32_chw_padded")
+        return out
+
     def semantic_confusion(self, sem_seg: DeviceArray, gt: DeviceArray, conf: Optional[DeviceArray] = None) -> DeviceArray:
         """sem_seg f32 [K,H,W], gt int32 [H,W] (ignore label already mapped outside [0,K)) -> int64 [(K+1),(K+1)] accumulated into conf."""
         K = sem_seg.shape[0]
@@ -311,6 +320,48 @@ class Context:
             hist = self.zeros((na, nb), np.int32)
         check(self.lib.odise_hip_pair_histogram(self.h, _p(a), _p(b), npix, int(na), int(nb), _p(hist)), "pair_histogram")
         return hist
+
+
+    def jpeg_decode(self, data: bytes, apply_orientation: bool = True, out: Optional[DeviceArray] = None) -> DeviceArray:
+        """read_image(file, "RGB") for a baseline JPEG: host Huffman decoding, IDCT / upsampling / colour conversion / EXIF transpose on
+        the device -> uint8 [H,W,3], bit-identical to Pillow.  Raises `UnsupportedInput` for progressive / CMYK / RGB-coded files."""
+        info = jpeg_info(data)
+        swap = apply_orientation and info["orientation"] >= 5
+        oh, ow = (info["width"], info["height"]) if swap else (info["height"], info["width"])
+        if out is None or out.nbytes < oh * ow * 3:
+            out = self.empty((oh, ow, 3), np.uint8)
+        h, w = C.c_int(0), C.c_int(0)
+        buf = (C.c_ubyte * len(data)).from_buffer_copy(data)
+        check(self.lib.odise_hip_jpeg_decode(self.h, buf, C.c_int64(len(data)), _p(out), C.c_int64(out.nbytes), int(bool(apply_orientation)),
+                                             C.byref(h), C.byref(w)), "jpeg_decode")
+        return out.view((h.value, w.value, 3)) if out.shape != (h.value, w.value, 3) else out
+
+
+def jpeg_info(data: bytes) -> dict:
+    """Header fields of a JPEG byte stream (host only)."""
+    from ._lib import JpegInfo, load
+    info = JpegInfo()
+    buf = (C.c_ubyte * len(data)).from_buffer_copy(data)
+    check(load().odise_hip_jpeg_info(buf, C.c_int64(len(data)), C.byref(info)), "jpeg_info")
+    return dict(width=info.width, height=info.height, components=info.components, h_samp=info.h_samp, v_samp=info.v_samp,
+                orientation=info.orientation, restart_interval=info.restart_interval, blocks_x=list(info.blocks_x)[:info.components],
+                blocks_y=list(info.blocks_y)[:info.components], coef_count=info.coef_count)
+
+
+def jpeg_entropy_decode(data: bytes):
+    """Host half of the decoder on its own: (info, [int16 [blocks_y, blocks_x, 64] per component], uint16 [components, 64] tables)."""
+    from ._lib import load
+    info = jpeg_info(data)
+    coefs = np.zeros(info["coef_count"], np.int16)
+    qt = np.zeros((info["components"], 64), np.uint16)
+    buf = (C.c_ubyte * len(data)).from_buffer_copy(data)
+    check(load().odise_hip_jpeg_entropy_decode(buf, C.c_int64(len(data)), coefs.ctypes.data_as(C.c_void_p), C.c_int64(coefs.size),
+                                               qt.ctypes.data_as(C.c_void_p)), "jpeg_entropy_decode")
+    out, off = [], 0
+    for by, bx in zip(info["blocks_y"], info["blocks_x"]):
+        out.append(coefs[off:off + by * bx * 64].reshape(by, bx, 64))
+        off += by * bx * 64
+    return info, out, qt
 
 
 _default: Optional[Context] = None

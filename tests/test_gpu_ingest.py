@@ -122,3 +122,8 @@ def test_ingested_checkpoints_and_device_vocabulary_match_oracle(ctx):
     exp2 = hip.forward([{"image": img}])[0]
     np.testing.assert_array_equal(got2["panoptic_seg"][0], exp2["panoptic_seg"][0])
     np.testing.assert_array_equal(got2["sem_seg"], exp2["sem_seg"])
+    # ---- an image already resident in HBM as uint8 [H,W,3] (HipDatasetMapper's output) takes the same path without a host round trip
+    hip.load_open_state_dict({"category_head.test_labels": LABELS, "thing_ids": THINGS, "instance_on": True})
+    dimg = ctx.to_device(np.ascontiguousarray(img.numpy().transpose(1, 2, 0)))
+    res = hip.forward([{"image": dimg, "height": 512, "width": 512}])[0]
+    assert (res["panoptic_seg"][0] == pan).mean() > 0.999 and res["panoptic_seg"][1] == info

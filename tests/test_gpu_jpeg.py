@@ -1,0 +1,79 @@
+"""GPU: JPEG decoding through the C ABI (`odise_hip_jpeg_decode`: host Huffman decoding, IDCT / fancy upsampling / colour conversion /
+EXIF transpose on the device) is bit-identical to Pillow = what the reference's `read_image(file, "RGB")` returns, and to the pinned
+oracle; `HipDatasetMapper` (decode + ResizeShortestEdge) reproduces the DatasetMapper's image."""
+import io
+
+import numpy as np
+import pytest
+from PIL import Image
+
+from odise_amd._lib import UnsupportedInput
+from odise_amd.ingest import HipDatasetMapper, resize_shortest_edge_shape
+from oracle import jpeg as oj
+from tests.test_oracle_jpeg import CASES, _jpeg, _picture, _pil
+
+pytestmark = pytest.mark.gpu
+
+
+def test_case_matrix_bit_exact(ctx):
+    for h, w, sub, q in CASES:
+        data = _jpeg(_picture(h, w, seed=h * 131 + w), quality=q, subsampling=sub)
+        got = ctx.jpeg_decode(data).numpy()
+        np.testing.assert_array_equal(got, _pil(data), err_msg=f"{h}x{w} subsampling {sub} quality {q}")
+        np.testing.assert_array_equal(got, oj.decode(data))
+
+
+@pytest.mark.parametrize("kw", [dict(quality=3, subsampling=2), dict(quality=100, subsampling=0), dict(quality=60, subsampling=2, optimize=True),
+                                dict(quality=85, subsampling=1, restart_marker_blocks=3), dict(quality=85, subsampling=2, restart_marker_rows=1)])
+def test_tables_restarts_and_extremes(ctx, kw):
+    for seed, smooth in ((1, True), (2, False)):
+        data = _jpeg(_picture(75, 99, seed, smooth), **kw)
+        np.testing.assert_array_equal(ctx.jpeg_decode(data).numpy(), _pil(data))
+
+
+def test_grey_orientation_and_buffer_reuse(ctx):
+    img = _picture(37, 52, 5)
+    data = _jpeg(img, mode="L", quality=80)
+    np.testing.assert_array_equal(ctx.jpeg_decode(data).numpy(), _pil(data))
+    for orient in range(1, 9):
+        ex = Image.Exif()
+        ex[0x0112] = orient
+        buf = io.BytesIO()
+        Image.fromarray(img).save(buf, "JPEG", quality=90, exif=ex.tobytes())
+        data = buf.getvalue()
+        np.testing.assert_array_equal(ctx.jpeg_decode(data).numpy(), _pil(data), err_msg=f"orientation {orient}")
+        raw = ctx.jpeg_decode(data, apply_orientation=False).numpy()
+        np.testing.assert_array_equal(raw, np.asarray(Image.open(io.BytesIO(data)).convert("RGB")))
+    big = _jpeg(_picture(768, 1024, 7), quality=85, subsampling=2)       # staging buffers grow, then are reused by a smaller image
+    np.testing.assert_array_equal(ctx.jpeg_decode(big).numpy(), _pil(big))
+    small = _jpeg(_picture(40, 24, 8), quality=70, subsampling=1)
+    np.testing.assert_array_equal(ctx.jpeg_decode(small).numpy(), _pil(small))
+    np.testing.assert_array_equal(ctx.jpeg_decode(big).numpy(), _pil(big))
+
+
+def test_unsupported_and_malformed(ctx):
+    img = _picture(32, 32, 9)
+    with pytest.raises(UnsupportedInput):
+        ctx.jpeg_decode(_jpeg(img, quality=80, progressive=True))
+    with pytest.raises(RuntimeError):
+        ctx.jpeg_decode(b"\xff\xd8\xff\xd9")
+    good = _jpeg(img, quality=80)
+    start = oj.parse(good)["data_start"]
+    cut = good[:start + 40]                                               # truncated scan: decodes (zero bits), like libjpeg with a warning
+    np.testing.assert_array_equal(ctx.jpeg_decode(cut).numpy(), oj.decode(cut))
+
+
+def test_dataset_mapper_matches_read_image_and_resize(ctx):
+    data = _jpeg(_picture(480, 640, 11), quality=90, subsampling=2)
+    mapper = HipDatasetMapper(ctx, short_edge_length=256, max_size=300)
+    out = mapper({"jpeg": data, "image_id": 7})
+    nh, nw = resize_shortest_edge_shape(480, 640, 256, 300)
+    assert (nh, nw) == (225, 300) and out["height"] == 480 and out["width"] == 640 and out["image_id"] == 7
+    ref = np.asarray(Image.fromarray(_pil(data)).resize((nw, nh), Image.BILINEAR))
+    np.testing.assert_array_equal(out["image"].numpy(), ref)
+    keep = HipDatasetMapper(ctx, short_edge_length=None)({"jpeg": data})
+    np.testing.assert_array_equal(keep["image"].numpy(), _pil(data))
+    padded = ctx.u8_hwc_to_f32_chw_padded(out["image"], 256, 320, 1.0 / 255.0).numpy()
+    want = np.zeros((3, 256, 320), np.float32)
+    want[:, :nh, :nw] = ref.transpose(2, 0, 1).astype(np.float32) * np.float32(1.0 / 255.0)
+    np.testing.assert_array_equal(padded, want)

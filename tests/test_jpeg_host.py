@@ -1,0 +1,95 @@
+"""Host half of the JPEG decoder in libodise_hip.so (marker parsing + Huffman entropy decoding, no device work): coefficients and
+tables equal the oracle's, and - pushed through the oracle's IDCT / upsampling / colour stages - reproduce Pillow on images that are
+too large for the oracle's pure-Python entropy decoder.  Malformed and unsupported streams are refused with the documented codes."""
+import io
+
+import numpy as np
+import pytest
+from PIL import Image
+
+from odise_amd._lib import UnsupportedInput
+from odise_amd.runtime import jpeg_entropy_decode, jpeg_info
+from oracle import jpeg as oj
+from tests.test_oracle_jpeg import _jpeg, _picture, _pil
+
+
+@pytest.mark.parametrize("h,w,kw", [(17, 23, dict(quality=75, subsampling=2)), (33, 70, dict(quality=90, subsampling=0)),
+                                    (64, 48, dict(quality=20, subsampling=1)), (5, 3, dict(quality=75, subsampling=2)),
+                                    (75, 99, dict(quality=60, subsampling=2, optimize=True)),
+                                    (75, 99, dict(quality=85, subsampling=1, restart_marker_blocks=3)),
+                                    (40, 57, dict(quality=3, subsampling=2))])
+def test_coefficients_equal_oracle(h, w, kw):
+    data = _jpeg(_picture(h, w, seed=h + w, smooth=(kw["quality"] > 3)), **kw)
+    info, coefs, qt = jpeg_entropy_decode(data)
+    ref_info, ref = oj.entropy_decode(data)
+    assert (info["width"], info["height"], info["components"]) == (w, h, 3)
+    assert (info["h_samp"], info["v_samp"]) == (ref_info["hmax"], ref_info["vmax"]) and info["restart_interval"] == ref_info["restart"]
+    for c in range(3):
+        np.testing.assert_array_equal(coefs[c], ref[c])
+        np.testing.assert_array_equal(qt[c], ref_info["qt"][ref_info["comps"][c]["tq"]])
+
+
+@pytest.mark.parametrize("h,w,kw", [(480, 640, dict(quality=75, subsampling=2)), (427, 640, dict(quality=92, subsampling=0)),
+                                    (333, 500, dict(quality=50, subsampling=1, restart_marker_rows=2)),
+                                    (600, 401, dict(quality=85, subsampling=2, optimize=True))])
+def test_large_images_reproduce_pillow(h, w, kw):
+    data = _jpeg(_picture(h, w, seed=w), **kw)
+    info, coefs, qt = jpeg_entropy_decode(data)
+    ref_info = oj.parse(data)
+    ref_info.update(hmax=info["h_samp"], vmax=info["v_samp"])
+    ref_info["comps"][0]["h"], ref_info["comps"][0]["v"] = info["h_samp"], info["v_samp"]
+    np.testing.assert_array_equal(oj.decode_planes(ref_info, coefs), _pil(data))
+
+
+def test_grey_and_orientation_fields():
+    img = _picture(37, 52, 5)
+    data = _jpeg(img, mode="L", quality=80)
+    info, coefs, _ = jpeg_entropy_decode(data)
+    assert info["components"] == 1 and coefs[0].shape == (5, 7, 64)
+    np.testing.assert_array_equal(coefs[0], oj.entropy_decode(data)[1][0])
+    ex = Image.Exif()
+    ex[0x0112] = 6
+    buf = io.BytesIO()
+    Image.fromarray(img).save(buf, "JPEG", quality=90, exif=ex.tobytes())
+    assert jpeg_info(buf.getvalue())["orientation"] == 6
+
+
+def test_refusals():
+    img = _picture(32, 32, 9)
+    with pytest.raises(UnsupportedInput):
+        jpeg_info(_jpeg(img, quality=80, progressive=True))
+    buf = io.BytesIO()
+    Image.fromarray(img).convert("CMYK").save(buf, "JPEG")
+    with pytest.raises(UnsupportedInput):
+        jpeg_info(buf.getvalue())
+    with pytest.raises(RuntimeError):
+        jpeg_info(b"definitely not a jpeg")
+    good = _jpeg(img, quality=80)
+    for cut in (3, 20, 100, 300):                                        # truncated headers are errors, never crashes
+        try:
+            jpeg_info(good[:cut])
+        except RuntimeError:
+            pass
+
+
+def test_truncated_and_corrupt_entropy_data_do_not_crash():
+    data = _jpeg(_picture(64, 64, 3), quality=80)
+    start = oj.parse(data)["data_start"]
+    cut = data[:start + (len(data) - start) // 2]                        # half of the scan is missing: zero bits from there on, like libjpeg
+    info, coefs, _ = jpeg_entropy_decode(cut)
+    ref = oj.entropy_decode(cut)[1]
+    for c in range(3):
+        np.testing.assert_array_equal(coefs[c], ref[c])
+    rng = np.random.default_rng(0)
+    for _ in range(50):
+        junk = bytearray(data)
+        for pos in rng.integers(start, len(data) - 2, 8):
+            junk[pos] = rng.integers(0, 256)
+        jpeg_entropy_decode(bytes(junk))
+        hdr = bytearray(data)
+        for pos in rng.integers(2, start, 4):
+            hdr[pos] = rng.integers(0, 256)
+        try:
+            jpeg_entropy_decode(bytes(hdr))
+        except RuntimeError:
+            pass
