@@ -273,6 +273,10 @@ int odise_hip_jpeg_entropy_decode(const void* data, int64_t len, int16_t* coefs,
  * out_h / out_w (height and width swap for EXIF orientations 5..8 when apply_orientation != 0).  Asynchronous on the context's stream. */
 int odise_hip_jpeg_decode(odise_hip_ctx* ctx, const void* data, int64_t len, void* dst_rgb, int64_t dst_capacity, int apply_orientation,
                           int* out_h, int* out_w);
+/* the device half on its own: coefficients and tables as produced by odise_hip_jpeg_entropy_decode (which is thread-safe and can run
+ * in loader threads while this context is busy with the previous image) */
+int odise_hip_jpeg_decode_coefs(odise_hip_ctx* ctx, const odise_jpeg_info* info, const int16_t* coefs, const uint16_t* qtables, void* dst_rgb,
+                                int64_t dst_capacity, int apply_orientation, int* out_h, int* out_w);
 
 #ifdef __cplusplus
 }

@@ -31,6 +31,10 @@ struct HuffTable {
     int32_t maxcode[18];     // largest code of each length (-1 = none); [17] is a sentinel that always matches
     int32_t valoff[17];      // symbol index = code + valoff[length]
     uint8_t vals[256];
+    // AC shortcut: when code + magnitude bits fit the 9-bit lookahead, the whole (run, value) pair comes from one lookup
+    uint8_t fast_len[512];   // code length + magnitude bits (0 = take the general path)
+    uint8_t fast_run[512];
+    int16_t fast_val[512];
 };
 
 static bool build_table(const uint8_t* counts, const uint8_t* symbols, int nsym, HuffTable& t) {
@@ -56,6 +60,17 @@ static bool build_table(const uint8_t* counts, const uint8_t* symbols, int nsym,
         code <<= 1;
     }
     t.maxcode[17] = 0x7fffffff;
+    for (int i = 0; i < 512; ++i) {
+        t.fast_len[i] = 0;
+        const int len = t.look_bits[i];
+        if (!len) continue;
+        const int rs = t.look_sym[i], mag = rs & 15;
+        if (mag == 0 || len + mag > 9) continue;
+        const int bits = (i >> (9 - len - mag)) & ((1 << mag) - 1);
+        t.fast_len[i] = (uint8_t)(len + mag);
+        t.fast_run[i] = (uint8_t)(rs >> 4);
+        t.fast_val[i] = (int16_t)(bits < (1 << (mag - 1)) ? bits - (1 << mag) + 1 : bits);
+    }
     t.present = true;
     return true;
 }
@@ -208,52 +223,65 @@ static int parse_header(const uint8_t* d, int64_t len, JpegHeader& H) {
     return ODISE_OK;
 }
 
-// Bit reader over the entropy-coded segment: removes the FF00 stuffing, stops at the first marker and then supplies zero bits.
-struct BitReader {
-    const uint8_t* p;
-    const uint8_t* end;
-    uint64_t acc = 0;
-    int n = 0;
-    bool marker = false;
-    inline void fill() {
-        while (n <= 56) {
-            unsigned b = 0;
-            if (!marker && p < end) {
-                b = *p++;
-                if (b == 0xFF) {
-                    const unsigned c = p < end ? *p : 0xD9u;
-                    if (c == 0) ++p;
-                    else { marker = true; --p; b = 0; }
-                }
-            }
-            acc = (acc << 8) | b;
-            n += 8;
-        }
+// The entropy-coded data is first copied out of the file with the FF00 stuffing removed and cut into restart segments; every segment
+// is followed by 16 zero bytes, so the bit reader below can load 8 bytes at a time without checks and a truncated or corrupt stream
+// decodes as zero bits (what libjpeg supplies after a premature end) instead of running into its neighbour.
+struct Segments {
+    std::vector<uint8_t> bytes;
+    std::vector<size_t> begin;  // per segment: offset of its first byte; its zero padding ends at the next segment's begin
+};
+
+static void unstuff(const uint8_t* d, int64_t len, int64_t start, Segments& S) {
+    S.bytes.clear();
+    S.begin.clear();
+    S.bytes.reserve((size_t)(len - start) + 64);
+    S.begin.push_back(0);
+    const uint8_t* p = d + start;
+    const uint8_t* end = d + len;
+    auto pad = [&]() { S.bytes.insert(S.bytes.end(), 16, (uint8_t)0); };
+    while (p < end) {
+        const uint8_t* ff = (const uint8_t*)memchr(p, 0xFF, (size_t)(end - p));
+        if (!ff) { S.bytes.insert(S.bytes.end(), p, end); break; }
+        S.bytes.insert(S.bytes.end(), p, ff);
+        p = ff + 1;
+        while (p < end && *p == 0xFF) ++p;  // fill bytes
+        if (p >= end) break;
+        const unsigned m = *p++;
+        if (m == 0) S.bytes.push_back(0xFF);
+        else if (m >= 0xD0 && m <= 0xD7) { pad(); S.begin.push_back(S.bytes.size()); }
+        else break;  // any other marker ends the scan
     }
-    inline unsigned peek(int k) const { return (unsigned)((acc >> (n - k)) & ((1u << k) - 1)); }
-    inline unsigned take(int k) { n -= k; return (unsigned)((acc >> n) & ((1u << k) - 1)); }
+    pad();
+    S.begin.push_back(S.bytes.size());
+}
+
+struct BitReader {
+    const uint8_t* p = nullptr;
+    const uint8_t* limit = nullptr;  // start of the segment's zero padding: loads never begin beyond it
+    uint64_t acc = 0;                // valid bits are MSB-aligned
+    int n = 0;
+    inline void open(const uint8_t* b, const uint8_t* e) { p = b; limit = e; acc = 0; n = 0; }
+    inline void fill() {             // afterwards n >= 56
+        if (p > limit) p = limit;
+        uint64_t w;
+        memcpy(&w, p, 8);
+        acc |= __builtin_bswap64(w) >> n;
+        p += (63 - n) >> 3;
+        n |= 56;
+    }
+    inline unsigned peek(int k) const { return (unsigned)(acc >> (64 - k)); }
+    inline void skip(int k) { acc <<= k; n -= k; }
+    inline unsigned take(int k) { const unsigned v = (unsigned)(acc >> (64 - k)); acc <<= k; n -= k; return v; }
     inline int symbol(const HuffTable& t) {  // needs >= 16 valid bits
         const unsigned look = peek(9);
         const int nb = t.look_bits[look];
-        if (nb) { n -= nb; return t.look_sym[look]; }
+        if (nb) { skip(nb); return t.look_sym[look]; }
         for (int len = 10; len <= 16; ++len) {
             const int code = (int)peek(len);
-            if (code <= t.maxcode[len]) { n -= len; return t.vals[(code + t.valoff[len]) & 255]; }
+            if (code <= t.maxcode[len]) { skip(len); return t.vals[(code + t.valoff[len]) & 255]; }
         }
-        n -= 16;
+        skip(16);
         return -1;  // not a code of this table (corrupt data)
-    }
-    // skip to just after the next RSTn (or stay at any other marker / the end)
-    inline void restart() {
-        acc = 0;
-        n = 0;
-        marker = false;
-        while (p + 1 < end && !(p[0] == 0xFF && p[1] >= 0xD0 && p[1] <= 0xD7)) {
-            if (p[0] == 0xFF && p[1] != 0 && p[1] != 0xFF) { marker = true; return; }  // some other marker: the data ends here
-            ++p;
-        }
-        if (p + 1 < end) p += 2;
-        else p = end;
     }
 };
 
@@ -261,16 +289,25 @@ static inline int extend(unsigned v, int s) { return (s && v < (1u << (s - 1))) 
 
 // coefs: H.coef_count int16, zero-filled by the caller; natural (row-major) order inside a block, not dequantised
 static void entropy_decode(const uint8_t* d, int64_t len, const JpegHeader& H, int16_t* coefs) {
+    Segments S;
+    unstuff(d, len, H.data_start, S);
+    const size_t nseg = S.begin.size() - 1;
+    static const uint8_t zeros[32] = {0};
+    size_t seg = 0;
     BitReader br;
-    br.p = d + H.data_start;
-    br.end = d + len;
+    auto open_segment = [&]() {
+        if (seg < nseg) br.open(S.bytes.data() + S.begin[seg], S.bytes.data() + S.begin[seg + 1] - 16);
+        else br.open(zeros, zeros);  // the stream has fewer restart segments than MCUs need: zero bits
+        ++seg;
+    };
+    open_segment();
     int pred[3] = {0, 0, 0};
     const int nm = H.mcus_x * H.mcus_y;
     int until_restart = H.restart;
     for (int mcu = 0; mcu < nm; ++mcu) {
         if (H.restart) {
             if (until_restart == 0) {
-                br.restart();
+                open_segment();
                 pred[0] = pred[1] = pred[2] = 0;
                 until_restart = H.restart;
             }
@@ -290,6 +327,15 @@ static void entropy_decode(const uint8_t* d, int64_t len, const JpegHeader& H, i
                     blk[0] = (int16_t)pred[c];
                     for (int k = 1; k < 64;) {
                         br.fill();
+                        const unsigned look = br.peek(9);
+                        const int fl = act.fast_len[look];
+                        if (fl) {  // code and magnitude bits inside the lookahead
+                            k += act.fast_run[look];
+                            if (k > 63) break;
+                            br.skip(fl);
+                            blk[kZigzag[k++]] = act.fast_val[look];
+                            continue;
+                        }
                         const int rs = br.symbol(act);
                         if (rs < 0) break;
                         const int r = rs >> 4;
@@ -505,36 +551,41 @@ extern "C" int odise_hip_jpeg_entropy_decode(const void* data, int64_t len, int1
     return ODISE_OK;
 }
 
-extern "C" int odise_hip_jpeg_decode(odise_hip_ctx* ctx, const void* data, int64_t len, void* dst_rgb, int64_t dst_capacity, int apply_orientation,
-                                     int* out_h, int* out_w) {
-    ODISE_REQUIRE(ctx && data && dst_rgb && len > 0, "jpeg_decode: null argument");
-    std::vector<JpegHeader> hv(1);
-    JpegHeader& H = hv[0];
-    int rc = parse_header((const uint8_t*)data, len, H);
-    if (rc != ODISE_OK) return rc;
-    const int orient = apply_orientation ? H.orientation : 1;
+namespace odise {
+struct JpegDims {
+    int width, height, ncomp, hmax, vmax, orientation;
+    int bx[3], by[3];
+    int64_t coef_off[3], coef_count;
+    uint16_t qt[3][64];
+};
+
+// Device half: `fill(int16_t* pinned)` produces the coefficients in the context's pinned staging buffer; upload, IDCT, colour.
+template <class Fill>
+static int jpeg_device_stage(odise_hip_ctx* ctx, const JpegDims& D, Fill&& fill, void* dst_rgb, int64_t dst_capacity, int apply_orientation, int* out_h,
+                             int* out_w) {
+    const int orient = apply_orientation ? D.orientation : 1;
     const bool swap = orient >= 5;
-    const int OH = swap ? H.width : H.height, OW = swap ? H.height : H.width;
+    const int OH = swap ? D.width : D.height, OW = swap ? D.height : D.width;
     if (out_h) *out_h = OH;
     if (out_w) *out_w = OW;
     ODISE_REQUIRE(dst_capacity >= (int64_t)OH * OW * 3, "jpeg_decode: output buffer too small for %dx%d RGB", OH, OW);
     ODISE_CHECK_HIP(hipSetDevice(ctx->device));
     // ---- staging: pinned host coefficients (reused once the previous image's upload has finished), device coefficients + planes
-    const size_t coef_bytes = (size_t)H.coef_count * sizeof(int16_t);
+    const size_t coef_bytes = (size_t)D.coef_count * sizeof(int16_t);
     JpegPlanes P;
     JpegColor G;
-    P.ncomp = G.ncomp = H.ncomp;
+    P.ncomp = G.ncomp = D.ncomp;
     int64_t poff = (int64_t)round_up((int64_t)coef_bytes, 256), nblk = 0;
     for (int c = 0; c < 3; ++c) {
-        const bool on = c < H.ncomp;
-        P.bx[c] = on ? H.bx[c] : 0;
-        P.by[c] = on ? H.by[c] : 0;
-        P.coef_off[c] = on ? H.coef_off[c] : 0;
+        const bool on = c < D.ncomp;
+        P.bx[c] = on ? D.bx[c] : 0;
+        P.by[c] = on ? D.by[c] : 0;
+        P.coef_off[c] = on ? D.coef_off[c] : 0;
         P.plane_off[c] = G.plane_off[c] = poff;
         P.first_block[c] = nblk;
         G.pitch[c] = P.bx[c] * 8;
         if (on) {
-            memcpy(P.qt[c], H.qt[H.tq[c]], sizeof(P.qt[c]));
+            memcpy(P.qt[c], D.qt[c], sizeof(P.qt[c]));
             poff += (int64_t)round_up((int64_t)P.bx[c] * P.by[c] * 64, 256);
             nblk += (int64_t)P.bx[c] * P.by[c];
         } else {
@@ -562,24 +613,82 @@ extern "C" int odise_hip_jpeg_decode(odise_hip_ctx* ctx, const void* data, int64
         ctx->jpeg_dev_bytes = want;
     }
     int16_t* hc = (int16_t*)ctx->jpeg_host;
-    memset(hc, 0, coef_bytes);
-    entropy_decode((const uint8_t*)data, len, H, hc);
+    fill(hc);
     ODISE_CHECK_HIP(hipMemcpyAsync(ctx->jpeg_dev, hc, coef_bytes, hipMemcpyHostToDevice, ctx->stream));
     ODISE_CHECK_HIP(hipEventRecord(ctx->jpeg_ev, ctx->stream));
     uint8_t* dev = (uint8_t*)ctx->jpeg_dev;
     hipLaunchKernelGGL(jpeg_idct_kernel, dim3((unsigned)ceil_div(nblk, 32)), dim3(256), 0, ctx->stream, (const int16_t*)dev, dev, P);
     ODISE_CHECK_HIP(hipGetLastError());
-    G.W = H.width;
-    G.H = H.height;
+    G.W = D.width;
+    G.H = D.height;
     G.OW = OW;
     G.OH = OH;
     G.orientation = orient;
-    G.hx = H.hmax;  // chroma is 1x1: its expansion factors are the luma sampling factors
-    G.vx = H.vmax;
-    G.dw = (H.width + H.hmax - 1) / H.hmax;
-    G.dh = (H.height + H.vmax - 1) / H.vmax;
+    G.hx = D.hmax;  // chroma is 1x1: its expansion factors are the luma sampling factors
+    G.vx = D.vmax;
+    G.dw = (D.width + D.hmax - 1) / D.hmax;
+    G.dh = (D.height + D.vmax - 1) / D.vmax;
     const int64_t npix = (int64_t)OW * OH;
     hipLaunchKernelGGL(jpeg_color_kernel, dim3((unsigned)ceil_div(npix, 256)), dim3(256), 0, ctx->stream, (const uint8_t*)dev, (uint8_t*)dst_rgb, G);
     ODISE_CHECK_HIP(hipGetLastError());
     return ODISE_OK;
+}
+}  // namespace odise
+
+extern "C" int odise_hip_jpeg_decode(odise_hip_ctx* ctx, const void* data, int64_t len, void* dst_rgb, int64_t dst_capacity, int apply_orientation,
+                                     int* out_h, int* out_w) {
+    ODISE_REQUIRE(ctx && data && dst_rgb && len > 0, "jpeg_decode: null argument");
+    std::vector<JpegHeader> hv(1);
+    JpegHeader& H = hv[0];
+    const int rc = parse_header((const uint8_t*)data, len, H);
+    if (rc != ODISE_OK) return rc;
+    JpegDims D;
+    D.width = H.width;
+    D.height = H.height;
+    D.ncomp = H.ncomp;
+    D.hmax = H.hmax;
+    D.vmax = H.vmax;
+    D.orientation = H.orientation;
+    D.coef_count = H.coef_count;
+    for (int c = 0; c < 3; ++c) {
+        D.bx[c] = H.bx[c];
+        D.by[c] = H.by[c];
+        D.coef_off[c] = H.coef_off[c];
+        if (c < H.ncomp) memcpy(D.qt[c], H.qt[H.tq[c]], sizeof(D.qt[c]));
+    }
+    return jpeg_device_stage(ctx, D, [&](int16_t* hc) {
+        memset(hc, 0, (size_t)H.coef_count * sizeof(int16_t));
+        entropy_decode((const uint8_t*)data, len, H, hc);
+    }, dst_rgb, dst_capacity, apply_orientation, out_h, out_w);
+}
+
+extern "C" int odise_hip_jpeg_decode_coefs(odise_hip_ctx* ctx, const odise_jpeg_info* info, const int16_t* coefs, const uint16_t* qtables, void* dst_rgb,
+                                           int64_t dst_capacity, int apply_orientation, int* out_h, int* out_w) {
+    ODISE_REQUIRE(ctx && info && coefs && qtables && dst_rgb, "jpeg_decode_coefs: null argument");
+    JpegDims D;
+    D.width = info->width;
+    D.height = info->height;
+    D.ncomp = info->components;
+    D.hmax = info->h_samp;
+    D.vmax = info->v_samp;
+    D.orientation = (info->orientation >= 1 && info->orientation <= 8) ? info->orientation : 1;
+    ODISE_REQUIRE(D.width > 0 && D.height > 0 && D.width <= 65535 && D.height <= 65535 && (D.ncomp == 1 || D.ncomp == 3), "jpeg_decode_coefs: bad image description");
+    const bool samp_ok = D.ncomp == 1 ? (D.hmax == 1 && D.vmax == 1) : ((D.hmax == 1 && D.vmax == 1) || (D.hmax == 2 && (D.vmax == 1 || D.vmax == 2)));
+    ODISE_REQUIRE(samp_ok, "jpeg_decode_coefs: sampling factors %dx%d are not supported", D.hmax, D.vmax);
+    const int mx = (D.width + 8 * D.hmax - 1) / (8 * D.hmax), my = (D.height + 8 * D.vmax - 1) / (8 * D.vmax);
+    int64_t off = 0;
+    for (int c = 0; c < 3; ++c) {
+        D.bx[c] = c < D.ncomp ? mx * (c == 0 ? D.hmax : 1) : 0;
+        D.by[c] = c < D.ncomp ? my * (c == 0 ? D.vmax : 1) : 0;
+        D.coef_off[c] = off;
+        off += (int64_t)D.bx[c] * D.by[c] * 64;
+        if (c < D.ncomp) {
+            ODISE_REQUIRE(info->blocks_x[c] == D.bx[c] && info->blocks_y[c] == D.by[c], "jpeg_decode_coefs: block grid does not match the image size");
+            memcpy(D.qt[c], qtables + 64 * c, sizeof(D.qt[c]));
+        }
+    }
+    D.coef_count = off;
+    ODISE_REQUIRE(info->coef_count == off, "jpeg_decode_coefs: coefficient count does not match the image size");
+    return jpeg_device_stage(ctx, D, [&](int16_t* hc) { memcpy(hc, coefs, (size_t)off * sizeof(int16_t)); }, dst_rgb, dst_capacity, apply_orientation,
+                             out_h, out_w);
 }

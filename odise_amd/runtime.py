@@ -337,6 +337,30 @@ class Context:
         return out.view((h.value, w.value, 3)) if out.shape != (h.value, w.value, 3) else out
 
 
+def _jpeg_info_struct(info: dict):
+    from ._lib import JpegInfo
+    st = JpegInfo()
+    for k in ("width", "height", "components", "h_samp", "v_samp", "orientation", "restart_interval", "coef_count"):
+        setattr(st, k, info[k])
+    for c in range(info["components"]):
+        st.blocks_x[c], st.blocks_y[c] = info["blocks_x"][c], info["blocks_y"][c]
+    return st
+
+
+def jpeg_decode_coefs(ctx: Context, info: dict, coefs, qt, apply_orientation: bool = True) -> DeviceArray:
+    """Device half of the decoder on coefficients from `jpeg_entropy_decode` (which may have run in a loader thread)."""
+    swap = apply_orientation and info["orientation"] >= 5
+    oh, ow = (info["width"], info["height"]) if swap else (info["height"], info["width"])
+    out = ctx.empty((oh, ow, 3), np.uint8)
+    flat = coefs if isinstance(coefs, np.ndarray) else np.concatenate([np.asarray(c).ravel() for c in coefs])
+    flat = np.ascontiguousarray(flat.ravel(), np.int16)
+    qt = np.ascontiguousarray(qt, np.uint16)
+    st = _jpeg_info_struct(info)
+    check(ctx.lib.odise_hip_jpeg_decode_coefs(ctx.h, C.byref(st), flat.ctypes.data_as(C.c_void_p), qt.ctypes.data_as(C.c_void_p), _p(out),
+                                              C.c_int64(out.nbytes), int(bool(apply_orientation)), None, None), "jpeg_decode_coefs")
+    return out
+
+
 def jpeg_info(data: bytes) -> dict:
     """Header fields of a JPEG byte stream (host only)."""
     from ._lib import JpegInfo, load
@@ -348,8 +372,9 @@ def jpeg_info(data: bytes) -> dict:
                 blocks_y=list(info.blocks_y)[:info.components], coef_count=info.coef_count)
 
 
-def jpeg_entropy_decode(data: bytes):
-    """Host half of the decoder on its own: (info, [int16 [blocks_y, blocks_x, 64] per component], uint16 [components, 64] tables)."""
+def jpeg_entropy_decode(data: bytes, flat: bool = False):
+    """Host half of the decoder on its own: (info, [int16 [blocks_y, blocks_x, 64] per component], uint16 [components, 64] tables);
+    `flat=True` returns the coefficients as the one int16 array `jpeg_decode_coefs` uploads.  Thread-safe (no context involved)."""
     from ._lib import load
     info = jpeg_info(data)
     coefs = np.zeros(info["coef_count"], np.int16)
@@ -357,9 +382,11 @@ def jpeg_entropy_decode(data: bytes):
     buf = (C.c_ubyte * len(data)).from_buffer_copy(data)
     check(load().odise_hip_jpeg_entropy_decode(buf, C.c_int64(len(data)), coefs.ctypes.data_as(C.c_void_p), C.c_int64(coefs.size),
                                                qt.ctypes.data_as(C.c_void_p)), "jpeg_entropy_decode")
+    if flat:
+        return info, coefs, qt
     out, off = [], 0
     for by, bx in zip(info["blocks_y"], info["blocks_x"]):
-        out.append(coefs[off:off + by * bx * 64].reshape(by, bx, 64))
+        out.append(coefs[off:off + by * bx * 64].reshape(by, bx, 64))    # views of one flat array (what jpeg_decode_coefs uploads)
         off += by * bx * 64
     return info, out, qt
 

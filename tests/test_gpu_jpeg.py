@@ -77,3 +77,21 @@ def test_dataset_mapper_matches_read_image_and_resize(ctx):
     want = np.zeros((3, 256, 320), np.float32)
     want[:, :nh, :nw] = ref.transpose(2, 0, 1).astype(np.float32) * np.float32(1.0 / 255.0)
     np.testing.assert_array_equal(padded, want)
+
+
+def test_loader_threads_give_the_same_images(ctx):
+    from odise_amd.runtime import jpeg_decode_coefs, jpeg_entropy_decode
+    dicts = [{"jpeg": _jpeg(_picture(h, w, seed=i), quality=80, subsampling=sub), "image_id": i}
+             for i, (h, w, sub) in enumerate([(120, 160, 2), (97, 64, 0), (64, 201, 1), (300, 200, 2), (33, 47, 2), (128, 128, 0), (250, 99, 1)])]
+    mapper = HipDatasetMapper(ctx, short_edge_length=96, max_size=200)
+    one_by_one = [mapper(d) for d in dicts]
+    threaded = list(mapper.map_many(dicts, workers=3))
+    assert [d["image_id"] for d in threaded] == list(range(len(dicts)))
+    for a, b in zip(one_by_one, threaded):
+        assert (a["height"], a["width"]) == (b["height"], b["width"])
+        np.testing.assert_array_equal(a["image"].numpy(), b["image"].numpy())
+    info, coefs, qt = jpeg_entropy_decode(dicts[3]["jpeg"])
+    np.testing.assert_array_equal(jpeg_decode_coefs(ctx, info, coefs, qt).numpy(), _pil(dicts[3]["jpeg"]))
+    bad = dict(info, width=info["width"] + 64)
+    with pytest.raises(RuntimeError):
+        jpeg_decode_coefs(ctx, bad, coefs, qt)

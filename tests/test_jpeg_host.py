@@ -93,3 +93,13 @@ def test_truncated_and_corrupt_entropy_data_do_not_crash():
             jpeg_entropy_decode(bytes(hdr))
         except RuntimeError:
             pass
+
+
+def test_entropy_decoder_is_thread_safe():
+    from concurrent.futures import ThreadPoolExecutor
+    datas = [_jpeg(_picture(90 + 7 * i, 120 + 5 * i, seed=i), quality=60 + 3 * i, subsampling=i % 3) for i in range(12)]
+    serial = [jpeg_entropy_decode(d, flat=True)[1] for d in datas]
+    with ThreadPoolExecutor(max_workers=6) as pool:
+        for _ in range(3):
+            for want, got in zip(serial, pool.map(lambda d: jpeg_entropy_decode(d, flat=True)[1], datas)):
+                np.testing.assert_array_equal(want, got)
