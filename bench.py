@@ -42,6 +42,7 @@ def parse():
     p.add_argument("--size", type=int, default=1024)
     p.add_argument("--stage", choices=["full", "unet"], default="full")
     p.add_argument("--no-cpu-baseline", action="store_true")
+    p.add_argument("--no-inclusive", action="store_true", help="skip the PCIe- / JPEG-inclusive legs")
     return p.parse_args()
 
 
@@ -120,7 +121,58 @@ def dominant_kernel(ctx):
     for a in (X, Wt, O):
         a.free()
     return {"kernel": "conv3_halo_kernel<256,2> (3x3 conv 512->512 @128x128, 16 crops)", "launch_us": us, "flops": flops,
-            "achieved": flops / (us * 1e-6) / 1e12, "traffic": traffic, "launches_per_step": 7}
+            "achieved": flops / (us * 1e-6) / 1e12, "traffic": traffic, "launches_per_step": 7, "ceiling": mfma_ceiling(ctx)}
+
+
+def mfma_ceiling(ctx):
+    """What the matrix pipes of THIS device sustain on random fp16 operands held in registers (no memory traffic at all; the ping-pong
+    barrier skeleton of the GEMM kernels): odise_amd/csrc/probe.hip, tools/mfma_rate.py.  The part is power-limited - the shader clock
+    drops from ~2.4 GHz (constant operands: 2.4-2.5 PFLOP/s) to ~1.6 GHz - so this, not the spec sheet, is what a GEMM can approach."""
+    import ctypes as C
+    ms, fl, mhz = C.c_float(0), C.c_double(0), C.c_double(0)
+    cus = ctx.device_info()[1]
+    if ctx.lib.odise_hip_mfma_rate(ctx.h, 8, 1000, cus * 4, 8, C.byref(ms), C.byref(fl), C.byref(mhz)) != 0:
+        return None
+    return {"tflops": fl.value / (ms.value * 1e-3) / 1e12, "shader_clock_mhz": mhz.value,
+            "what": "v_mfma_f32_32x32x16_f16 on register-resident random operands, 2 waves/SIMD, barrier skeleton of the GEMM kernels, 8 launches"}
+
+
+def inclusive_rates(ctx, hip, img, S, B, steps):
+    """images/s of the same batch when the boundary hands over (a) uint8 HWC host arrays (upload + conversion on the device) and
+    (b) JPEG files (odise_amd.ingest.HipDatasetMapper: Huffman decoding on host threads, the rest on the device)."""
+    import io
+    u8 = [np.ascontiguousarray((img[b].transpose(1, 2, 0) * 255.0).astype(np.uint8)) for b in range(B)]
+
+    def timed(fn):
+        fn()
+        ctx.sync()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            fn()
+        ctx.sync()
+        return (time.perf_counter() - t0) / steps
+
+    t_host = timed(lambda: hip.forward([{"image": ctx.to_device(u), "height": S, "width": S} for u in u8], to_host=False))
+    out = {"host_u8": {"value": B / t_host, "unit": "images/s", "ms_per_step": t_host * 1e3,
+                       "what": f"{B} uint8 [{S},{S},3] host arrays uploaded over PCIe and converted on the device every step"}}
+    try:
+        from PIL import Image
+        from odise_amd.ingest import HipDatasetMapper
+        jpegs = []
+        for u in u8:
+            yy, xx = np.mgrid[0:S, 0:S]
+            pic = np.stack([128 + 100 * np.sin(xx / 37.0) * np.cos(yy / 29.0), 128 + 90 * np.cos(xx / 23.0 - yy / 41.0), (xx + yy) % 256], -1)
+            pic = np.clip(pic + (u.astype(np.float32) - 128) * 0.08, 0, 255).astype(np.uint8)   # photo-like statistics (~2 bits/pixel)
+            buf = io.BytesIO()
+            Image.fromarray(pic).save(buf, "JPEG", quality=90, subsampling=2)
+            jpegs.append(buf.getvalue())
+        mapper = HipDatasetMapper(ctx)
+        t_jpeg = timed(lambda: hip.forward(list(mapper.map_many([{"jpeg": j} for j in jpegs], workers=4)), to_host=False))
+        out["jpeg"] = {"value": B / t_jpeg, "unit": "images/s", "ms_per_step": t_jpeg * 1e3,
+                       "what": f"{B} baseline JPEG files ({sum(map(len, jpegs)) // B // 1000} kB each, 4:2:0, quality 90) decoded every step"}
+    except ImportError:  # Pillow only writes the test files
+        pass
+    return out
 
 
 def main():
@@ -221,6 +273,12 @@ def main():
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         wall, ev_ms = float(tt[0]), float(tt[1])
 
+    # Boundary variants, reported beside `value` (never as it): the same step fed from host memory over PCIe, and from JPEG bytes
+    # (host Huffman decoding in loader threads + device IDCT / resize).  Outputs stay on the device as in the reference.
+    inclusive = None
+    if rank == 0 and world == 1 and args.stage == "full" and not args.no_inclusive:
+        inclusive = inclusive_rates(ctx, hip, img, S, B, max(2, min(args.steps, 3)))
+
     dom = dominant_kernel(ctx) if (rank == 0 and args.stage == "full") else None
     if rank == 0:
         ms_per_step = wall * 1e3 / args.steps
@@ -244,7 +302,11 @@ def main():
                                "frac": dom["achieved"] * 1e12 / MFMA_F16_PEAK, "traffic": dom["traffic"], "kernel": dom["kernel"],
                                "launch_us": dom["launch_us"], "algorithmic_flops_per_launch": dom["flops"], "launches_per_step": dom["launches_per_step"],
                                "step_achieved": achieved, "step_frac": achieved * 1e12 / MFMA_F16_PEAK,
+                               "measured_ceiling": dom["ceiling"],
+                               "frac_of_measured_ceiling": (dom["achieved"] / dom["ceiling"]["tflops"]) if dom["ceiling"] else None,
                                "algorithmic_flops_per_unit": flops_per_unit, "event_ms_per_step": step_ms_ev}
+        if inclusive is not None:
+            out["inclusive"] = inclusive
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = baseline()
         print(json.dumps(out), flush=True)

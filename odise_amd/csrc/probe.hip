@@ -42,3 +42,106 @@ extern "C" int odise_hip_mfma_probe(odise_hip_ctx* ctx, float* host_out /* [3][6
     ODISE_CHECK_HIP(hipFree(d));
     return ODISE_OK;
 }
+
+// ---- MFMA issue-rate probe (tools/mfma_rate.py): what the matrix pipes sustain on this part without any operand traffic -----------
+// Every wave runs `iters` rounds of 16 v_mfma_f32_32x32x16_f16 over CHAINS independent accumulator tiles.  MODE selects the
+// synchronisation skeleton around each round: 0 none (free running), 1 one workgroup barrier per round, 2 the ping-pong skeleton of
+// gemm_pp_kernel (two barriers per round, wave group 1 staggered by one barrier), 3 one barrier per two rounds.
+namespace odise {
+// RANDOM: four distinct A and B fragments of pseudo-random fp16 values in [-1, 1) (what a real GEMM feeds the multipliers: the
+// power drawn by the matrix pipes depends on how many operand bits toggle between consecutive instructions) instead of one constant pair.
+template <int CHAINS, int MODE, int THREADS, bool RANDOM>
+__global__ void __launch_bounds__(THREADS) mfma_rate_kernel(float* out, int iters, float seed, unsigned long long* clocks) {
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
+    const int grp = wave >> 2;
+    unsigned long long c0 = 0, r0 = 0;
+    if (blockIdx.x == 0 && threadIdx.x == 0) { c0 = __builtin_readcyclecounter(); r0 = wall_clock64(); }
+    f16x8 af[4], bf[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            if (RANDOM) {
+                unsigned h = (unsigned)(threadIdx.x * 8 + e) * 2654435761u + (unsigned)q * 40503u + blockIdx.x * 97u;
+                h ^= h >> 15; h *= 2246822519u; h ^= h >> 13;
+                af[q][e] = (f16)(seed * ((float)(h & 0xffff) / 32768.f - 1.f));
+                bf[q][e] = (f16)(seed * ((float)(h >> 16) / 32768.f - 1.f));
+            } else {
+                af[q][e] = (f16)(seed * (float)((lane + e) & 3));
+                bf[q][e] = (f16)(seed * (float)((lane * 3 + e) & 1));
+            }
+        }
+    f32x16 acc[CHAINS];
+#pragma unroll
+    for (int c = 0; c < CHAINS; ++c)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[c][r] = 0.f;
+    if (MODE == 2 && grp == 1) __builtin_amdgcn_s_barrier();
+    for (int it = 0; it < iters; ++it) {
+        if (MODE == 2) { __builtin_amdgcn_sched_barrier(0); __builtin_amdgcn_s_barrier(); __builtin_amdgcn_sched_barrier(0); }
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int s = 0; s < 16 / CHAINS; ++s)
+#pragma unroll
+            for (int c = 0; c < CHAINS; ++c)
+                acc[c] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[RANDOM ? (c & 1) * 2 + (s & 1) : 0], bf[RANDOM ? (c >> 1 & 1) * 2 + (s >> 1 & 1) : 0], acc[c], 0, 0, 0);
+        __builtin_amdgcn_s_setprio(0);
+        if (MODE == 1 || MODE == 2 || (MODE == 3 && (it & 1))) {
+            __builtin_amdgcn_sched_barrier(0);
+            __builtin_amdgcn_s_barrier();
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+    if (MODE == 2 && grp == 0) __builtin_amdgcn_s_barrier();
+    float s = 0.f;
+#pragma unroll
+    for (int c = 0; c < CHAINS; ++c)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) s += acc[c][r];
+    if (s == 12345.678f) out[threadIdx.x] = s;  // keeps the accumulators alive; never true for the seeds used
+    if (blockIdx.x == 0 && threadIdx.x == 0) {     // shader cycles and 100 MHz reference ticks of this workgroup: the clock it ran at
+        clocks[0] = __builtin_readcyclecounter() - c0;
+        clocks[1] = wall_clock64() - r0;
+    }
+}
+}  // namespace odise
+
+// variant: 0 free/2 waves per SIMD/4 chains, 1 free/1 wave per SIMD/4 chains, 2 ping-pong skeleton, 3 barrier per round,
+// 4 barrier per two rounds, 5 free/2 waves/8 chains, 6 free/1 wave/8 chains, 7 = 0 with random operands, 8 = 2 with random operands,
+// 9 = 6 with random operands.  Returns the average launch time of `reps` launches and the shader clock (MHz) of the last one.
+extern "C" int odise_hip_mfma_rate(odise_hip_ctx* ctx, int variant, int iters, int blocks, int reps, float* ms_out, double* flops_out, double* mhz_out) {
+    using namespace odise;
+    ODISE_REQUIRE(ctx && ms_out && flops_out && iters > 0 && blocks > 0 && reps > 0, "mfma_rate: bad argument");
+    float* d = (float*)ctx->ws;
+    unsigned long long* clk = (unsigned long long*)((char*)ctx->ws + 65536);
+    int threads = 512;
+    auto launch = [&]() {
+        switch (variant) {
+            case 0: hipLaunchKernelGGL((mfma_rate_kernel<4, 0, 512, false>), dim3(blocks), dim3(512), 0, ctx->stream, d, iters, 0.5f, clk); break;
+            case 1: threads = 256; hipLaunchKernelGGL((mfma_rate_kernel<4, 0, 256, false>), dim3(blocks), dim3(256), 0, ctx->stream, d, iters, 0.5f, clk); break;
+            case 2: hipLaunchKernelGGL((mfma_rate_kernel<4, 2, 512, false>), dim3(blocks), dim3(512), 0, ctx->stream, d, iters, 0.5f, clk); break;
+            case 3: hipLaunchKernelGGL((mfma_rate_kernel<4, 1, 512, false>), dim3(blocks), dim3(512), 0, ctx->stream, d, iters, 0.5f, clk); break;
+            case 4: hipLaunchKernelGGL((mfma_rate_kernel<4, 3, 512, false>), dim3(blocks), dim3(512), 0, ctx->stream, d, iters, 0.5f, clk); break;
+            case 5: hipLaunchKernelGGL((mfma_rate_kernel<8, 0, 512, false>), dim3(blocks), dim3(512), 0, ctx->stream, d, iters, 0.5f, clk); break;
+            case 6: threads = 256; hipLaunchKernelGGL((mfma_rate_kernel<8, 0, 256, false>), dim3(blocks), dim3(256), 0, ctx->stream, d, iters, 0.5f, clk); break;
+            case 7: hipLaunchKernelGGL((mfma_rate_kernel<4, 0, 512, true>), dim3(blocks), dim3(512), 0, ctx->stream, d, iters, 0.5f, clk); break;
+            case 8: hipLaunchKernelGGL((mfma_rate_kernel<4, 2, 512, true>), dim3(blocks), dim3(512), 0, ctx->stream, d, iters, 0.5f, clk); break;
+            default: threads = 256; hipLaunchKernelGGL((mfma_rate_kernel<8, 0, 256, true>), dim3(blocks), dim3(256), 0, ctx->stream, d, iters, 0.5f, clk); break;
+        }
+    };
+    launch();  // warm-up
+    ODISE_CHECK_HIP(hipEventRecord(ctx->ev0, ctx->stream));
+    for (int r = 0; r < reps; ++r) launch();
+    ODISE_CHECK_HIP(hipEventRecord(ctx->ev1, ctx->stream));
+    ODISE_CHECK_HIP(hipEventSynchronize(ctx->ev1));
+    ODISE_CHECK_HIP(hipGetLastError());
+    float ms = 0.f;
+    ODISE_CHECK_HIP(hipEventElapsedTime(&ms, ctx->ev0, ctx->ev1));
+    *ms_out = ms / reps;
+    *flops_out = (double)blocks * (threads / 64) * (double)iters * 16.0 * 32768.0;
+    unsigned long long hc[2] = {0, 0};
+    ODISE_CHECK_HIP(hipMemcpy(hc, clk, sizeof(hc), hipMemcpyDeviceToHost));
+    if (mhz_out) *mhz_out = hc[1] ? 100.0 * (double)hc[0] / (double)hc[1] : 0.0;
+    return ODISE_OK;
+}

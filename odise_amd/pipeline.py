@@ -338,11 +338,12 @@ class HipCategoryODISE(HipODISE):
         return self.postprocess_batch(mask_cls, (Hp, Wp), (H, W), out_sizes, to_host=to_host,
                                       pan_out=dict(enumerate(pan_out)) if pan_out is not None else None)
 
-    def forward(self, batched_inputs) -> list:
+    def forward(self, batched_inputs, to_host: bool = True) -> list:
         """CategoryODISE.forward, eval branch (odise.py:236-246, 282-372) for a batch of equally sized images.  "image" is a CHW uint8 /
-        float array on the host (values 0..255), or a DeviceArray uint8 [H,W,3] already in HBM (odise_amd.ingest.HipDatasetMapper)."""
+        float array on the host (values 0..255), or a DeviceArray uint8 [H,W,3] already in HBM (odise_amd.ingest.HipDatasetMapper).
+        `to_host=False` leaves the large outputs (sem_seg, panoptic map, instance masks) on the device, like the reference does."""
         if isinstance(batched_inputs[0]["image"], DeviceArray):
-            return self._forward_resident(batched_inputs)
+            return self._forward_resident(batched_inputs, to_host)
         imgs = []
         for x in batched_inputs:
             im = x["image"]
@@ -362,10 +363,9 @@ class HipCategoryODISE(HipODISE):
         self.head_device(None, B, Hp // 4, Wp // 4)
         mask_cls = self.classify_device(self.ctx.to_device(img01)).numpy()
         sizes = [(int(x.get("height", H)), int(x.get("width", W))) for x in batched_inputs]
-        return self.postprocess_batch(mask_cls, (Hp, Wp), (H, W), sizes)
+        return self.postprocess_batch(mask_cls, (Hp, Wp), (H, W), sizes, to_host=to_host)
 
-
-    def _forward_resident(self, batched_inputs) -> list:
+    def _forward_resident(self, batched_inputs, to_host: bool = True) -> list:
         ims = [x["image"] for x in batched_inputs]
         H, W = ims[0].shape[:2]
         assert all(i.dtype == np.uint8 and i.shape == (H, W, 3) for i in ims), "device images: uint8 [H,W,3] of one size"
@@ -378,7 +378,7 @@ class HipCategoryODISE(HipODISE):
             if img01 is not padded:
                 self.ctx.u8_hwc_to_f32_chw_padded(im, H, W, 1.0 / 255.0, out=img01.view((3, H, W), offset_bytes=b * 3 * H * W * 4))
         sizes = [(int(x.get("height", H)), int(x.get("width", W))) for x in batched_inputs]
-        return self.forward_device(padded, img01, sizes, to_host=True)
+        return self.forward_device(padded, img01, sizes, to_host=to_host)
 
 
 class HipCaptionODISE(HipCategoryODISE):
