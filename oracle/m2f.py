@@ -10,7 +10,8 @@ the checkpoint keys `sem_seg_head.pixel_decoder.*`, `sem_seg_head.predictor.*`):
   ODISEMultiScaleMaskedTransformerDecoder       odise/modeling/meta_arch/odise.py:642-776
   PseudoClassEmbed / MaskPooling / PooledMaskEmbed   odise/modeling/meta_arch/odise.py:910-1015
 (M2F = third_party/Mask2Former/mask2former).  The sampling core is oracle.msda.msda_forward_torch, which is pinned to the
-reference's ms_deform_attn_core_pytorch by tests/golden.  Hyper-parameters: configs/common/models/mask_generator_with_label.py.
+reference's ms_deform_attn_core_pytorch by tests/golden.  PINNED as a whole: tests/test_oracle_golden.py replays golden vectors
+written by the reference's own MaskFormerHead (tests/golden/make_golden_m2f.py).  Hyper-parameters: configs/common/models/mask_generator_with_label.py.
 """
 from __future__ import annotations
 

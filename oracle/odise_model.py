@@ -9,7 +9,8 @@ Follows, line by line:
                                              odise/modeling/meta_arch/clip.py:252-361
   MaskFormer.semantic_/panoptic_/instance_inference   third_party/Mask2Former/mask2former/maskformer_model.py:280-380
   detectron2 sem_seg_postprocess (absent; restated from SURVEY.md Appendix A.4: crop to image_size, bilinear to (h, w))
-The CLIP text tower is not restated yet: text banks enter as precomputed [K_tot, 768] embeddings (the reference caches them per
+PINNED: tests/test_oracle_golden.py replays golden vectors written by the reference's own `CategoryODISE.forward`
+(tests/golden/make_golden_heads.py).  The CLIP text tower lives in oracle/clip_text.py: text banks enter as precomputed [K_tot, 768] embeddings (the reference caches them per
 label set, odise.py:1281-1288); `labels` is the nested synonym list whose group sizes drive the max-ensemble.
 """
 from __future__ import annotations

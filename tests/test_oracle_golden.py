@@ -1,0 +1,79 @@
+"""The oracle against golden vectors produced by the REFERENCE's own modules.  The fixtures under tests/golden/ were
+written in the build container by tests/golden/make_golden_m2f.py / make_golden_heads.py, which import
+third_party/Mask2Former/mask2former/... and odise/modeling/meta_arch/odise.py from /root/reference (third-party imports stubbed by
+tests/golden/ref_stubs.py) and run them on seeded inputs with the oracle's seeded weights; here only the .npz files are read."""
+import glob
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle.m2f import SemSegHead, init_synthetic_
+
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def _close(got, ref, tol, what):
+    got, ref = np.asarray(got, np.float64), np.asarray(ref, np.float64)
+    assert got.shape == ref.shape, (what, got.shape, ref.shape)
+    err = np.abs(got - ref).max() / max(np.abs(ref).max(), 1e-12)
+    assert err < tol, f"{what}: {err:.3e}"
+
+
+@pytest.mark.parametrize("path", sorted(glob.glob(os.path.join(GOLD, "m2f_head_*.npz"))))
+def test_mask_generator_matches_reference_modules(path):
+    """MaskFormerHead = MSDeformAttnPixelDecoder + ODISEMultiScaleMaskedTransformerDecoder (+ PooledMaskEmbed / MaskPooling): every
+    tensor the hot path consumes, fp32, within 5e-5 of max|ref| (summation order differs, nothing else may)."""
+    z = np.load(path)
+    head = init_synthetic_(SemSegHead(small=True, num_classes=int(z["num_classes"]), in_channels=int(z["in_channels"])), seed=int(z["seed"]))
+    feats = {k[3:]: torch.from_numpy(z[k]) for k in z.files if k.startswith("in_")}
+    with torch.no_grad():
+        mask_features, _enc, multi_scale = head.pixel_decoder.forward_features(feats)
+        out = head(feats)
+    _close(mask_features, z["out_mask_features"], 2e-5, "mask_features")
+    for i, m in enumerate(multi_scale):
+        _close(m, z[f"out_multi_scale_{i}"], 2e-5, f"multi_scale[{i}]")
+    for k in ("pred_logits", "pred_masks", "mask_embed", "mask_pooled_features"):
+        _close(out[k], z["out_" + k], 5e-5, k)
+    _close(out["logit_scale"], z["out_logit_scale"], 1e-6, "logit_scale")
+
+
+@pytest.mark.parametrize("path", sorted(glob.glob(os.path.join(GOLD, "heads_*.npz"))))
+def test_classification_and_postprocessing_match_reference_forward(path):
+    """`CategoryODISE.forward` eval branch of the reference (category logits + ensemble, MaskCLIP with mask tokens, PoolingCLIPHead,
+    null merge, upsampling, sem_seg_postprocess, semantic / panoptic / instance inference) replayed through oracle/odise_model.py."""
+    from oracle import clip_vit, odise_model as om
+    z = np.load(path)
+    seed, C = int(z["seed"]), int(z["in_channels"])
+    groups, things = z["group_sizes"].tolist(), set(z["things"].tolist())
+    K = len(groups)
+    head = init_synthetic_(SemSegHead(small=True, num_classes=K, in_channels=C), seed=seed)
+    clip = clip_vit.init_synthetic_(clip_vit.CLIPVisual(image_size=56, patch_size=14, width=128, layers=2, heads=2, output_dim=48), seed=seed + 5).eval()
+    heads = om.OpenVocabHeads(clip, groups, projection_dim=64, seed=seed + 7, overlap=z["overlap"].tolist(), alpha=0.35, beta=0.65)
+    feats = {k[5:]: torch.from_numpy(z[k]) for k in z.files if k.startswith("feat_")}
+    sizes, out_sizes = [tuple(s) for s in z["sizes"].tolist()], [tuple(s) for s in z["out_sizes"].tolist()]
+    B = len(sizes)
+    assert len(set(sizes)) == 1
+    images01 = torch.stack([torch.from_numpy(z[f"image_{b}"]).float() / 255.0 for b in range(B)])
+    Hp, Wp = feats["s2"].shape[-2] * 4, feats["s2"].shape[-1] * 4
+    with torch.no_grad():
+        outputs = head(feats)
+        mask_cls = heads.classify(outputs, images01)
+        res = om.postprocess(mask_cls, outputs["pred_masks"], (Hp, Wp), sizes, out_sizes, K, things, float(z["overlap_threshold"]), int(z["topk"]))
+    for b in range(B):
+        ref_cls = z[f"mask_cls_{b}"]
+        assert np.abs(mask_cls[b].numpy() - ref_cls).max() < 2e-4 * max(1.0, np.abs(ref_cls).max()), "mask_cls"
+        sem = res[b]["sem_seg"].numpy()
+        assert np.abs(sem - z[f"sem_seg_{b}"].astype(np.float32)).max() < 2e-3 * np.abs(sem).max()          # fixture stored as fp16
+        assert (sem.argmax(0) == z[f"sem_argmax_{b}"]).mean() > 0.999
+        pan, info = res[b]["panoptic_seg"]
+        want_info = [{"id": int(i), "isthing": bool(t), "category_id": int(c)} for i, t, c in z[f"pan_info_{b}"]]
+        assert info == want_info
+        assert (pan.numpy() == z[f"pan_{b}"]).mean() > 0.999
+        inst = res[b]["instances"]
+        order, want_order = np.argsort(-inst["scores"].numpy(), kind="stable"), np.argsort(-z[f"inst_scores_{b}"], kind="stable")
+        np.testing.assert_allclose(inst["scores"].numpy()[order], z[f"inst_scores_{b}"][want_order], rtol=2e-4, atol=1e-6)
+        np.testing.assert_array_equal(inst["pred_classes"].numpy()[order], z[f"inst_classes_{b}"][want_order])
+        area = inst["pred_masks"].flatten(1).sum(1).numpy()
+        assert np.abs(area[order] - z[f"inst_area_{b}"][want_order]).max() <= 2
