@@ -48,7 +48,7 @@ def _worker(rank, world, port, n_images, h, w, q):
     for i, img in enumerate(range(b, e)):   # "prediction" of image `img`: a map filled with img+1 and one segment per image
         D.pack_record(np.full((h, w), img + 1, np.int32), [{"id": 1, "isthing": bool(img % 2), "category_id": img}], local[i])
     allrec = D.allgather_records(local)
-    q.put((rank, allrec.clone()))
+    q.put((rank, allrec.numpy().copy()))   # by value: a tensor would travel as a shared-memory handle that dies with this process
     dist.barrier()
     dist.destroy_process_group()
 
@@ -67,7 +67,7 @@ def test_allgather_predictions_gloo_world2(n_images):
         p.join(timeout=60)
         assert p.exitcode == 0
     for r in range(world):
-        rec = results[r]
+        rec = torch.from_numpy(results[r])
         assert rec.shape == (n_images, D.record_size(h, w))      # every rank holds every image, in global order
         for img in range(n_images):
             seg, info = D.unpack_record(rec[img], h, w)
@@ -85,7 +85,7 @@ def _conf_worker(rank, world, port, q):
     for img in range(b, e):
         rng = np.random.default_rng(img)
         conf += torch.from_numpy(semantic_confusion(rng.standard_normal((K, 6, 7)).astype(np.float32), rng.integers(0, K, (6, 7))))
-    q.put((rank, D.sum_confusion(conf).clone()))
+    q.put((rank, D.sum_confusion(conf).numpy().copy()))
     dist.barrier()
     dist.destroy_process_group()
 
@@ -107,4 +107,4 @@ def test_confusion_matrix_allreduce_gloo_world2():
         rng = np.random.default_rng(img)
         ref += semantic_confusion(rng.standard_normal((4, 6, 7)).astype(np.float32), rng.integers(0, 4, (6, 7)))
     for r in range(world):
-        np.testing.assert_array_equal(results[r].numpy(), ref)
+        np.testing.assert_array_equal(results[r], ref)
