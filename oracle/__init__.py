@@ -13,6 +13,10 @@ Pinning status:
                           and by its `CategoryODISE.forward` eval branch (tests/golden/make_golden_m2f.py,
                           make_golden_heads.py import them from /root/reference with the third-party imports
                           stubbed by tests/golden/ref_stubs.py; tests/test_oracle_golden.py).
+  * oracle.backbone / oracle.ldm_extractor — DRIVER LOGIC PINNED the same way (make_golden_backbone.py: the reference's
+                          FeatureExtractorBackbone over a stand-in tap extractor; make_golden_extractor.py: the reference's
+                          LdmImplicitCaptionerExtractor / LdmExtractor forward and its own GaussianDiffusion.q_sample walking
+                          the oracle's UNet / VAE / CLIP modules).
   * oracle.jpeg / oracle.eval_ops — PINNED against Pillow (= libjpeg-turbo / Resample.c), the library behind
                           the reference's `read_image` and `ResizeTransform`.
   * oracle.sd_unet / sd_vae / clip_vit / d2_blocks — PARITY UNPINNED: the arithmetic lives in pip

@@ -1,7 +1,9 @@
 """Oracle: FeatureExtractorBackbone (TEST INFRASTRUCTURE — see oracle/__init__.py).
 
 Follows odise/modeling/backbone/feature_extractor.py line by line: `single_forward` 139-155, `forward_features` 157-179,
-`slide_forward` 181-250.  detectron2 v0.6 is absent from /root/reference (PARITY UNPINNED for its pieces): `BottleneckBlock`
+`slide_forward` 181-250.  PINNED for the window placement / resize / projection-sum / overlap averaging: tests/test_oracle_golden.py
+replays golden vectors written by the reference's own class (tests/golden/make_golden_backbone.py).  detectron2 v0.6 is absent from
+/root/reference (its pieces are restated here AND in tests/golden/ref_stubs.py, so they are not independently pinned): `BottleneckBlock`
 (detectron2/modeling/backbone/resnet.py) and `ImageList.from_tensors` are restated from SURVEY.md Appendix A.4:
 conv1 1x1 (in->128) + GN32 + ReLU -> conv2 3x3 (128->128) + GN32 + ReLU -> conv3 1x1 (128->512) + GN32;
 shortcut 1x1 (in->512) + GN32 iff in != 512; ReLU(out + shortcut); convs bias-free; keys `convN.weight`, `convN.norm.*`.
@@ -116,6 +118,25 @@ class FeatureExtractorBackbone(nn.Module):
         for k in outs:
             outs[k] /= counts[k]
         return outs
+
+
+class TapStandIn(nn.Module):
+    """A cheap feature extractor with LdmExtractor's interface (8 maps at FEATURE_STRIDES): average pooling + a fixed 1x1 mixing of the
+    RGB planes.  tests/golden/make_golden_backbone.py feeds it to the REFERENCE's FeatureExtractorBackbone and to the class above, which
+    pins the sliding-window logic of this file to the reference's."""
+
+    feature_strides = FEATURE_STRIDES
+    grouped_indices = [[i] for i in range(8)]
+
+    def __init__(self, dims: List[int], seed: int):
+        super().__init__()
+        self.feature_dims = list(dims)
+        g = torch.Generator().manual_seed(seed)
+        self.mix = [torch.randn(d, 3, generator=g) for d in dims]
+
+    def forward(self, x):
+        img = x["img"] if isinstance(x, dict) else x
+        return [torch.einsum("oc,bchw->bohw", m, F.avg_pool2d(img, s)) for m, s in zip(self.mix, FEATURE_STRIDES)]
 
 
 def crop_boxes(h_img: int, w_img: int, crop: int = 512):

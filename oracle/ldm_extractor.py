@@ -9,6 +9,8 @@ Follows odise/modeling/meta_arch/ldm.py line by line:
 The SD / CLIP sub-networks are the restatements in oracle/sd_unet.py, oracle/sd_vae.py, oracle/clip_vit.py (parity unpinned
 for ldm, HF-cross-checked for CLIP).  `uncond_inputs` (= frozen text encoder of "", ldm.py:116) is a constant [1,77,768]
 buffer; with synthetic weights it is a seeded random tensor.
+PINNED (driver logic): tests/test_oracle_golden.py replays golden vectors written by the reference's own forward walking these
+modules (tests/golden/make_golden_extractor.py); the UNet / VAE / CLIP arithmetic itself lives in absent pip packages (unpinned).
 """
 from __future__ import annotations
 

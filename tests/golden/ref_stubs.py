@@ -9,7 +9,8 @@ installed here.  This module makes those imports succeed WITHOUT running any thi
   * the handful of detectron2 / fvcore helpers the inference path really executes are restated here (detectron2 v0.6 semantics):
     `configurable` (explicit-kwargs construction only), `Conv2d` (conv -> norm -> activation), `get_norm("GN")`, `ShapeSpec`,
     `ImageList.from_tensors`, `sem_seg_postprocess`, `retry_if_cuda_oom`, `Boxes` / `Instances` / `BitMasks.get_bounding_boxes`,
-    the registries' `register()` decorator, `c2_xavier_fill` / `c2_msra_fill`;
+    the registries' `register()` decorator, `c2_xavier_fill` / `c2_msra_fill`, `Backbone`, resnet `BottleneckBlock` / `ResNet.make_stage`,
+    torchvision's tensor `Resize`;
   * every other name of those packages resolves to an inert placeholder that may be used as a decorator / base class / constant while
     the reference modules are being imported and raises as soon as anything CALLS it afterwards (`seal()`), so a fixture can never
     silently depend on a stub.
@@ -225,10 +226,111 @@ class BitMasks:
         return Boxes(boxes)
 
 
+class Backbone(nn.Module):
+    """detectron2.modeling.backbone.Backbone: an nn.Module with shape bookkeeping (nothing numeric)."""
+
+    @property
+    def size_divisibility(self):
+        return 0
+
+    def output_shape(self):
+        return {name: ShapeSpec(channels=self._out_feature_channels[name], stride=self._out_feature_strides[name]) for name in self._out_features}
+
+
+class BottleneckBlock(nn.Module):
+    """detectron2.modeling.backbone.resnet.BottleneckBlock (v0.6): 1x1 -> 3x3 -> 1x1 convolutions, each bias-free with its norm, ReLU after
+    the first two, projection shortcut iff in != out, ReLU(out + shortcut)."""
+
+    def __init__(self, in_channels, out_channels, *, bottleneck_channels, stride=1, num_groups=1, norm="BN", stride_in_1x1=False, dilation=1):
+        super().__init__()
+        self.in_channels, self.out_channels, self.stride = in_channels, out_channels, stride
+        if in_channels != out_channels:
+            self.shortcut = Conv2d(in_channels, out_channels, kernel_size=1, stride=stride, bias=False, norm=get_norm(norm, out_channels))
+        else:
+            self.shortcut = None
+        stride_1x1, stride_3x3 = (stride, 1) if stride_in_1x1 else (1, stride)
+        self.conv1 = Conv2d(in_channels, bottleneck_channels, kernel_size=1, stride=stride_1x1, bias=False, norm=get_norm(norm, bottleneck_channels))
+        self.conv2 = Conv2d(bottleneck_channels, bottleneck_channels, kernel_size=3, stride=stride_3x3, padding=1 * dilation, bias=False,
+                            groups=num_groups, dilation=dilation, norm=get_norm(norm, bottleneck_channels))
+        self.conv3 = Conv2d(bottleneck_channels, out_channels, kernel_size=1, bias=False, norm=get_norm(norm, out_channels))
+        for layer in [self.conv1, self.conv2, self.conv3, self.shortcut]:
+            if layer is not None:
+                c2_msra_fill(layer)
+
+    def forward(self, x):
+        out = F.relu_(self.conv1(x))
+        out = F.relu_(self.conv2(out))
+        out = self.conv3(out)
+        shortcut = self.shortcut(x) if self.shortcut is not None else x
+        out += shortcut
+        return F.relu_(out)
+
+
+class ResNet:
+    @staticmethod
+    def make_stage(block_class, num_blocks, *, in_channels, out_channels, **kwargs):
+        blocks = []
+        for i in range(num_blocks):
+            curr = {}
+            for k, v in kwargs.items():
+                if k.endswith("_per_block"):
+                    curr[k[: -len("_per_block")]] = v[i]
+                else:
+                    curr[k] = v
+            blocks.append(block_class(in_channels=in_channels, out_channels=out_channels, **curr))
+            in_channels = out_channels
+        return blocks
+
+
+class InterpolationMode:
+    BICUBIC = "bicubic"
+    BILINEAR = "bilinear"
+
+
+class Resize(nn.Module):
+    """torchvision.transforms.Resize on a float tensor (0.14: F.interpolate, align_corners=False, no antialias); `size` = (h, w)."""
+
+    def __init__(self, size, interpolation="bilinear", max_size=None, antialias=None):
+        super().__init__()
+        if not isinstance(size, (tuple, list)) or len(size) != 2 or max_size is not None:
+            raise NotImplementedError("Resize: only an explicit (h, w)")
+        self.size, self.interpolation = tuple(size), interpolation
+
+    def forward(self, img):
+        if tuple(img.shape[-2:]) == self.size:
+            return img
+        return F.interpolate(img, size=self.size, mode=self.interpolation, align_corners=False)
+
+
+def timestep_embedding(timesteps, dim, max_period=10000, repeat_only=False):
+    """ldm.modules.diffusionmodules.util.timestep_embedding (sinusoidal, cos first)."""
+    import math
+    half = dim // 2
+    freqs = torch.exp(-math.log(max_period) * torch.arange(start=0, end=half, dtype=torch.float32) / half).to(device=timesteps.device)
+    args = timesteps[:, None].float() * freqs[None]
+    embedding = torch.cat([torch.cos(args), torch.sin(args)], dim=-1)
+    if dim % 2:
+        embedding = torch.cat([embedding, torch.zeros_like(embedding[:, :1])], dim=-1)
+    return embedding
+
+
+class DiagonalGaussianDistribution:
+    """ldm.modules.distributions.distributions.DiagonalGaussianDistribution: only `.mean` is used (deterministic encoding)."""
+
+    def __init__(self, parameters):
+        self.mean, self.logvar = torch.chunk(parameters, 2, dim=1)
+
+
 _REAL = {
     "detectron2.config": dict(configurable=configurable),
     "detectron2.layers": dict(Conv2d=Conv2d, ShapeSpec=ShapeSpec, get_norm=get_norm),
     "detectron2.modeling": dict(SEM_SEG_HEADS_REGISTRY=_Registry(), META_ARCH_REGISTRY=_Registry(), BACKBONE_REGISTRY=_Registry()),
+    "detectron2.modeling.backbone": dict(Backbone=Backbone),
+    "detectron2.modeling.backbone.resnet": dict(BottleneckBlock=BottleneckBlock, ResNet=ResNet),
+    "torchvision.transforms": dict(Resize=Resize, InterpolationMode=InterpolationMode),
+    "ldm.modules.diffusionmodules.openaimodel": dict(timestep_embedding=timestep_embedding),
+    "ldm.modules.distributions.distributions": dict(DiagonalGaussianDistribution=DiagonalGaussianDistribution),
+    "timm.models.layers": dict(trunc_normal_=nn.init.trunc_normal_),
     "detectron2.modeling.postprocessing": dict(sem_seg_postprocess=sem_seg_postprocess),
     "detectron2.structures": dict(ImageList=ImageList, Boxes=Boxes, Instances=Instances, BitMasks=BitMasks),
     "detectron2.utils.memory": dict(retry_if_cuda_oom=retry_if_cuda_oom),

@@ -77,3 +77,38 @@ def test_classification_and_postprocessing_match_reference_forward(path):
         np.testing.assert_array_equal(inst["pred_classes"].numpy()[order], z[f"inst_classes_{b}"][want_order])
         area = inst["pred_masks"].flatten(1).sum(1).numpy()
         assert np.abs(area[order] - z[f"inst_area_{b}"][want_order]).max() <= 2
+
+
+@pytest.mark.parametrize("path", sorted(glob.glob(os.path.join(GOLD, "backbone_*.npz"))))
+def test_sliding_window_backbone_matches_reference_class(path):
+    """`FeatureExtractorBackbone.slide_forward / single_forward / forward_features` of the reference (window placement, bicubic resize of
+    small windows, nearest restore, per-tap projection and sum, overlap averaging) over a stand-in tap extractor."""
+    from oracle.backbone import FeatureExtractorBackbone, TapStandIn
+    z = np.load(path)
+    seed, crop = int(z["seed"]), int(z["crop"])
+    dims = [16, 16, 32, 24, 16, 16, 16, 16]
+    bb = FeatureExtractorBackbone(TapStandIn(dims, seed), dims, projection_dim=256, backbone_in_size=(crop, crop), seed=seed + 1)
+    with torch.no_grad():
+        out = bb(torch.from_numpy(z["image"]))
+    for k in ("s2", "s3", "s4", "s5"):
+        ref = z["out_" + k]
+        _close(out[k], ref.astype(np.float32), 2e-3 if ref.dtype == np.float16 else 2e-5, k)
+
+
+@pytest.mark.parametrize("path", sorted(glob.glob(os.path.join(GOLD, "extractor_*.npz"))))
+def test_feature_extractor_driver_matches_reference_forward(path):
+    """`LdmImplicitCaptionerExtractor.forward` -> `LdmExtractor.forward` of the reference (normalisation, deterministic latent, the
+    reference's own GaussianDiffusion.q_sample on the shared noise, implicit-caption conditioning, tap selection and order) walking
+    the oracle's narrow UNet / VAE / CLIP modules, against oracle/ldm_extractor.py on the same modules."""
+    from oracle.backbone import FEATURE_STRIDES
+    from oracle.ldm_extractor import ImplicitCaptionerExtractor
+    z = np.load(path)
+    ext = ImplicitCaptionerExtractor(unet_div=10, vae_div=4, clip_kw=dict(image_size=56, patch_size=14, width=128, layers=2, heads=2, output_dim=32),
+                                     context_dim=64, seed=int(z["seed"]))
+    assert z["feature_strides"].tolist() == FEATURE_STRIDES
+    with torch.no_grad():
+        feats = ext(torch.from_numpy(z["image"]))
+    assert len(feats) == 8 and [f.shape[1] for f in feats] == z["feature_dims"].tolist()
+    for i, f in enumerate(feats):
+        ref = z[f"feat_{i}"]
+        _close(f, ref.astype(np.float32), 2e-3 if ref.dtype == np.float16 else 5e-5, f"tap {i}")
