@@ -338,6 +338,9 @@ class HipCategoryODISE(HipODISE):
         return self.postprocess_batch(mask_cls, (Hp, Wp), (H, W), out_sizes, to_host=to_host,
                                       pan_out=dict(enumerate(pan_out)) if pan_out is not None else None)
 
+    def __call__(self, *args, **kwargs):                                   # nn.Module-style call: the reference's wrappers do `self.model(batched_inputs)`
+        return self.forward(*args, **kwargs)
+
     def forward(self, batched_inputs, to_host: bool = True) -> list:
         """CategoryODISE.forward, eval branch (odise.py:236-246, 282-372) for a batch of equally sized images.  "image" is a CHW uint8 /
         float array on the host (values 0..255), or a DeviceArray uint8 [H,W,3] already in HBM (odise_amd.ingest.HipDatasetMapper).

@@ -1,7 +1,10 @@
 """Host logic of the open-vocabulary state protocol (OpenPanopticInference, odise/modeling/wrapper/pano_wrapper.py:20-70): the wrapper
 swaps labels / metadata / task switches for one call and the model's own come back afterwards.  No device: the model's device calls
 are stubbed, the text encoder is a deterministic fake."""
+import os
+
 import numpy as np
+import pytest
 
 from odise_amd.pipeline import HipCategoryODISE, HipOpenPanopticInference
 
@@ -85,3 +88,25 @@ def test_wrapper_restores_after_an_exception():
     except RuntimeError:
         pass
     assert m.test_labels == A and m.panoptic_on is True
+
+
+REF_WRAPPER = "/root/reference/odise/modeling/wrapper/pano_wrapper.py"
+
+
+@pytest.mark.skipif(not os.path.exists(REF_WRAPPER), reason="the reference checkout exists only in the build container")
+def test_the_reference_wrapper_itself_drives_this_model():
+    """Drop-in at the caller's side: the REFERENCE's own `OpenPanopticInference` (loaded from its file, it needs nothing but torch) wraps
+    this model class through `open_state_dict / load_open_state_dict / __call__` and behaves exactly like `HipOpenPanopticInference`."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("ref_pano_wrapper", REF_WRAPPER)
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    m = _Model()
+    m.attach_text(_Tok(), _Enc(), train_labels=[["sky"], ["cat"]])
+    m.set_labels(A, thing_ids={0, 2})
+    ref = mod.OpenPanopticInference(m, B, metadata={"thing_ids": [0]}, instance_on=False, test_topk_per_image=7).eval()
+    mine = HipOpenPanopticInference(m, B, metadata={"thing_ids": [0]}, instance_on=False, test_topk_per_image=7)
+    assert dict(ref.open_state_dict) == mine.open_state_dict
+    assert ref([{"image": None}])[0] == dict(labels=B, K=2, things={0}, inst=False, topk=7)
+    assert m.forward([0])[0] == dict(labels=A, K=3, things={0, 2}, inst=True, topk=100)
+    assert ref([{"image": None}]) == mine([{"image": None}])
