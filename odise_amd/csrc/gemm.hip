@@ -733,6 +733,7 @@ __global__ void __launch_bounds__(512) gemm_pp_kernel(GemmArgs g) {
         return t;
     };
     auto advance = [&](TileK& t) {
+        if (g.dbg & 16) return;  // timing experiment (ODISE_GEMM_FREEZE_K): every K-tile re-reads the first one - hot lines, wrong results
         if (CONV) {
             if (g.cg.chunk_major) {
                 if (++t.kx == g.cg.KW) {
@@ -1737,7 +1738,8 @@ static int launch_gemm(odise_hip_ctx* ctx, GemmArgs& g, int batch, int force_til
         if (!ok) { g.epi.gn_stats = nullptr; g.stats_blocks = 0; }
     }
     g.zeros = (const f16*)ctx->zeros;
-    g.dbg = g_gemm_debug;
+    static const int freeze_k = getenv("ODISE_GEMM_FREEZE_K") ? 16 : 0;
+    g.dbg = g_gemm_debug | freeze_k;
     // the 256-row tiles run the ping-pong pipelined kernel whenever its preconditions hold
     if (tile >= 7) {
         g.cg.chunk_major = 1;

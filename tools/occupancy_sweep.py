@@ -1,4 +1,5 @@
-"""Per-CU throughput of the ping-pong GEMM as the grid fills more of the chip (N=1024, K=4096, 256x256 tiles, one tile per CU up to
+"""(ODISE_GEMM_FREEZE_K=1: every K-tile re-reads the first one = hot lines, timing only.)
+Per-CU throughput of the ping-pong GEMM as the grid fills more of the chip (N=1024, K=4096, 256x256 tiles, one tile per CU up to
 256 tiles, then whole rounds): separates what the instruction schedule can do from what the chip sustains (clock, fabric)."""
 import os
 import sys
@@ -9,6 +10,7 @@ sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."
 from odise_amd.runtime import Context  # noqa: E402
 
 ctx = Context(0)
+ctx.lib.odise_hip_gemm_debug(1024 << 4)   # gemm_pp_kernel for every size (no pp2), so that ODISE_GEMM_FREEZE_K=1 applies throughout
 rng = np.random.default_rng(0)
 N, K = 1024, 4096
 W = ctx.to_device((rng.standard_normal((N, K), dtype=np.float32) * K ** -0.5).astype(np.float16))
