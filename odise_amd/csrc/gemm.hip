@@ -614,7 +614,10 @@ __device__ __forceinline__ void wait_vmcnt() {
 //   NP = 3: (t,0) issues B2,B3,B4 of tile t+1, (t,1) issues A0,A1,A2 of tile t+2, (t,2) issues A3,B0,B1 of tile t+2
 template <int BM, int BN, int WAVES_N, int PT, bool CONV>
 __global__ void __launch_bounds__(512) gemm_pp_kernel(GemmArgs g) {
-    // (measured and rejected: issuing the DMA before the fragment reads -17 %, dropping s_setprio +-1 %)
+    // (measured and rejected: issuing the DMA before the fragment reads -17 %, dropping s_setprio +-1 %; a persistent form - 256 resident
+    // blocks walking the tile list - is bit-identical but 5-9 % SLOWER: vmcnt also counts stores on this part, so the next tile's first
+    // counted wait drains the previous tile's global stores, which a retiring block leaves to the memory system while the dispatcher
+    // already starts its successor)
     constexpr int BK = 64, WAVES_M = 8 / WAVES_N;
     constexpr int WTN = BN / WAVES_N;
     constexpr int TM = 2, TN = WTN / 32;
