@@ -137,6 +137,6 @@ if __name__ == "__main__":
     TRAIN = [["sky"], ["car", "truck"], ["dog"], ["person"]]
     case("a", seed=77, sizes=[(100, 140)], out_sizes=[(150, 210)], labels=LABELS, things={0, 3, 6}, train_labels=TRAIN)
     case("b", seed=5, sizes=[(128, 128), (128, 128)], out_sizes=[(128, 128), (96, 64)], labels=LABELS[:5], things={0, 3}, train_labels=TRAIN,
-         overlap_threshold=0.5, topk=15)
+         overlap_threshold=0.33, topk=15)
     case("c", seed=55, sizes=[(192, 128)], out_sizes=[(192, 128)], labels=LABELS, things={0, 3, 6}, train_labels=TRAIN, overlap_threshold=0.0, topk=40)
     case("d", seed=56, sizes=[(192, 128)], out_sizes=[(144, 96)], labels=LABELS, things={0, 3, 6}, train_labels=TRAIN, overlap_threshold=0.0, topk=40)
