@@ -68,10 +68,12 @@ def normalize_only(image):   # clip_preprocess on an image that already has the 
     return (image - mean) / std
 
 
-def case(name, seed, sizes, out_sizes, labels, things, train_labels, in_channels=32, topk=30, overlap_threshold=0.8):
+def case(name, seed, sizes, out_sizes, labels, things, train_labels, in_channels=32, topk=30, overlap_threshold=0.8, caption=False):
+    """caption=True: `CaptionODISE.forward` (odise.py:545-619) with `WordEmbed.forward` eval (1206-1216) and the learned 2-way
+    `class_embed` of the decoder (mask_generator_with_caption.py) instead of `CategoryODISE` / `CategoryEmbed` / `PseudoClassEmbed`."""
     K = len(labels)
     group_sizes = [len(l) for l in labels]
-    head_o = init_synthetic_(SemSegHead(small=True, num_classes=K, in_channels=in_channels), seed=seed)
+    head_o = init_synthetic_(SemSegHead(small=True, num_classes=1 if caption else K, in_channels=in_channels, learned_class_embed=caption), seed=seed)
     clip_o = clip_vit.init_synthetic_(clip_vit.CLIPVisual(image_size=56, patch_size=14, width=128, layers=2, heads=2, output_dim=48), seed=seed + 5).eval()
     overlap = [int(not {s for l in train_labels for s in l}.isdisjoint(set(l))) for l in labels]
     heads_o = om.OpenVocabHeads(clip_o, group_sizes, projection_dim=64, seed=seed + 7, overlap=overlap, alpha=0.35, beta=0.65)
@@ -83,8 +85,9 @@ def case(name, seed, sizes, out_sizes, labels, things, train_labels, in_channels
     feats = {f"s{i}": torch.randn(B, in_channels, Hp >> i, Wp >> i, generator=g) for i in (2, 3, 4, 5)}
     images = [torch.randint(0, 256, (3, h, w), generator=g, dtype=torch.uint8) for h, w in sizes]
 
-    ref_head = reference_head(K, in_channels, 64, 64, 2, 128, 64, 20, 128, 3)
+    ref_head = reference_head(1 if caption else K, in_channels, 64, 64, 2, 128, 64, 20, 128, 3, learned_class_embed=caption)
     ref_head.load_state_dict(head_o.state_dict(), strict=True)
+    ref_head.num_classes = K     # what OpenPanopticInference writes into `sem_seg_head.num_classes` at test time (pano_wrapper.py:40-41)
 
     cat = ro.CategoryEmbed.__new__(ro.CategoryEmbed)
     nn.Module.__init__(cat)
@@ -94,6 +97,15 @@ def case(name, seed, sizes, out_sizes, labels, things, train_labels, in_channels
     cat.text_proj.load_state_dict(heads_o.text_proj.state_dict())
     cat.null_embed = nn.Parameter(heads_o.null_embed.detach().clone())
     cat._test_text_embed_dict = {ro.to_tuple(prompt_labels(labels, None)): heads_o.text_embed.clone()}
+    if caption:
+        from collections import OrderedDict
+        cat = ro.WordEmbed.__new__(ro.WordEmbed)
+        nn.Module.__init__(cat)
+        cat.prompt, cat.test_labels = "photo", labels
+        cat.clip = types.SimpleNamespace(device=torch.device("cpu"))
+        cat.text_proj = nn.Linear(48, 64)
+        cat.text_proj.load_state_dict(heads_o.text_proj.state_dict())
+        cat._test_text_embed_dict = OrderedDict({ro.to_tuple(prompt_labels(labels, "photo")): heads_o.text_embed.clone()})
 
     mclip = MaskCLIP.__new__(MaskCLIP)
     nn.Module.__init__(mclip)
@@ -105,10 +117,11 @@ def case(name, seed, sizes, out_sizes, labels, things, train_labels, in_channels
     pool._test_text_embed_dict = {ro.to_tuple(prompt_labels(labels, "photo")): heads_o.clip_text_embed.clone()}
 
     meta = types.SimpleNamespace(thing_dataset_id_to_contiguous_id={100 + t: t for t in things})
-    model = ro.CategoryODISE(backbone=SeededBackbone(feats), sem_seg_head=ref_head, criterion=None, num_queries=20, object_mask_threshold=0.0,
-                             overlap_threshold=overlap_threshold, metadata=meta, size_divisibility=64, sem_seg_postprocess_before_inference=True,
-                             pixel_mean=[0.0, 0.0, 0.0], pixel_std=[255.0, 255.0, 255.0], semantic_on=True, instance_on=True, panoptic_on=True,
-                             test_topk_per_image=topk, category_head=cat, clip_head=pool).eval()
+    common = dict(backbone=SeededBackbone(feats), sem_seg_head=ref_head, criterion=None, num_queries=20, object_mask_threshold=0.0,
+                  overlap_threshold=overlap_threshold, metadata=meta, size_divisibility=64, sem_seg_postprocess_before_inference=True,
+                  pixel_mean=[0.0, 0.0, 0.0], pixel_std=[255.0, 255.0, 255.0], semantic_on=True, instance_on=True, panoptic_on=True,
+                  test_topk_per_image=topk, clip_head=pool)
+    model = (ro.CaptionODISE(word_head=cat, grounding_criterion=None, **common) if caption else ro.CategoryODISE(category_head=cat, **common)).eval()
     captured = []
     real_sem = model.semantic_inference
     model.semantic_inference = lambda mask_cls, mask_pred: (captured.append(mask_cls.clone()), real_sem(mask_cls, mask_pred))[1]
@@ -118,7 +131,7 @@ def case(name, seed, sizes, out_sizes, labels, things, train_labels, in_channels
 
     arrays = {f"feat_{k}": v.numpy() for k, v in feats.items()}
     arrays.update(seed=np.int64(seed), in_channels=np.int64(in_channels), group_sizes=np.array(group_sizes), things=np.array(sorted(things)),
-                  overlap=np.array(overlap), topk=np.int64(topk), overlap_threshold=np.float64(overlap_threshold),
+                  overlap=np.array(overlap), topk=np.int64(topk), overlap_threshold=np.float64(overlap_threshold), caption=np.int64(caption),
                   sizes=np.array(sizes), out_sizes=np.array(out_sizes))
     for b, (im, r) in enumerate(zip(images, results)):
         pan, info = r["panoptic_seg"]
@@ -139,4 +152,6 @@ if __name__ == "__main__":
     case("b", seed=5, sizes=[(128, 128), (128, 128)], out_sizes=[(128, 128), (96, 64)], labels=LABELS[:5], things={0, 3}, train_labels=TRAIN,
          overlap_threshold=0.33, topk=15)
     case("c", seed=55, sizes=[(192, 128)], out_sizes=[(192, 128)], labels=LABELS, things={0, 3, 6}, train_labels=TRAIN, overlap_threshold=0.0, topk=40)
+    case("e_caption", seed=55, sizes=[(128, 192)], out_sizes=[(96, 144)], labels=LABELS, things={0, 3, 6}, train_labels=TRAIN, overlap_threshold=0.0,
+         topk=25, caption=True)
     case("d", seed=56, sizes=[(192, 128)], out_sizes=[(144, 96)], labels=LABELS, things={0, 3, 6}, train_labels=TRAIN, overlap_threshold=0.0, topk=40)

@@ -32,13 +32,13 @@ ref_stubs.seal()
 from oracle.m2f import SemSegHead, init_synthetic_  # noqa: E402
 
 
-def reference_head(num_classes, in_channels, conv_dim, mask_dim, enc_layers, d_ffn_enc, hidden, queries, d_ffn_dec, dec_layers):
+def reference_head(num_classes, in_channels, conv_dim, mask_dim, enc_layers, d_ffn_enc, hidden, queries, d_ffn_dec, dec_layers, learned_class_embed=False):
     shapes = {f"s{i}": ref_stubs.ShapeSpec(channels=in_channels, stride=2 ** i) for i in (2, 3, 4, 5)}
     pixel_decoder = MSDeformAttnPixelDecoder(shapes, conv_dim=conv_dim, mask_dim=mask_dim, norm="GN", transformer_dropout=0.0, transformer_nheads=8,
                                              transformer_dim_feedforward=d_ffn_enc, transformer_enc_layers=enc_layers,
                                              transformer_in_features=["s3", "s4", "s5"], common_stride=4)
     predictor = ODISEMultiScaleMaskedTransformerDecoder(
-        class_embed=PseudoClassEmbed(num_classes=num_classes), hidden_dim=hidden,
+        class_embed=None if learned_class_embed else PseudoClassEmbed(num_classes=num_classes), hidden_dim=hidden,   # None: the decoder's own Linear(hidden, num_classes + 1)
         post_mask_embed=PooledMaskEmbed(hidden_dim=hidden, mask_dim=mask_dim, projection_dim=mask_dim), in_channels=conv_dim,
         mask_classification=True, num_classes=num_classes, num_queries=queries, nheads=8, dim_feedforward=d_ffn_dec, dec_layers=dec_layers,
         pre_norm=False, enforce_input_project=False, mask_dim=mask_dim)

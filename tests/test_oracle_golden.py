@@ -48,7 +48,8 @@ def test_classification_and_postprocessing_match_reference_forward(path):
     seed, C = int(z["seed"]), int(z["in_channels"])
     groups, things = z["group_sizes"].tolist(), set(z["things"].tolist())
     K = len(groups)
-    head = init_synthetic_(SemSegHead(small=True, num_classes=K, in_channels=C), seed=seed)
+    caption = bool(int(z["caption"]))                                      # CaptionODISE.forward + WordEmbed + the learned 2-way class_embed
+    head = init_synthetic_(SemSegHead(small=True, num_classes=1 if caption else K, in_channels=C, learned_class_embed=caption), seed=seed)
     clip = clip_vit.init_synthetic_(clip_vit.CLIPVisual(image_size=56, patch_size=14, width=128, layers=2, heads=2, output_dim=48), seed=seed + 5).eval()
     heads = om.OpenVocabHeads(clip, groups, projection_dim=64, seed=seed + 7, overlap=z["overlap"].tolist(), alpha=0.35, beta=0.65)
     feats = {k[5:]: torch.from_numpy(z[k]) for k in z.files if k.startswith("feat_")}
@@ -59,7 +60,7 @@ def test_classification_and_postprocessing_match_reference_forward(path):
     Hp, Wp = feats["s2"].shape[-2] * 4, feats["s2"].shape[-1] * 4
     with torch.no_grad():
         outputs = head(feats)
-        mask_cls = heads.classify(outputs, images01)
+        mask_cls = om.caption_classify(heads, outputs, images01) if caption else heads.classify(outputs, images01)
         res = om.postprocess(mask_cls, outputs["pred_masks"], (Hp, Wp), sizes, out_sizes, K, things, float(z["overlap_threshold"]), int(z["topk"]))
     for b in range(B):
         ref_cls = z[f"mask_cls_{b}"]
