@@ -166,3 +166,22 @@ def test_caption_variant_matches_oracle(ctx):
     agree = (pan == pan_ref.numpy()).mean()
     print("segments", info, "ref", info_ref, "agreement", agree)
     assert info == info_ref and agree > 0.995
+
+
+def test_panoptic_map_written_into_a_caller_owned_buffer(models):
+    """The multi-GPU step (bench.py --gpus N) lets the device write every panoptic map straight into this rank's slice of the all-gather
+    buffer, a torch CUDA tensor: same map as the host-returning call, nothing returned for it."""
+    from odise_amd import distributed as D
+    _, _, _, hip = models
+    img = _image_u8(512, 512, seed=3)
+    ref = hip.forward([{"image": img}])[0]
+    rec = torch.zeros((1, D.record_size(512, 512)), dtype=torch.int32, device="cuda")
+    d = hip.ctx.to_device((img.float() / 255.0)[None].numpy())
+    out = hip.forward_device(d, d, [(512, 512)], to_host=False, pan_out=[rec[0].data_ptr()])[0]
+    hip.ctx.sync()
+    assert out["panoptic_seg"][0] is None and out["panoptic_seg"][1] == ref["panoptic_seg"][1]
+    np.testing.assert_array_equal(rec[0, :512 * 512].cpu().numpy().reshape(512, 512), ref["panoptic_seg"][0])
+    D.pack_record(ref["panoptic_seg"][0], ref["panoptic_seg"][1], rec[0])            # the segment table goes in from the host side
+    seg, info = D.unpack_record(rec[0], 512, 512)
+    np.testing.assert_array_equal(seg, ref["panoptic_seg"][0])
+    assert info == ref["panoptic_seg"][1]
