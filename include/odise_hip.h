@@ -40,7 +40,7 @@ enum {
     ODISE_ERR_HIP = -2,      /* a HIP runtime call failed           */
     ODISE_ERR_STATE = -3,    /* missing weights / wrong call order  */
     ODISE_ERR_NOMEM = -4,    /* workspace / arena exhausted         */
-    ODISE_ERR_UNSUPPORTED = -5 /* a valid input this library does not handle (e.g. progressive JPEG) */
+    ODISE_ERR_UNSUPPORTED = -5 /* a valid input this library does not handle (e.g. an arithmetic-coded JPEG) */
 };
 
 /* ---- context / plumbing ------------------------------------------------------------ */
@@ -254,7 +254,8 @@ int odise_hip_pair_histogram(odise_hip_ctx* ctx, const int* a, const int* b, int
  * Replaces detectron2 `read_image(file, "RGB")` = PIL.Image.open -> EXIF transpose -> convert("RGB") of the DatasetMapper
  * (configs/common/data/pano_open_d2_eval.py:74-107; demo/demo.py:399) for baseline JPEG files, bit-identical to Pillow /
  * libjpeg-turbo defaults (islow IDCT, fancy upsampling).  Huffman decoding runs on the host, everything per-sample on the device.
- * 8-bit SOF0/SOF1, one interleaved scan, grey or YCbCr with luma sampling 1x1 / 2x1 / 2x2; anything else: ODISE_ERR_UNSUPPORTED. */
+ * 8-bit Huffman files: baseline / extended sequential (SOF0 / SOF1) and progressive (SOF2), grey or YCbCr with luma sampling
+ * 1x1 / 2x1 / 2x2; anything else (arithmetic coding, lossless, CMYK, RGB-coded): ODISE_ERR_UNSUPPORTED. */
 typedef struct odise_jpeg_info {
     int32_t width, height;        /* coded size (before the EXIF orientation is applied) */
     int32_t components;           /* 1 (grey) or 3 (YCbCr) */

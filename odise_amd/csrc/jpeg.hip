@@ -8,8 +8,9 @@
 //                      owns a column in pass 1 and a row in pass 2, the 8x8 int32 workspace is exchanged through LDS
 //   jpeg_color_kernel  triangle-filter ("fancy") h2v1 / h2v2 chroma upsampling evaluated per output pixel from the decoded planes,
 //                      the 16-bit fixed-point YCbCr -> RGB conversion, the EXIF orientation as an index map, packed RGB store
-// Scope: 8-bit SOF0 / SOF1 Huffman files with one interleaved scan, grey or YCbCr, luma sampling 1x1 / 2x1 / 2x2 and 1x1 chroma -
-// progressive, arithmetic-coded, CMYK and RGB-coded files return ODISE_ERR_UNSUPPORTED (the caller decides what to do with them;
+// Scope: 8-bit Huffman files - baseline / extended sequential (SOF0 / SOF1, one or several scans) and progressive (SOF2: spectral
+// selection + successive approximation) - grey or YCbCr, luma sampling 1x1 / 2x1 / 2x2 and 1x1 chroma; arithmetic-coded, lossless,
+// CMYK and RGB-coded files return ODISE_ERR_UNSUPPORTED (the caller decides what to do with them;
 // there is no CPU decode path in this library).  The input bytes are untrusted: every read is bounds-checked, truncated entropy data
 // decodes as zero bits like libjpeg does.
 #include <string.h>
@@ -77,16 +78,16 @@ static bool build_table(const uint8_t* counts, const uint8_t* symbols, int nsym,
 
 struct JpegHeader {
     int width = 0, height = 0, ncomp = 0;
-    int id[3] = {0, 0, 0}, h[3] = {1, 1, 1}, v[3] = {1, 1, 1}, tq[3] = {0, 0, 0}, td[3] = {0, 0, 0}, ta[3] = {0, 0, 0};
+    int id[3] = {0, 0, 0}, h[3] = {1, 1, 1}, v[3] = {1, 1, 1}, tq[3] = {0, 0, 0};
     int hmax = 1, vmax = 1, mcus_x = 0, mcus_y = 0;
     int bx[3] = {0, 0, 0}, by[3] = {0, 0, 0};  // component block grids (padded to whole MCUs)
     int64_t coef_off[3] = {0, 0, 0}, coef_count = 0;
     int restart = 0, orientation = 1, adobe = -1;
-    bool jfif = false, have_sof = false;
+    bool jfif = false, have_sof = false, progressive = false, scans_started = false;
+    int64_t sos_pos = -1;  // offset of the first SOS segment's length field
     bool qt_ok[4] = {false, false, false, false};
     uint16_t qt[4][64];
     HuffTable dc[4], ac[4];
-    int64_t data_start = 0;
 };
 
 static int exif_orientation(const uint8_t* t, int64_t n) {
@@ -120,85 +121,96 @@ static int exif_orientation(const uint8_t* t, int64_t n) {
         return code;                \
     } while (0)
 
-// Marker segments up to and including the first SOS header; validates what the decoder relies on.
-static int parse_header(const uint8_t* d, int64_t len, JpegHeader& H) {
-    if (!d || len < 4 || d[0] != 0xFF || d[1] != 0xD8) JPEG_FAIL(ODISE_ERR_ARG, "jpeg: not a JPEG stream (no SOI)");
-    int64_t p = 2;
+// One marker segment other than SOS (tables, frame header, application data): shared by the header pass and the inter-scan pass.
+static int handle_segment(int m, const uint8_t* s, int n, JpegHeader& H) {
+    if (m == 0xDB) {
+        int q = 0;
+        while (q < n) {
+            const int pq = s[q] >> 4, tq = s[q] & 15;
+            const int bytes = pq ? 128 : 64;
+            if (tq > 3 || pq > 1 || q + 1 + bytes > n) JPEG_FAIL(ODISE_ERR_ARG, "jpeg: bad DQT");
+            if (!H.scans_started) {  // the tables a component uses are latched when decoding starts (jdinput.c latch_quant_tables)
+                for (int i = 0; i < 64; ++i) H.qt[tq][kZigzag[i]] = pq ? (uint16_t)((s[q + 1 + 2 * i] << 8) | s[q + 2 + 2 * i]) : s[q + 1 + i];
+                H.qt_ok[tq] = true;
+            }
+            q += 1 + bytes;
+        }
+    } else if (m == 0xC0 || m == 0xC1 || m == 0xC2) {
+        if (H.have_sof || n < 6) JPEG_FAIL(ODISE_ERR_ARG, "jpeg: bad SOF");
+        if (s[0] != 8) JPEG_FAIL(ODISE_ERR_UNSUPPORTED, "jpeg: %d-bit samples are not supported", (int)s[0]);
+        H.progressive = m == 0xC2;
+        H.height = (s[1] << 8) | s[2];
+        H.width = (s[3] << 8) | s[4];
+        H.ncomp = s[5];
+        if (H.ncomp != 1 && H.ncomp != 3) JPEG_FAIL(ODISE_ERR_UNSUPPORTED, "jpeg: %d components (CMYK / YCCK) are not supported", H.ncomp);
+        if (n < 6 + 3 * H.ncomp || H.width == 0 || H.height == 0) JPEG_FAIL(ODISE_ERR_ARG, "jpeg: bad SOF");
+        for (int i = 0; i < H.ncomp; ++i) {
+            H.id[i] = s[6 + 3 * i];
+            H.h[i] = s[7 + 3 * i] >> 4;
+            H.v[i] = s[7 + 3 * i] & 15;
+            H.tq[i] = s[8 + 3 * i];
+            if (H.tq[i] > 3 || H.h[i] < 1 || H.v[i] < 1 || H.h[i] > 4 || H.v[i] > 4) JPEG_FAIL(ODISE_ERR_ARG, "jpeg: bad component spec");
+        }
+        H.have_sof = true;
+    } else if (m == 0xC3 || (m >= 0xC5 && m <= 0xC7) || (m >= 0xC9 && m <= 0xCB) || (m >= 0xCD && m <= 0xCF)) {
+        JPEG_FAIL(ODISE_ERR_UNSUPPORTED, "jpeg: SOF marker 0x%02x (lossless / hierarchical / arithmetic coding) is not supported", m);
+    } else if (m == 0xC4) {
+        int q = 0;
+        while (q < n) {
+            if (q + 17 > n) JPEG_FAIL(ODISE_ERR_ARG, "jpeg: bad DHT");
+            const int tc = s[q] >> 4, th = s[q] & 15;
+            int total = 0;
+            for (int i = 0; i < 16; ++i) total += s[q + 1 + i];
+            if (tc > 1 || th > 3 || total > 256 || q + 17 + total > n) JPEG_FAIL(ODISE_ERR_ARG, "jpeg: bad DHT");
+            if (!build_table(s + q + 1, s + q + 17, total, tc ? H.ac[th] : H.dc[th])) JPEG_FAIL(ODISE_ERR_ARG, "jpeg: bad Huffman table");
+            q += 17 + total;
+        }
+    } else if (m == 0xDD) {
+        if (n < 2) JPEG_FAIL(ODISE_ERR_ARG, "jpeg: bad DRI");
+        H.restart = (s[0] << 8) | s[1];
+    } else if (m == 0xE0 && n >= 5 && memcmp(s, "JFIF\0", 5) == 0) {
+        H.jfif = true;
+    } else if (m == 0xEE && n >= 12 && memcmp(s, "Adobe", 5) == 0) {
+        H.adobe = s[11];
+    } else if (m == 0xE1 && n >= 6 && memcmp(s, "Exif\0\0", 6) == 0 && !H.scans_started) {
+        H.orientation = exif_orientation(s + 6, n - 6);
+    }
+    return ODISE_OK;
+}
+
+// Walks marker segments from offset p to the next SOS.  Returns ODISE_OK with *sos = offset of that SOS segment's length field, or
+// *sos = -1 when the stream ends (EOI / no more data) first.
+static int next_sos(const uint8_t* d, int64_t len, int64_t p, JpegHeader& H, int64_t* sos) {
+    *sos = -1;
     for (;;) {
         while (p < len && d[p] != 0xFF) ++p;
         while (p < len && d[p] == 0xFF) ++p;
-        if (p >= len) JPEG_FAIL(ODISE_ERR_ARG, "jpeg: truncated before the scan");
+        if (p >= len) return ODISE_OK;
         const int m = d[p++];
         if (m == 0xD8 || m == 0x01 || (m >= 0xD0 && m <= 0xD7)) continue;
-        if (m == 0xD9) JPEG_FAIL(ODISE_ERR_ARG, "jpeg: EOI before any scan");
+        if (m == 0xD9) return ODISE_OK;
         if (p + 2 > len) JPEG_FAIL(ODISE_ERR_ARG, "jpeg: truncated marker segment");
         const int L = (d[p] << 8) | d[p + 1];
         if (L < 2 || p + L > len) JPEG_FAIL(ODISE_ERR_ARG, "jpeg: bad marker segment length");
-        const uint8_t* s = d + p + 2;
-        const int n = L - 2;
-        p += L;
-        if (m == 0xDB) {
-            int q = 0;
-            while (q < n) {
-                const int pq = s[q] >> 4, tq = s[q] & 15;
-                const int bytes = pq ? 128 : 64;
-                if (tq > 3 || pq > 1 || q + 1 + bytes > n) JPEG_FAIL(ODISE_ERR_ARG, "jpeg: bad DQT");
-                for (int i = 0; i < 64; ++i) H.qt[tq][kZigzag[i]] = pq ? (uint16_t)((s[q + 1 + 2 * i] << 8) | s[q + 2 + 2 * i]) : s[q + 1 + i];
-                H.qt_ok[tq] = true;
-                q += 1 + bytes;
-            }
-        } else if (m == 0xC0 || m == 0xC1) {
-            if (H.have_sof || n < 6) JPEG_FAIL(ODISE_ERR_ARG, "jpeg: bad SOF");
-            if (s[0] != 8) JPEG_FAIL(ODISE_ERR_UNSUPPORTED, "jpeg: %d-bit samples are not supported", (int)s[0]);
-            H.height = (s[1] << 8) | s[2];
-            H.width = (s[3] << 8) | s[4];
-            H.ncomp = s[5];
-            if (H.ncomp != 1 && H.ncomp != 3) JPEG_FAIL(ODISE_ERR_UNSUPPORTED, "jpeg: %d components (CMYK / YCCK) are not supported", H.ncomp);
-            if (n < 6 + 3 * H.ncomp || H.width == 0 || H.height == 0) JPEG_FAIL(ODISE_ERR_ARG, "jpeg: bad SOF");
-            for (int i = 0; i < H.ncomp; ++i) {
-                H.id[i] = s[6 + 3 * i];
-                H.h[i] = s[7 + 3 * i] >> 4;
-                H.v[i] = s[7 + 3 * i] & 15;
-                H.tq[i] = s[8 + 3 * i];
-                if (H.tq[i] > 3 || H.h[i] < 1 || H.v[i] < 1 || H.h[i] > 4 || H.v[i] > 4) JPEG_FAIL(ODISE_ERR_ARG, "jpeg: bad component spec");
-            }
-            H.have_sof = true;
-        } else if (m == 0xC2 || m == 0xC3 || (m >= 0xC5 && m <= 0xC7) || (m >= 0xC9 && m <= 0xCB) || (m >= 0xCD && m <= 0xCF)) {
-            JPEG_FAIL(ODISE_ERR_UNSUPPORTED, "jpeg: SOF marker 0x%02x (progressive / lossless / arithmetic coding) is not supported", m);
-        } else if (m == 0xC4) {
-            int q = 0;
-            while (q < n) {
-                if (q + 17 > n) JPEG_FAIL(ODISE_ERR_ARG, "jpeg: bad DHT");
-                const int tc = s[q] >> 4, th = s[q] & 15;
-                int total = 0;
-                for (int i = 0; i < 16; ++i) total += s[q + 1 + i];
-                if (tc > 1 || th > 3 || total > 256 || q + 17 + total > n) JPEG_FAIL(ODISE_ERR_ARG, "jpeg: bad DHT");
-                if (!build_table(s + q + 1, s + q + 17, total, tc ? H.ac[th] : H.dc[th])) JPEG_FAIL(ODISE_ERR_ARG, "jpeg: bad Huffman table");
-                q += 17 + total;
-            }
-        } else if (m == 0xDD) {
-            if (n < 2) JPEG_FAIL(ODISE_ERR_ARG, "jpeg: bad DRI");
-            H.restart = (s[0] << 8) | s[1];
-        } else if (m == 0xE0 && n >= 5 && memcmp(s, "JFIF\0", 5) == 0) {
-            H.jfif = true;
-        } else if (m == 0xEE && n >= 12 && memcmp(s, "Adobe", 5) == 0) {
-            H.adobe = s[11];
-        } else if (m == 0xE1 && n >= 6 && memcmp(s, "Exif\0\0", 6) == 0) {
-            H.orientation = exif_orientation(s + 6, n - 6);
-        } else if (m == 0xDA) {
-            if (!H.have_sof) JPEG_FAIL(ODISE_ERR_ARG, "jpeg: SOS before SOF");
-            if (n < 1 || s[0] != H.ncomp || n < 1 + 2 * H.ncomp + 3) JPEG_FAIL(ODISE_ERR_UNSUPPORTED, "jpeg: multi-scan files are not supported");
-            for (int i = 0; i < H.ncomp; ++i) {
-                if (s[1 + 2 * i] != H.id[i]) JPEG_FAIL(ODISE_ERR_UNSUPPORTED, "jpeg: scan component order differs from the frame");
-                H.td[i] = s[2 + 2 * i] >> 4;
-                H.ta[i] = s[2 + 2 * i] & 15;
-                if (H.td[i] > 3 || H.ta[i] > 3 || !H.dc[H.td[i]].present || !H.ac[H.ta[i]].present) JPEG_FAIL(ODISE_ERR_ARG, "jpeg: scan refers to a missing Huffman table");
-                if (!H.qt_ok[H.tq[i]]) JPEG_FAIL(ODISE_ERR_ARG, "jpeg: component refers to a missing quantisation table");
-            }
-            H.data_start = p;
-            break;
+        if (m == 0xDA) {
+            *sos = p;
+            return ODISE_OK;
         }
+        const int rc = handle_segment(m, d + p + 2, L - 2, H);
+        if (rc != ODISE_OK) return rc;
+        p += L;
     }
+}
+
+// Header pass: everything up to the first SOS (which stays unconsumed at H.sos_pos); validates what the decoder relies on.
+static int parse_header(const uint8_t* d, int64_t len, JpegHeader& H) {
+    if (!d || len < 4 || d[0] != 0xFF || d[1] != 0xD8) JPEG_FAIL(ODISE_ERR_ARG, "jpeg: not a JPEG stream (no SOI)");
+    int rc = next_sos(d, len, 2, H, &H.sos_pos);
+    if (rc != ODISE_OK) return rc;
+    if (H.sos_pos < 0) JPEG_FAIL(ODISE_ERR_ARG, "jpeg: no scan in the stream");
+    if (!H.have_sof) JPEG_FAIL(ODISE_ERR_ARG, "jpeg: SOS before SOF");
+    for (int i = 0; i < H.ncomp; ++i)
+        if (!H.qt_ok[H.tq[i]]) JPEG_FAIL(ODISE_ERR_ARG, "jpeg: component refers to a missing quantisation table");
     if (H.ncomp == 3) {
         const bool rgb_ids = H.id[0] == 'R' && H.id[1] == 'G' && H.id[2] == 'B';
         if (H.adobe == 0 || (!H.jfif && H.adobe < 0 && rgb_ids)) JPEG_FAIL(ODISE_ERR_UNSUPPORTED, "jpeg: RGB-coded files are not supported");
@@ -231,13 +243,15 @@ struct Segments {
     std::vector<size_t> begin;  // per segment: offset of its first byte; its zero padding ends at the next segment's begin
 };
 
-static void unstuff(const uint8_t* d, int64_t len, int64_t start, Segments& S) {
+// Returns the offset at which the scan's data ends (the 0xFF of the marker that terminates it, or len).
+static int64_t unstuff(const uint8_t* d, int64_t len, int64_t start, Segments& S) {
     S.bytes.clear();
     S.begin.clear();
     S.bytes.reserve((size_t)(len - start) + 64);
     S.begin.push_back(0);
     const uint8_t* p = d + start;
     const uint8_t* end = d + len;
+    int64_t stop = len;
     auto pad = [&]() { S.bytes.insert(S.bytes.end(), 16, (uint8_t)0); };
     while (p < end) {
         const uint8_t* ff = (const uint8_t*)memchr(p, 0xFF, (size_t)(end - p));
@@ -249,10 +263,11 @@ static void unstuff(const uint8_t* d, int64_t len, int64_t start, Segments& S) {
         const unsigned m = *p++;
         if (m == 0) S.bytes.push_back(0xFF);
         else if (m >= 0xD0 && m <= 0xD7) { pad(); S.begin.push_back(S.bytes.size()); }
-        else break;  // any other marker ends the scan
+        else { stop = (p - 2) - d; break; }  // any other marker ends the scan
     }
     pad();
     S.begin.push_back(S.bytes.size());
+    return stop;
 }
 
 struct BitReader {
@@ -287,10 +302,58 @@ struct BitReader {
 
 static inline int extend(unsigned v, int s) { return (s && v < (1u << (s - 1))) ? (int)v - (1 << s) + 1 : (int)v; }
 
-// coefs: H.coef_count int16, zero-filled by the caller; natural (row-major) order inside a block, not dequantised
-static void entropy_decode(const uint8_t* d, int64_t len, const JpegHeader& H, int16_t* coefs) {
-    Segments S;
-    unstuff(d, len, H.data_start, S);
+struct ScanSpec {
+    int ncomp = 0;
+    int ci[3] = {0, 0, 0};               // frame component index of every scan component
+    int td[3] = {0, 0, 0}, ta[3] = {0, 0, 0};
+    int ss = 0, se = 63, ah = 0, al = 0;  // spectral selection and successive approximation (0, 63, 0, 0 for sequential scans)
+};
+
+static int parse_scan_header(const uint8_t* d, int64_t len, int64_t pos, const JpegHeader& H, ScanSpec& sp, int64_t* data_start) {
+    const int L = (d[pos] << 8) | d[pos + 1];  // validated by next_sos
+    const uint8_t* s = d + pos + 2;
+    const int n = L - 2;
+    if (n < 1) JPEG_FAIL(ODISE_ERR_ARG, "jpeg: bad SOS");
+    sp.ncomp = s[0];
+    if (sp.ncomp < 1 || sp.ncomp > H.ncomp || n < 1 + 2 * sp.ncomp + 3) JPEG_FAIL(ODISE_ERR_ARG, "jpeg: bad SOS");
+    if (sp.ncomp > 1 && sp.ncomp != H.ncomp) JPEG_FAIL(ODISE_ERR_UNSUPPORTED, "jpeg: interleaved scans over a subset of the components are not supported");
+    for (int i = 0; i < sp.ncomp; ++i) {
+        int c = -1;
+        for (int k = 0; k < H.ncomp; ++k)
+            if (H.id[k] == s[1 + 2 * i]) c = k;
+        if (c < 0 || (i > 0 && c <= sp.ci[i - 1])) JPEG_FAIL(ODISE_ERR_ARG, "jpeg: bad scan component");
+        sp.ci[i] = c;
+        sp.td[i] = s[2 + 2 * i] >> 4;
+        sp.ta[i] = s[2 + 2 * i] & 15;
+        if (sp.td[i] > 3 || sp.ta[i] > 3) JPEG_FAIL(ODISE_ERR_ARG, "jpeg: bad Huffman table index");
+    }
+    const uint8_t* t = s + 1 + 2 * sp.ncomp;
+    sp.ss = t[0];
+    sp.se = t[1];
+    sp.ah = t[2] >> 4;
+    sp.al = t[2] & 15;
+    if (H.progressive) {
+        const bool ok = sp.ss <= sp.se && sp.se <= 63 && sp.ah <= 13 && sp.al <= 13 && (sp.ss == 0 ? sp.se == 0 : sp.ncomp == 1) &&
+                        (sp.ah == 0 || sp.ah == sp.al + 1);
+        if (!ok) JPEG_FAIL(ODISE_ERR_ARG, "jpeg: bad progressive scan parameters");
+    } else {
+        sp.ss = 0;
+        sp.se = 63;
+        sp.ah = sp.al = 0;
+    }
+    const bool need_dc = sp.ss == 0 && sp.ah == 0, need_ac = sp.se > 0;
+    for (int i = 0; i < sp.ncomp; ++i) {
+        if (need_dc && !H.dc[sp.td[i]].present) JPEG_FAIL(ODISE_ERR_ARG, "jpeg: scan refers to a missing DC Huffman table");
+        if (need_ac && !H.ac[sp.ta[i]].present) JPEG_FAIL(ODISE_ERR_ARG, "jpeg: scan refers to a missing AC Huffman table");
+    }
+    *data_start = pos + L;
+    return ODISE_OK;
+}
+
+// Block walk of one scan: interleaved scans visit MCUs (h x v blocks of every component), single-component scans visit the component's
+// own ceil(w/8) x ceil(h/8) blocks in raster order (A.2.3 of the standard); `blk(c, by, bx)` = the block inside the MCU-padded grid.
+template <class Body>
+static void walk_scan(const JpegHeader& H, const ScanSpec& sp, const Segments& S, Body&& body) {
     const size_t nseg = S.begin.size() - 1;
     static const uint8_t zeros[32] = {0};
     size_t seg = 0;
@@ -301,58 +364,214 @@ static void entropy_decode(const uint8_t* d, int64_t len, const JpegHeader& H, i
         ++seg;
     };
     open_segment();
-    int pred[3] = {0, 0, 0};
-    const int nm = H.mcus_x * H.mcus_y;
+    int units_x, units_y;
+    if (sp.ncomp > 1) {
+        units_x = H.mcus_x;
+        units_y = H.mcus_y;
+    } else {
+        const int c = sp.ci[0];
+        const int cw = (H.width * H.h[c] + H.hmax - 1) / H.hmax, ch = (H.height * H.v[c] + H.vmax - 1) / H.vmax;
+        units_x = (cw + 7) / 8;
+        units_y = (ch + 7) / 8;
+    }
     int until_restart = H.restart;
-    for (int mcu = 0; mcu < nm; ++mcu) {
-        if (H.restart) {
-            if (until_restart == 0) {
-                open_segment();
-                pred[0] = pred[1] = pred[2] = 0;
-                until_restart = H.restart;
+    for (int uy = 0; uy < units_y; ++uy)
+        for (int ux = 0; ux < units_x; ++ux) {
+            bool restarted = false;
+            if (H.restart) {
+                if (until_restart == 0) {
+                    open_segment();
+                    until_restart = H.restart;
+                    restarted = true;
+                }
+                --until_restart;
             }
-            --until_restart;
+            body(br, uy, ux, restarted);
         }
-        const int my = mcu / H.mcus_x, mx = mcu - my * H.mcus_x;
-        for (int c = 0; c < H.ncomp; ++c) {
-            const HuffTable& dct = H.dc[H.td[c]];
-            const HuffTable& act = H.ac[H.ta[c]];
-            for (int v = 0; v < H.v[c]; ++v)
-                for (int h = 0; h < H.h[c]; ++h) {
-                    int16_t* blk = coefs + H.coef_off[c] + ((int64_t)(my * H.v[c] + v) * H.bx[c] + (mx * H.h[c] + h)) * 64;
-                    br.fill();
-                    int s = br.symbol(dct);
-                    if (s < 0 || s > 16) s = 0;
-                    pred[c] += extend(s ? br.take(s) : 0u, s);
-                    blk[0] = (int16_t)pred[c];
-                    for (int k = 1; k < 64;) {
-                        br.fill();
-                        const unsigned look = br.peek(9);
-                        const int fl = act.fast_len[look];
-                        if (fl) {  // code and magnitude bits inside the lookahead
-                            k += act.fast_run[look];
-                            if (k > 63) break;
-                            br.skip(fl);
-                            blk[kZigzag[k++]] = act.fast_val[look];
-                            continue;
+}
+
+// Sequential (baseline / extended) scan: DC difference + run-length coded AC coefficients of every block.
+static void decode_scan_sequential(const JpegHeader& H, const ScanSpec& sp, const Segments& S, int16_t* coefs) {
+    int pred[3] = {0, 0, 0};
+    auto block = [&](BitReader& br, int i, int by, int bx) {
+        const int c = sp.ci[i];
+        const HuffTable& dct = H.dc[sp.td[i]];
+        const HuffTable& act = H.ac[sp.ta[i]];
+        int16_t* blk = coefs + H.coef_off[c] + ((int64_t)by * H.bx[c] + bx) * 64;
+        br.fill();
+        int s = br.symbol(dct);
+        if (s < 0 || s > 16) s = 0;
+        pred[i] += extend(s ? br.take(s) : 0u, s);
+        blk[0] = (int16_t)pred[i];
+        for (int k = 1; k < 64;) {
+            br.fill();
+            const unsigned look = br.peek(9);
+            const int fl = act.fast_len[look];
+            if (fl) {  // code and magnitude bits inside the lookahead
+                k += act.fast_run[look];
+                if (k > 63) break;
+                br.skip(fl);
+                blk[kZigzag[k++]] = act.fast_val[look];
+                continue;
+            }
+            const int rs = br.symbol(act);
+            if (rs < 0) break;
+            const int r = rs >> 4;
+            s = rs & 15;
+            if (s == 0) {
+                if (r != 15) break;  // EOB
+                k += 16;
+                continue;
+            }
+            k += r;
+            if (k > 63) break;  // corrupt data
+            blk[kZigzag[k]] = (int16_t)extend(br.take(s), s);
+            ++k;
+        }
+    };
+    walk_scan(H, sp, S, [&](BitReader& br, int uy, int ux, bool restarted) {
+        if (restarted) pred[0] = pred[1] = pred[2] = 0;
+        if (sp.ncomp > 1) {
+            for (int i = 0; i < sp.ncomp; ++i) {
+                const int c = sp.ci[i];
+                for (int v = 0; v < H.v[c]; ++v)
+                    for (int h = 0; h < H.h[c]; ++h) block(br, i, uy * H.v[c] + v, ux * H.h[c] + h);
+            }
+        } else {
+            block(br, 0, uy, ux);
+        }
+    });
+}
+
+// Progressive scans (ITU T.81 annex G, jdphuff.c): DC first / refinement over interleaved MCUs, AC first / refinement over the blocks
+// of one component for the band [ss, se], successive approximation bit `al`, end-of-band runs.
+static void decode_scan_progressive(const JpegHeader& H, const ScanSpec& sp, const Segments& S, int16_t* coefs) {
+    int pred[3] = {0, 0, 0};
+    int eobrun = 0;
+    const int al = sp.al;
+    auto dc_block = [&](BitReader& br, int i, int by, int bx) {
+        const int c = sp.ci[i];
+        int16_t* blk = coefs + H.coef_off[c] + ((int64_t)by * H.bx[c] + bx) * 64;
+        br.fill();
+        if (sp.ah == 0) {
+            int s = br.symbol(H.dc[sp.td[i]]);
+            if (s < 0 || s > 16) s = 0;
+            pred[i] += extend(s ? br.take(s) : 0u, s);
+            blk[0] = (int16_t)(pred[i] * (1 << al));
+        } else if (br.take(1)) {
+            blk[0] = (int16_t)(blk[0] | (1 << al));
+        }
+    };
+    auto ac_first = [&](BitReader& br, int16_t* blk) {
+        if (eobrun > 0) { --eobrun; return; }
+        const HuffTable& act = H.ac[sp.ta[0]];
+        for (int k = sp.ss; k <= sp.se;) {
+            br.fill();
+            const int rs = br.symbol(act);
+            if (rs < 0) return;
+            const int r = rs >> 4, s = rs & 15;
+            if (s == 0) {
+                if (r < 15) {  // EOBr: this block and the next 2^r + extra - 1 blocks have no more coefficients in the band
+                    eobrun = (1 << r) - 1;
+                    if (r) eobrun += (int)br.take(r);
+                    return;
+                }
+                k += 16;  // ZRL
+                continue;
+            }
+            k += r;
+            if (k > 63) return;  // corrupt data
+            blk[kZigzag[k]] = (int16_t)(extend(br.take(s), s) * (1 << al));
+            ++k;
+        }
+    };
+    auto refine_nonzero = [&](BitReader& br, int16_t& v) {  // one correction bit for a coefficient with history
+        br.fill();
+        if (br.take(1) && (v & (1 << al)) == 0) v = (int16_t)(v >= 0 ? v + (1 << al) : v - (1 << al));
+    };
+    auto ac_refine = [&](BitReader& br, int16_t* blk) {
+        const HuffTable& act = H.ac[sp.ta[0]];
+        int k = sp.ss;
+        if (eobrun == 0) {
+            while (k <= sp.se) {
+                br.fill();
+                const int rs = br.symbol(act);
+                if (rs < 0) return;
+                int r = rs >> 4;
+                const int s = rs & 15;
+                int value = 0;
+                if (s == 0) {
+                    if (r < 15) {
+                        eobrun = 1 << r;
+                        if (r) eobrun += (int)br.take(r);
+                        break;  // the rest of this block is handled as part of the run
+                    }
+                    // ZRL: skip 16 zero-history coefficients
+                } else {
+                    value = br.take(1) ? (1 << al) : -(1 << al);  // s must be 1
+                }
+                for (; k <= sp.se; ++k) {
+                    int16_t& v = blk[kZigzag[k]];
+                    if (v != 0) {
+                        refine_nonzero(br, v);
+                    } else {
+                        if (r == 0) {
+                            if (value) v = (int16_t)value;
+                            ++k;
+                            break;
                         }
-                        const int rs = br.symbol(act);
-                        if (rs < 0) break;
-                        const int r = rs >> 4;
-                        s = rs & 15;
-                        if (s == 0) {
-                            if (r != 15) break;  // EOB
-                            k += 16;
-                            continue;
-                        }
-                        k += r;
-                        if (k > 63) break;  // corrupt data
-                        blk[kZigzag[k]] = (int16_t)extend(br.take(s), s);
-                        ++k;
+                        --r;
                     }
                 }
+            }
         }
+        if (eobrun > 0) {  // inside an end-of-band run: only correction bits for the coefficients that already have history
+            for (; k <= sp.se; ++k) {
+                int16_t& v = blk[kZigzag[k]];
+                if (v != 0) refine_nonzero(br, v);
+            }
+            --eobrun;
+        }
+    };
+    walk_scan(H, sp, S, [&](BitReader& br, int uy, int ux, bool restarted) {
+        if (restarted) { pred[0] = pred[1] = pred[2] = 0; eobrun = 0; }
+        if (sp.ss == 0) {
+            if (sp.ncomp > 1) {
+                for (int i = 0; i < sp.ncomp; ++i) {
+                    const int c = sp.ci[i];
+                    for (int v = 0; v < H.v[c]; ++v)
+                        for (int h = 0; h < H.h[c]; ++h) dc_block(br, i, uy * H.v[c] + v, ux * H.h[c] + h);
+                }
+            } else {
+                dc_block(br, 0, uy, ux);
+            }
+        } else {
+            const int c = sp.ci[0];
+            int16_t* blk = coefs + H.coef_off[c] + ((int64_t)uy * H.bx[c] + ux) * 64;
+            if (sp.ah == 0) ac_first(br, blk);
+            else ac_refine(br, blk);
+        }
+    });
+}
+
+// All scans of the stream into coefs (H.coef_count int16, zero-filled by the caller; natural order inside a block, not dequantised).
+// Tables defined between scans (DHT, DRI) take effect for the following scans.
+static int entropy_decode(const uint8_t* d, int64_t len, JpegHeader& H, int16_t* coefs) {
+    Segments S;
+    int64_t pos = H.sos_pos;
+    H.scans_started = true;
+    for (int scans = 0; pos >= 0; ++scans) {
+        if (scans >= 256) JPEG_FAIL(ODISE_ERR_ARG, "jpeg: too many scans");
+        ScanSpec sp;
+        int64_t data_start = 0;
+        int rc = parse_scan_header(d, len, pos, H, sp, &data_start);
+        if (rc != ODISE_OK) return scans ? (int)ODISE_OK : rc;  // damage after the first scan: keep what has been decoded (libjpeg warns and goes on)
+        const int64_t stop = unstuff(d, len, data_start, S);
+        if (H.progressive) decode_scan_progressive(H, sp, S, coefs);
+        else decode_scan_sequential(H, sp, S, coefs);
+        if (next_sos(d, len, stop, H, &pos) != ODISE_OK) break;
     }
+    return ODISE_OK;
 }
 
 // ---- device side -----------------------------------------------------------------------------------------------------------------
@@ -545,7 +764,8 @@ extern "C" int odise_hip_jpeg_entropy_decode(const void* data, int64_t len, int1
     if (rc != ODISE_OK) return rc;
     ODISE_REQUIRE(capacity >= H.coef_count, "jpeg_entropy_decode: coefficient buffer too small (%lld < %lld)", (long long)capacity, (long long)H.coef_count);
     memset(coefs, 0, (size_t)H.coef_count * sizeof(int16_t));
-    entropy_decode((const uint8_t*)data, len, H, coefs);
+    const int drc = entropy_decode((const uint8_t*)data, len, H, coefs);
+    if (drc != ODISE_OK) return drc;
     if (qtables)
         for (int c = 0; c < H.ncomp; ++c) memcpy(qtables + 64 * c, H.qt[H.tq[c]], 64 * sizeof(uint16_t));
     return ODISE_OK;
@@ -613,7 +833,8 @@ static int jpeg_device_stage(odise_hip_ctx* ctx, const JpegDims& D, Fill&& fill,
         ctx->jpeg_dev_bytes = want;
     }
     int16_t* hc = (int16_t*)ctx->jpeg_host;
-    fill(hc);
+    const int frc = fill(hc);
+    if (frc != ODISE_OK) return frc;
     ODISE_CHECK_HIP(hipMemcpyAsync(ctx->jpeg_dev, hc, coef_bytes, hipMemcpyHostToDevice, ctx->stream));
     ODISE_CHECK_HIP(hipEventRecord(ctx->jpeg_ev, ctx->stream));
     uint8_t* dev = (uint8_t*)ctx->jpeg_dev;
@@ -658,7 +879,7 @@ extern "C" int odise_hip_jpeg_decode(odise_hip_ctx* ctx, const void* data, int64
     }
     return jpeg_device_stage(ctx, D, [&](int16_t* hc) {
         memset(hc, 0, (size_t)H.coef_count * sizeof(int16_t));
-        entropy_decode((const uint8_t*)data, len, H, hc);
+        return entropy_decode((const uint8_t*)data, len, H, hc);
     }, dst_rgb, dst_capacity, apply_orientation, out_h, out_w);
 }
 
@@ -689,6 +910,6 @@ extern "C" int odise_hip_jpeg_decode_coefs(odise_hip_ctx* ctx, const odise_jpeg_
     }
     D.coef_count = off;
     ODISE_REQUIRE(info->coef_count == off, "jpeg_decode_coefs: coefficient count does not match the image size");
-    return jpeg_device_stage(ctx, D, [&](int16_t* hc) { memcpy(hc, coefs, (size_t)off * sizeof(int16_t)); }, dst_rgb, dst_capacity, apply_orientation,
+    return jpeg_device_stage(ctx, D, [&](int16_t* hc) { memcpy(hc, coefs, (size_t)off * sizeof(int16_t)); return (int)ODISE_OK; }, dst_rgb, dst_capacity, apply_orientation,
                              out_h, out_w);
 }

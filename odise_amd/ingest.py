@@ -5,7 +5,7 @@ sample_style="choice")], image_format="RGB")` as configured in configs/common/da
 `utils.read_image(file_name, "RGB")` (Pillow decode + EXIF transpose) -> `ResizeTransform` (PIL bilinear) -> CHW tensor, with
 `height` / `width` of the ORIGINAL image kept for `sem_seg_postprocess`.  JPEG decoding (`odise_hip_jpeg_decode`) and the resize
 (`odise_hip_resize_bilinear_u8`) are bit-identical to Pillow; the image stays on the device as uint8 [H,W,3] and
-`HipCategoryODISE.forward` converts / pads it there.  Files the decoder refuses (progressive, CMYK, PNG ...) raise
+`HipCategoryODISE.forward` converts / pads it there.  Files the decoder refuses (arithmetic-coded, CMYK, PNG ...) raise
 `UnsupportedInput`: there is no CPU decode path here - the caller may hand such images over as arrays, as before.
 """
 from __future__ import annotations

@@ -324,7 +324,7 @@ class Context:
 
     def jpeg_decode(self, data: bytes, apply_orientation: bool = True, out: Optional[DeviceArray] = None) -> DeviceArray:
         """read_image(file, "RGB") for a baseline JPEG: host Huffman decoding, IDCT / upsampling / colour conversion / EXIF transpose on
-        the device -> uint8 [H,W,3], bit-identical to Pillow.  Raises `UnsupportedInput` for progressive / CMYK / RGB-coded files."""
+        the device -> uint8 [H,W,3], bit-identical to Pillow.  Baseline, extended-sequential and progressive files; raises `UnsupportedInput` for arithmetic-coded / CMYK / RGB-coded ones."""
         info = jpeg_info(data)
         swap = apply_orientation and info["orientation"] >= 5
         oh, ow = (info["width"], info["height"]) if swap else (info["height"], info["width"])

@@ -51,10 +51,22 @@ def test_grey_orientation_and_buffer_reuse(ctx):
     np.testing.assert_array_equal(ctx.jpeg_decode(big).numpy(), _pil(big))
 
 
+def test_progressive_files(ctx):
+    """Progressive JPEG (SOF2): the host half assembles the coefficients over the scans, the device half is the same."""
+    for (h, w, kw) in [(75, 99, dict(quality=60, subsampling=1, optimize=True)), (100, 131, dict(quality=20, subsampling=2)),
+                       (64, 48, dict(quality=90, subsampling=0)), (90, 120, dict(quality=85, subsampling=2, restart_marker_blocks=7))]:
+        data = _jpeg(_picture(h, w, seed=h + w), progressive=True, **kw)
+        np.testing.assert_array_equal(ctx.jpeg_decode(data).numpy(), _pil(data), err_msg=f"{h}x{w} {kw}")
+    grey = _jpeg(_picture(61, 83, 4), mode="L", quality=70, progressive=True)
+    np.testing.assert_array_equal(ctx.jpeg_decode(grey).numpy(), _pil(grey))
+
+
 def test_unsupported_and_malformed(ctx):
     img = _picture(32, 32, 9)
+    buf = io.BytesIO()
+    Image.fromarray(img).convert("CMYK").save(buf, "JPEG")
     with pytest.raises(UnsupportedInput):
-        ctx.jpeg_decode(_jpeg(img, quality=80, progressive=True))
+        ctx.jpeg_decode(buf.getvalue())
     with pytest.raises(RuntimeError):
         ctx.jpeg_decode(b"\xff\xd8\xff\xd9")
     good = _jpeg(img, quality=80)
