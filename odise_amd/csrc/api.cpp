@@ -51,15 +51,15 @@ extern "C" int odise_hip_create(int device, odise_hip_ctx** out) {
 
 extern "C" int odise_hip_destroy(odise_hip_ctx* ctx) {
     if (!ctx) return ODISE_OK;
-    hipSetDevice(ctx->device);
-    hipStreamSynchronize(ctx->stream);
+    (void)hipSetDevice(ctx->device);  // teardown: nothing useful can be done about a failing call here
+    (void)hipStreamSynchronize(ctx->stream);
     models_destroy(ctx);
     odise::jpeg_release(ctx);
-    if (ctx->ws) hipFree(ctx->ws);
-    if (ctx->zeros) hipFree(ctx->zeros);
-    if (ctx->ev0) hipEventDestroy(ctx->ev0);
-    if (ctx->ev1) hipEventDestroy(ctx->ev1);
-    if (ctx->own_stream && ctx->stream) hipStreamDestroy(ctx->stream);
+    if (ctx->ws) (void)hipFree(ctx->ws);
+    if (ctx->zeros) (void)hipFree(ctx->zeros);
+    if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
+    if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
+    if (ctx->own_stream && ctx->stream) (void)hipStreamDestroy(ctx->stream);
     delete ctx;
     return ODISE_OK;
 }
@@ -74,7 +74,7 @@ extern "C" int odise_hip_set_stream(odise_hip_ctx* ctx, void* hip_stream) {
         }
         return ODISE_OK;
     }
-    if (ctx->own_stream && ctx->stream) hipStreamDestroy(ctx->stream);
+    if (ctx->own_stream && ctx->stream) (void)hipStreamDestroy(ctx->stream);
     ctx->stream = (hipStream_t)hip_stream;
     ctx->own_stream = false;
     return ODISE_OK;

@@ -157,8 +157,8 @@ extern "C" int odise_hip_mask_pooling(odise_hip_ctx* ctx, const float* x, const 
         d.alpha = 1.f; d.batch = 1;
         rc = odise_hip_gemm(ctx, &d);
     }
-    hipFreeAsync(x16, ctx->stream);
-    hipFreeAsync(m16, ctx->stream);
-    hipFreeAsync(inv, ctx->stream);
+    (void)hipFreeAsync(x16, ctx->stream);
+    (void)hipFreeAsync(m16, ctx->stream);
+    (void)hipFreeAsync(inv, ctx->stream);
     return rc;
 }

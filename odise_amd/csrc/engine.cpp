@@ -24,8 +24,8 @@ void models_destroy(odise_hip_ctx* ctx) {
     extractor_destroy(ms);
     maskgen_destroy(ms);
     classify_destroy(ms);
-    for (void* p : ms->dev_allocs) hipFree(p);
-    if (ms->arena.base) hipFree(ms->arena.base);
+    for (void* p : ms->dev_allocs) (void)hipFree(p);
+    if (ms->arena.base) (void)hipFree(ms->arena.base);
     delete ms;
     ctx->models = nullptr;
 }

@@ -70,7 +70,7 @@ double unet_last_macs(ModelStore* ms) { return ms->unet ? ms->unet->last_macs : 
 
 void unet_destroy(ModelStore* ms) {
     if (!ms->unet) return;
-    if (ms->unet->graph_exec) hipGraphExecDestroy(ms->unet->graph_exec);
+    if (ms->unet->graph_exec) (void)hipGraphExecDestroy(ms->unet->graph_exec);
     delete ms->unet;
     ms->unet = nullptr;
 }
@@ -497,7 +497,7 @@ int unet_prepare_timestep(odise_hip_ctx* ctx, ModelStore* ms, UNetModel* u, int 
         ODISE_CHECK_HIP(hipMemcpy(u->temb_in, te.data(), te.size() * 2, hipMemcpyHostToDevice));
         u->cached_t = t;
         u->cached_B = B;
-        if (u->graph_exec) { hipGraphExecDestroy(u->graph_exec); u->graph_exec = nullptr; }
+        if (u->graph_exec) { (void)hipGraphExecDestroy(u->graph_exec); u->graph_exec = nullptr; }
     }
     return ODISE_OK;
 }
@@ -522,13 +522,13 @@ static int unet_forward(odise_hip_ctx* ctx, const float* x_t, const float* conte
     const bool same = u->graph_exec && u->graph_B == B && u->graph_h == h && u->graph_w == w && u->graph_x == x_t &&
                       u->graph_ctx == context && u->graph_ce == cond_emb && u->graph_arena == ms->arena.base;
     if (!same) {
-        if (u->graph_exec) { hipGraphExecDestroy(u->graph_exec); u->graph_exec = nullptr; }
+        if (u->graph_exec) { (void)hipGraphExecDestroy(u->graph_exec); u->graph_exec = nullptr; }
         hipGraph_t graph = nullptr;
         ODISE_CHECK_HIP(hipStreamBeginCapture(ctx->stream, hipStreamCaptureModeThreadLocal));
         const int rc = unet_launch(ctx, ms, u, x_t, nullptr, context, cond_emb, B, h, w, true);
         const hipError_t e = hipStreamEndCapture(ctx->stream, &graph);
         if (rc != ODISE_OK) {
-            if (graph) hipGraphDestroy(graph);
+            if (graph) (void)hipGraphDestroy(graph);
             return rc;
         }
         ODISE_CHECK_HIP(e);
