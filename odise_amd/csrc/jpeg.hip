@@ -209,6 +209,8 @@ static int parse_header(const uint8_t* d, int64_t len, JpegHeader& H) {
     if (rc != ODISE_OK) return rc;
     if (H.sos_pos < 0) JPEG_FAIL(ODISE_ERR_ARG, "jpeg: no scan in the stream");
     if (!H.have_sof) JPEG_FAIL(ODISE_ERR_ARG, "jpeg: SOS before SOF");
+    // the header alone decides how much memory the decoder asks for: refuse absurd frames instead of allocating for them
+    if ((int64_t)H.width * H.height > ((int64_t)1 << 28)) JPEG_FAIL(ODISE_ERR_UNSUPPORTED, "jpeg: %dx%d is larger than the 2^28-pixel limit", H.width, H.height);
     for (int i = 0; i < H.ncomp; ++i)
         if (!H.qt_ok[H.tq[i]]) JPEG_FAIL(ODISE_ERR_ARG, "jpeg: component refers to a missing quantisation table");
     if (H.ncomp == 3) {

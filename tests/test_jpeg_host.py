@@ -115,6 +115,11 @@ def test_refusals():
     with pytest.raises(RuntimeError):
         jpeg_info(b"definitely not a jpeg")
     good = _jpeg(img, quality=80)
+    huge = bytearray(good)                                               # a header that claims 65535 x 65535 pixels must not make anyone allocate
+    sof = good.index(b"\xff\xc0")
+    huge[sof + 5:sof + 9] = b"\xff\xff\xff\xff"
+    with pytest.raises(UnsupportedInput):
+        jpeg_info(bytes(huge))
     for cut in (3, 20, 100, 300):                                        # truncated headers are errors, never crashes
         try:
             jpeg_info(good[:cut])
