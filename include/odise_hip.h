@@ -75,7 +75,12 @@ int odise_hip_ms_deform_attn_forward(odise_hip_ctx* ctx, const void* value, cons
                                      const float* attn_weight, int B, int S, int M, int D, int Lq, int L, int P,
                                      int im2col_step, int value_dtype, void* out);
 
-/* ---- GEMM: C[M,N] = epilogue(alpha * A[M,K] * W[N,K]^T) ----------------------------- */
+/* ---- GEMM: C[M,N] = epilogue(alpha * A[M,K] * W[N,K]^T) -----------------------------
+ * Replaces every nn.Linear / projection of the path (W in PyTorch's [out, in] layout, bias_n = bias): the q/k/v/out projections and
+ * FFNs of M2F/modeling/transformer_decoder/mask2former_transformer_decoder.py:17-204 and of MSDeformAttn (ops/modules/ms_deform_attn.py:98-125),
+ * PooledMaskEmbed's pool_proj / mask_embed MLPs (odise/modeling/meta_arch/odise.py:975-1009), PositionalLinear (ldm.py:624-635), the
+ * CLIP and SD-UNet transformer blocks driven from clip.py:252-280 / ldm.py:469-491 (GEGLU, per-row terms and row-group adds are their
+ * fused tails), text_proj and the cosine logits of odise.py:181-207. */
 typedef struct {
     int M, N, K;              /* K % 8 == 0 */
     const void* A; int64_t lda;   /* f16, row-major, lda % 8 == 0, 16-byte aligned */
@@ -98,7 +103,11 @@ typedef struct {
 } odise_gemm_desc;
 int odise_hip_gemm(odise_hip_ctx* ctx, const odise_gemm_desc* d);
 
-/* ---- implicit-GEMM convolution, NHWC f16 -------------------------------------------- */
+/* ---- implicit-GEMM convolution, NHWC f16 --------------------------------------------
+ * Replaces nn.Conv2d / detectron2.layers.Conv2d wherever the path convolves: the SD UNet and VAE blocks walked by ldm.py:424-533
+ * (incl. Upsample = nearest 2x + 3x3 conv -> upsample2x, the time-embedding broadcast -> per_image_add), the BottleneckBlock projections
+ * of feature_extractor.py:53-66, the pixel decoder's input_proj / lateral / output / mask_features convs
+ * (M2F/modeling/pixel_decoder/msdeformattn.py:206-286) and CLIP's patch embedding (clip.py:253). */
 typedef struct {
     int N, H, W, Cin;         /* input  X [N,H,W,Cin] f16, Cin % 8 == 0 */
     int Cout, KH, KW, stride, pad_t, pad_l, OH, OW;
@@ -114,7 +123,10 @@ typedef struct {
 } odise_conv_desc;
 int odise_hip_conv2d(odise_hip_ctx* ctx, const odise_conv_desc* d);
 
-/* ---- normalisation ------------------------------------------------------------------- */
+/* ---- normalisation -------------------------------------------------------------------
+ * GroupNorm: nn.GroupNorm(32, C) of msdeformattn.py:218-225 / get_norm("GN") of the detectron2 Conv2d wrappers and BottleneckBlocks,
+ * ldm's Normalize in every ResnetBlock / ResBlock (+ fused SiLU).  LayerNorm: decoder norms (mask2former_transformer_decoder.py:26, 84,
+ * 149), decoder_norm, PooledMaskEmbed (odise.py:975-977), CLIP ln_pre / ln_1 / ln_2 / ln_post (clip.py:264-276). */
 /* GroupNorm over NHWC f16 x[N,HW,C]; stats in fp32; y = act(gn(x)*gamma+beta) (f16) */
 int odise_hip_group_norm(odise_hip_ctx* ctx, const void* x, void* y, const float* gamma, const float* beta,
                          int N, int HW, int C, int groups, float eps, int act);
@@ -126,7 +138,10 @@ int odise_hip_group_norm_ex(odise_hip_ctx* ctx, const void* x, void* y, const fl
 int odise_hip_layer_norm(odise_hip_ctx* ctx, const void* x, void* y, const float* gamma, const float* beta,
                          int rows, int C, float eps);
 
-/* ---- fused attention ------------------------------------------------------------------- */
+/* ---- fused attention -------------------------------------------------------------------
+ * Replaces nn.MultiheadAttention of the masked decoder (mask2former_transformer_decoder.py:22, 80: self-attention and cross-attention
+ * with the boolean attn_mask of odise.py:763-775), CLIP's transformer with the mask-token attention mask (clip.py:271, 300-323) and the
+ * SD UNet's CrossAttention (self and text-conditioned, d_head 40..160) reached through ldm.py:469-491. */
 /* O[b,q,h*D+d] = softmax_k(scale * Q[b,q,h*D+:] . K[b,k,h*D+:] + mask) V
  * Q  [B, Lq, ldq] f16, K [B, Lk, ldk] f16, Vt [B, H*D, ldvt] f16 (V TRANSPOSED: row h*D+d, col key),
  * O  [B, Lq, ldo] f16.  mask: optional u8 [B, Lq, ldmask] (1 = key not visible), shared by heads.
