@@ -113,3 +113,19 @@ def test_feature_extractor_driver_matches_reference_forward(path):
     for i, f in enumerate(feats):
         ref = z[f"feat_{i}"]
         _close(f, ref.astype(np.float32), 2e-3 if ref.dtype == np.float16 else 5e-5, f"tap {i}")
+
+
+def test_text_encoder_and_prompts_match_reference_code():
+    """`ClipAdapter._encode_text` (clip.py:148-162) over the oracle's text tower, and `prompt_labels` (odise/data/build.py:54-71)."""
+    import json
+    from odise_amd.checkpoint import prompt_labels
+    from oracle.clip_text import CLIPText, encode_hidden, encode_text, init_synthetic_ as init_text
+    z = np.load(os.path.join(GOLD, "text_encode.npz"))
+    model = init_text(CLIPText(vocab_size=49408, context_length=77, width=64, layers=2, heads=2, output_dim=32), seed=7).eval()
+    tokens = torch.from_numpy(z["tokens"])
+    with torch.no_grad():
+        _close(encode_text(model, tokens), z["embed"], 2e-5, "text_embed")
+        _close(encode_hidden(model, tokens), z["hidden"].astype(np.float32), 2e-3, "text_encodings")
+    j = json.load(open(os.path.join(GOLD, "prompt_labels.json")))
+    for prompt, want in j["prompted"].items():
+        assert prompt_labels(j["labels"], None if prompt == "None" else prompt) == want
