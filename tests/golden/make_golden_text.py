@@ -2,7 +2,8 @@
   * `ClipAdapter._encode_text` (odise/modeling/meta_arch/clip.py:148-162) walking the oracle's narrow CLIP text tower (open_clip is
     absent; the tower keeps its attribute names: token_embedding, positional_embedding, transformer(x, attn_mask=), ln_final,
     text_projection, attn_mask) -> text_encode.npz: pins oracle.clip_text.encode_hidden / encode_text (causal mask, EOT pooling);
-  * `prompt_labels` (odise/data/build.py:54-71) -> prompt_labels.json: pins odise_amd.checkpoint.prompt_labels (product host code).
+  * `prompt_labels` (odise/data/build.py:54-71) -> prompt_labels.json: pins odise_amd.checkpoint.prompt_labels (product host code);
+  * `ODISEHandler` / `StableDiffusionHandler` (odise/utils/file_io.py:22-96) -> file_io.json: pins odise_amd.checkpoint.resolve.
 
     python tests/golden/make_golden_text.py
 """
@@ -23,6 +24,7 @@ import ref_stubs  # noqa: E402
 ref_stubs.install()
 from odise.data.build import prompt_labels  # noqa: E402
 from odise.modeling.meta_arch.clip import ClipAdapter  # noqa: E402
+from odise.utils.file_io import ODISEHandler, StableDiffusionHandler  # noqa: E402
 
 ref_stubs.seal()
 from oracle.clip_text import EOT, SOT, CLIPText, init_synthetic_  # noqa: E402
@@ -49,7 +51,19 @@ def main():
     labels = [["person", "child"], ["sky"], ["tree", "trees", "bush"], ["traffic light"]]
     out = {str(p): prompt_labels(labels, p) for p in (None, "a", "photo", "scene")}
     json.dump({"labels": labels, "prompted": out}, open(os.path.join(HERE, "prompt_labels.json"), "w"), indent=1)
-    print({k: v[0] for k, v in out.items()}, embed.shape)
+    # odise:// and sd:// resolution (odise/utils/file_io.py:22-96): the name -> URL tables and the model-zoo rule of _get_local_path
+    import tempfile
+    import odise.utils.file_io as fio
+    with tempfile.TemporaryDirectory() as zoo:
+        os.environ["ODISE_MODEL_ZOO"] = zoo
+        fio.PathManager = type("PM", (), {"get_local_path": staticmethod(lambda path, **kw: path)})   # the handlers' last step: identity here
+        local = {}
+        for h in (ODISEHandler(), StableDiffusionHandler()):
+            for name, url in h.URLS.items():
+                open(os.path.join(zoo, os.path.basename(url)), "w").close()
+                local[h.PREFIX + name] = os.path.relpath(h._get_local_path(h.PREFIX + name), zoo)
+    json.dump({"odise": ODISEHandler.URLS, "sd": StableDiffusionHandler.URLS, "zoo_relative": local}, open(os.path.join(HERE, "file_io.json"), "w"), indent=1)
+    print({k: v[0] for k, v in out.items()}, embed.shape, len(local))
 
 
 if __name__ == "__main__":

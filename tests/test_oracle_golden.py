@@ -129,3 +129,21 @@ def test_text_encoder_and_prompts_match_reference_code():
     j = json.load(open(os.path.join(GOLD, "prompt_labels.json")))
     for prompt, want in j["prompted"].items():
         assert prompt_labels(j["labels"], None if prompt == "None" else prompt) == want
+
+
+def test_checkpoint_uri_resolution_matches_reference_handlers(tmp_path, monkeypatch):
+    """`odise://` / `sd://` (odise/utils/file_io.py:22-96): same names, same URLs, same `$ODISE_MODEL_ZOO/<basename>` rule for the SD v1
+    checkpoints this path supports (the v2 entries of the reference's table belong to a different UNet)."""
+    import json
+    from odise_amd import checkpoint as ck
+    j = json.load(open(os.path.join(GOLD, "file_io.json")))
+    assert ck.ODISE_URLS == j["odise"]
+    assert ck.SD_URLS == {k: v for k, v in j["sd"].items() if k.startswith("v1-")}
+    monkeypatch.setenv("ODISE_MODEL_ZOO", str(tmp_path))
+    for uri, rel in j["zoo_relative"].items():
+        if uri.startswith("sd://v2"):
+            with pytest.raises(KeyError):
+                ck.resolve(uri)
+            continue
+        (tmp_path / rel).write_bytes(b"x")
+        assert ck.resolve(uri) == str(tmp_path / rel)
