@@ -148,6 +148,21 @@ def prompt_labels(labels: Sequence[Sequence[str]], prompt: Optional[str]) -> Lis
     return [[fmt.format(s) for s in l] for l in labels]
 
 
+def read_openseg_labels(path: str, invalid_name: str = "invalid_class_id") -> List[List[str]]:
+    """The label files the reference ships under odise/data/datasets/openseg_labels/ (`<id>:<name>[,<synonym>...]` per line; the
+    `*_with_prompt_eng.txt` variants carry the synonyms) -> nested label list, as `get_openseg_labels` returns it
+    (odise/data/build.py:17-51: lines whose name is `invalid_class_id` are skipped, ids are not used for ordering)."""
+    out = []
+    with open(path, "r") as f:
+        for line in f.read().splitlines():
+            _id, name = line.split(":")
+            if name == invalid_name:
+                continue
+            int(_id)                                                   # malformed ids are errors there too
+            out.append(name.split(","))
+    return out
+
+
 def category_overlapping_mask(train_labels: Sequence[Sequence[str]], test_labels: Sequence[Sequence[str]]) -> np.ndarray:
     """PoolingCLIPHead.forward, odise.py:1479-1491: 1 where a test category shares a name with any training category."""
     train = {s for l in train_labels for s in l}

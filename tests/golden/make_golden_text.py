@@ -22,7 +22,7 @@ sys.path.insert(0, os.path.join(HERE, "..", ".."))
 import ref_stubs  # noqa: E402
 
 ref_stubs.install()
-from odise.data.build import prompt_labels  # noqa: E402
+from odise.data.build import get_openseg_labels, prompt_labels  # noqa: E402
 from odise.modeling.meta_arch.clip import ClipAdapter  # noqa: E402
 from odise.utils.file_io import ODISEHandler, StableDiffusionHandler  # noqa: E402
 
@@ -63,7 +63,16 @@ def main():
                 open(os.path.join(zoo, os.path.basename(url)), "w").close()
                 local[h.PREFIX + name] = os.path.relpath(h._get_local_path(h.PREFIX + name), zoo)
     json.dump({"odise": ODISEHandler.URLS, "sd": StableDiffusionHandler.URLS, "zoo_relative": local}, open(os.path.join(HERE, "file_io.json"), "w"), indent=1)
-    print({k: v[0] for k, v in out.items()}, embed.shape, len(local))
+    # label files (odise/data/build.py:17-51): only counts and a digest are recorded - the files themselves stay in the reference
+    import hashlib
+    summary = {}
+    for ds in ("coco_panoptic", "ade20k_150", "ade20k_847", "lvis_1203"):
+        for pe in (False, True):
+            ls = get_openseg_labels(ds, prompt_engineered=pe)
+            summary[f"{ds}{'_with_prompt_eng' if pe else ''}"] = dict(categories=len(ls), strings=sum(len(l) for l in ls),
+                                                                     sha256=hashlib.sha256(json.dumps(ls).encode()).hexdigest())
+    json.dump(summary, open(os.path.join(HERE, "openseg_labels.json"), "w"), indent=1)
+    print({k: v[0] for k, v in out.items()}, embed.shape, len(local), summary["coco_panoptic_with_prompt_eng"])
 
 
 if __name__ == "__main__":

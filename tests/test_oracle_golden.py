@@ -147,3 +147,22 @@ def test_checkpoint_uri_resolution_matches_reference_handlers(tmp_path, monkeypa
             continue
         (tmp_path / rel).write_bytes(b"x")
         assert ck.resolve(uri) == str(tmp_path / rel)
+
+
+def test_label_file_parser(tmp_path):
+    """`get_openseg_labels` (odise/data/build.py:17-51) -> odise_amd.checkpoint.read_openseg_labels: the format on a hand-written file,
+    and - where the reference checkout exists - every label file of the reference against the digests its own function produced."""
+    import hashlib
+    import json
+    from odise_amd.checkpoint import read_openseg_labels
+    f = tmp_path / "labels.txt"
+    f.write_text("0:invalid_class_id\n1:person,child\n7:traffic light\n3:sky\n")
+    assert read_openseg_labels(str(f)) == [["person", "child"], ["traffic light"], ["sky"]]
+    summary = json.load(open(os.path.join(GOLD, "openseg_labels.json")))
+    assert summary["coco_panoptic_with_prompt_eng"]["categories"] == 133 and summary["coco_panoptic_with_prompt_eng"]["strings"] == 254
+    root = "/root/reference/odise/data/datasets/openseg_labels"
+    if os.path.isdir(root):
+        for name, want in summary.items():
+            ls = read_openseg_labels(os.path.join(root, name + ".txt"))
+            assert (len(ls), sum(len(l) for l in ls)) == (want["categories"], want["strings"])
+            assert hashlib.sha256(json.dumps(ls).encode()).hexdigest() == want["sha256"], name
