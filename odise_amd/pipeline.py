@@ -192,6 +192,8 @@ class HipCategoryODISE(HipODISE):
                 self.set_vocabulary(*banks, self.thing_ids, self._alpha, self._beta)
         elif labels is not None and [list(l) for l in labels] != self.test_labels:
             from .checkpoint import build_vocabulary
+            if getattr(self, "_tokenizer", None) is None or getattr(self, "_text_encoder", None) is None:
+                raise RuntimeError("label strings need a tokenizer and a text encoder: call attach_text() first (or hand over banks with set_vocabulary)")
             key = tuple(tuple(l) for l in labels)
             if key not in self._vocab_cache:                               # the reference caches text embeddings per label tuple (odise.py:1281-1288)
                 self._vocab_cache[key] = build_vocabulary(labels, self._tokenizer, self._text_encoder, train_labels=self._train_labels,

@@ -77,6 +77,13 @@ def test_wrapper_restores_banks_set_without_labels():
     np.testing.assert_array_equal(m.uploads[-1][0], cat)
 
 
+def test_labels_without_a_text_encoder_are_refused():
+    m = _Model()
+    with pytest.raises(RuntimeError, match="attach_text"):
+        m.set_labels(A, thing_ids={0})
+    assert m.uploads == [] and m.test_labels is None
+
+
 def test_wrapper_restores_after_an_exception():
     m = _Model()
     m.attach_text(_Tok(), _Enc())
