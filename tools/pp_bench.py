@@ -1,5 +1,5 @@
-"""Ping-pong pipelined 256-row GEMM/conv kernel vs the plain one (same tile): time (min over interleaved rounds) and max
-|difference| of the outputs.  usage: pp_bench.py [tile=4]"""
+"""The two ping-pong kernels against each other on the same tile (gemm_pp_kernel: fragment reads in the load segment; gemm_pp2_kernel: under the
+MFMAs): time (min over interleaved rounds) and max |difference| of the outputs.  usage: pp_bench.py [tile=4]"""
 import os
 import sys
 
