@@ -323,7 +323,10 @@ def main():
         if inclusive is not None:
             out["inclusive"] = inclusive
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = baseline()
+            try:
+                out["cpu_baseline"] = baseline()
+            except Exception as exc:
+                out["cpu_baseline"] = {"value": None, "error": f"{type(exc).__name__}: {exc}"}
         print(json.dumps(out), flush=True)
     if dist is not None:
         dist.barrier()
