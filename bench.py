@@ -28,7 +28,11 @@ sys.path.insert(0, ROOT)
 import numpy as np  # noqa: E402
 
 # analytic live work (SURVEY.md §8d / BASELINE.md §2)
-FLOPS_PER_IMAGE_1024 = 12.5e12    # 4 crops x (CLIP 0.382 + VAE-enc 1.117 + UNet 0.740 + VAE-dec 0.623) + heads ~1.05 TFLOP
+# Algorithmic FLOPs (2 x MAC) of the live path, counted with torch.utils.flop_counter over the full-size oracle (tests/test_flop_accounting.py
+# re-derives the extractor / UNet part on the meta device): per 512^2 crop CLIP 0.382 + VAE encoder 1.117 + UNet 0.740 + truncated VAE decoder
+# 0.623 = 2.8625 TFLOP; per 1024^2 image 4 crops = 11.450, tap projections 0.125, mask generator 0.391, classification (MaskCLIP with 100
+# mask tokens, text logits) 0.410, post-processing einsum 0.028.
+FLOPS_PER_IMAGE_1024 = 12.40e12
 UNET_FLOPS_LIVE = 0.7401e12
 MFMA_F16_PEAK = 2.5e15            # dense fp16 MFMA, /opt/skills/guides/MI355X_MICROARCH.md
 
