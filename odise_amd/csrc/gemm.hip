@@ -1069,7 +1069,7 @@ __device__ __forceinline__ void wait_phase(int p) {  // p is a compile-time cons
 }
 }  // namespace pp2
 
-template <int BM, int BN, int WAVES_N, int PT, bool CONV>
+template <int BM, int BN, int WAVES_N, int PT, bool CONV, bool TR = false>  // TR: see gemm_pp_kernel
 __global__ void __launch_bounds__(512) gemm_pp2_kernel(GemmArgs g) {
     constexpr int BK = 64, WAVES_M = 8 / WAVES_N;
     constexpr int WTN = BN / WAVES_N;
@@ -1309,7 +1309,8 @@ __global__ void __launch_bounds__(512) gemm_pp2_kernel(GemmArgs g) {
                 for (int jj = 0; jj < PT; ++jj)
 #pragma unroll
                     for (int i = 0; i < TM; ++i)
-                        acc[i][j0 + jj] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[i][s], bf[jj][s], acc[i][j0 + jj], 0, 0, 0);
+                        acc[i][j0 + jj] = TR ? __builtin_amdgcn_mfma_f32_32x32x16_f16(bf[jj][s], af[i][s], acc[i][j0 + jj], 0, 0, 0)
+                                             : __builtin_amdgcn_mfma_f32_32x32x16_f16(af[i][s], bf[jj][s], acc[i][j0 + jj], 0, 0, 0);
                 if (have_next) {
                     if (!next_in_tile) {
 #pragma unroll
@@ -1331,7 +1332,8 @@ __global__ void __launch_bounds__(512) gemm_pp2_kernel(GemmArgs g) {
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
     __syncthreads();
     if (g.dbg & 4) return;
-    gemm_epilogue<BM, BN, WAVES_M, WAVES_N, epi_wave_rows(BM, BN, WAVES_M, pp_lds_bytes(BM, BN, WAVES_M)), false, CONV>(g, acc, smem, m0, n0, z, zb, split);
+    if constexpr (TR) gemm_epilogue_direct<BM, BN, WAVES_M, WAVES_N>(g, acc, m0, n0, z, zb, split);
+    else gemm_epilogue<BM, BN, WAVES_M, WAVES_N, epi_wave_rows(BM, BN, WAVES_M, pp_lds_bytes(BM, BN, WAVES_M)), false, CONV>(g, acc, smem, m0, n0, z, zb, split);
 }
 
 // (A third structure - every wave free-running through the four k-steps with register double-buffered fragments and ONE barrier per
@@ -1659,14 +1661,17 @@ template <int BM, int BN, int WAVES_N, int PT, bool CONV>
 static int launch_gemm_pp2(odise_hip_ctx* ctx, GemmArgs& g, int batch) {
     static_assert((BN / WAVES_N / 32) % PT == 0, "whole phases");
     constexpr int lds = pp_lds_bytes(BM, BN, 8 / WAVES_N);
-    auto kern = gemm_pp2_kernel<BM, BN, WAVES_N, PT, CONV>;
+    auto kern = gemm_pp2_kernel<BM, BN, WAVES_N, PT, CONV, false>;
+    auto kern_tr = gemm_pp2_kernel<BM, BN, WAVES_N, PT, CONV, true>;
     static bool attr_set = false;  // per instantiation
     if (!attr_set) {
         ODISE_CHECK_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+        ODISE_CHECK_HIP(hipFuncSetAttribute((const void*)kern_tr, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
         attr_set = true;
     }
     dim3 grid((unsigned)ceil_div(g.N, BN), (unsigned)ceil_div(g.M, BM), (unsigned)(g.splitk > 1 ? g.splitk : batch));
-    hipLaunchKernelGGL(kern, grid, dim3(512), lds, ctx->stream, g);
+    const bool direct = g.direct_epilogue && g.epi.fast && (g.N & 7) == 0 && g.epi.gn_stats == nullptr;  // experiment, see launch_gemm_pp
+    hipLaunchKernelGGL(direct ? kern_tr : kern, grid, dim3(512), lds, ctx->stream, g);
     ODISE_CHECK_HIP(hipGetLastError());
     if (g.splitk > 1) {
         const int64_t total = (int64_t)g.M * ceil_div(g.N, 8);

@@ -11,7 +11,7 @@ from odise_amd.runtime import Context  # noqa: E402
 
 ctx = Context(0)
 rng = np.random.default_rng(0)
-BASE = 1024 << 4          # gemm_pp_kernel everywhere (no pp2)
+BASE = (512 if os.environ.get("PP2") else 1024) << 4   # gemm_pp_kernel everywhere (PP2=1: gemm_pp2_kernel everywhere)
 
 
 def dev(a):
