@@ -145,3 +145,64 @@ extern "C" int odise_hip_mfma_rate(odise_hip_ctx* ctx, int variant, int iters, i
     if (mhz_out) *mhz_out = hc[1] ? 100.0 * (double)hc[0] / (double)hc[1] : 0.0;
     return ODISE_OK;
 }
+
+// ---- LDS port probe (EXPERIMENT, tools/lds_rate.py): how fast LDS-DMA data lands in LDS, alone and next to fragment reads ------------------
+// One workgroup of 8 waves per CU, 128 KiB of LDS.  Per round every thread issues LOADS global_load_lds_dwordx4 (8 = the 64 KiB per
+// K-tile of a 256x256x64 GEMM step) from a 64 KiB source that stays hot in L2, and / or READS ds_read_b128 (24 = the fragment reads of
+// that step), then waits for both and passes a barrier.  Reported: clocks per round on the device's own cycle counter.
+namespace odise {
+template <int LOADS, int READS>
+__global__ void __launch_bounds__(512) lds_rate_kernel(const uint4* __restrict__ src, float* out, int rounds, unsigned long long* clocks) {
+    extern __shared__ __attribute__((aligned(16))) char lsm[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    unsigned long long c0 = 0;
+    if (blockIdx.x == 0 && tid == 0) c0 = __builtin_readcyclecounter();
+    uint4 acc = {0u, 0u, 0u, 0u};
+    for (int r = 0; r < rounds; ++r) {
+        const int stage = (r & 1) * 65536;
+#pragma unroll
+        for (int j = 0; j < LOADS; ++j)  // wave-instruction j fills 1 KiB at lsm + stage + (j * 8 + wave) * 1024, lane-linear
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + (j * 8 + wave) * 64 + lane),
+                                             (__attribute__((address_space(3))) void*)(lsm + stage + (j * 8 + wave) * 1024), 16, 0, 0);
+#pragma unroll
+        for (int k = 0; k < READS; ++k) {  // conflict-free 16-byte reads of the other stage
+            const uint4 v = *reinterpret_cast<const uint4*>(lsm + (stage ^ 65536) + ((k * 512 + tid) & 4095) * 16);
+            acc.x ^= v.x; acc.y += v.y; acc.z ^= v.z; acc.w += v.w;
+        }
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+    }
+    if ((acc.x ^ acc.y ^ acc.z ^ acc.w) == 0x12345u) out[tid] = 1.f;  // keeps the reads alive
+    if (blockIdx.x == 0 && tid == 0) clocks[0] = __builtin_readcyclecounter() - c0;
+}
+}  // namespace odise
+
+// variant: 0 = 8 DMA loads per round, 1 = 24 reads per round, 2 = both, 3 = 4 DMA loads + 24 reads, 4 = 16 DMA loads.  clocks_per_round: device cycles.
+extern "C" int odise_hip_lds_rate(odise_hip_ctx* ctx, int variant, int rounds, int blocks, double* clocks_per_round, float* ms_out) {
+    using namespace odise;
+    ODISE_REQUIRE(ctx && clocks_per_round && ms_out && rounds > 0 && blocks > 0, "lds_rate: bad argument");
+    const uint4* src = (const uint4*)ctx->ws;  // 64 KiB .. 128 KiB of whatever the workspace holds
+    float* out = (float*)((char*)ctx->ws + (1 << 20));
+    unsigned long long* clk = (unsigned long long*)((char*)ctx->ws + (2 << 20));
+    const size_t lds = 131072;
+    auto launch = [&]() -> hipError_t {
+        switch (variant) {
+            case 0: { auto k = lds_rate_kernel<8, 0>; (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); hipLaunchKernelGGL(k, dim3(blocks), dim3(512), lds, ctx->stream, src, out, rounds, clk); break; }
+            case 1: { auto k = lds_rate_kernel<0, 24>; (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); hipLaunchKernelGGL(k, dim3(blocks), dim3(512), lds, ctx->stream, src, out, rounds, clk); break; }
+            case 2: { auto k = lds_rate_kernel<8, 24>; (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); hipLaunchKernelGGL(k, dim3(blocks), dim3(512), lds, ctx->stream, src, out, rounds, clk); break; }
+            case 3: { auto k = lds_rate_kernel<4, 24>; (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); hipLaunchKernelGGL(k, dim3(blocks), dim3(512), lds, ctx->stream, src, out, rounds, clk); break; }
+            default: { auto k = lds_rate_kernel<16, 0>; (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); hipLaunchKernelGGL(k, dim3(blocks), dim3(512), lds, ctx->stream, src, out, rounds, clk); break; }
+        }
+        return hipGetLastError();
+    };
+    ODISE_CHECK_HIP(launch());
+    ODISE_CHECK_HIP(hipEventRecord(ctx->ev0, ctx->stream));
+    ODISE_CHECK_HIP(launch());
+    ODISE_CHECK_HIP(hipEventRecord(ctx->ev1, ctx->stream));
+    ODISE_CHECK_HIP(hipEventSynchronize(ctx->ev1));
+    ODISE_CHECK_HIP(hipEventElapsedTime(ms_out, ctx->ev0, ctx->ev1));
+    unsigned long long hc = 0;
+    ODISE_CHECK_HIP(hipMemcpy(&hc, clk, sizeof(hc), hipMemcpyDeviceToHost));
+    *clocks_per_round = (double)hc / rounds;
+    return ODISE_OK;
+}
