@@ -294,6 +294,27 @@ int odise_hip_jpeg_decode(odise_hip_ctx* ctx, const void* data, int64_t len, voi
 int odise_hip_jpeg_decode_coefs(odise_hip_ctx* ctx, const odise_jpeg_info* info, const int16_t* coefs, const uint16_t* qtables, void* dst_rgb,
                                 int64_t dst_capacity, int apply_orientation, int* out_h, int* out_w);
 
+/* ---- multi-GPU exchange step ---------------------------------------------------------------------------------------
+ * One process per GPU; images are independent units sharded across ranks, there is no collective inside the model forward, and
+ * exactly one exchange: an RCCL all-gather (xGMI) of fixed-size int32 prediction records, replacing detectron2's pickled
+ * `comm.gather` of per-image predictions reached from odise/evaluation/evaluator.py:144 (inference_on_dataset -> evaluator.evaluate)
+ * and, for semantic evaluation, the gather behind SemSegEvaluator.evaluate (odise/evaluation/d2_evaluator.py:63) -> one all-reduce of
+ * the (K+1)^2 int64 confusion counters.  The communicator belongs to the context; collectives run on a second HIP stream ordered after
+ * the work queued on the compute stream so far, so the next batch's kernels overlap the exchange.  A world of one rank is valid. */
+#define ODISE_COMM_ID_BYTES 128
+/* rank 0: fill id128 (ODISE_COMM_ID_BYTES host bytes) - the launcher broadcasts it to the other ranks over its CPU rendezvous */
+int odise_hip_comm_unique_id(void* id128);
+int odise_hip_comm_init(odise_hip_ctx* ctx, const void* id128, int rank, int world);
+int odise_hip_comm_destroy(odise_hip_ctx* ctx);
+int odise_hip_comm_info(odise_hip_ctx* ctx, int* rank, int* world);   /* world = 0 when no communicator exists */
+/* all [world * count] = concatenation over ranks of local [count] (device int32; count identical on every rank).  Record layout per
+ * image (odise_amd/distributed.py): panoptic_seg [H*W] | n_segments | segments [100][3] = (id, isthing, category_id).  Asynchronous. */
+int odise_hip_allgather_predictions(odise_hip_ctx* ctx, const int32_t* local, int64_t count, int32_t* all);
+/* data [count] int64 device, summed in place over ranks (confusion matrices of odise_hip_semantic_confusion).  Asynchronous. */
+int odise_hip_allreduce_sum_i64(odise_hip_ctx* ctx, int64_t* data, int64_t count);
+/* join the last collective: block_host != 0 waits on the host, otherwise makes the compute stream wait for it */
+int odise_hip_comm_wait(odise_hip_ctx* ctx, int block_host);
+
 #ifdef __cplusplus
 }
 #endif

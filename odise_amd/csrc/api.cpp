@@ -55,6 +55,7 @@ extern "C" int odise_hip_destroy(odise_hip_ctx* ctx) {
     (void)hipStreamSynchronize(ctx->stream);
     models_destroy(ctx);
     odise::jpeg_release(ctx);
+    odise::comm_release(ctx);
     if (ctx->ws) (void)hipFree(ctx->ws);
     if (ctx->zeros) (void)hipFree(ctx->zeros);
     if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);

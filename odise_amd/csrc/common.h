@@ -69,8 +69,10 @@ struct odise_hip_ctx {
     void* jpeg_dev = nullptr;
     size_t jpeg_dev_bytes = 0;
     hipEvent_t jpeg_ev = nullptr;
+    void* comm = nullptr;  // odise::Comm* (comm.cpp): RCCL communicator + exchange stream, created by odise_hip_comm_init
 };
 
 namespace odise {
 void jpeg_release(odise_hip_ctx* ctx);
+void comm_release(odise_hip_ctx* ctx);
 }

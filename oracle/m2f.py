@@ -306,7 +306,12 @@ class SemSegHead(nn.Module):
         return self.predictor(multi_scale, mask_features)
 
 
-def init_synthetic_(model: nn.Module, seed: int = 777) -> nn.Module:
+def init_synthetic_(model: nn.Module, seed: int = 777, qk_gain: float = 1.0, level_gain: float = 1.0) -> nn.Module:
+    """Seeded weights.  With the defaults the 100 queries of the full-size decoder collapse onto one mask: every attention sublayer adds
+    the same vector (W_v . mean(src), dominated by the O(1) level embedding) to all queries and the post-norm keeps halving their distinct
+    part, 18 times.  `qk_gain` > 1 sharpens the masked decoder's attention (q / k rows of in_proj scaled) and `level_gain` < 1 shrinks its
+    level embedding, so queries attend to different regions and predict different masks - the regime a trained model works in
+    (tests/fullsize.py uses 4 / 0.1).  The random draws are the same for every gain."""
     g = torch.Generator().manual_seed(seed)
     with torch.no_grad():
         for name, p in sorted(model.named_parameters()):
@@ -326,4 +331,10 @@ def init_synthetic_(model: nn.Module, seed: int = 777) -> nn.Module:
         for emb in (model.predictor.query_feat, model.predictor.query_embed, model.predictor.level_embed):
             emb.weight.copy_(torch.randn(emb.weight.shape, generator=g))
         model.pixel_decoder.transformer.level_embed.copy_(torch.randn(model.pixel_decoder.transformer.level_embed.shape, generator=g))
+        if qk_gain != 1.0:
+            for name, p in model.predictor.named_parameters():
+                if name.endswith("in_proj_weight"):
+                    p[: 2 * p.shape[1]].mul_(qk_gain)
+        if level_gain != 1.0:
+            model.predictor.level_embed.weight.mul_(level_gain)
     return model.eval()

@@ -15,75 +15,29 @@ import numpy as np
 import pytest
 import torch
 
+from fullsize import build_models, export_state, reference
 from odise_amd.pipeline import HipCategoryODISE
-from odise_amd.synthetic import synthetic_vocabulary
 from oracle import odise_model as om
-from oracle.backbone import FeatureExtractorBackbone
-from oracle.ldm_extractor import ImplicitCaptionerExtractor
-from oracle.m2f import SemSegHead, init_synthetic_
 
 pytestmark = pytest.mark.gpu
 torch.set_num_threads(min(32, torch.get_num_threads()))
 
 K, K_TOT = 133, 254
 THINGS = set(range(80))                     # COCO panoptic: contiguous ids 0..79 are things
-FEATURE_DIMS = [512, 512, 2560, 1920, 960, 640, 512, 512]   # enc5, enc7, u2, u5, u8, u11, dec2, dec5 (ldm.py:284-346)
 TAU_MASK = 6e-3      # fp16 bound on a mask logit, as a fraction of max|logit| of the image (measured: see the printed stage errors)
 TAU_PROB = 2e-2      # bound on a class probability (absolute)
 
 
-def image_u8(h, w, seed=0):
-    """SURVEY.md 8d config 1/3 input: seeded uniform uint8 noise smoothed by a 9x9 box filter."""
-    rng = np.random.default_rng(seed)
-    x = torch.from_numpy(rng.integers(0, 256, size=(1, 3, h, w)).astype(np.float32))
-    x = torch.nn.functional.avg_pool2d(torch.nn.functional.pad(x, (4, 4, 4, 4), mode="reflect"), 9, stride=1)
-    x = (x - x.amin()) / (x.amax() - x.amin())
-    return (x[0] * 255).round().to(torch.uint8)
-
-
-def build_oracle(seed_heads=31):
-    ext = ImplicitCaptionerExtractor()
-    bb = FeatureExtractorBackbone(ext, FEATURE_DIMS)
-    head = init_synthetic_(SemSegHead(num_classes=K))
-    cat, clp, sizes, overlap = synthetic_vocabulary(K, K_TOT, 768)
-    heads = om.OpenVocabHeads(ext.clip, [int(s) for s in sizes], projection_dim=256, seed=seed_heads, overlap=torch.from_numpy(overlap.astype(bool)))
-    heads.text_embed.copy_(torch.from_numpy(cat))
-    heads.clip_text_embed.copy_(torch.from_numpy(clp))
-    return ext, bb, head, heads
-
-
-def export_state(ext, bb, head, heads):
-    state = ext.export_state()
-    state.update({"backbone.feature_projections." + k: v for k, v in bb.feature_projections.state_dict().items()})
-    state.update({"sem_seg_head." + k: v for k, v in head.state_dict().items()})
-    state["category_head.text_proj.weight"] = heads.text_proj.weight.detach()
-    state["category_head.text_proj.bias"] = heads.text_proj.bias.detach()
-    state["category_head.null_embed"] = heads.null_embed.detach()
-    return state
-
-
-def oracle_forward(bb, head, heads, img_u8, out_hw, overlap_threshold=0.8):
-    img = img_u8.float()[None] / 255.0
-    H, W = img.shape[-2:]
-    Hp, Wp = (H + 63) // 64 * 64, (W + 63) // 64 * 64
-    padded = torch.zeros(1, 3, Hp, Wp)
-    padded[:, :, :H, :W] = img
-    feats = bb(padded)
-    outputs = head(feats)
-    mask_cls = heads.classify(outputs, img)
-    res = om.postprocess(mask_cls, outputs["pred_masks"], (Hp, Wp), [(H, W)], [out_hw], K, THINGS, overlap_threshold)
-    return feats, outputs, mask_cls, res[0]
-
-
 @pytest.fixture(scope="module")
 def full(ctx):
-    ext, bb, head, heads = build_oracle()
+    ext, bb, head = build_models(K)
+    img, heads, r = reference(bb, head, ext, 1024, K, K_TOT)
     hip = HipCategoryODISE(ctx, export_state(ext, bb, head, heads), overlap_threshold=0.8)
     hip.set_vocabulary(heads.text_embed.numpy(), heads.clip_text_embed.numpy(), heads.group_sizes, heads.category_overlapping_mask.numpy(), THINGS,
                        heads.alpha, heads.beta)
-    img = image_u8(1024, 1024, seed=0)
-    ref = oracle_forward(bb, head, heads, img, (1024, 1024))
-    return dict(bb=bb, head=head, heads=heads, hip=hip, img=img, ref=ref)
+    feats = {k: r[k] for k in ("s2", "s3", "s4", "s5")}
+    post = {ot: om.postprocess(r["mask_cls"], r["pred_masks"], (1024, 1024), [(1024, 1024)], [(1024, 1024)], K, THINGS, ot)[0] for ot in (0.8, 0.0)}
+    return dict(heads=heads, hip=hip, img=img, ref=(feats, r, r["mask_cls"], post))
 
 
 def _rel(got, ref):
@@ -140,7 +94,7 @@ def test_classification_full_size(full, ctx):
     img01 = (img.float()[None] / 255.0).numpy()
     got, ce = hip.classify_device(ctx.to_device(img01), want_clip_embed=True)
     got, ce = got.numpy(), ce.numpy()
-    ce_ref = om.mask_clip_embed(heads.clip, torch.from_numpy(img01), out_ref["pred_masks"]).numpy()
+    ce_ref = out_ref["clip_embed"].numpy()
     err, cos, scale = _rel(ce, ce_ref)
     print(f"MaskCLIP embed {ce.shape} max|ref| {scale:.3f} max-err/scale {err:.3e} cos {cos:.6f}")
     assert err < 2e-2 and cos > 0.9995
@@ -156,12 +110,16 @@ def test_classification_full_size(full, ctx):
     assert same[decided].all(), "argmax label differs on a query whose reference margin exceeds the fp16 bound"
 
 
-def test_end_to_end_contract(full):
+@pytest.mark.parametrize("overlap_threshold", [0.8, 0.0])   # evaluation config / demo config (demo.py:316-318)
+def test_end_to_end_contract(full, overlap_threshold):
     """One `model(batched_inputs)` call at 1024x1024 against the oracle's: identical segments_info, identical per-query label,
     per-query mask IoU >= 1 - 1e-3 (see the module docstring for how fp16 margins are handled)."""
     hip, img = full["hip"], full["img"]
-    _, out_ref, cls_ref, ref = full["ref"]
+    _, out_ref, cls_ref, post = full["ref"]
+    ref = post[overlap_threshold]
+    hip.overlap_threshold = overlap_threshold
     got = hip.forward([{"image": img, "height": 1024, "width": 1024}])[0]
+    hip.overlap_threshold = 0.8
     # ---- panoptic
     pan_ref, info_ref = ref["panoptic_seg"]
     pan, info = got["panoptic_seg"]
