@@ -248,6 +248,57 @@ int odise_hip_panoptic_write(odise_hip_ctx* ctx, const int* ids, const int* map,
 int odise_hip_instance_masks(odise_hip_ctx* ctx, int b, const int* idx, int n, int pad_h, int pad_w, int img_h, int img_w, int out_h,
                              int out_w, float* out);
 
+/* ---- the three inference heads for a whole batch, decisions on the device (odise.py:336-370; maskformer_model.py:280-380) --------
+ * Consumes the mask logits of the last odise_hip_head_forward and mask_cls of odise_hip_classify.  Everything the reference decides
+ * on the host from device tensors - kept queries, the per-segment loop with its `.item()` round trips (maskformer_model.py:312-340),
+ * the top-k of the instance head (:349-369) - is decided by kernels, so a call enqueues work and never synchronises; the caller reads
+ * the small tables back when it needs them.  Per image b the outputs are (HOST arrays of B device pointers; an array or an entry may
+ * be NULL to skip that output):
+ *   sem_seg[b]     fp32 [K, oh, ow]                    semantic_inference (:280-284)
+ *   sem_argmax[b]  int32 [oh*ow]                       argmax over classes of the same scores WITHOUT materialising [K, oh, ow]
+ *                                                      (what detectron2's SemSegEvaluator keeps; A-847 at 1280x1280 is 5.5 GB otherwise)
+ *   panoptic[b]    int32 record [oh*ow | 1 | 3*ODISE_MAX_SEGMENTS]: panoptic ids, n_segments, (id, isthing, category_id) rows -
+ *                  the per-image record of the multi-GPU exchange (odise_hip_allgather_predictions)
+ *   inst_masks[b]  fp32 [topk, oh, ow] (first n valid) ; inst_table (device, [B][1 + 2*topk] int32: n | query index | class) ;
+ *                  inst_scores (device, [B][topk] fp32), sorted by class score descending (instance_inference, :344-380) */
+#define ODISE_MAX_SEGMENTS 100
+typedef struct {
+    int B;                        /* batch of the last head_forward */
+    int pad_h, pad_w;             /* padded network input size (ImageList.from_tensors(images, size_divisibility), odise.py:240) */
+    const int* img_hw;            /* HOST [B][2] true image sizes (the crop of sem_seg_postprocess) */
+    const int* out_hw;            /* HOST [B][2] requested output sizes ("height" / "width" of the input dicts) */
+    const float* mask_cls;        /* device [B,Q,K+1] log-probabilities (output of odise_hip_classify) */
+    const uint8_t* isthing;       /* HOST [K]: 1 for "thing" classes (metadata.thing_dataset_id_to_contiguous_id) */
+    int semantic_on, panoptic_on, instance_on;
+    float object_mask_threshold;  /* maskformer_model.py:290 */
+    double overlap_threshold;     /* :318 (double: compared against an integer ratio exactly like the reference's Python float) */
+    int topk;                     /* test_topk_per_image */
+    float* const* sem_seg;
+    int32_t* const* sem_argmax;
+    int32_t* const* panoptic;
+    float* const* inst_masks;
+    int32_t* inst_table;
+    float* inst_scores;
+} odise_post_desc;
+int odise_hip_postprocess_batch(odise_hip_ctx* ctx, const odise_post_desc* d);
+
+/* ---- CategoryODISE.forward / CaptionODISE.forward, eval branch, as ONE call (odise.py:236-246, 282-372; the call
+ * `self.model(batched_inputs)` of OpenPanopticInference.forward, odise/modeling/wrapper/pano_wrapper.py:64) ------------------------
+ * images[b]: device pointer to image b, uint8 [h_b, w_b, 3] (image_layout 0: HWC, the DatasetMapper's decoded picture),
+ * uint8 [3, h_b, w_b] (1: CHW, the "image" tensor of the reference's input dicts) or fp32 [3, h_b, w_b] with values 0..255 (2).
+ * The library normalises ((x - 0) / 255), pads to the batch maximum rounded up to 64 (backbone input) and to the batch maximum
+ * (MaskCLIP input, odise.py:242-244), runs backbone -> head -> classification -> the three heads.  post.B / pad_h / pad_w / img_hw /
+ * mask_cls are filled in by the library (post.out_hw NULL = image sizes).  mask_cls_out (optional): device [B,Q,K+1] fp32. */
+typedef struct {
+    int B;
+    const void* const* images;    /* HOST [B] device pointers */
+    int image_layout;
+    const int* img_hw;            /* HOST [B][2] */
+    float* mask_cls_out;
+    odise_post_desc post;
+} odise_infer_desc;
+int odise_hip_infer(odise_hip_ctx* ctx, const odise_infer_desc* d);
+
 /* ---- input resize and evaluator reductions of the eval loop --------------------------------------------
  * Replaces, on device buffers: detectron2 T.ResizeShortestEdge -> PIL.Image.resize(BILINEAR) of the DatasetMapper
  * (configs/common/data/pano_open_d2_eval.py:74-107) and the per-pixel parts of the evaluators configured there

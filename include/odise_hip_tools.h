@@ -1,0 +1,37 @@
+/*
+ * odise_hip_tools.h — developer / measurement hooks of libodise_hip.so.  NOT part of the drop-in boundary (include/odise_hip.h):
+ * nothing on the product path calls these; tools/ (tile calibration, A/B runs of kernel generations, the MFMA and LDS rate probes)
+ * and the ABI self-check of tests/test_lib_abi.py do.
+ */
+#ifndef ODISE_HIP_TOOLS_H
+#define ODISE_HIP_TOOLS_H
+
+#include "odise_hip.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* sizeof of the descriptor structs as the library was compiled (tests validate the ctypes mirrors against them) */
+int odise_hip_sizeof_gemm_desc(void);
+int odise_hip_sizeof_conv_desc(void);
+int odise_hip_sizeof_attn_desc(void);
+int odise_hip_sizeof_post_desc(void);
+int odise_hip_sizeof_infer_desc(void);
+
+/* odise_hip_gemm / odise_hip_conv2d with the tile shape and the split-K factor forced instead of chosen by the cost model
+ * (tile ids: gemm.hip kTileBM / kTileBN; -1 / 0 = automatic) */
+int odise_hip_gemm_forced(odise_hip_ctx* ctx, const odise_gemm_desc* d, int tile, int splitk);
+int odise_hip_conv2d_forced(odise_hip_ctx* ctx, const odise_conv_desc* d, int tile, int splitk);
+/* process-wide kernel-selection switches for A/B measurements (bits: gemm.hip launch_gemm) */
+int odise_hip_gemm_debug(int flags);
+
+/* probes (probe.hip): MFMA output layout, sustained MFMA rate on register-resident operands, LDS port rates */
+int odise_hip_mfma_probe(odise_hip_ctx* ctx, float* host_out);
+int odise_hip_mfma_rate(odise_hip_ctx* ctx, int variant, int iters, int blocks, int reps, float* ms_out, double* flops_out, double* mhz_out);
+int odise_hip_lds_rate(odise_hip_ctx* ctx, int variant, int rounds, int blocks, double* clocks_per_round, float* ms_out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* ODISE_HIP_TOOLS_H */

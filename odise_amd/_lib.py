@@ -13,6 +13,7 @@ import re
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("ODISE_HIP_LIB") or os.path.join(HERE, "lib", "libodise_hip.so")  # env: developer A/B builds
 HEADER_PATH = os.path.join(HERE, "..", "include", "odise_hip.h")
+TOOLS_HEADER_PATH = os.path.join(HERE, "..", "include", "odise_hip_tools.h")   # developer hooks: not part of the boundary
 
 F16, F32 = 0, 1
 ACT_NONE, ACT_SILU, ACT_RELU, ACT_GELU, ACT_QUICKGELU = 0, 1, 2, 3, 4
@@ -67,16 +68,86 @@ class JpegInfo(C.Structure):
                 ("coef_count", C.c_int64)]
 
 
+class PostDesc(C.Structure):
+    """odise_post_desc (include/odise_hip.h)."""
+    _fields_ = [("B", c_int), ("pad_h", c_int), ("pad_w", c_int), ("img_hw", c_void_p), ("out_hw", c_void_p), ("mask_cls", c_void_p),
+                ("isthing", c_void_p), ("semantic_on", c_int), ("panoptic_on", c_int), ("instance_on", c_int),
+                ("object_mask_threshold", c_float), ("overlap_threshold", C.c_double), ("topk", c_int),
+                ("sem_seg", c_void_p), ("sem_argmax", c_void_p), ("panoptic", c_void_p), ("inst_masks", c_void_p),
+                ("inst_table", c_void_p), ("inst_scores", c_void_p)]
+
+
+class InferDesc(C.Structure):
+    """odise_infer_desc (include/odise_hip.h)."""
+    _fields_ = [("B", c_int), ("images", c_void_p), ("image_layout", c_int), ("img_hw", c_void_p), ("mask_cls_out", c_void_p),
+                ("post", PostDesc)]
+
+
+MAX_SEGMENTS = 100          # ODISE_MAX_SEGMENTS
+COMM_ID_BYTES = 128         # ODISE_COMM_ID_BYTES
+
+
 class UnsupportedInput(RuntimeError):
     """ODISE_ERR_UNSUPPORTED: a valid input the library does not handle (e.g. a progressive JPEG); nothing was computed."""
 
 
-def header_symbols() -> list[str]:
-    """Every function name declared in include/odise_hip.h."""
-    with open(HEADER_PATH) as f:
+def _header_text(path: str = HEADER_PATH) -> str:
+    with open(path) as f:
         text = f.read()
-    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
-    return sorted(set(re.findall(r"\b(odise_hip_[a-z0-9_]+)\s*\(", text)))
+    return re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+
+
+def header_symbols(path: str = HEADER_PATH) -> list[str]:
+    """Every function name declared in include/odise_hip.h (or the given header)."""
+    return sorted(set(re.findall(r"\b(odise_hip_[a-z0-9_]+)\s*\(", _header_text(path))))
+
+
+# ---- argument marshalling derived from the header's prototypes ----------------------------------------------------------------------
+# Scalars are converted to the width the C prototype declares whatever the call site passed (a Python int, numpy integer or any ctypes
+# scalar): without this ctypes would push a bare Python int as a 32-bit C int and silently truncate an int64_t / size_t argument.
+def _scalar(ctype, conv):
+    class _S(ctype):
+        @classmethod
+        def from_param(cls, v):
+            return ctype(conv(getattr(v, "value", v)))
+    _S.__name__ = "arg_" + ctype.__name__
+    return _S
+
+
+class _Ptr(c_void_p):
+    @classmethod
+    def from_param(cls, v):
+        if v is None or isinstance(v, int):
+            return c_void_p(v)
+        if hasattr(v, "ptr") and not isinstance(v, (C._SimpleCData, C.Array, C.Structure)):   # runtime.DeviceArray
+            return c_void_p(v.ptr)
+        if isinstance(v, (bytes, bytearray)):
+            return C.c_char_p(bytes(v))
+        return v            # ctypes pointers, arrays, byref(...) results, c_void_p / c_char_p instances
+
+
+_ARG = {"int": _scalar(c_int, int), "int64_t": _scalar(c_int64, int), "size_t": _scalar(c_size_t, int), "float": _scalar(c_float, float),
+        "double": _scalar(C.c_double, float)}
+
+
+def header_prototypes(path: str = HEADER_PATH) -> dict:
+    """name -> list of (C type text, ctypes marshaller) per parameter, parsed from include/odise_hip.h (or the given header)."""
+    protos = {}
+    for m in re.finditer(r"\b(?:int|const char\*)\s+(odise_hip_[a-z0-9_]+)\s*\(([^;{]*?)\)\s*;", _header_text(path), flags=re.S):
+        name, params = m.group(1), " ".join(m.group(2).split())
+        args = []
+        if params not in ("", "void"):
+            for prm in params.split(","):
+                prm = prm.strip()
+                if "*" in prm:
+                    args.append((prm, _Ptr))
+                else:
+                    base = prm.replace("const ", "").split()[0]
+                    if base not in _ARG:
+                        raise RuntimeError(f"{name}: cannot marshal parameter '{prm}'")
+                    args.append((prm, _ARG[base]))
+        protos[name] = args
+    return protos
 
 
 _lib = None
@@ -92,13 +163,15 @@ def load() -> C.CDLL:
             f"{LIB_PATH} is missing: run `python -m odise_amd.build` (hipcc --offload-arch=gfx950). "
             "There is no CPU fallback for the ODISE hot path.")
     lib = C.CDLL(LIB_PATH)
-    missing = [s for s in header_symbols() if not hasattr(lib, s)]
+    missing = [s for s in header_symbols() + header_symbols(TOOLS_HEADER_PATH) if not hasattr(lib, s)]
     if missing:
         raise RuntimeError(f"libodise_hip.so does not export: {missing}")
     lib.odise_hip_last_error.restype = C.c_char_p
-    for name in header_symbols():
+    for name, args in {**header_prototypes(), **header_prototypes(TOOLS_HEADER_PATH)}.items():
+        fn = getattr(lib, name)
         if name != "odise_hip_last_error":
-            getattr(lib, name).restype = c_int
+            fn.restype = c_int
+        fn.argtypes = [a for _, a in args]
     _lib = lib
     return lib
 

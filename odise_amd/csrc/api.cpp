@@ -5,6 +5,7 @@
 #include <mutex>
 
 #include "common.h"
+#include "../../include/odise_hip_tools.h"
 
 namespace odise {
 static thread_local char g_err[1024] = "";
@@ -148,3 +149,5 @@ extern "C" int odise_hip_device_info(odise_hip_ctx* ctx, char* name_buf, int buf
 extern "C" int odise_hip_sizeof_gemm_desc(void) { return (int)sizeof(odise_gemm_desc); }
 extern "C" int odise_hip_sizeof_conv_desc(void) { return (int)sizeof(odise_conv_desc); }
 extern "C" int odise_hip_sizeof_attn_desc(void) { return (int)sizeof(odise_attn_desc); }
+extern "C" int odise_hip_sizeof_post_desc(void) { return (int)sizeof(odise_post_desc); }
+extern "C" int odise_hip_sizeof_infer_desc(void) { return (int)sizeof(odise_infer_desc); }

@@ -12,6 +12,9 @@
 #include <math.h>
 #include <string.h>
 
+#include <algorithm>
+#include <vector>
+
 #include "engine.h"
 
 namespace odise {
@@ -30,9 +33,58 @@ struct ClassifyModel {
     int* seg = nullptr;  // [K+1]
     int* ovl = nullptr;  // [K]
     float alpha = 0.3f, beta = 0.7f;
+    // growable device scratch of the post-processing stage (pixel-major sigmoid matrix, argmax ids, decision state) and of odise_hip_infer
+    // (converted / padded inputs, mask_cls): outside the arena, whose size is fixed by the network input, because the requested OUTPUT size
+    // ("height" / "width") is unrelated to it
+    // device banks of recently used vocabularies (the reference caches text embeddings per label tuple and keeps <= 4, odise.py:1092-1102,
+    // 1281-1288): OpenPanopticInference swaps the vocabulary in and out around EVERY call (pano_wrapper.py:62-66), which must not cost
+    // allocations, uploads or a synchronisation
+    struct Bank {
+        uint64_t key = 0;
+        int K = 0, Ktot = 0;
+        f16* T1 = nullptr;
+        f16* T2 = nullptr;
+        int* seg = nullptr;
+        int* ovl = nullptr;
+        float alpha = 0.f, beta = 0.f;
+        uint64_t stamp = 0;
+    };
+    std::vector<Bank> banks;
+    uint64_t bank_clock = 0;
+    void* post_buf = nullptr;
+    size_t post_cap = 0;
+    void* in_buf = nullptr;
+    size_t in_cap = 0;
+};
+
+static int scratch_reserve(odise_hip_ctx* ctx, void** buf, size_t* cap, size_t bytes) {
+    if (*cap >= bytes) return ODISE_OK;
+    ODISE_CHECK_HIP(hipStreamSynchronize(ctx->stream));
+    if (*buf) ODISE_CHECK_HIP(hipFree(*buf));
+    *buf = nullptr;
+    *cap = 0;
+    const size_t want = bytes + bytes / 8;
+    ODISE_CHECK_HIP(hipMalloc(buf, want));
+    *cap = want;
+    return ODISE_OK;
+}
+
+// releases the arena mark on every exit path
+struct ArenaScope {
+    Arena& a;
+    size_t mk;
+    explicit ArenaScope(Arena& arena) : a(arena), mk(arena.mark()) {}
+    ~ArenaScope() { a.release(mk); }
 };
 
 void classify_destroy(ModelStore* ms) {
+    if (ms->classify) {
+        for (auto& bk : ms->classify->banks) {
+            (void)hipFree(bk.T1); (void)hipFree(bk.T2); (void)hipFree(bk.seg); (void)hipFree(bk.ovl);
+        }
+        if (ms->classify->post_buf) (void)hipFree(ms->classify->post_buf);
+        if (ms->classify->in_buf) (void)hipFree(ms->classify->in_buf);
+    }
     delete ms->classify;
     ms->classify = nullptr;
 }
@@ -99,34 +151,71 @@ extern "C" int odise_hip_set_vocabulary(odise_hip_ctx* ctx, const float* cat_tex
     }
     ODISE_REQUIRE(seg[K] == K_tot, "set_vocabulary: group sizes sum to %d, expected %d", seg[K], K_tot);
     ODISE_CHECK_HIP(hipSetDevice(ctx->device));
+    // ---- cached? (FNV-1a over every input byte)
+    uint64_t key = 1469598103934665603ull;
+    auto mix = [&](const void* p, size_t n) {
+        const unsigned char* b = (const unsigned char*)p;
+        for (size_t i = 0; i < n; ++i) { key ^= b[i]; key *= 1099511628211ull; }
+    };
+    mix(cat_text, (size_t)K_tot * dim * 4); mix(clip_text, (size_t)K_tot * dim * 4); mix(group_sizes, (size_t)K * 4); mix(overlap, (size_t)K * 4);
+    mix(&alpha, 4); mix(&beta, 4); mix(&K_tot, 4);
+    auto activate = [&](ClassifyModel::Bank& bk) {
+        c->T1 = bk.T1; c->T2 = bk.T2; c->seg = bk.seg; c->ovl = bk.ovl;
+        c->K = bk.K; c->Ktot = bk.Ktot; c->alpha = bk.alpha; c->beta = bk.beta;
+        bk.stamp = ++c->bank_clock;
+        c->has_vocab = true;
+    };
+    for (auto& bk : c->banks)
+        if (bk.key == key && bk.K == K && bk.Ktot == K_tot) { activate(bk); return ODISE_OK; }
+    ODISE_CHECK_HIP(hipStreamSynchronize(ctx->stream));   // a new bank: queued work may still read the one about to be evicted
+    if (c->banks.size() >= 8) {
+        size_t lru = 0;
+        for (size_t i = 1; i < c->banks.size(); ++i) if (c->banks[i].stamp < c->banks[lru].stamp) lru = i;
+        ClassifyModel::Bank& ev = c->banks[lru];
+        (void)hipFree(ev.T1); (void)hipFree(ev.T2); (void)hipFree(ev.seg); (void)hipFree(ev.ovl);
+        c->banks.erase(c->banks.begin() + lru);
+    }
     // T1 = normalize(text_proj([cat_text; null_embed])) ; T2 = normalize(clip_text)
     std::vector<f16> in16((size_t)(K_tot + 1) * dim);
     for (size_t i = 0; i < (size_t)K_tot * dim; ++i) in16[i] = (f16)cat_text[i];
     for (int i = 0; i < dim; ++i) in16[(size_t)K_tot * dim + i] = (f16)c->null_embed[i];
+    ClassifyModel::Bank bk;
+    bk.key = key; bk.K = K; bk.Ktot = K_tot; bk.alpha = alpha; bk.beta = beta;
     f16* d_in = nullptr;
     float* d_proj = nullptr;
     float* d_clip = nullptr;
-    ODISE_TRY(dev_upload(ctx, ms, in16.data(), in16.size() * 2, (void**)&d_in));
-    ODISE_CHECK_HIP(hipMalloc((void**)&d_proj, (size_t)(K_tot + 1) * c->pdim * 4));
-    ms->dev_allocs.push_back(d_proj);
-    ODISE_TRY(dev_upload(ctx, ms, clip_text, (size_t)K_tot * dim * 4, (void**)&d_clip));
-    ODISE_CHECK_HIP(hipMalloc((void**)&c->T1, (size_t)(K_tot + 1) * c->pdim * 2));
-    ms->dev_allocs.push_back(c->T1);
-    ODISE_CHECK_HIP(hipMalloc((void**)&c->T2, (size_t)K_tot * dim * 2));
-    ms->dev_allocs.push_back(c->T2);
-    odise_gemm_desc d;
-    memset(&d, 0, sizeof(d));
-    d.M = K_tot + 1; d.N = c->pdim; d.K = dim;
-    d.A = d_in; d.lda = dim; d.W = c->text_proj.w; d.ldw = dim;
-    d.C = d_proj; d.ldc = c->pdim; d.c_dtype = ODISE_F32; d.bias_n = c->text_proj.b; d.alpha = 1.f; d.batch = 1;
-    ODISE_TRY(odise_hip_gemm(ctx, &d));
-    ODISE_TRY(launch_l2_normalize_f32(ctx, d_proj, c->T1, K_tot + 1, c->pdim));
-    ODISE_TRY(launch_l2_normalize_f32(ctx, d_clip, c->T2, K_tot, dim));
-    ODISE_TRY(dev_upload(ctx, ms, seg.data(), seg.size() * sizeof(int), (void**)&c->seg));
-    ODISE_TRY(dev_upload(ctx, ms, overlap, (size_t)K * sizeof(int), (void**)&c->ovl));
-    c->K = K; c->Ktot = K_tot; c->alpha = alpha; c->beta = beta;
-    c->has_vocab = true;
-    ODISE_CHECK_HIP(hipStreamSynchronize(ctx->stream));
+    auto up = [&](const void* host, size_t bytes, void** dev) -> int {
+        ODISE_CHECK_HIP(hipMalloc(dev, bytes ? bytes : 16));
+        ODISE_CHECK_HIP(hipMemcpy(*dev, host, bytes, hipMemcpyHostToDevice));
+        return ODISE_OK;
+    };
+    int rc = up(in16.data(), in16.size() * 2, (void**)&d_in);
+    if (rc == ODISE_OK) rc = up(clip_text, (size_t)K_tot * dim * 4, (void**)&d_clip);
+    if (rc == ODISE_OK && hipMalloc((void**)&d_proj, (size_t)(K_tot + 1) * c->pdim * 4) != hipSuccess) rc = ODISE_ERR_NOMEM;
+    if (rc == ODISE_OK && hipMalloc((void**)&bk.T1, (size_t)(K_tot + 1) * c->pdim * 2) != hipSuccess) rc = ODISE_ERR_NOMEM;
+    if (rc == ODISE_OK && hipMalloc((void**)&bk.T2, (size_t)K_tot * dim * 2) != hipSuccess) rc = ODISE_ERR_NOMEM;
+    if (rc == ODISE_OK) rc = up(seg.data(), seg.size() * sizeof(int), (void**)&bk.seg);
+    if (rc == ODISE_OK) rc = up(overlap, (size_t)K * sizeof(int), (void**)&bk.ovl);
+    if (rc == ODISE_OK) {
+        odise_gemm_desc d;
+        memset(&d, 0, sizeof(d));
+        d.M = K_tot + 1; d.N = c->pdim; d.K = dim;
+        d.A = d_in; d.lda = dim; d.W = c->text_proj.w; d.ldw = dim;
+        d.C = d_proj; d.ldc = c->pdim; d.c_dtype = ODISE_F32; d.bias_n = c->text_proj.b; d.alpha = 1.f; d.batch = 1;
+        rc = odise_hip_gemm(ctx, &d);
+    }
+    if (rc == ODISE_OK) rc = launch_l2_normalize_f32(ctx, d_proj, bk.T1, K_tot + 1, c->pdim);
+    if (rc == ODISE_OK) rc = launch_l2_normalize_f32(ctx, d_clip, bk.T2, K_tot, dim);
+    const hipError_t se = hipStreamSynchronize(ctx->stream);
+    (void)hipFree(d_in); (void)hipFree(d_proj); (void)hipFree(d_clip);
+    if (rc != ODISE_OK || se != hipSuccess) {
+        (void)hipFree(bk.T1); (void)hipFree(bk.T2); (void)hipFree(bk.seg); (void)hipFree(bk.ovl);
+        if (rc == ODISE_ERR_NOMEM) set_error("set_vocabulary: out of device memory");
+        if (rc == ODISE_OK) { set_error("set_vocabulary: %s", hipGetErrorString(se)); rc = ODISE_ERR_HIP; }
+        return rc;
+    }
+    c->banks.push_back(bk);
+    activate(c->banks.back());
     return ODISE_OK;
 }
 
@@ -150,7 +239,7 @@ extern "C" int odise_hip_classify(odise_hip_ctx* ctx, const float* image, int B,
     }
     ODISE_REQUIRE(cdim == c->dim, "classify: CLIP output dim %d != text dim %d", cdim, c->dim);
     Exec ex{ctx, ms};
-    const size_t mk = ms->arena.mark();
+    ArenaScope scope(ms->arena);
     const int Q = ho.Q;
     const int64_t MQ = (int64_t)B * Q;
     // ---- category logits: cos(mask_embed, text_proj(text bank)) --------------------------------------------------------
@@ -190,7 +279,6 @@ extern "C" int odise_hip_classify(odise_hip_ctx* ctx, const float* image, int B,
     }
     ODISE_TRY(launch_classify_rows(ctx, L1, L2, c->seg, c->ovl, c->caption ? ho.class_logits : nullptr, mask_cls, MQ, c->K, c->Ktot,
                                    ho.logit_scale, 100.0f, c->alpha, c->beta));
-    ms->arena.release(mk);
     return ODISE_OK;
 }
 
@@ -211,11 +299,16 @@ extern "C" int odise_hip_postprocess_pixels(odise_hip_ctx* ctx, int b, const flo
     g.h4 = ho.h4; g.w4 = ho.w4; g.ph = pad_h; g.pw = pad_w; g.ih = img_h; g.iw = img_w; g.oh = out_h; g.ow = out_w;
     g.Q = ho.Q; g.Qpad = (int)round_up(ho.Q, 8);
     Exec ex{ctx, ms};
-    const size_t mk = ms->arena.mark();
+    ArenaScope scope(ms->arena);
     const int npix = out_h * out_w;
     const bool need_S = (sem_seg && semT) || inst_stats;
     f16* S = need_S ? (f16*)ex.alloc_bytes((size_t)npix * g.Qpad * 2) : nullptr;
-    if (need_S && !S) return ODISE_ERR_NOMEM;
+    if (need_S && !S) {   // outputs much larger than the network input: the arena (sized by the input) is too small for S
+        ClassifyModel* cm = ms->classify;
+        if (!cm) { set_error("postprocess_pixels: call odise_hip_classify_build first"); return ODISE_ERR_STATE; }
+        ODISE_TRY(scratch_reserve(ctx, &cm->post_buf, &cm->post_cap, (size_t)npix * g.Qpad * 2));
+        S = (f16*)cm->post_buf;
+    }
     if (counts) ODISE_CHECK_HIP(hipMemsetAsync(counts, 0, 3 * (size_t)ho.Q * sizeof(int), ctx->stream));
     int* cnt = counts;
     if (!cnt) {
@@ -231,7 +324,6 @@ extern "C" int odise_hip_postprocess_pixels(odise_hip_ctx* ctx, int b, const flo
         if (!A) return ODISE_ERR_NOMEM;
         ODISE_CHECK_HIP(hipMemsetAsync(A, 0, (size_t)K * g.Qpad * 2, ctx->stream));
         // semT fp32 [K, Q] -> fp16 [K, Qpad] (row pitch change via 2D copy is not possible with a dtype change: cast row-wise)
-        for (int k0 = 0; k0 < K; k0 += 4096) (void)k0;
         f16* tmp = (f16*)ex.alloc_bytes((size_t)K * ho.Q * 2);
         if (!tmp) return ODISE_ERR_NOMEM;
         ODISE_TRY(odise_hip_cast_f32_to_f16(ctx, semT, tmp, (size_t)K * ho.Q));
@@ -248,7 +340,6 @@ extern "C" int odise_hip_postprocess_pixels(odise_hip_ctx* ctx, int b, const flo
         if (!partial) return ODISE_ERR_NOMEM;
         ODISE_TRY(launch_column_stats(ctx, S, partial, inst_stats, npix, g.Qpad));
     }
-    ms->arena.release(mk);
     return ODISE_OK;
 }
 
@@ -268,4 +359,137 @@ extern "C" int odise_hip_instance_masks(odise_hip_ctx* ctx, int b, const int* id
     g.h4 = ho.h4; g.w4 = ho.w4; g.ph = pad_h; g.pw = pad_w; g.ih = img_h; g.iw = img_w; g.oh = out_h; g.ow = out_w;
     g.Q = ho.Q; g.Qpad = (int)round_up(ho.Q, 8);
     return launch_instance_masks(ctx, ho.pred_masks + (size_t)b * ho.Q * ho.h4 * ho.w4, idx, out, n, g);
+}
+
+// ---- the three heads for a batch, decisions on the device -------------------------------------------------------------------------------
+extern "C" int odise_hip_postprocess_batch(odise_hip_ctx* ctx, const odise_post_desc* d) {
+    ODISE_REQUIRE(ctx && d, "postprocess_batch: null argument");
+    ModelStore* ms = store_of(ctx);
+    ClassifyModel* c = ms->classify;
+    if (!c || !c->has_vocab) {
+        set_error("postprocess_batch: call odise_hip_classify_build and odise_hip_set_vocabulary first");
+        return ODISE_ERR_STATE;
+    }
+    HeadOutputs ho;
+    ODISE_TRY(head_outputs(ms, &ho));
+    const int B = d->B, Q = ho.Q, K = c->K, Qpad = (int)round_up(Q, 8);
+    ODISE_REQUIRE(B == ho.B, "postprocess_batch: batch %d differs from the last head_forward (%d)", B, ho.B);
+    ODISE_REQUIRE(d->mask_cls && d->img_hw, "postprocess_batch: mask_cls / img_hw missing");
+    ODISE_REQUIRE(!(d->panoptic_on || d->instance_on) || d->isthing, "postprocess_batch: isthing[K] is required by the panoptic and instance heads");
+    ODISE_REQUIRE(d->pad_h == 4 * ho.h4 && d->pad_w == 4 * ho.w4, "postprocess_batch: padded size %dx%d does not match the mask logits (%dx%d x 4)", d->pad_h,
+                  d->pad_w, ho.h4, ho.w4);
+    const bool want_pan = d->panoptic_on && d->panoptic, want_inst = d->instance_on && d->inst_table && d->inst_scores;
+    const bool want_sem = d->semantic_on && (d->sem_seg || d->sem_argmax);
+    const int topk = d->topk > 0 ? d->topk : 100;
+    int max_pix = 1;
+    for (int b = 0; b < B; ++b) {
+        const int ih = d->img_hw[2 * b], iw = d->img_hw[2 * b + 1];
+        const int oh = d->out_hw ? d->out_hw[2 * b] : ih, ow = d->out_hw ? d->out_hw[2 * b + 1] : iw;
+        ODISE_REQUIRE(ih >= 1 && iw >= 1 && ih <= d->pad_h && iw <= d->pad_w && oh >= 1 && ow >= 1 && (int64_t)oh * ow < (1ll << 30),
+                      "postprocess_batch: bad geometry of image %d", b);
+        max_pix = std::max(max_pix, oh * ow);
+    }
+    // ---- scratch layout (256-byte aligned pieces)
+    size_t off = 0;
+    auto take = [&](size_t bytes) { const size_t o = off; off = (off + bytes + 255) & ~(size_t)255; return o; };
+    const size_t o_kscore = take((size_t)B * Q * 4), o_label = take((size_t)B * Q * 4), o_map = take((size_t)B * Q * 4);
+    const size_t o_counts = take((size_t)B * 3 * Q * 4), o_stats = take((size_t)B * 2 * Qpad * 4), o_stuff = take((size_t)K * 4);
+    const size_t o_thing = take((size_t)K), o_probs = take(want_inst ? (size_t)B * Q * K * 4 : 0), o_semT = take((size_t)B * K * Qpad * 2);
+    const size_t o_partial = take((size_t)512 * 2 * Qpad * 4);
+    const size_t o_ids = take((size_t)max_pix * 4), o_S = take((size_t)max_pix * Qpad * 2);
+    ODISE_TRY(scratch_reserve(ctx, &c->post_buf, &c->post_cap, off));
+    char* base = (char*)c->post_buf;
+    float* kscore = (float*)(base + o_kscore);
+    int* label = (int*)(base + o_label);
+    int* map = (int*)(base + o_map);
+    int* counts = (int*)(base + o_counts);
+    float* stats = (float*)(base + o_stats);
+    int* stuff = (int*)(base + o_stuff);
+    uint8_t* thing = (uint8_t*)(base + o_thing);
+    float* probs = want_inst ? (float*)(base + o_probs) : nullptr;
+    f16* semT = (f16*)(base + o_semT);
+    float* partial = (float*)(base + o_partial);
+    int* ids = (int*)(base + o_ids);
+    f16* S = (f16*)(base + o_S);
+    if (d->isthing) ODISE_CHECK_HIP(hipMemcpyAsync(thing, d->isthing, (size_t)K, hipMemcpyHostToDevice, ctx->stream));
+    ODISE_CHECK_HIP(hipMemsetAsync(counts, 0, (size_t)B * 3 * Q * 4, ctx->stream));
+    ODISE_TRY(launch_post_decide(ctx, d->mask_cls, kscore, label, semT, probs, B, Q, Qpad, K, d->object_mask_threshold));
+    Exec ex{ctx, ms};
+    for (int b = 0; b < B; ++b) {
+        PostGeom g;
+        g.h4 = ho.h4; g.w4 = ho.w4; g.ph = d->pad_h; g.pw = d->pad_w; g.ih = d->img_hw[2 * b]; g.iw = d->img_hw[2 * b + 1];
+        g.oh = d->out_hw ? d->out_hw[2 * b] : g.ih; g.ow = d->out_hw ? d->out_hw[2 * b + 1] : g.iw;
+        g.Q = Q; g.Qpad = Qpad;
+        const int npix = g.oh * g.ow;
+        const f16* logits = ho.pred_masks + (size_t)b * Q * ho.h4 * ho.w4;
+        float* sem = (want_sem && d->sem_seg) ? d->sem_seg[b] : nullptr;
+        int* amax = (want_sem && d->sem_argmax) ? d->sem_argmax[b] : nullptr;
+        int* pan = want_pan ? d->panoptic[b] : nullptr;
+        const bool inst = want_inst;
+        const bool need_S = sem || amax || inst;
+        if (!need_S && !pan) continue;
+        ODISE_TRY(launch_postprocess_pixels(ctx, logits, kscore + (size_t)b * Q, need_S ? S : nullptr, pan ? ids : nullptr, counts + (size_t)b * 3 * Q, g));
+        if (sem) {   // sem_seg[c, p] = sum_q softmax(mask_cls)[q, c] * sigmoid(mask)[q, p]  (maskformer_model.py:280-284) as an MFMA GEMM
+            odise_gemm_desc gd;
+            memset(&gd, 0, sizeof(gd));
+            gd.M = K; gd.N = npix; gd.K = Qpad;
+            gd.A = semT + (size_t)b * K * Qpad; gd.lda = Qpad; gd.W = S; gd.ldw = Qpad;
+            gd.C = sem; gd.ldc = npix; gd.c_dtype = ODISE_F32; gd.alpha = 1.f; gd.batch = 1;
+            ODISE_TRY(ex.gemm(gd));
+        }
+        if (amax) ODISE_TRY(launch_semantic_argmax(ctx, S, semT + (size_t)b * K * Qpad, amax, npix, Qpad, K));
+        if (inst) ODISE_TRY(launch_column_stats(ctx, S, partial, stats + (size_t)b * 2 * Qpad, npix, Qpad));
+        if (pan) {
+            ODISE_TRY(launch_panoptic_decide(ctx, counts + (size_t)b * 3 * Q, kscore + (size_t)b * Q, label + (size_t)b * Q, thing, map + (size_t)b * Q,
+                                             pan + npix, Q, K, d->overlap_threshold, ODISE_MAX_SEGMENTS, stuff));
+            ODISE_TRY(launch_panoptic_write(ctx, ids, map + (size_t)b * Q, pan, npix));
+        }
+        if (inst) {
+            int* tb = d->inst_table + (size_t)b * (1 + 2 * topk);
+            ODISE_TRY(launch_instance_topk(ctx, probs + (size_t)b * Q * K, stats + (size_t)b * 2 * Qpad, thing, tb, d->inst_scores + (size_t)b * topk, Q, Qpad,
+                                           K, topk, d->panoptic_on ? 1 : 0));
+            if (d->inst_masks && d->inst_masks[b])
+                ODISE_TRY(launch_instance_masks(ctx, logits, tb + 1, d->inst_masks[b], std::min(topk, Q * K), g, tb));
+        }
+    }
+    return ODISE_OK;
+}
+
+extern "C" int odise_hip_infer(odise_hip_ctx* ctx, const odise_infer_desc* d) {
+    ODISE_REQUIRE(ctx && d && d->images && d->img_hw && d->B >= 1, "infer: null argument");
+    ModelStore* ms = store_of(ctx);
+    ClassifyModel* c = ms->classify;
+    if (!c || !c->has_vocab) {
+        set_error("infer: call odise_hip_classify_build and odise_hip_set_vocabulary first");
+        return ODISE_ERR_STATE;
+    }
+    ODISE_REQUIRE(d->image_layout >= 0 && d->image_layout <= 2, "infer: image_layout %d", d->image_layout);
+    const int B = d->B;
+    int H = 0, W = 0;
+    for (int b = 0; b < B; ++b) {
+        ODISE_REQUIRE(d->images[b] && d->img_hw[2 * b] >= 1 && d->img_hw[2 * b + 1] >= 1, "infer: bad image %d", b);
+        H = std::max(H, d->img_hw[2 * b]);
+        W = std::max(W, d->img_hw[2 * b + 1]);
+    }
+    const int Hp = (int)round_up(H, 64), Wp = (int)round_up(W, 64);   // size_divisibility = 64 (feature_extractor.py:126-128)
+    int Q = 0;
+    ODISE_TRY(odise_hip_maskgen_info(ctx, &Q, nullptr, nullptr));
+    const size_t n_pad = (size_t)B * 3 * Hp * Wp, n_img = (size_t)B * 3 * H * W, n_cls = (size_t)B * Q * (c->K + 1);
+    const bool same = Hp == H && Wp == W;
+    ODISE_TRY(scratch_reserve(ctx, &c->in_buf, &c->in_cap, (n_pad + (same ? 0 : n_img) + n_cls) * 4 + 1024));
+    float* padded = (float*)c->in_buf;
+    float* img01 = same ? padded : padded + n_pad;
+    float* mask_cls = (same ? padded + n_pad : img01 + n_img);
+    for (int b = 0; b < B; ++b) {
+        const int h = d->img_hw[2 * b], w = d->img_hw[2 * b + 1];
+        ODISE_TRY(launch_image_pad(ctx, d->images[b], d->image_layout, h, w, padded + (size_t)b * 3 * Hp * Wp, Hp, Wp));
+        if (!same) ODISE_TRY(launch_image_pad(ctx, d->images[b], d->image_layout, h, w, img01 + (size_t)b * 3 * H * W, H, W));
+    }
+    ODISE_TRY(odise_hip_backbone_forward(ctx, padded, B, Hp, Wp, nullptr));
+    ODISE_TRY(odise_hip_head_forward(ctx, nullptr, B, 0, Hp / 4, Wp / 4, nullptr, nullptr, nullptr, nullptr));
+    ODISE_TRY(odise_hip_classify(ctx, img01, B, H, W, mask_cls, nullptr));
+    if (d->mask_cls_out) ODISE_CHECK_HIP(hipMemcpyAsync(d->mask_cls_out, mask_cls, n_cls * 4, hipMemcpyDeviceToDevice, ctx->stream));
+    odise_post_desc p = d->post;
+    p.B = B; p.pad_h = Hp; p.pad_w = Wp; p.img_hw = d->img_hw; p.mask_cls = mask_cls;
+    return odise_hip_postprocess_batch(ctx, &p);
 }

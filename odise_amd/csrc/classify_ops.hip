@@ -192,6 +192,14 @@ __device__ __forceinline__ float sample_mask(const f16* lr, const PostGeom& g, i
     return top + ty * (bot - top);
 }
 
+// fp16 sigmoid for the pixel-major matrix S.  The instance head counts a pixel as inside the mask iff its LOGIT is positive
+// (maskformer_model.py:371 `mask_pred > 0`) and averages sigmoid over exactly those pixels (:376-377); sigmoid(v) for 0 < v < ~1e-3
+// rounds to 0.5 in fp16, so such pixels get the next representable value above 0.5: `S > 0.5` then reproduces `logit > 0` exactly.
+__device__ __forceinline__ f16 sig_f16(float sg, float v) {
+    const f16 h = (f16)sg;
+    return (v > 0.f && !(h > (f16)0.5f)) ? (f16)0.50048828125f : h;
+}
+
 // thread per output pixel.  kscore[q] = panoptic score of query q if it is kept (label != null, score > threshold) else < 0.
 // S [npix, Qpad] f16 sigmoid (optional); ids [npix] int32 = argmax kept query | (sigmoid>=0.5 ? 1<<16 : 0), -1 if nothing kept;
 // counts [3][Q] int32: mask_area (argmax == q), original_area (sigmoid >= 0.5), intersection.
@@ -217,7 +225,7 @@ __global__ void __launch_bounds__(256) postprocess_pixels_kernel(const f16* __re
             if (q < Q) {  // uniform branch
                 const float v = ok ? sample_mask(logits + (int64_t)q * g.h4 * g.w4, g, oy, ox) : -1.f;
                 const float sg = 1.f / (1.f + expf(-v));
-                sv[j] = (f16)sg;
+                sv[j] = sig_f16(sg, v);
                 const float ks = kscore[q];
                 const bool pos = sg >= 0.5f;
                 if (ks >= 0.f) {
@@ -290,7 +298,7 @@ __global__ void __launch_bounds__(256) postprocess_pixels_x4_kernel(const f16* _
                     const float top = v00 + tx * (v01 - v00), bot = v10 + tx * (v11 - v10);
                     const float v = ok[k] ? top + ty * (bot - top) : -1.f;
                     const float sg = 1.f / (1.f + expf(-v));
-                    sv[k][j] = (f16)sg;
+                    sv[k][j] = sig_f16(sg, v);
                     const bool pos = sg >= 0.5f;
                     if (ks >= 0.f) {
                         const unsigned long long bal = __ballot(ok[k] && pos);
@@ -377,8 +385,9 @@ __global__ void __launch_bounds__(256) panoptic_write_kernel(const int* __restri
 
 // out[n, p] = (upsampled logit of query idx[n] at pixel p > 0) ? 1 : 0   (maskformer_model.py:371)
 __global__ void __launch_bounds__(256) instance_masks_kernel(const f16* __restrict__ logits, const int* __restrict__ idx, float* __restrict__ out,
-                                                            PostGeom g) {
+                                                            PostGeom g, const int* __restrict__ n_dev) {
     const int n = blockIdx.y;
+    if (n_dev && n >= *n_dev) return;  // launched for the maximum count; the selection's size lives on the device
     const int p = blockIdx.x * blockDim.x + threadIdx.x;
     const int npix = g.oh * g.ow;
     if (p >= npix) return;
@@ -390,8 +399,9 @@ __global__ void __launch_bounds__(256) instance_masks_kernel(const f16* __restri
 // x4 specialisation of instance_masks_kernel (same tap pattern as postprocess_pixels_x4_kernel): a thread writes the 4 pixels of a
 // cell column as one 16-byte store
 __global__ void __launch_bounds__(256) instance_masks_x4_kernel(const f16* __restrict__ logits, const int* __restrict__ idx,
-                                                               float* __restrict__ out, PostGeom g) {
+                                                               float* __restrict__ out, PostGeom g, const int* __restrict__ n_dev) {
     const int n = blockIdx.y;
+    if (n_dev && n >= *n_dev) return;
     const int cw = g.ow >> 2;  // ow % 4 == 0 on this path
     const int t = blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= g.oh * cw) return;
@@ -412,6 +422,286 @@ __global__ void __launch_bounds__(256) instance_masks_x4_kernel(const f16* __res
         o[k] = (top + ty * (bot - top)) > 0.f ? 1.f : 0.f;
     }
     *reinterpret_cast<float4*>(out + (int64_t)n * g.oh * g.ow + (int64_t)oy * g.ow + 4 * cx) = make_float4(o[0], o[1], o[2], o[3]);
+}
+
+
+// ---- device-side decisions of the three inference heads (maskformer_model.py:286-380) -------------------------------------------------
+// The reference takes them on the host from device tensors (`.item()` per segment, maskformer_model.py:312-340); round 1 of this
+// library took them in numpy after a read-back of mask_cls.  Here they stay on the device, so one model call is one stream of kernels
+// and a single small read-back (segment / instance tables) at the end, and the multi-GPU record is written where it is produced.
+
+// One block per image.  mask_cls [Q, K+1] log-probabilities -> F.softmax again (maskformer_model.py:287, 281, 349), then
+//   kscore [Q]       max probability if the query is kept (label != K and score > threshold, :289-290), -1 otherwise
+//   label  [Q]       argmax (first maximum)
+//   semT   [K, Qpad] f16 probabilities of the K real classes, transposed (A operand of the semantic GEMM, :281-283); optional
+//   probs  [Q, K]    f32 probabilities (instance top-k, :349); optional
+__global__ void __launch_bounds__(256) post_decide_kernel(const float* __restrict__ mask_cls, float* __restrict__ kscore, int* __restrict__ label,
+                                                         f16* __restrict__ semT, float* __restrict__ probs, int Q, int Qpad, int K,
+                                                         float object_mask_threshold, int64_t cls_stride, int64_t out_stride_q, int64_t semT_stride,
+                                                         int64_t probs_stride) {
+    const int b = blockIdx.x;
+    const float* mc = mask_cls + (int64_t)b * cls_stride;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (semT) {   // zero the padding columns q in [Q, Qpad)
+        f16* st = semT + (int64_t)b * semT_stride;
+        for (int i = threadIdx.x; i < K * (Qpad - Q); i += blockDim.x) st[(int64_t)(i / (Qpad - Q)) * Qpad + Q + i % (Qpad - Q)] = (f16)0.f;
+    }
+    for (int q = wave; q < Q; q += 4) {
+        const float* row = mc + (int64_t)q * (K + 1);
+        float m = -INFINITY;
+        for (int k = lane; k <= K; k += 64) m = fmaxf(m, row[k]);
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
+        float ssum = 0.f;
+        for (int k = lane; k <= K; k += 64) ssum += expf(row[k] - m);
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) ssum += __shfl_xor(ssum, o);
+        float best = -1.f;
+        int best_k = 0x7fffffff;
+        for (int k = lane; k <= K; k += 64) {
+            const float pr = expf(row[k] - m) / ssum;
+            if (k < K) {
+                if (semT) semT[(int64_t)b * semT_stride + (int64_t)k * Qpad + q] = (f16)pr;
+                if (probs) probs[(int64_t)b * probs_stride + (int64_t)q * K + k] = pr;
+            }
+            if (pr > best) { best = pr; best_k = k; }   // ascending k per lane: the first maximum of the lane
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            const float ob = __shfl_xor(best, o);
+            const int ok = __shfl_xor(best_k, o);
+            if (ob > best || (ob == best && ok < best_k)) { best = ob; best_k = ok; }
+        }
+        if (lane == 0) {
+            const bool keep = best_k != K && best > object_mask_threshold;
+            kscore[(int64_t)b * out_stride_q + q] = keep ? best : -1.f;
+            label[(int64_t)b * out_stride_q + q] = best_k;
+        }
+    }
+}
+
+// One thread per image walks the kept queries in order (maskformer_model.py:312-340): areas from the integer counters of the
+// per-pixel pass, overlap test, stuff merging by class, sequential segment ids.  map [Q] = segment id of every query (0 = none);
+// table = n_segments | (id, isthing, category_id) x n  (the tail of the image's prediction record, odise_amd/distributed.py).
+__global__ void panoptic_decide_kernel(const int* __restrict__ cnt, const float* __restrict__ ks, const int* __restrict__ lb,
+                                       const uint8_t* __restrict__ isthing, int* __restrict__ mp, int* __restrict__ table, int Q, int K,
+                                       double overlap_threshold, int max_segments, int* __restrict__ stuff) {
+    // stuff[k] = segment id of a stuff class already emitted, 0 = none
+    for (int k = threadIdx.x; k < K; k += blockDim.x) stuff[k] = 0;
+    __syncthreads();
+    if (threadIdx.x != 0) return;
+    int current = 0, n = 0;
+    for (int q = 0; q < Q; ++q) {
+        mp[q] = 0;
+        if (!(ks[q] >= 0.f)) continue;
+        const int cls = lb[q];
+        const int mask_area = cnt[q], original_area = cnt[Q + q], inter = cnt[2 * Q + q];
+        if (mask_area > 0 && original_area > 0 && inter > 0) {
+            if ((double)mask_area / (double)original_area < overlap_threshold) continue;
+            const bool thing = isthing[cls] != 0;
+            if (!thing) {
+                if (stuff[cls]) { mp[q] = stuff[cls]; continue; }
+                stuff[cls] = current + 1;
+            }
+            ++current;
+            mp[q] = current;
+            if (table && n < max_segments) {
+                table[1 + 3 * n] = current;
+                table[2 + 3 * n] = thing ? 1 : 0;
+                table[3 + 3 * n] = cls;
+            }
+            ++n;
+        }
+    }
+    if (table) {
+        const int m = n < max_segments ? n : max_segments;
+        table[0] = m;
+        for (int i = m; i < max_segments; ++i) table[1 + 3 * i] = table[2 + 3 * i] = table[3 + 3 * i] = 0;
+    }
+}
+
+// Instance head (maskformer_model.py:344-380): one block per image selects the top-k of the Q*K class probabilities (radix select on
+// the float bits - probabilities are non-negative, so unsigned order = float order), sorts them (score descending, flat index
+// ascending on ties), keeps "thing" classes when the panoptic head is on (:363-369) and multiplies with the mask score
+// sum(sigmoid * [logit > 0]) / (count + 1e-6) (:376-377) from the per-pixel pass.
+//   table [1 + 2*topk] int32: n | query index x topk | class x topk ;  scores [topk] f32 (entries >= n are zero)
+__global__ void __launch_bounds__(1024) instance_topk_kernel(const float* __restrict__ probs, const float* __restrict__ inst_stats,
+                                                            const uint8_t* __restrict__ isthing, int* __restrict__ table, float* __restrict__ scores,
+                                                            int Q, int Qpad, int K, int topk, int things_only) {
+    extern __shared__ unsigned int sm_u[];
+    unsigned int* hist = sm_u;                 // [256]
+    unsigned int* sel_key = sm_u + 256;        // [topk]
+    int* sel_idx = (int*)(sm_u + 256 + topk);  // [topk]
+    __shared__ unsigned int s_prefix, s_need, s_count, s_base;
+    const float* pr = probs;
+    const unsigned int* keys = reinterpret_cast<const unsigned int*>(pr);
+    const int N = Q * K;
+    const int k_sel = topk < N ? topk : N;
+    const int tid = threadIdx.x, nt = blockDim.x;
+    // ---- radix select: the k_sel-th largest key
+    if (tid == 0) { s_prefix = 0; s_need = (unsigned)k_sel; }
+    __syncthreads();
+    for (int pass = 0; pass < 4; ++pass) {
+        const int shift = 24 - 8 * pass;
+        for (int i = tid; i < 256; i += nt) hist[i] = 0;
+        __syncthreads();
+        const unsigned int prefix = s_prefix;
+        const unsigned int himask = pass == 0 ? 0u : (0xffffffffu << (shift + 8));
+        for (int i = tid; i < N; i += nt) {
+            const unsigned int kx = keys[i];
+            if ((kx & himask) == prefix) atomicAdd(&hist[(kx >> shift) & 255u], 1u);
+        }
+        __syncthreads();
+        if (tid == 0) {
+            unsigned int need = s_need, acc = 0;
+            int d = 255;
+            for (; d > 0; --d) {
+                if (acc + hist[d] >= need) break;
+                acc += hist[d];
+            }
+            s_need = need - acc;                     // how many of digit d (and the finer digits below) are still needed
+            s_prefix = prefix | ((unsigned)d << shift);
+        }
+        __syncthreads();
+    }
+    const unsigned int T = s_prefix;          // key of the k_sel-th largest element
+    const unsigned int need_eq = s_need;      // elements equal to T that belong to the selection (taken in index order)
+    // ---- compaction: keys > T fill sel[0, c_gt), the first need_eq keys == T (in index order) fill sel[c_gt, k_sel)
+    const unsigned int c_gt = (unsigned)k_sel - need_eq;
+    if (tid == 0) { s_count = 0; s_base = 0; }
+    __syncthreads();
+    for (int base = 0; base < N; base += nt) {
+        const int i = base + tid;
+        const unsigned int kx = i < N ? keys[i] : 0u;
+        const bool gt = i < N && kx > T, eq = i < N && kx == T;
+        const unsigned long long bg = __ballot(gt), be = __ballot(eq);
+        const int lane = tid & 63, w = tid >> 6;
+        __shared__ unsigned int wg[16], we[16];
+        if (lane == 0) { wg[w] = __popcll(bg); we[w] = __popcll(be); }
+        __syncthreads();
+        unsigned int og = 0, oe = 0, tg = 0, te = 0;   // exclusive offsets of this thread, totals of the chunk
+        for (int j = 0; j < (nt >> 6); ++j) {
+            if (j < w) { og += wg[j]; oe += we[j]; }
+            tg += wg[j];
+            te += we[j];
+        }
+        const unsigned long long below = lane ? (~0ull >> (64 - lane)) : 0ull;
+        og += __popcll(bg & below);
+        oe += __popcll(be & below);
+        const unsigned int g0 = s_count, e0 = s_base;
+        if (gt) {
+            sel_key[g0 + og] = kx;
+            sel_idx[g0 + og] = i;
+        } else if (eq && e0 + oe < need_eq) {
+            sel_key[c_gt + e0 + oe] = kx;
+            sel_idx[c_gt + e0 + oe] = i;
+        }
+        __syncthreads();
+        if (tid == 0) { s_count = g0 + tg; s_base = e0 + te; }
+        __syncthreads();
+    }
+    // ---- rank sort of the k_sel selected entries (score descending, index ascending), thing filter, mask scores
+    int* tb = table;
+    float* sc = scores;
+    const float* st = inst_stats;
+    // rank of entry t = number of entries that precede it
+    for (int t = tid; t < k_sel; t += nt) {
+        const unsigned int kt = sel_key[t];
+        const int it = sel_idx[t];
+        int rank = 0;
+        for (int u = 0; u < k_sel; ++u) {
+            const unsigned int ku = sel_key[u];
+            const int iu = sel_idx[u];
+            rank += (ku > kt || (ku == kt && iu < it)) ? 1 : 0;
+        }
+        // stash (rank -> entry) in the output table temporarily: query index slot holds the flat index
+        tb[1 + rank] = it;
+    }
+    for (int t = k_sel + tid; t < topk; t += nt) tb[1 + t] = -1;
+    __syncthreads();
+    if (tid == 0) {
+        int n = 0;
+        for (int t = 0; t < k_sel; ++t) {
+            const int flat = tb[1 + t];
+            const int q = flat / K, c = flat - q * K;
+            if (things_only && !isthing[c]) continue;
+            const float s = pr[flat];
+            const float mask_score = st[q] / (st[Qpad + q] + 1e-6f);
+            tb[1 + n] = q;
+            tb[1 + topk + n] = c;
+            sc[n] = s * mask_score;
+            ++n;
+        }
+        for (int t = n; t < topk; ++t) { tb[1 + t] = 0; tb[1 + topk + t] = 0; sc[t] = 0.f; }
+        tb[0] = n;
+    }
+}
+
+
+// ---- semantic argmax without the [K, H, W] tensor (A-847 at 1280x1280 would materialise 5.5 GB of fp32) --------
+// out[p] = argmax_k sum_q P[q,k] * sigmoid(mask)[q,p]  (maskformer_model.py:280-284 followed by the evaluator's `.argmax(dim=0)`,
+// detectron2 SemSegEvaluator.process reached from odise/evaluation/d2_evaluator.py:63).  MFMA with the CLASS tile as the row operand:
+// the 32x32 result then has classes along the registers and the pixel along the lane, so the running (max, argmax) over all K classes
+// is per-lane register work - no cross-lane reduction until the two lane halves are merged once at the end.  A wave owns 32 pixels:
+// their S rows (Qpad fp16 each) stay in registers for the whole class loop; PT ([K, Qpad] fp16, <= 250 KB) streams from L2.
+template <int KS>  // k-steps of 16: Qpad <= 16 * KS
+__global__ void __launch_bounds__(256) semantic_argmax_kernel(const f16* __restrict__ S, const f16* __restrict__ PT, int* __restrict__ out, int npix,
+                                                             int Qpad, int K) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int hi = lane >> 5, l31 = lane & 31;
+    const int64_t p = ((int64_t)blockIdx.x * 4 + wave) * 32 + l31;
+    f16x8 pf[KS];
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+        const int ko = ks * 16 + hi * 8;
+        pf[ks] = f16x8{0, 0, 0, 0, 0, 0, 0, 0};
+        if (p < npix && ko + 8 <= Qpad) pf[ks] = *reinterpret_cast<const f16x8*>(S + p * Qpad + ko);
+    }
+    float best = -INFINITY;
+    int best_k = 0;
+    for (int c0 = 0; c0 < K; c0 += 32) {
+        const int c = c0 + l31;
+        f32x16 acc;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+            const int ko = ks * 16 + hi * 8;
+            f16x8 cf = {0, 0, 0, 0, 0, 0, 0, 0};
+            if (c < K && ko + 8 <= Qpad) cf = *reinterpret_cast<const f16x8*>(PT + (int64_t)c * Qpad + ko);
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(cf, pf[ks], acc, 0, 0, 0);
+        }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int cls = c0 + (r & 3) + 8 * (r >> 2) + 4 * hi;   // ascending in r: `>` keeps the first maximum
+            if (cls < K && acc[r] > best) { best = acc[r]; best_k = cls; }
+        }
+    }
+    const float ob = __shfl_xor(best, 32);
+    const int ok = __shfl_xor(best_k, 32);
+    if (ob > best || (ob == best && ok < best_k)) { best = ob; best_k = ok; }
+    if (hi == 0 && p < npix) out[p] = best_k;
+}
+
+
+// dst fp32 [3,Hp,Wp] = src / 255 in the top-left h x w corner, zeros elsewhere: the (x - pixel_mean) / pixel_std normalisation
+// (mean 0, std 255: configs/common/models/odise_with_label.py) followed by ImageList.from_tensors (odise.py:238-244).
+// layout 0: uint8 [h,w,3]; 1: uint8 [3,h,w]; 2: fp32 [3,h,w]
+__global__ void __launch_bounds__(256) image_pad_kernel(const void* __restrict__ src, int layout, int h, int w, float* __restrict__ dst, int Hp, int Wp) {
+    const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t plane = (int64_t)Hp * Wp;
+    if (idx >= plane * 3) return;
+    const int c = (int)(idx / plane);
+    const int64_t p = idx - c * plane;
+    const int y = (int)(p / Wp), x = (int)(p - (int64_t)y * Wp);
+    float v = 0.f;
+    if (y < h && x < w) {
+        if (layout == 0) v = (float)((const uint8_t*)src)[((int64_t)y * w + x) * 3 + c];
+        else if (layout == 1) v = (float)((const uint8_t*)src)[((int64_t)c * h + y) * w + x];
+        else v = ((const float*)src)[((int64_t)c * h + y) * w + x];
+        v = v / 255.0f;   // a true division, like the reference's (x - 0) / 255 and x / 255.0
+    }
+    dst[idx] = v;
 }
 
 // ---- launchers -------------------------------------------------------------------------------------------------------
@@ -468,22 +758,59 @@ int launch_column_stats(odise_hip_ctx* ctx, const f16* S, float* partial, float*
     ODISE_CHECK_HIP(hipGetLastError());
     return ODISE_OK;
 }
+int launch_post_decide(odise_hip_ctx* ctx, const float* mask_cls, float* kscore, int* label, f16* semT, float* probs, int B, int Q, int Qpad, int K,
+                       float object_mask_threshold) {
+    hipLaunchKernelGGL(post_decide_kernel, dim3((unsigned)B), dim3(256), 0, ctx->stream, mask_cls, kscore, label, semT, probs, Q, Qpad, K,
+                       object_mask_threshold, (int64_t)Q * (K + 1), (int64_t)Q, (int64_t)K * Qpad, (int64_t)Q * K);
+    ODISE_CHECK_HIP(hipGetLastError());
+    return ODISE_OK;
+}
+int launch_panoptic_decide(odise_hip_ctx* ctx, const int* counts, const float* kscore, const int* label, const uint8_t* isthing, int* map, int* table,
+                           int Q, int K, double overlap_threshold, int max_segments, int* stuff_scratch) {
+    hipLaunchKernelGGL(panoptic_decide_kernel, dim3(1), dim3(256), 0, ctx->stream, counts, kscore, label, isthing, map, table, Q, K, overlap_threshold,
+                       max_segments, stuff_scratch);
+    ODISE_CHECK_HIP(hipGetLastError());
+    return ODISE_OK;
+}
+int launch_instance_topk(odise_hip_ctx* ctx, const float* probs, const float* inst_stats, const uint8_t* isthing, int* table, float* scores, int Q,
+                         int Qpad, int K, int topk, int things_only) {
+    ODISE_REQUIRE(topk >= 1 && topk <= 4096, "instance_topk: topk %d out of range", topk);
+    const size_t lds = (256 + 2 * (size_t)topk) * sizeof(unsigned int);
+    hipLaunchKernelGGL(instance_topk_kernel, dim3(1), dim3(1024), lds, ctx->stream, probs, inst_stats, isthing, table, scores, Q, Qpad, K, topk,
+                       things_only);
+    ODISE_CHECK_HIP(hipGetLastError());
+    return ODISE_OK;
+}
+int launch_semantic_argmax(odise_hip_ctx* ctx, const f16* S, const f16* PT, int* out, int npix, int Qpad, int K) {
+    const unsigned blocks = (unsigned)ceil_div(npix, 128);
+    ODISE_REQUIRE(Qpad % 8 == 0 && Qpad <= 304, "semantic_argmax: %d queries unsupported", Qpad);
+    if (Qpad <= 112) hipLaunchKernelGGL(semantic_argmax_kernel<7>, dim3(blocks), dim3(256), 0, ctx->stream, S, PT, out, npix, Qpad, K);
+    else if (Qpad <= 208) hipLaunchKernelGGL(semantic_argmax_kernel<13>, dim3(blocks), dim3(256), 0, ctx->stream, S, PT, out, npix, Qpad, K);
+    else hipLaunchKernelGGL(semantic_argmax_kernel<19>, dim3(blocks), dim3(256), 0, ctx->stream, S, PT, out, npix, Qpad, K);
+    ODISE_CHECK_HIP(hipGetLastError());
+    return ODISE_OK;
+}
+int launch_image_pad(odise_hip_ctx* ctx, const void* src, int layout, int h, int w, float* dst, int Hp, int Wp) {
+    hipLaunchKernelGGL(image_pad_kernel, dim3((unsigned)ceil_div((int64_t)3 * Hp * Wp, 256)), dim3(256), 0, ctx->stream, src, layout, h, w, dst, Hp, Wp);
+    ODISE_CHECK_HIP(hipGetLastError());
+    return ODISE_OK;
+}
 int launch_panoptic_write(odise_hip_ctx* ctx, const int* ids, const int* map, int* seg, int npix) {
     hipLaunchKernelGGL(panoptic_write_kernel, dim3((unsigned)ceil_div(npix, 256)), dim3(256), 0, ctx->stream, ids, map, seg, npix);
     ODISE_CHECK_HIP(hipGetLastError());
     return ODISE_OK;
 }
-int launch_instance_masks(odise_hip_ctx* ctx, const f16* logits, const int* idx, float* out, int n, const PostGeom& g) {
+int launch_instance_masks(odise_hip_ctx* ctx, const f16* logits, const int* idx, float* out, int n, const PostGeom& g, const int* n_dev) {
     if (n == 0) return ODISE_OK;
     if (g.oh == g.ih && g.ow == g.iw && g.ph == 4 * g.h4 && g.pw == 4 * g.w4 && g.ow % 4 == 0 && ((uintptr_t)out & 15) == 0 &&
         !getenv("ODISE_POST_GENERIC")) {
         dim3 grid4((unsigned)ceil_div(g.oh * (g.ow / 4), 256), (unsigned)n);
-        hipLaunchKernelGGL(instance_masks_x4_kernel, grid4, dim3(256), 0, ctx->stream, logits, idx, out, g);
+        hipLaunchKernelGGL(instance_masks_x4_kernel, grid4, dim3(256), 0, ctx->stream, logits, idx, out, g, n_dev);
         ODISE_CHECK_HIP(hipGetLastError());
         return ODISE_OK;
     }
     dim3 grid((unsigned)ceil_div(g.oh * g.ow, 256), (unsigned)n);
-    hipLaunchKernelGGL(instance_masks_kernel, grid, dim3(256), 0, ctx->stream, logits, idx, out, g);
+    hipLaunchKernelGGL(instance_masks_kernel, grid, dim3(256), 0, ctx->stream, logits, idx, out, g, n_dev);
     ODISE_CHECK_HIP(hipGetLastError());
     return ODISE_OK;
 }

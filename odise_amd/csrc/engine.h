@@ -189,7 +189,15 @@ int launch_classify_rows(odise_hip_ctx* ctx, const float* L1, const float* L2, c
 int launch_postprocess_pixels(odise_hip_ctx* ctx, const f16* logits, const float* kscore, f16* S, int* ids, int* counts, const PostGeom& g);
 int launch_column_stats(odise_hip_ctx* ctx, const f16* S, float* partial, float* out2, int npix, int Qpad);
 int launch_panoptic_write(odise_hip_ctx* ctx, const int* ids, const int* map, int* seg, int npix);
-int launch_instance_masks(odise_hip_ctx* ctx, const f16* logits, const int* idx, float* out, int n, const PostGeom& g);
+int launch_instance_masks(odise_hip_ctx* ctx, const f16* logits, const int* idx, float* out, int n, const PostGeom& g, const int* n_dev = nullptr);
+int launch_post_decide(odise_hip_ctx* ctx, const float* mask_cls, float* kscore, int* label, f16* semT, float* probs, int B, int Q, int Qpad, int K,
+                       float object_mask_threshold);
+int launch_panoptic_decide(odise_hip_ctx* ctx, const int* counts, const float* kscore, const int* label, const uint8_t* isthing, int* map, int* table,
+                           int Q, int K, double overlap_threshold, int max_segments, int* stuff_scratch);
+int launch_instance_topk(odise_hip_ctx* ctx, const float* probs, const float* inst_stats, const uint8_t* isthing, int* table, float* scores, int Q,
+                         int Qpad, int K, int topk, int things_only);
+int launch_image_pad(odise_hip_ctx* ctx, const void* src, int layout, int h, int w, float* dst, int Hp, int Wp);
+int launch_semantic_argmax(odise_hip_ctx* ctx, const f16* S, const f16* PT, int* out, int npix, int Qpad, int K);
 // maskgen.cpp accessors used by classify.cpp
 struct HeadOutputs {
     const f16* pred_masks;   // [B, Q, h4*w4] logits
