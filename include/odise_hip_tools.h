@@ -26,6 +26,9 @@ int odise_hip_conv2d_forced(odise_hip_ctx* ctx, const odise_conv_desc* d, int ti
 /* process-wide kernel-selection switches for A/B measurements (bits: gemm.hip launch_gemm) */
 int odise_hip_gemm_debug(int flags);
 
+/* 1: the post-processing kernels never take their exact-x4-upsampling specialisations (tests assert both forms are bit-identical) */
+int odise_hip_post_generic(int on);
+
 /* probes (probe.hip): MFMA output layout, sustained MFMA rate on register-resident operands, LDS port rates */
 int odise_hip_mfma_probe(odise_hip_ctx* ctx, float* host_out);
 int odise_hip_mfma_rate(odise_hip_ctx* ctx, int variant, int iters, int blocks, int reps, float* ms_out, double* flops_out, double* mhz_out);

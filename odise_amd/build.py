@@ -41,12 +41,16 @@ def _headers_mtime() -> float:
     return m
 
 
-def build(verbose: bool = True, force: bool = False) -> str:
-    os.makedirs(OBJDIR, exist_ok=True)
+def build(verbose: bool = True, force: bool = False, tools: bool = False) -> str:
+    """tools=True builds the measurement variant (libodise_hip_tools.so, -DODISE_TOOLS: timing ablations and the ODISE_GEMM_FLAGS /
+    ODISE_NO_GN_FUSION environment switches compiled in); tools/ scripts select it with ODISE_HIP_LIB.  The product library has none."""
+    objdir = OBJDIR + ("_tools" if tools else "")
+    lib_path = os.path.join(LIBDIR, "libodise_hip_tools.so") if tools else LIB
+    os.makedirs(objdir, exist_ok=True)
     hipcc = _hipcc()
     hm = _headers_mtime()
-    flags = ["-O3", "-std=c++17", "-fPIC", f"--offload-arch={ARCH}", 
-             "-Wno-unused-result", "-x", "hip"]
+    flags = ["-O3", "-std=c++17", "-fPIC", f"--offload-arch={ARCH}",
+             "-Wno-unused-result", "-x", "hip"] + (["-DODISE_TOOLS=1"] if tools else [])
     # per-source extras.  attn.hip: MFMA results are consumed by VALU code every tile (softmax, rescale), so keep them in VGPRs -
     # the default AGPR form costs a v_accvgpr_read/write per element (128 VALU slots per tile) and a wave of occupancy.
     extra = {"attn.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form"]}
@@ -54,7 +58,7 @@ def build(verbose: bool = True, force: bool = False) -> str:
     objs = []
     for src in _sources():
         sp = os.path.join(CSRC, src)
-        op = os.path.join(OBJDIR, src.rsplit(".", 1)[0] + ".o")
+        op = os.path.join(objdir, src.rsplit(".", 1)[0] + ".o")
         objs.append(op)
         if force or not os.path.exists(op) or os.path.getmtime(op) < max(os.path.getmtime(sp), hm):
             jobs.append((sp, op))
@@ -73,15 +77,15 @@ def build(verbose: bool = True, force: bool = False) -> str:
     if jobs:
         with ThreadPoolExecutor(max_workers=min(len(jobs), os.cpu_count() or 4)) as ex:
             list(ex.map(_compile, jobs))
-    if jobs or not os.path.exists(LIB) or any(os.path.getmtime(o) > os.path.getmtime(LIB) for o in objs):
-        cmd = [hipcc, "-shared", "-fPIC", f"--offload-arch={ARCH}", "-o", LIB, *objs]
+    if jobs or not os.path.exists(lib_path) or any(os.path.getmtime(o) > os.path.getmtime(lib_path) for o in objs):
+        cmd = [hipcc, "-shared", "-fPIC", f"--offload-arch={ARCH}", "-o", lib_path, *objs]
         if verbose:
             print("[odise_amd.build]", " ".join(cmd), flush=True)
         r = subprocess.run(cmd, capture_output=True, text=True)
         if r.returncode != 0:
             raise RuntimeError(f"link failed:\n{r.stdout}\n{r.stderr}")
-    return LIB
+    return lib_path
 
 
 if __name__ == "__main__":
-    print(build(force="--force" in sys.argv))
+    print(build(force="--force" in sys.argv, tools="--tools" in sys.argv))

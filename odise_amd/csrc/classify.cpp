@@ -413,6 +413,9 @@ extern "C" int odise_hip_postprocess_batch(odise_hip_ctx* ctx, const odise_post_
     f16* S = (f16*)(base + o_S);
     if (d->isthing) ODISE_CHECK_HIP(hipMemcpyAsync(thing, d->isthing, (size_t)K, hipMemcpyHostToDevice, ctx->stream));
     ODISE_CHECK_HIP(hipMemsetAsync(counts, 0, (size_t)B * 3 * Q * 4, ctx->stream));
+    // the panoptic records may be the source buffer of the previous batch's all-gather (still running on the exchange stream while the
+    // backbone / head / classification of this batch executed): order the first write after it - a stream-side wait, the host never blocks
+    if (want_pan && ctx->comm) ODISE_TRY(odise_hip_comm_wait(ctx, 0));
     ODISE_TRY(launch_post_decide(ctx, d->mask_cls, kscore, label, semT, probs, B, Q, Qpad, K, d->object_mask_threshold));
     Exec ex{ctx, ms};
     for (int b = 0; b < B; ++b) {

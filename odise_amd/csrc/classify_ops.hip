@@ -705,6 +705,7 @@ __global__ void __launch_bounds__(256) image_pad_kernel(const void* __restrict__
 }
 
 // ---- launchers -------------------------------------------------------------------------------------------------------
+static int g_post_generic = 0;  // tools hook (odise_hip_post_generic): 1 = never take the x4 specialisations (bit-equality tests)
 int launch_resize_bilinear_norm(odise_hip_ctx* ctx, const float* x, f16* y, int B, int H, int W, int S) {
     dim3 grid((unsigned)ceil_div(S * S, 256), (unsigned)B);
     hipLaunchKernelGGL(resize_bilinear_norm_kernel, grid, dim3(256), 0, ctx->stream, x, y, H, W, S);
@@ -736,7 +737,7 @@ int launch_classify_rows(odise_hip_ctx* ctx, const float* L1, const float* L2, c
 }
 int launch_postprocess_pixels(odise_hip_ctx* ctx, const f16* logits, const float* kscore, f16* S, int* ids, int* counts, const PostGeom& g) {
     const int npix = g.oh * g.ow;
-    if (g.oh == g.ih && g.ow == g.iw && g.ph == 4 * g.h4 && g.pw == 4 * g.w4 && !getenv("ODISE_POST_GENERIC")) {
+    if (g.oh == g.ih && g.ow == g.iw && g.ph == 4 * g.h4 && g.pw == 4 * g.w4 && !g_post_generic) {
         const int nthreads = g.oh * ((g.ow + 3) / 4);
         hipLaunchKernelGGL(postprocess_pixels_x4_kernel, dim3((unsigned)ceil_div(nthreads, 256)), dim3(256), 3 * (size_t)g.Q * sizeof(int),
                            ctx->stream, logits, kscore, S, ids, counts, g);
@@ -803,7 +804,7 @@ int launch_panoptic_write(odise_hip_ctx* ctx, const int* ids, const int* map, in
 int launch_instance_masks(odise_hip_ctx* ctx, const f16* logits, const int* idx, float* out, int n, const PostGeom& g, const int* n_dev) {
     if (n == 0) return ODISE_OK;
     if (g.oh == g.ih && g.ow == g.iw && g.ph == 4 * g.h4 && g.pw == 4 * g.w4 && g.ow % 4 == 0 && ((uintptr_t)out & 15) == 0 &&
-        !getenv("ODISE_POST_GENERIC")) {
+        !g_post_generic) {
         dim3 grid4((unsigned)ceil_div(g.oh * (g.ow / 4), 256), (unsigned)n);
         hipLaunchKernelGGL(instance_masks_x4_kernel, grid4, dim3(256), 0, ctx->stream, logits, idx, out, g, n_dev);
         ODISE_CHECK_HIP(hipGetLastError());
@@ -816,3 +817,5 @@ int launch_instance_masks(odise_hip_ctx* ctx, const f16* logits, const int* idx,
 }
 
 }  // namespace odise
+
+extern "C" int odise_hip_post_generic(int on) { odise::g_post_generic = on ? 1 : 0; return 0; }

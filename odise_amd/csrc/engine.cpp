@@ -166,7 +166,10 @@ int Exec::conv(const Act& x, const ConvW& w, Act& y, int stride, int pad, bool u
     d.act = act;
     ms->macs += (double)x.n * oh * ow * w.cout * w.k * w.k * w.cin;
     y.gn_blocks = 0;
-    if (y.gn_part && !getenv("ODISE_NO_GN_FUSION")) return conv_forced(ctx, &d, -1, 0, y.gn_part, &y.gn_blocks);
+#ifdef ODISE_TOOLS
+    if (y.gn_part && getenv("ODISE_NO_GN_FUSION")) return odise_hip_conv2d(ctx, &d);   // A/B: separate GroupNorm statistics pass
+#endif
+    if (y.gn_part) return conv_forced(ctx, &d, -1, 0, y.gn_part, &y.gn_blocks);
     return odise_hip_conv2d(ctx, &d);
 }
 

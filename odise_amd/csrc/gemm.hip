@@ -21,6 +21,15 @@
 #include "common.h"
 #include <stdlib.h>
 
+// Timing-only ablation switches (GemmArgs::dbg: drop the operand DMA / fragment reads / epilogue, freeze the K walk) and the
+// ODISE_GEMM_FLAGS / ODISE_GEMM_FREEZE_K environment switches exist only in the measurement build of the library
+// (`python -m odise_amd.build --tools` -> libodise_hip_tools.so, -DODISE_TOOLS); the product build compiles them out.
+#ifdef ODISE_TOOLS
+#define ODISE_ABLATE(g, bit) ((g).dbg & (bit))
+#else
+#define ODISE_ABLATE(g, bit) false
+#endif
+
 namespace odise {
 
 struct GemmEpi {
@@ -333,7 +342,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& g, f32x16 (&acc)[B
                     } else {
                         for (int i = 0; i < nv; ++i) w[i] = v[i];
                     }
-                } else if (!(g.dbg & 8) || v[0] == 12345.678f) {  // dbg 8: ablate the global store + epilogue math
+                } else if (!(ODISE_ABLATE(g, 8)) || v[0] == 12345.678f) {  // dbg 8: ablate the global store + epilogue math
                     if (g.epi.fast && n + 8 <= g.N) {
                         if (stats) {
                             float r8[8];
@@ -647,7 +656,7 @@ __global__ void __launch_bounds__(64 * WAVES_M * WAVES_N) gemm_kernel(GemmArgs g
         // the other buffer (they finished compute(kt-1) before arriving here), so it can be refilled.
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
-        const bool dma = more && !(g.dbg & 1);
+        const bool dma = more && !(ODISE_ABLATE(g, 1));
         if (dma) {
             if (INTERLEAVE) prep_tile(kt + 1);
             else issue_tile(kt + 1, cur ^ 1);
@@ -658,7 +667,7 @@ __global__ void __launch_bounds__(64 * WAVES_M * WAVES_N) gemm_kernel(GemmArgs g
         f16x8 af[TM], bf[TN];
 #pragma unroll
         for (int s = 0; s < 4; ++s) {
-            if (!(g.dbg & 2) || (kt == kt_begin && s == 0)) {
+            if (!(ODISE_ABLATE(g, 2)) || (kt == kt_begin && s == 0)) {
 #pragma unroll
                 for (int i = 0; i < TM; ++i) af[i] = *reinterpret_cast<const f16x8*>(fa + koff[s] + i * 4096);
 #pragma unroll
@@ -682,7 +691,7 @@ __global__ void __launch_bounds__(64 * WAVES_M * WAVES_N) gemm_kernel(GemmArgs g
         }
     }
     __syncthreads();  // every wave is done with the operand tiles before the staging buffer is reused
-    if (g.dbg & 4) return;  // ablation: main loop only
+    if (ODISE_ABLATE(g, 4)) return;  // ablation: main loop only
 
     gemm_epilogue<BM, BN, WAVES_M, WAVES_N, epi_wave_rows(BM, BN, WAVES_M, plain_lds_bytes(BM, BN, WAVES_M))>(g, acc, smem, m0, n0, z, zb, split);
 }
@@ -833,7 +842,7 @@ __global__ void __launch_bounds__(512) gemm_pp_kernel(GemmArgs g) {
         return t;
     };
     auto advance = [&](TileK& t) {
-        if (g.dbg & 16) return;  // timing experiment (ODISE_GEMM_FREEZE_K): every K-tile re-reads the first one - hot lines, wrong results
+        if (ODISE_ABLATE(g, 16)) return;  // timing experiment (ODISE_GEMM_FREEZE_K): every K-tile re-reads the first one - hot lines, wrong results
         if (CONV) {
             if (g.cg.chunk_major) {
                 if (++t.kx == g.cg.KW) {
@@ -914,10 +923,10 @@ __global__ void __launch_bounds__(512) gemm_pp_kernel(GemmArgs g) {
     f16x8 af[TM][4], bf[PT][4];
     for (int kt = kt_begin; kt < kt_end; ++kt) {
         const int cur = (kt - kt_begin) & 1;
-        const bool has1 = (kt + 1) < kt_end && !(g.dbg & 1), has2 = (kt + 2) < kt_end && !(g.dbg & 1);  // dbg 1: ablate the DMA
+        const bool has1 = (kt + 1) < kt_end && !(ODISE_ABLATE(g, 1)), has2 = (kt + 2) < kt_end && !(ODISE_ABLATE(g, 1));  // dbg 1: ablate the DMA
         const char* fa = smem + cur * STAGE_BYTES + a_lane_off;
         const char* fb = smem + cur * STAGE_BYTES + b_lane_off;
-        const bool rd = !(g.dbg & 2) || kt == kt_begin;  // dbg 2: ablate the fragment reads
+        const bool rd = !(ODISE_ABLATE(g, 2)) || kt == kt_begin;  // dbg 2: ablate the fragment reads
 #pragma unroll
         for (int p = 0; p < NP; ++p) {
             const int j0 = PT * p;
@@ -1012,7 +1021,7 @@ __global__ void __launch_bounds__(512) gemm_pp_kernel(GemmArgs g) {
     }
     if (grp == 0) __builtin_amdgcn_s_barrier();  // re-align the two groups
     __syncthreads();
-    if (g.dbg & 4) return;
+    if (ODISE_ABLATE(g, 4)) return;
     if constexpr (TR) gemm_epilogue_direct<BM, BN, WAVES_M, WAVES_N>(g, acc, m0, n0, z, zb, split);
     else gemm_epilogue<BM, BN, WAVES_M, WAVES_N, epi_wave_rows(BM, BN, WAVES_M, pp_lds_bytes(BM, BN, WAVES_M)), false, (CONV && BM == 512)>(g, acc, smem, m0, n0, z, zb, split);
 }
@@ -1331,7 +1340,7 @@ __global__ void __launch_bounds__(512) gemm_pp2_kernel(GemmArgs g) {
     if (grp == 0) __builtin_amdgcn_s_barrier();  // re-align the two groups
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
     __syncthreads();
-    if (g.dbg & 4) return;
+    if (ODISE_ABLATE(g, 4)) return;
     if constexpr (TR) gemm_epilogue_direct<BM, BN, WAVES_M, WAVES_N>(g, acc, m0, n0, z, zb, split);
     else gemm_epilogue<BM, BN, WAVES_M, WAVES_N, epi_wave_rows(BM, BN, WAVES_M, pp_lds_bytes(BM, BN, WAVES_M)), false, CONV>(g, acc, smem, m0, n0, z, zb, split);
 }
@@ -1745,12 +1754,16 @@ static const TileCost kTileCostPP[2] = {
 static const TileCost kTileCostOld[kNumTiles] = {{1.68, 9.5, 2}, {1.58, 4.1, 3}, {1.28, 2.4, 4}, {3.04, 29.0, 1}, {2.58, 22.0, 1},
                                                  {1.75, 10.6, 1}, {2.25, 12.0, 1}, {1.92, 12.0, 1}, {1.32, 10.0, 1}};
 static int env_gemm_flags() {
+#ifdef ODISE_TOOLS
     static int v = -1;
     if (v < 0) {
         const char* e = getenv("ODISE_GEMM_FLAGS");  // developer switch: same bits as odise_hip_gemm_debug(flags) >> 4
         v = e ? atoi(e) : 0;
     }
     return v;
+#else
+    return 0;
+#endif
 }
 
 template <bool CONV>
@@ -1850,8 +1863,12 @@ static int launch_gemm(odise_hip_ctx* ctx, GemmArgs& g, int batch, int force_til
         if (!ok) { g.epi.gn_stats = nullptr; g.stats_blocks = 0; }
     }
     g.zeros = (const f16*)ctx->zeros;
+#ifdef ODISE_TOOLS
     static const int freeze_k = getenv("ODISE_GEMM_FREEZE_K") ? 16 : 0;
     g.dbg = g_gemm_debug | freeze_k;
+#else
+    g.dbg = 0;
+#endif
     // the 256-row tiles run the ping-pong pipelined kernel whenever its preconditions hold
     if (tile >= 7) {
         g.cg.chunk_major = 1;

@@ -1,7 +1,12 @@
 """Data-parallel sharding of the inference path: one process per GPU, images are independent units sharded
 contiguously across ranks (detectron2's InferenceSampler convention, odise/data/build.py:145-151), no collective inside the model
-forward, and exactly one exchange step: an all-gather of fixed-size per-image prediction records (RCCL `ncclAllGather` over xGMI when
-the process group is NCCL; gloo on CPU in the tests), replacing detectron2's pickled `comm.gather` at evaluation time.
+forward, and exactly one exchange step: an all-gather of fixed-size per-image prediction records, replacing detectron2's pickled
+`comm.gather` at evaluation time (odise/evaluation/evaluator.py:144).
+
+On GPUs the exchange belongs to the library (`Exchange`: an RCCL communicator and a second HIP stream inside libodise_hip.so,
+`ncclAllGather` over xGMI on device buffers the post-processing kernels wrote the records into; the launcher only broadcasts the
+128-byte unique id over its CPU rendezvous).  `allgather_records` / `sum_confusion` are the same exchange on CPU tensors through
+torch.distributed (gloo): what the CPU tests of the record layout and of uneven shards run, and what a CPU-side evaluator would use.
 
 Record layout per image (all int32 so the gather is one contiguous buffer):
     panoptic_seg [H, W] | n_segments | segments [MAX_SEGMENTS, 3] = (id, isthing, category_id)
@@ -78,3 +83,51 @@ def sum_confusion(conf: torch.Tensor) -> torch.Tensor:
     out = conf.clone()
     dist.all_reduce(out, op=dist.ReduceOp.SUM)
     return out
+
+
+class Exchange:
+    """The library-owned RCCL exchange (include/odise_hip.h: odise_hip_comm_*).  `broadcast(id_bytes_or_None) -> id_bytes` must deliver
+    rank 0's unique id to every rank (e.g. `gloo_broadcast`); a world of one rank needs none and takes the same code path."""
+
+    def __init__(self, ctx, rank: int = 0, world: int = 1, broadcast=None):
+        import ctypes as C
+        from ._lib import COMM_ID_BYTES, check
+        self.ctx, self.rank, self.world = ctx, rank, world
+        buf = (C.c_ubyte * COMM_ID_BYTES)()
+        if rank == 0:
+            check(ctx.lib.odise_hip_comm_unique_id(buf), "comm_unique_id")
+        if world > 1:
+            if broadcast is None:
+                raise ValueError("world > 1 needs a broadcast callable for the communicator id")
+            data = broadcast(bytes(buf) if rank == 0 else None)
+            buf = (C.c_ubyte * COMM_ID_BYTES).from_buffer_copy(data)
+        check(ctx.lib.odise_hip_comm_init(ctx.h, buf, rank, world), "comm_init")
+
+    def allgather(self, local, out) -> None:
+        """out [world * n] = every rank's local [n] (device int32 buffers: runtime.DeviceArray).  Asynchronous: runs on the library's
+        exchange stream after everything queued on the compute stream so far; `wait()` joins it."""
+        from ._lib import check
+        n = int(np.prod(local.shape))
+        assert int(np.prod(out.shape)) == n * self.world and local.dtype == np.int32 and out.dtype == np.int32
+        check(self.ctx.lib.odise_hip_allgather_predictions(self.ctx.h, local.ptr, n, out.ptr), "allgather_predictions")
+
+    def allreduce_sum_i64(self, data) -> None:
+        from ._lib import check
+        assert data.dtype == np.int64
+        check(self.ctx.lib.odise_hip_allreduce_sum_i64(self.ctx.h, data.ptr, int(np.prod(data.shape))), "allreduce_sum_i64")
+
+    def wait(self, host: bool = True) -> None:
+        from ._lib import check
+        check(self.ctx.lib.odise_hip_comm_wait(self.ctx.h, 1 if host else 0), "comm_wait")
+
+    def close(self) -> None:
+        if self.ctx is not None and self.ctx.h:
+            self.ctx.lib.odise_hip_comm_destroy(self.ctx.h)
+        self.ctx = None
+
+
+def gloo_broadcast(data):
+    """Broadcast rank 0's bytes over the (CPU) default process group of torch.distributed - the launcher's rendezvous."""
+    box = [data]
+    dist.broadcast_object_list(box, src=0)
+    return box[0]

@@ -93,16 +93,12 @@ class HipODISE:
 # ---------------------------------------------------------------------------------------------------------------------
 # Open-vocabulary classification + post-processing (CategoryODISE.forward eval branch, odise.py:282-372)
 # ---------------------------------------------------------------------------------------------------------------------
-def _softmax(x, axis=-1):
-    x = x - x.max(axis=axis, keepdims=True)
-    e = np.exp(x)
-    return e / e.sum(axis=axis, keepdims=True)
-
-
 class HipCategoryODISE(HipODISE):
     """The whole CategoryODISE eval forward on the device.  `forward(batched_inputs)` takes the reference's input format
-    (list of {"image": uint8/float CHW, "height", "width"}) and returns the reference's output format (list of dicts with
-    "sem_seg" [K,h,w] fp32, "panoptic_seg" (int32 [h,w], segments_info), "instances" {pred_masks, scores, pred_classes})."""
+    (list of {"image": uint8/float CHW, "height", "width"}; images of one call may differ in size, odise.py:238-244) and returns the
+    reference's output format (list of dicts with "sem_seg" [K,h,w] fp32, "panoptic_seg" (int32 [h,w], segments_info), "instances"
+    {pred_masks, scores, pred_classes}).  One library call per batch (`odise_hip_infer`); every decision of the three heads is taken on
+    the device, the host reads back the segment / instance tables (a few hundred bytes per image) once at the end."""
 
     HEAD_KEYS = ("category_head.text_proj.weight", "category_head.text_proj.bias", "category_head.null_embed")
 
@@ -110,7 +106,6 @@ class HipCategoryODISE(HipODISE):
                  overlap_threshold=0.8, test_topk_per_image=100, size_divisibility=64):
         super().__init__(ctx, {k: v for k, v in state.items()})
         # category_head weights are loaded through the same store: re-register them (the store was cleared after build)
-        n = 0
         for key in self.HEAD_KEYS:
             val = state[key]
             if hasattr(val, "detach"):
@@ -118,12 +113,13 @@ class HipCategoryODISE(HipODISE):
             arr = np.ascontiguousarray(val, dtype=np.float32)
             shape = (C.c_int64 * max(arr.ndim, 1))(*arr.shape)
             check(ctx.lib.odise_hip_load_weight(ctx.h, key.encode(), arr.ctypes.data_as(C.POINTER(C.c_float)), shape, arr.ndim), key)
-            n += 1
         check(ctx.lib.odise_hip_classify_build(ctx.h), "classify_build")
         check(ctx.lib.odise_hip_clear_host_weights(ctx.h), "clear_host_weights")
         self.semantic_on, self.panoptic_on, self.instance_on = semantic_on, panoptic_on, instance_on
+        self.semantic_argmax = False          # True: "sem_seg_argmax" int32 [h,w] instead of "sem_seg" [K,h,w] (never materialised)
         self.object_mask_threshold, self.overlap_threshold = object_mask_threshold, overlap_threshold
         self.test_topk_per_image, self.size_divisibility = test_topk_per_image, size_divisibility
+        assert size_divisibility == 64, "the feature extractor fixes size_divisibility at 64 (feature_extractor.py:126-128)"
         self.num_classes = 0
         self.thing_ids = set()
         self.metadata, self.test_labels = None, None
@@ -148,7 +144,9 @@ class HipCategoryODISE(HipODISE):
     # ---- open-vocabulary state (OpenPanopticInference's protocol, odise/modeling/wrapper/pano_wrapper.py:20-70) ------------------
     def attach_text(self, tokenizer, text_encoder, train_labels=None, clip_text_encoder=None):
         """Give the model what `load_open_state_dict` needs to turn label lists into text banks on the device
-        (odise_amd.tokenizer.SimpleTokenizer, odise_amd.text.HipTextEncoder; `train_labels` decide the seen/unseen ensemble weights)."""
+        (odise_amd.tokenizer.SimpleTokenizer, odise_amd.text.HipTextEncoder).  `train_labels` decide the seen / unseen ensemble weights
+        (PoolingCLIPHead, odise.py:1446-1447, 1479-1491); None = the reference's default, COCO panoptic with prompt engineering, read
+        from the label files (see odise_amd.checkpoint.default_train_labels)."""
         self._tokenizer, self._text_encoder, self._clip_text_encoder = tokenizer, text_encoder, clip_text_encoder
         self._train_labels = train_labels
         self._vocab_cache = {}
@@ -222,168 +220,134 @@ class HipCategoryODISE(HipODISE):
             self._pool[key] = cur
         return cur.view(shape, dtype)
 
-    def postprocess_image(self, b: int, mask_cls: np.ndarray, pad_hw, img_hw, out_hw, to_host: bool = True, pan_out=None) -> dict:
-        """Post-processing of image b alone (see postprocess_batch)."""
-        return self.postprocess_batch({b: mask_cls}, pad_hw, img_hw, {b: out_hw}, to_host=to_host,
-                                      pan_out={b: pan_out} if pan_out is not None else None)[0]
+    # ---- outputs of one call ------------------------------------------------------------------------------------------------------
+    def _post_desc(self, n: int, out_sizes, pan_out=None) -> tuple:
+        """Pooled output buffers of `n` images + a PostDesc pointing at them (B / pad / img_hw / mask_cls are left to the caller)."""
+        from ._lib import MAX_SEGMENTS, PostDesc
+        K, topk = self.num_classes, int(self.test_topk_per_image)
+        d = PostDesc()
+        keep = []                                                          # ctypes arrays must outlive the call
+        ohw = (C.c_int * (2 * n))(*[int(v) for s in out_sizes for v in s])
+        thing = (C.c_uint8 * max(K, 1))(*[1 if k in self.thing_ids else 0 for k in range(K)])
+        keep += [ohw, thing]
+        d.out_hw, d.isthing = C.cast(ohw, C.c_void_p), C.cast(thing, C.c_void_p)
+        d.semantic_on, d.panoptic_on, d.instance_on = int(bool(self.semantic_on)), int(bool(self.panoptic_on)), int(bool(self.instance_on))
+        d.object_mask_threshold, d.overlap_threshold, d.topk = float(self.object_mask_threshold), float(self.overlap_threshold), topk
+        bufs = {"sem": [None] * n, "amax": [None] * n, "pan": [None] * n, "masks": [None] * n, "pan_ext": [False] * n}
+        for i, (oh, ow) in enumerate(out_sizes):
+            if self.semantic_on and not self.semantic_argmax:
+                bufs["sem"][i] = self._buf(f"sem{i}", (K, oh, ow), np.float32)
+            if self.semantic_on and self.semantic_argmax:
+                bufs["amax"][i] = self._buf(f"amax{i}", (oh, ow), np.int32)
+            if self.panoptic_on:
+                ext = pan_out[i] if pan_out is not None else None
+                if ext is not None:                                        # caller-owned record (this rank's slice of the gather buffer)
+                    bufs["pan"][i], bufs["pan_ext"][i] = ext, True
+                else:
+                    bufs["pan"][i] = self._buf(f"pan{i}", (oh * ow + 1 + 3 * MAX_SEGMENTS,), np.int32)
+            if self.instance_on:
+                bufs["masks"][i] = self._buf(f"masks{i}", (topk, oh, ow), np.float32)
 
-    def postprocess_batch(self, mask_cls, pad_hw, img_hw, out_sizes, to_host: bool = True, pan_out=None) -> list:
-        """Post-processing (odise.py:336-370) of the images in `mask_cls` ({b: [Q,K+1]} or an array [B,Q,K+1], host) from the
-        device-resident mask logits.  The work is staged ACROSS images - every host decision (kept queries, panoptic segment
-        ids, instance top-k) is taken for the whole batch between two rounds of kernel launches - so a step has two device
-        synchronisations instead of three per image.  to_host=False keeps the large results (sem_seg, panoptic map, instance
-        masks) on the device, like the reference, whose outputs are device tensors; they live in pooled buffers that the next
-        call reuses."""
-        ctx, lib = self.ctx, self.ctx.lib
-        Q, K = self.num_queries, self.num_classes
-        items = list(mask_cls.items()) if isinstance(mask_cls, dict) else list(enumerate(mask_cls))
-        sizes = out_sizes if isinstance(out_sizes, dict) else dict(enumerate(out_sizes))
-        n = len(items)
-        qpad = (Q + 7) // 8 * 8
-        p = lambda a: C.c_void_p(a.ptr) if a is not None else None
-        # ---- stage A (host): class probabilities, kept queries; one upload for the batch
-        probs = [_softmax(np.asarray(mc, np.float32)) for _, mc in items]
-        scores = [pr.max(-1) for pr in probs]
-        labels = [pr.argmax(-1) for pr in probs]
-        keep = [(lb != K) & (sc > self.object_mask_threshold) for lb, sc in zip(labels, scores)]   # maskformer_model.py:290
-        up = np.zeros((n, Q + K * Q), np.float32)
-        for i in range(n):
-            up[i, :Q] = np.where(keep[i], scores[i], -1.0)
-            if self.semantic_on:
-                up[i, Q:] = np.ascontiguousarray(probs[i][:, :-1].T).reshape(-1)
-        dup = self._buf("post_in", up.shape, np.float32).copy_from(up)
-        dcnt = self._buf("post_counts", (n, 3 * Q + 2 * qpad), np.float32)   # [3,Q] int32 counters + [2,qpad] fp32 instance stats
-        row = (3 * Q + 2 * qpad) * 4
-        sems, idss = [], []
-        # ---- stage B (device): per-pixel pass of every image
-        for i, (b, _) in enumerate(items):
-            oh, ow = sizes[b]
-            kscore = dup.view((Q,), np.float32, i * up.shape[1] * 4)
-            semT = dup.view((K, Q), np.float32, (i * up.shape[1] + Q) * 4) if self.semantic_on else None
-            sem = self._buf(f"sem{i}", (K, oh, ow), np.float32) if self.semantic_on else None
-            ids = self._buf(f"ids{i}", (oh * ow,), np.int32)
-            counts = dcnt.view((3, Q), np.int32, i * row)
-            inst = dcnt.view((2, qpad), np.float32, i * row + 3 * Q * 4) if self.instance_on else None
-            check(lib.odise_hip_postprocess_pixels(ctx.h, b, p(kscore), p(semT), K, pad_hw[0], pad_hw[1], img_hw[0], img_hw[1], oh, ow, p(sem),
-                                                   p(ids), p(counts), p(inst)), "postprocess_pixels")
-            sems.append(sem)
-            idss.append(ids)
-        # ---- stage C: one read-back (synchronises), host decisions for the batch
-        raw = dcnt.numpy()
+        def parr(lst):
+            a = (C.c_void_p * n)(*[(b.ptr if isinstance(b, DeviceArray) else b) for b in lst])
+            keep.append(a)
+            return C.cast(a, C.c_void_p)
+
+        if self.semantic_on and not self.semantic_argmax:
+            d.sem_seg = parr(bufs["sem"])
+        if self.semantic_on and self.semantic_argmax:
+            d.sem_argmax = parr(bufs["amax"])
+        if self.panoptic_on:
+            d.panoptic = parr(bufs["pan"])
+        if self.instance_on:
+            d.inst_masks = parr(bufs["masks"])
+            bufs["itable"] = self._buf("inst_table", (n, 1 + 2 * topk), np.int32)
+            bufs["iscores"] = self._buf("inst_scores", (n, topk), np.float32)
+            d.inst_table, d.inst_scores = bufs["itable"].ptr, bufs["iscores"].ptr
+        return d, bufs, keep
+
+    def _collect(self, bufs, out_sizes, to_host: bool) -> list:
+        """Read the small tables back (one synchronisation) and assemble the reference's result dicts."""
+        from ._lib import MAX_SEGMENTS
+        n, topk = len(out_sizes), int(self.test_topk_per_image)
         results = [dict() for _ in range(n)]
-        maps = np.zeros((n, Q + self.test_topk_per_image), np.int32)   # [seg_map | instance query indices]
-        inst_sel = []
-        for i, (b, _) in enumerate(items):
+        itable = bufs["itable"].numpy() if self.instance_on else None
+        iscores = bufs["iscores"].numpy() if self.instance_on else None
+        for i, (oh, ow) in enumerate(out_sizes):
+            r = results[i]
+            if self.semantic_on and not self.semantic_argmax:
+                r["sem_seg"] = bufs["sem"][i].numpy() if to_host else bufs["sem"][i]
+            if self.semantic_on and self.semantic_argmax:
+                r["sem_seg_argmax"] = bufs["amax"][i].numpy() if to_host else bufs["amax"][i]
             if self.panoptic_on:
-                cnt = raw[i, :3 * Q].view(np.int32).reshape(3, Q)
-                segments_info, stuff_memory, current = [], {}, 0
-                for q in np.nonzero(keep[i])[0]:                                            # kept queries in order (maskformer_model.py:312-340)
-                    pred_class = int(labels[i][q])
-                    isthing = pred_class in self.thing_ids
-                    mask_area, original_area, inter = int(cnt[0, q]), int(cnt[1, q]), int(cnt[2, q])
-                    if mask_area > 0 and original_area > 0 and inter > 0:
-                        if mask_area / original_area < self.overlap_threshold:
-                            continue
-                        if not isthing:
-                            if pred_class in stuff_memory:
-                                maps[i, q] = stuff_memory[pred_class]
-                                continue
-                            stuff_memory[pred_class] = current + 1
-                        current += 1
-                        maps[i, q] = current
-                        segments_info.append({"id": current, "isthing": bool(isthing), "category_id": pred_class})
-                results[i]["panoptic_seg"] = (None, segments_info)
+                rec = bufs["pan"][i]
+                if bufs["pan_ext"][i]:
+                    r["panoptic_seg"] = (None, None)                       # the record lives in the caller's buffer (decode with distributed.unpack_record)
+                else:
+                    tail = rec.view((1 + 3 * MAX_SEGMENTS,), np.int32, oh * ow * 4).numpy()
+                    info = [{"id": int(a), "isthing": bool(b), "category_id": int(c)} for a, b, c in tail[1:1 + 3 * int(tail[0])].reshape(-1, 3)]
+                    seg = rec.view((oh, ow), np.int32)
+                    r["panoptic_seg"] = (seg.numpy() if to_host else seg, info)
             if self.instance_on:
-                sc = probs[i][:, :-1].reshape(-1)                                           # maskformer_model.py:349-357
-                topk = min(self.test_topk_per_image, sc.size)
-                top = np.argpartition(-sc, topk - 1)[:topk]
-                top = top[np.argsort(-sc[top], kind="stable")]
-                cls, qidx, s = top % K, top // K, sc[top]
-                if self.panoptic_on:
-                    thing = np.array([int(c) in self.thing_ids for c in cls], bool)
-                    cls, qidx, s = cls[thing], qidx[thing], s[thing]
-                st = raw[i, 3 * Q:].reshape(2, qpad)
-                mask_scores = st[0, qidx] / (st[1, qidx] + 1e-6)
-                maps[i, Q:Q + len(qidx)] = qidx
-                inst_sel.append((cls, qidx, s, mask_scores))
-        dmaps = self._buf("post_maps", maps.shape, np.int32).copy_from(maps)
-        # ---- stage D (device): panoptic map and instance masks of every image
-        for i, (b, _) in enumerate(items):
-            oh, ow = sizes[b]
-            if self.panoptic_on:
-                ext = pan_out[b] if pan_out is not None and pan_out[b] is not None else None
-                seg = self._buf(f"seg{i}", (oh, ow), np.int32) if ext is None else None
-                dst = p(seg) if seg is not None else C.c_void_p(int(ext))   # optionally write into a caller-owned buffer (gather slice)
-                dmap = dmaps.view((Q,), np.int32, i * maps.shape[1] * 4)
-                check(lib.odise_hip_panoptic_write(ctx.h, p(idss[i]), p(dmap), dst, oh * ow), "panoptic_write")
-                results[i]["panoptic_seg"] = ((seg.numpy() if to_host else seg) if seg is not None else None, results[i]["panoptic_seg"][1])
-            if self.semantic_on:
-                results[i]["sem_seg"] = sems[i].numpy() if to_host else sems[i]
-            if self.instance_on:
-                cls, qidx, s, mask_scores = inst_sel[i]
-                masks = self._buf(f"masks{i}", (max(len(qidx), 1), oh, ow), np.float32).view((len(qidx), oh, ow))
-                if len(qidx):
-                    didx = dmaps.view((len(qidx),), np.int32, (i * maps.shape[1] + Q) * 4)
-                    check(lib.odise_hip_instance_masks(ctx.h, b, p(didx), len(qidx), pad_hw[0], pad_hw[1], img_hw[0], img_hw[1], oh, ow, p(masks)),
-                          "instance_masks")
-                results[i]["instances"] = {"pred_masks": masks.numpy() if to_host else masks, "scores": (s * mask_scores).astype(np.float32),
-                                           "pred_classes": cls.astype(np.int64), "query_index": qidx}
+                cnt = int(itable[i, 0])
+                masks = bufs["masks"][i].view((cnt, oh, ow))
+                r["instances"] = {"pred_masks": masks.numpy() if to_host else masks, "scores": iscores[i, :cnt].copy(),
+                                  "pred_classes": itable[i, 1 + topk:1 + topk + cnt].astype(np.int64), "query_index": itable[i, 1:1 + cnt].copy()}
         return results
 
-    def forward_device(self, padded: DeviceArray, img01: DeviceArray, out_sizes, to_host: bool = False, pan_out=None) -> list:
-        """Hot path with inputs already resident in HBM: padded [B,3,Hp,Wp] and img01 [B,3,H,W] fp32 in [0,1]."""
-        B, _, Hp, Wp = padded.shape
-        H, W = img01.shape[-2:]
-        self.backbone_device(padded, want_outputs=False)
-        self.head_device(None, B, Hp // 4, Wp // 4, want_outputs=False)
-        mask_cls = self.classify_device(img01).numpy()
-        return self.postprocess_batch(mask_cls, (Hp, Wp), (H, W), out_sizes, to_host=to_host,
-                                      pan_out=dict(enumerate(pan_out)) if pan_out is not None else None)
+    def postprocess_batch(self, mask_cls, pad_hw, img_hw, out_sizes, to_host: bool = True, pan_out=None) -> list:
+        """Post-processing (odise.py:336-370) of the images of the last head_forward from their class log-probabilities `mask_cls`
+        ([B,Q,K+1], host array or DeviceArray).  img_hw: one (h, w) for all images or a list; out_sizes: list of (h, w)."""
+        dcls = mask_cls if isinstance(mask_cls, DeviceArray) else self.ctx.to_device(np.ascontiguousarray(mask_cls, np.float32))
+        n = dcls.shape[0]
+        sizes = [tuple(out_sizes[b]) for b in range(n)] if not isinstance(out_sizes, dict) else [tuple(out_sizes[b]) for b in sorted(out_sizes)]
+        ihw = [tuple(img_hw)] * n if isinstance(img_hw[0], (int, np.integer)) else [tuple(x) for x in img_hw]
+        d, bufs, keep = self._post_desc(n, sizes, pan_out)
+        iarr = (C.c_int * (2 * n))(*[int(v) for s in ihw for v in s])
+        d.B, d.pad_h, d.pad_w, d.img_hw, d.mask_cls = n, int(pad_hw[0]), int(pad_hw[1]), C.cast(iarr, C.c_void_p), dcls.ptr
+        check(self.ctx.lib.odise_hip_postprocess_batch(self.ctx.h, C.byref(d)), "postprocess_batch")
+        return self._collect(bufs, sizes, to_host)
+
+    def infer_device(self, images, layout: int, img_hw, out_sizes, to_host: bool = False, pan_out=None, mask_cls_out=None) -> list:
+        """One `odise_hip_infer` call: `images` = device pointers (DeviceArray or int) of uint8 HWC (layout 0) / uint8 CHW (1) / fp32 CHW
+        0..255 (2) pictures with sizes img_hw [(h, w)]."""
+        n = len(images)
+        from ._lib import InferDesc
+        d = InferDesc()
+        post, bufs, keep = self._post_desc(n, out_sizes, pan_out)
+        ptrs = (C.c_void_p * n)(*[(im.ptr if isinstance(im, DeviceArray) else im) for im in images])
+        iarr = (C.c_int * (2 * n))(*[int(v) for s in img_hw for v in s])
+        d.B, d.images, d.image_layout, d.img_hw = n, C.cast(ptrs, C.c_void_p), layout, C.cast(iarr, C.c_void_p)
+        d.mask_cls_out = mask_cls_out.ptr if mask_cls_out is not None else None
+        d.post = post
+        check(self.ctx.lib.odise_hip_infer(self.ctx.h, C.byref(d)), "infer")
+        return self._collect(bufs, out_sizes, to_host)
 
     def __call__(self, *args, **kwargs):                                   # nn.Module-style call: the reference's wrappers do `self.model(batched_inputs)`
         return self.forward(*args, **kwargs)
 
     def forward(self, batched_inputs, to_host: bool = True) -> list:
-        """CategoryODISE.forward, eval branch (odise.py:236-246, 282-372) for a batch of equally sized images.  "image" is a CHW uint8 /
-        float array on the host (values 0..255), or a DeviceArray uint8 [H,W,3] already in HBM (odise_amd.ingest.HipDatasetMapper).
+        """CategoryODISE.forward, eval branch (odise.py:236-246, 282-372).  "image" is a CHW uint8 / float array or CPU tensor (values
+        0..255, the reference's format), or a DeviceArray uint8 [H,W,3] already in HBM (odise_amd.ingest.HipDatasetMapper).
         `to_host=False` leaves the large outputs (sem_seg, panoptic map, instance masks) on the device, like the reference does."""
-        if isinstance(batched_inputs[0]["image"], DeviceArray):
-            return self._forward_resident(batched_inputs, to_host)
-        imgs = []
-        for x in batched_inputs:
-            im = x["image"]
-            if hasattr(im, "detach"):
-                im = im.detach().cpu().numpy()
-            imgs.append(np.asarray(im, np.float32) / 255.0)                                 # (x - 0) / 255  (pixel_mean 0, pixel_std 255)
-        H, W = imgs[0].shape[-2:]
-        assert all(i.shape[-2:] == (H, W) for i in imgs), "batched images must share one size (use one call per size)"
-        d = self.size_divisibility
-        Hp, Wp = (H + d - 1) // d * d, (W + d - 1) // d * d
-        B = len(imgs)
-        img01 = np.stack(imgs)
-        padded = np.zeros((B, 3, Hp, Wp), np.float32)                                        # ImageList.from_tensors(images, 64): zero pad
-        padded[:, :, :H, :W] = img01
-        dpad = self.ctx.to_device(padded)
-        self.backbone_device(dpad, want_outputs=False)
-        self.head_device(None, B, Hp // 4, Wp // 4)
-        mask_cls = self.classify_device(self.ctx.to_device(img01)).numpy()
-        sizes = [(int(x.get("height", H)), int(x.get("width", W))) for x in batched_inputs]
-        return self.postprocess_batch(mask_cls, (Hp, Wp), (H, W), sizes, to_host=to_host)
-
-    def _forward_resident(self, batched_inputs, to_host: bool = True) -> list:
-        ims = [x["image"] for x in batched_inputs]
-        H, W = ims[0].shape[:2]
-        assert all(i.dtype == np.uint8 and i.shape == (H, W, 3) for i in ims), "device images: uint8 [H,W,3] of one size"
-        d = self.size_divisibility
-        Hp, Wp, B = (H + d - 1) // d * d, (W + d - 1) // d * d, len(ims)
-        padded = self._buf("in_padded", (B, 3, Hp, Wp), np.float32)
-        img01 = padded if (Hp, Wp) == (H, W) else self._buf("in_img01", (B, 3, H, W), np.float32)
-        for b, im in enumerate(ims):                                      # (x - 0) / 255 and ImageList.from_tensors(images, 64), on the device
-            self.ctx.u8_hwc_to_f32_chw_padded(im, Hp, Wp, 1.0 / 255.0, out=padded.view((3, Hp, Wp), offset_bytes=b * 3 * Hp * Wp * 4))
-            if img01 is not padded:
-                self.ctx.u8_hwc_to_f32_chw_padded(im, H, W, 1.0 / 255.0, out=img01.view((3, H, W), offset_bytes=b * 3 * H * W * 4))
-        sizes = [(int(x.get("height", H)), int(x.get("width", W))) for x in batched_inputs]
-        return self.forward_device(padded, img01, sizes, to_host=to_host)
+        first = batched_inputs[0]["image"]
+        if isinstance(first, DeviceArray):
+            ims = [x["image"] for x in batched_inputs]
+            assert all(i.dtype == np.uint8 and len(i.shape) == 3 and i.shape[2] == 3 for i in ims), "device images: uint8 [H,W,3]"
+            layout, hw = 0, [tuple(i.shape[:2]) for i in ims]
+        else:
+            host = []
+            for x in batched_inputs:
+                im = x["image"]
+                if hasattr(im, "detach"):
+                    im = im.detach().cpu().numpy()
+                host.append(np.asarray(im))
+            u8 = all(h.dtype == np.uint8 for h in host)
+            layout = 1 if u8 else 2
+            hw = [tuple(h.shape[-2:]) for h in host]
+            ims = [self.ctx.to_device(np.ascontiguousarray(h, np.uint8 if u8 else np.float32)) for h in host]
+        sizes = [(int(x.get("height", s[0])), int(x.get("width", s[1]))) for x, s in zip(batched_inputs, hw)]
+        return self.infer_device(ims, layout, hw, sizes, to_host=to_host)
 
 
 class HipCaptionODISE(HipCategoryODISE):
