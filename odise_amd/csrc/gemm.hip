@@ -293,9 +293,9 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& g, f32x16 (&acc)[B
     // (sum, sum of squares) over its rows in registers; the block folds the NT / CH row lanes in LDS in a fixed order afterwards
     // (STATS is only instantiated for the conv kernels that feed GroupNorms: the 16 accumulators cost registers in a 128-accumulator epilogue)
     const bool stats = STATS && (NT % CH == 0) && g.epi.gn_stats != nullptr && !split;
-    float s8[8], q8[8];
+    float s8[8], q8[8], bn8[8];
 #pragma unroll
-    for (int i = 0; i < 8; ++i) s8[i] = q8[i] = 0.f;
+    for (int i = 0; i < 8; ++i) s8[i] = q8[i] = bn8[i] = 0.f;
 #pragma unroll
     for (int gp = 0; gp < WAVES_M / WG; ++gp) {
         if (gp > 0) lds_barrier();  // staging reads of the previous pass are done (global stores may still fly)
@@ -313,6 +313,137 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& g, f32x16 (&acc)[B
                 }
         }
         lds_barrier();
+        // ---- read phase.  Common case (lean epilogue, whole column chunks, NT % CH == 0): a thread keeps ONE 8-column chunk over the pass
+        // and walks rows row0, row0 + NT/CH, ... - the trip count is a compile-time constant, so the rows are processed in groups of U with
+        // every load of the group (staged accumulators, residual, per-image vector) issued before the first dependent instruction; bias_n is
+        // loaded once per kernel.  The runtime-flag-per-element form below serialised a global-load round trip per row (8-16 per tile).
+        // Same operations in the same order per element as epi_fast8: results are bit-identical.
+        if constexpr ((NT % CH == 0) && ((ROWS * CH) % NT == 0)) {
+            if (g.epi.fast && !split && n0 + BN <= g.N && !ODISE_ABLATE(g, 8 | 32)) {   // tools: ODISE_EPI_OLD=1 (bit 32) keeps the previous form for A/B runs
+                constexpr int IT = (ROWS * CH) / NT, RSTEP = NT / CH;
+                constexpr int U = IT % 2 == 0 ? 2 : 1;   // 4 spills: half the waves still hold 128 accumulators during the first pass
+                const GemmEpi& e = g.epi;
+                const int c8 = tid % CH, row0 = tid / CH;
+                const int n = n0 + c8 * 8;
+                if (gp == 0 && e.bias_n) {
+                    const float4 b0 = *reinterpret_cast<const float4*>(e.bias_n + n);
+                    const float4 b1 = *reinterpret_cast<const float4*>(e.bias_n + n + 4);
+                    bn8[0] = b0.x; bn8[1] = b0.y; bn8[2] = b0.z; bn8[3] = b0.w; bn8[4] = b1.x; bn8[5] = b1.y; bn8[6] = b1.z; bn8[7] = b1.w;
+                }
+                // the per-image vector (time-embedding term) of the pass's first row: almost always the group of every row of the pass
+                float bg8[8];
+                unsigned grp0 = 0xffffffffu;
+#pragma unroll
+                for (int i = 0; i < 8; ++i) bg8[i] = bn8[i];
+                if (e.rowgroup_add) {
+                    int mf = m0 + gp * ROWS + row0;
+                    if (HALO) mf = -1;   // patch rows are not consecutive pixels: look the group up per row below
+                    if (mf >= 0 && mf < g.M) {
+                        grp0 = (unsigned)mf / (unsigned)e.rows_per_group;
+                        const float* rg = e.rowgroup_add + (int64_t)grp0 * e.ldg + n;
+                        const float4 r0 = *reinterpret_cast<const float4*>(rg);
+                        const float4 r1 = *reinterpret_cast<const float4*>(rg + 4);
+                        bg8[0] += r0.x; bg8[1] += r0.y; bg8[2] += r0.z; bg8[3] += r0.w; bg8[4] += r1.x; bg8[5] += r1.y; bg8[6] += r1.z; bg8[7] += r1.w;
+                    }
+                }
+#pragma unroll
+                for (int it0 = 0; it0 < IT; it0 += U) {
+                    int mm[U];
+                    float4 t0[U], t1[U];
+                    f16x8 rr[U];
+#pragma unroll
+                    for (int u = 0; u < U; ++u) {
+                        const int row = row0 + (it0 + u) * RSTEP;
+                        int m = m0 + gp * ROWS + row;
+                        if (HALO) {
+                            const int rt = gp * ROWS + row;
+                            const int patch = m0 / BM;
+                            const int per_img = g.cg.halo_tx * g.cg.halo_ty;
+                            const int img = patch / per_img, pr = patch - img * per_img;
+                            const int oy = (pr / g.cg.halo_tx) * 16 + (rt >> 4), ox = (pr % g.cg.halo_tx) * 16 + (rt & 15);
+                            m = (oy < g.cg.OH && ox < g.cg.OW) ? (img * g.cg.OH + oy) * g.cg.OW + ox : g.M;
+                        }
+                        mm[u] = m;
+                        t0[u] = *reinterpret_cast<const float4*>(&stg[row * LDS_LD + c8 * 8]);
+                        t1[u] = *reinterpret_cast<const float4*>(&stg[row * LDS_LD + c8 * 8 + 4]);
+                        rr[u] = f16x8{0, 0, 0, 0, 0, 0, 0, 0};
+                        if (m < g.M && e.residual) rr[u] = *reinterpret_cast<const f16x8*>(e.residual + (int64_t)zb * e.strideR + (int64_t)m * e.ldr + n);
+                    }
+#pragma unroll
+                    for (int u = 0; u < U; ++u) {
+                        const int m = mm[u];
+                        if (m >= g.M) continue;
+                        float v[8] = {t0[u].x, t0[u].y, t0[u].z, t0[u].w, t1[u].x, t1[u].y, t1[u].z, t1[u].w};
+                        float b[8];
+#pragma unroll
+                        for (int i = 0; i < 8; ++i) b[i] = bg8[i];
+                        if (e.rowgroup_add) {
+                            const unsigned grp = (unsigned)m / (unsigned)e.rows_per_group;
+                            if (grp != grp0) {   // a pass that straddles two images (or a halo patch): this row's own vector
+                                const float* rg = e.rowgroup_add + (int64_t)grp * e.ldg + n;
+                                const float4 r0 = *reinterpret_cast<const float4*>(rg);
+                                const float4 r1 = *reinterpret_cast<const float4*>(rg + 4);
+                                b[0] = bn8[0] + r0.x; b[1] = bn8[1] + r0.y; b[2] = bn8[2] + r0.z; b[3] = bn8[3] + r0.w;
+                                b[4] = bn8[4] + r1.x; b[5] = bn8[5] + r1.y; b[6] = bn8[6] + r1.z; b[7] = bn8[7] + r1.w;
+                            }
+                        }
+                        float alpha = e.alpha;
+                        if (e.scale_m) alpha *= e.scale_m[m];
+                        if (e.bias_m) {
+                            const float bm = e.bias_m[m];
+#pragma unroll
+                            for (int i = 0; i < 8; ++i) b[i] += bm;
+                        }
+#pragma unroll
+                        for (int i = 0; i < 8; ++i) v[i] = v[i] * alpha + b[i];
+                        if (e.geglu) {
+                            float o[4];
+#pragma unroll
+                            for (int i = 0; i < 4; ++i) o[i] = v[2 * i] * gelu_exact(v[2 * i + 1]);
+                            const int64_t off = (int64_t)zb * e.strideC + (int64_t)m * e.ldc + (n >> 1);
+                            if (e.c_dtype == ODISE_F16) {
+                                f16x4 t;
+#pragma unroll
+                                for (int i = 0; i < 4; ++i) t[i] = (f16)o[i];
+                                *reinterpret_cast<f16x4*>((f16*)e.C + off) = t;
+                            } else {
+                                *reinterpret_cast<float4*>((float*)e.C + off) = make_float4(o[0], o[1], o[2], o[3]);
+                            }
+                            continue;
+                        }
+                        if (e.act == ODISE_ACT_SILU) {
+#pragma unroll
+                            for (int i = 0; i < 8; ++i) v[i] = v[i] / (1.0f + __expf(-v[i]));
+                        } else if (e.act == ODISE_ACT_RELU) {
+#pragma unroll
+                            for (int i = 0; i < 8; ++i) v[i] = v[i] > 0.f ? v[i] : 0.f;
+                        } else if (e.act == ODISE_ACT_QUICKGELU) {
+#pragma unroll
+                            for (int i = 0; i < 8; ++i) v[i] = v[i] / (1.0f + __expf(-1.702f * v[i]));
+                        } else if (e.act == ODISE_ACT_GELU) {
+#pragma unroll
+                            for (int i = 0; i < 8; ++i) v[i] = gelu_exact(v[i]);
+                        }
+                        const int64_t off = (int64_t)zb * e.strideC + (int64_t)m * e.ldc + n;
+                        if (e.c_dtype == ODISE_F16) {
+                            f16x8 t;
+#pragma unroll
+                            for (int i = 0; i < 8; ++i) t[i] = (f16)(v[i] + (float)rr[u][i]);
+                            *reinterpret_cast<f16x8*>((f16*)e.C + off) = t;
+                            if (stats) {
+#pragma unroll
+                                for (int i = 0; i < 8; ++i) { const float r = (float)t[i]; s8[i] += r; q8[i] += r * r; }
+                            }
+                        } else {
+                            float* c = (float*)e.C + off;
+                            *reinterpret_cast<float4*>(c) = make_float4(v[0] + (float)rr[u][0], v[1] + (float)rr[u][1], v[2] + (float)rr[u][2], v[3] + (float)rr[u][3]);
+                            *reinterpret_cast<float4*>(c + 4) = make_float4(v[4] + (float)rr[u][4], v[5] + (float)rr[u][5], v[6] + (float)rr[u][6], v[7] + (float)rr[u][7]);
+                        }
+                    }
+                }
+                continue;   // next pass
+            }
+        }
         for (int c = tid; c < ROWS * CH; c += NT) {
             const int row = c / CH;
             const int c8 = c - row * CH;
@@ -1864,7 +1995,7 @@ static int launch_gemm(odise_hip_ctx* ctx, GemmArgs& g, int batch, int force_til
     }
     g.zeros = (const f16*)ctx->zeros;
 #ifdef ODISE_TOOLS
-    static const int freeze_k = getenv("ODISE_GEMM_FREEZE_K") ? 16 : 0;
+    static const int freeze_k = (getenv("ODISE_GEMM_FREEZE_K") ? 16 : 0) | (getenv("ODISE_EPI_OLD") ? 32 : 0);
     g.dbg = g_gemm_debug | freeze_k;
 #else
     g.dbg = 0;

@@ -306,12 +306,14 @@ class SemSegHead(nn.Module):
         return self.predictor(multi_scale, mask_features)
 
 
-def init_synthetic_(model: nn.Module, seed: int = 777, qk_gain: float = 1.0, level_gain: float = 1.0) -> nn.Module:
+def init_synthetic_(model: nn.Module, seed: int = 777, branch_gain: float = 1.0, qk_gain: float = 1.0, level_gain: float = 1.0) -> nn.Module:
     """Seeded weights.  With the defaults the 100 queries of the full-size decoder collapse onto one mask: every attention sublayer adds
-    the same vector (W_v . mean(src), dominated by the O(1) level embedding) to all queries and the post-norm keeps halving their distinct
-    part, 18 times.  `qk_gain` > 1 sharpens the masked decoder's attention (q / k rows of in_proj scaled) and `level_gain` < 1 shrinks its
-    level embedding, so queries attend to different regions and predict different masks - the regime a trained model works in
-    (tests/fullsize.py uses 4 / 0.1).  The random draws are the same for every gain."""
+    (nearly) the same vector to all queries - W_v . mean(src), as large as the query itself - and the post-norm halves their distinct part,
+    18 times.  `branch_gain` < 1 scales the residual branches of the masked decoder (attention out_proj and FFN linear2 weights), the
+    regime of a trained network whose branches refine the query instead of replacing it: queries stay distinct (tests/fullsize.py uses
+    0.3).  `qk_gain` > 1 sharpens the decoder's attention instead and `level_gain` shrinks its level embedding; that also separates the
+    queries but makes the fp32 model itself chaotic - rounding weights and inputs to fp16 moves its mask logits by 22 % at qk_gain 4
+    (tools/oracle_sensitivity.py) - so it is not used for parity.  The random draws are the same for every gain."""
     g = torch.Generator().manual_seed(seed)
     with torch.no_grad():
         for name, p in sorted(model.named_parameters()):
@@ -331,10 +333,11 @@ def init_synthetic_(model: nn.Module, seed: int = 777, qk_gain: float = 1.0, lev
         for emb in (model.predictor.query_feat, model.predictor.query_embed, model.predictor.level_embed):
             emb.weight.copy_(torch.randn(emb.weight.shape, generator=g))
         model.pixel_decoder.transformer.level_embed.copy_(torch.randn(model.pixel_decoder.transformer.level_embed.shape, generator=g))
-        if qk_gain != 1.0:
-            for name, p in model.predictor.named_parameters():
-                if name.endswith("in_proj_weight"):
-                    p[: 2 * p.shape[1]].mul_(qk_gain)
+        for name, p in model.predictor.named_parameters():
+            if qk_gain != 1.0 and name.endswith("in_proj_weight"):
+                p[: 2 * p.shape[1]].mul_(qk_gain)
+            if branch_gain != 1.0 and (name.endswith("out_proj.weight") or name.endswith("linear2.weight")):
+                p.mul_(branch_gain)
         if level_gain != 1.0:
             model.predictor.level_embed.weight.mul_(level_gain)
     return model.eval()

@@ -27,7 +27,7 @@ from oracle.m2f import SemSegHead, init_synthetic_
 
 FEATURE_DIMS = [512, 512, 2560, 1920, 960, 640, 512, 512]   # enc5, enc7, u2, u5, u8, u11, dec2, dec5 (ldm.py:284-346)
 CACHE = os.path.join(os.path.dirname(os.path.abspath(__file__)), ".oracle_cache")
-VERSION = "v4"
+VERSION = "v6"
 
 
 def image_u8(h, w, seed=0):
@@ -42,13 +42,13 @@ def image_u8(h, w, seed=0):
 def build_models(num_classes):
     ext = ImplicitCaptionerExtractor()
     bb = FeatureExtractorBackbone(ext, FEATURE_DIMS)
-    head = init_synthetic_(SemSegHead(num_classes=num_classes), qk_gain=4.0, level_gain=0.1)
+    head = init_synthetic_(SemSegHead(num_classes=num_classes), branch_gain=0.3)
     with torch.no_grad():   # the learned temperature at its clamp (odise.py:1013 clamps exp(logit_scale) at 100): class distributions as peaked as a trained model's
         head.predictor.post_mask_embed.logit_scale.fill_(math.log(100.0))
     return ext, bb, head
 
 
-def spread_vocabulary(heads: om.OpenVocabHeads, mask_embed, clip_embed, seed=5, null_queries=6, null_bias=0.05):
+def spread_vocabulary(heads: om.OpenVocabHeads, mask_embed, clip_embed, seed=5, null_queries=6, null_bias=0.07):
     """Overwrite the text banks / null embedding of `heads` (see the module docstring).  mask_embed [Q,256], clip_embed [Q,768]."""
     g = torch.Generator().manual_seed(seed)
     Q = mask_embed.shape[0]
@@ -85,6 +85,25 @@ def spread_vocabulary(heads: om.OpenVocabHeads, mask_embed, clip_embed, seed=5, 
     return heads
 
 
+def centre_mask_logits(head, feats, positive_fraction=0.15, rounds=2):
+    """With seeded weights the mask logits of every query are positive on most of the image (the queries' common embedding component
+    times the mask features), so all masks overlap, nearly nothing passes the 0.8 overlap test and every MaskCLIP mask token sees every
+    patch.  A trained model's masks cover a fraction of the image: shift `mask_features.bias` (a per-query constant on the logits,
+    me_q . b) so that about `positive_fraction` of the logits are positive.  Deterministic, part of the weights both sides load."""
+    grab = {}
+    hook = head.predictor.mask_embed.register_forward_hook(lambda m, i, o: grab.__setitem__("me", o.detach()))
+    try:
+        for _ in range(rounds):
+            out = head(feats)
+            me = grab["me"][0].double()                                        # [Q, C]: mask embeddings of the final prediction head
+            s = torch.quantile(out["pred_masks"].flatten()[::97].double(), 1.0 - positive_fraction)
+            delta = -(s * (torch.linalg.pinv(me) @ torch.ones(me.shape[0], 1, dtype=torch.float64)))[:, 0]   # me_q . delta = -s for every q
+            with torch.no_grad():
+                head.pixel_decoder.mask_features.bias.add_(delta.float())
+    finally:
+        hook.remove()
+
+
 def export_state(ext, bb, head, heads):
     state = ext.export_state()
     state.update({"backbone.feature_projections." + k: v for k, v in bb.feature_projections.state_dict().items()})
@@ -119,6 +138,7 @@ def reference(bb, head, ext, size, num_classes, num_strings, seed=0, use_cache=T
         return out
 
     feats = cached(f"feats_{size}_{seed}", lambda: bb(img01))                 # size is a multiple of 64: no padding
+    centre_mask_logits(head, feats)
 
     def run_head():
         out = head(feats)
