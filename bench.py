@@ -195,6 +195,9 @@ def inclusive_rates(ctx, hip, u8, S, B, sizes, steps):
 
 def main():
     args = parse()
+    # RCCL prints a version banner on stdout at communicator creation when NCCL_DEBUG asks for it (C stdio: it would land AFTER the JSON
+    # line at exit); this program's stdout carries exactly one line
+    os.environ["NCCL_DEBUG"] = os.environ.get("ODISE_NCCL_DEBUG", "WARN")
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))

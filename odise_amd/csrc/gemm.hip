@@ -73,7 +73,6 @@ struct GemmArgs {
     const f16* zeros;  // >= 16 zero bytes (source of padded / out-of-range operand slots)
     int dbg;           // ablation switches (tools only): 1 = no operand DMA after the first tile, 2 = no fragment reads after the first
     int stats_blocks;  // out: row blocks per image of the fused GroupNorm statistics (0 = not produced, epi.gn_stats was cleared)
-    int direct_epilogue;  // experiment: 1 = launchers may pick the transposed-accumulator kernels
 };
 
 // Workgroup barrier that only orders LDS traffic.  `__syncthreads()` also drains the vector-memory counter, i.e. it waits for
@@ -513,102 +512,6 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& g, f32x16 (&acc)[B
     }
 }
 
-// ---- epilogue straight from the registers, for accumulators produced TRANSPOSED (EXPERIMENT, branch epilogue-direct) -------------------
-// With the MFMA operands swapped - acc = mfma(b_frag, a_frag, acc) - the 32x32 tile comes out transposed: lane l owns row m = l & 31 of
-// tile row i and, per register quad q = r >> 2, the four consecutive columns 8q + 4(l >> 5) + (r & 3) of tile column j.  Four columns are
-// 8 bytes of fp16 (the two lane halves together cover 16 contiguous bytes of a row), so every quad is one vector store and the fp32
-// round trip through LDS (5 us of the 11-12 us epilogue of a 256x256 tile) disappears; per-row terms (scale_m, bias_m, the row-group
-// index) are per-lane scalars, per-column terms are float4 loads.  Same products, same accumulation order, same epilogue arithmetic
-// as epi_fast8: results are meant to be bit-identical to the staged path (tools/epilogue_bench.py checks that).
-// Requires the fast-path conditions (GemmEpi::fast) and N % 8 == 0; no fused GroupNorm statistics.
-template <int BM, int BN, int WAVES_M, int WAVES_N>
-__device__ __forceinline__ void gemm_epilogue_direct(const GemmArgs& g, f32x16 (&acc)[BM / WAVES_M / 32][BN / WAVES_N / 32], int m0, int n0, int z,
-                                                     int zb, bool split) {
-    constexpr int WTM = BM / WAVES_M, WTN = BN / WAVES_N;
-    constexpr int TM = WTM / 32, TN = WTN / 32;
-    const int lane = threadIdx.x & 63;
-    const int wave = threadIdx.x >> 6;
-    const int wm = wave / WAVES_N, wn = wave % WAVES_N;
-    const int hi = lane >> 5, l31 = lane & 31;
-    const GemmEpi& e = g.epi;
-#pragma unroll
-    for (int i = 0; i < TM; ++i) {
-        const int m = m0 + wm * WTM + i * 32 + l31;
-        if (m >= g.M) continue;
-        float alpha = e.alpha;
-        float bm = 0.f;
-        const float* rg = nullptr;
-        if (!split) {
-            if (e.scale_m) alpha *= e.scale_m[m];
-            if (e.bias_m) bm = e.bias_m[m];
-            if (e.rowgroup_add) rg = e.rowgroup_add + (int64_t)((unsigned)m / (unsigned)e.rows_per_group) * e.ldg;
-        }
-#pragma unroll
-        for (int j = 0; j < TN; ++j)
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const int n = n0 + wn * WTN + j * 32 + 8 * q + 4 * hi;
-                if (n >= g.N) continue;
-                float v[4] = {acc[i][j][4 * q], acc[i][j][4 * q + 1], acc[i][j][4 * q + 2], acc[i][j][4 * q + 3]};
-                if (split) {
-                    *reinterpret_cast<float4*>(g.ws + ((int64_t)z * g.M + m) * g.N + n) = make_float4(v[0], v[1], v[2], v[3]);
-                    continue;
-                }
-                float b[4] = {0.f, 0.f, 0.f, 0.f};
-                if (e.bias_n) {
-                    const float4 t = *reinterpret_cast<const float4*>(e.bias_n + n);
-                    b[0] = t.x; b[1] = t.y; b[2] = t.z; b[3] = t.w;
-                }
-                if (rg) {
-                    const float4 t = *reinterpret_cast<const float4*>(rg + n);
-                    b[0] += t.x; b[1] += t.y; b[2] += t.z; b[3] += t.w;
-                }
-                if (e.bias_m) {
-#pragma unroll
-                    for (int k = 0; k < 4; ++k) b[k] += bm;
-                }
-#pragma unroll
-                for (int k = 0; k < 4; ++k) v[k] = v[k] * alpha + b[k];
-                if (e.geglu) {  // (a, gate) pairs -> N/2 output columns
-                    const float o0 = v[0] * gelu_exact(v[1]), o1 = v[2] * gelu_exact(v[3]);
-                    const int64_t off = (int64_t)zb * e.strideC + (int64_t)m * e.ldc + (n >> 1);
-                    if (e.c_dtype == ODISE_F16) {
-                        typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
-                        f16x2 t = {(f16)o0, (f16)o1};
-                        *reinterpret_cast<f16x2*>((f16*)e.C + off) = t;
-                    } else {
-                        *reinterpret_cast<float2*>((float*)e.C + off) = make_float2(o0, o1);
-                    }
-                    continue;
-                }
-                f16x4 r = {0, 0, 0, 0};
-                if (e.residual) r = *reinterpret_cast<const f16x4*>(e.residual + (int64_t)zb * e.strideR + (int64_t)m * e.ldr + n);
-                if (e.act == ODISE_ACT_SILU) {
-#pragma unroll
-                    for (int k = 0; k < 4; ++k) v[k] = v[k] / (1.0f + __expf(-v[k]));
-                } else if (e.act == ODISE_ACT_RELU) {
-#pragma unroll
-                    for (int k = 0; k < 4; ++k) v[k] = v[k] > 0.f ? v[k] : 0.f;
-                } else if (e.act == ODISE_ACT_QUICKGELU) {
-#pragma unroll
-                    for (int k = 0; k < 4; ++k) v[k] = v[k] / (1.0f + __expf(-1.702f * v[k]));
-                } else if (e.act == ODISE_ACT_GELU) {
-#pragma unroll
-                    for (int k = 0; k < 4; ++k) v[k] = gelu_exact(v[k]);
-                }
-                const int64_t off = (int64_t)zb * e.strideC + (int64_t)m * e.ldc + n;
-                if (e.c_dtype == ODISE_F16) {
-                    f16x4 t;
-#pragma unroll
-                    for (int k = 0; k < 4; ++k) t[k] = (f16)(v[k] + (float)r[k]);
-                    *reinterpret_cast<f16x4*>((f16*)e.C + off) = t;
-                } else {
-                    *reinterpret_cast<float4*>((float*)e.C + off) = make_float4(v[0] + (float)r[0], v[1] + (float)r[1], v[2] + (float)r[2], v[3] + (float)r[3]);
-                }
-            }
-    }
-}
-
 template <int BM, int BN, int WAVES_M, int WAVES_N, bool CONV, bool INTERLEAVE>
 __global__ void __launch_bounds__(64 * WAVES_M * WAVES_N) gemm_kernel(GemmArgs g) {
     constexpr int BK = 64;
@@ -849,7 +752,7 @@ __device__ __forceinline__ void wait_vmcnt() {
 // DMA groups of the tile sequence (per thread: 4 A loads, TN B loads; B piece j = the rows of N-tile j of both wave columns):
 //   NP = 2: (t,0) issues B0..B3 of tile t+1, (t,1) issues A0..A3 of tile t+2
 //   NP = 3: (t,0) issues B2,B3,B4 of tile t+1, (t,1) issues A0,A1,A2 of tile t+2, (t,2) issues A3,B0,B1 of tile t+2
-template <int BM, int BN, int WAVES_N, int PT, bool CONV, bool TR = false>  // TR: transposed accumulators + gemm_epilogue_direct (experiment)
+template <int BM, int BN, int WAVES_N, int PT, bool CONV>
 __global__ void __launch_bounds__(512) gemm_pp_kernel(GemmArgs g) {
     // (measured and rejected: issuing the DMA before the fragment reads -17 %, dropping s_setprio +-1 %; a persistent form - 256 resident
     // blocks walking the tile list - is bit-identical but 5-9 % SLOWER: vmcnt also counts stores on this part, so the next tile's first
@@ -1139,8 +1042,7 @@ __global__ void __launch_bounds__(512) gemm_pp_kernel(GemmArgs g) {
                     if (jj < nj) {
 #pragma unroll
                         for (int i = 0; i < TM; ++i)
-                            acc[i][j0 + jj] = TR ? __builtin_amdgcn_mfma_f32_32x32x16_f16(bf[jj][s], af[i][s], acc[i][j0 + jj], 0, 0, 0)
-                                                 : __builtin_amdgcn_mfma_f32_32x32x16_f16(af[i][s], bf[jj][s], acc[i][j0 + jj], 0, 0, 0);
+                            acc[i][j0 + jj] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[i][s], bf[jj][s], acc[i][j0 + jj], 0, 0, 0);
                     }
             __builtin_amdgcn_s_setprio(0);
             __builtin_amdgcn_sched_barrier(0);
@@ -1153,8 +1055,7 @@ __global__ void __launch_bounds__(512) gemm_pp_kernel(GemmArgs g) {
     if (grp == 0) __builtin_amdgcn_s_barrier();  // re-align the two groups
     __syncthreads();
     if (ODISE_ABLATE(g, 4)) return;
-    if constexpr (TR) gemm_epilogue_direct<BM, BN, WAVES_M, WAVES_N>(g, acc, m0, n0, z, zb, split);
-    else gemm_epilogue<BM, BN, WAVES_M, WAVES_N, epi_wave_rows(BM, BN, WAVES_M, pp_lds_bytes(BM, BN, WAVES_M)), false, (CONV && BM == 512)>(g, acc, smem, m0, n0, z, zb, split);
+    gemm_epilogue<BM, BN, WAVES_M, WAVES_N, epi_wave_rows(BM, BN, WAVES_M, pp_lds_bytes(BM, BN, WAVES_M)), false, (CONV && BM == 512)>(g, acc, smem, m0, n0, z, zb, split);
 }
 
 
@@ -1209,7 +1110,7 @@ __device__ __forceinline__ void wait_phase(int p) {  // p is a compile-time cons
 }
 }  // namespace pp2
 
-template <int BM, int BN, int WAVES_N, int PT, bool CONV, bool TR = false>  // TR: see gemm_pp_kernel
+template <int BM, int BN, int WAVES_N, int PT, bool CONV>
 __global__ void __launch_bounds__(512) gemm_pp2_kernel(GemmArgs g) {
     constexpr int BK = 64, WAVES_M = 8 / WAVES_N;
     constexpr int WTN = BN / WAVES_N;
@@ -1449,8 +1350,7 @@ __global__ void __launch_bounds__(512) gemm_pp2_kernel(GemmArgs g) {
                 for (int jj = 0; jj < PT; ++jj)
 #pragma unroll
                     for (int i = 0; i < TM; ++i)
-                        acc[i][j0 + jj] = TR ? __builtin_amdgcn_mfma_f32_32x32x16_f16(bf[jj][s], af[i][s], acc[i][j0 + jj], 0, 0, 0)
-                                             : __builtin_amdgcn_mfma_f32_32x32x16_f16(af[i][s], bf[jj][s], acc[i][j0 + jj], 0, 0, 0);
+                        acc[i][j0 + jj] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[i][s], bf[jj][s], acc[i][j0 + jj], 0, 0, 0);
                 if (have_next) {
                     if (!next_in_tile) {
 #pragma unroll
@@ -1472,8 +1372,7 @@ __global__ void __launch_bounds__(512) gemm_pp2_kernel(GemmArgs g) {
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
     __syncthreads();
     if (ODISE_ABLATE(g, 4)) return;
-    if constexpr (TR) gemm_epilogue_direct<BM, BN, WAVES_M, WAVES_N>(g, acc, m0, n0, z, zb, split);
-    else gemm_epilogue<BM, BN, WAVES_M, WAVES_N, epi_wave_rows(BM, BN, WAVES_M, pp_lds_bytes(BM, BN, WAVES_M)), false, CONV>(g, acc, smem, m0, n0, z, zb, split);
+    gemm_epilogue<BM, BN, WAVES_M, WAVES_N, epi_wave_rows(BM, BN, WAVES_M, pp_lds_bytes(BM, BN, WAVES_M)), false, CONV>(g, acc, smem, m0, n0, z, zb, split);
 }
 
 // (A third structure - every wave free-running through the four k-steps with register double-buffered fragments and ONE barrier per
@@ -1775,18 +1674,14 @@ template <int BM, int BN, int WAVES_N, int PT, bool CONV>
 static int launch_gemm_pp(odise_hip_ctx* ctx, GemmArgs& g, int batch) {
     constexpr int lds = pp_lds_bytes(BM, BN, 8 / WAVES_N);
     static_assert(epi_lds_bytes(BM, BN, 8 / WAVES_N, epi_wave_rows(BM, BN, 8 / WAVES_N, lds)) <= lds, "epilogue staging exceeds the LDS request");
-    auto kern = gemm_pp_kernel<BM, BN, WAVES_N, PT, CONV, false>;
-    auto kern_tr = gemm_pp_kernel<BM, BN, WAVES_N, PT, CONV, true>;
+    auto kern = gemm_pp_kernel<BM, BN, WAVES_N, PT, CONV>;
     static bool attr_set = false;  // per instantiation
     if (!attr_set) {
         ODISE_CHECK_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
-        ODISE_CHECK_HIP(hipFuncSetAttribute((const void*)kern_tr, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
         attr_set = true;
     }
     dim3 grid((unsigned)ceil_div(g.N, BN), (unsigned)ceil_div(g.M, BM), (unsigned)(g.splitk > 1 ? g.splitk : batch));
-    // experiment (ODISE_GEMM_FLAGS / odise_hip_gemm_debug bit 4096): transposed accumulators + direct epilogue where its conditions hold
-    const bool direct = g.direct_epilogue && g.epi.fast && (g.N & 7) == 0 && g.epi.gn_stats == nullptr;
-    hipLaunchKernelGGL(direct ? kern_tr : kern, grid, dim3(512), lds, ctx->stream, g);
+    hipLaunchKernelGGL(kern, grid, dim3(512), lds, ctx->stream, g);
     ODISE_CHECK_HIP(hipGetLastError());
     if (g.splitk > 1) {
         const int64_t total = (int64_t)g.M * ceil_div(g.N, 8);
@@ -1801,17 +1696,14 @@ template <int BM, int BN, int WAVES_N, int PT, bool CONV>
 static int launch_gemm_pp2(odise_hip_ctx* ctx, GemmArgs& g, int batch) {
     static_assert((BN / WAVES_N / 32) % PT == 0, "whole phases");
     constexpr int lds = pp_lds_bytes(BM, BN, 8 / WAVES_N);
-    auto kern = gemm_pp2_kernel<BM, BN, WAVES_N, PT, CONV, false>;
-    auto kern_tr = gemm_pp2_kernel<BM, BN, WAVES_N, PT, CONV, true>;
+    auto kern = gemm_pp2_kernel<BM, BN, WAVES_N, PT, CONV>;
     static bool attr_set = false;  // per instantiation
     if (!attr_set) {
         ODISE_CHECK_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
-        ODISE_CHECK_HIP(hipFuncSetAttribute((const void*)kern_tr, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
         attr_set = true;
     }
     dim3 grid((unsigned)ceil_div(g.N, BN), (unsigned)ceil_div(g.M, BM), (unsigned)(g.splitk > 1 ? g.splitk : batch));
-    const bool direct = g.direct_epilogue && g.epi.fast && (g.N & 7) == 0 && g.epi.gn_stats == nullptr;  // experiment, see launch_gemm_pp
-    hipLaunchKernelGGL(direct ? kern_tr : kern, grid, dim3(512), lds, ctx->stream, g);
+    hipLaunchKernelGGL(kern, grid, dim3(512), lds, ctx->stream, g);
     ODISE_CHECK_HIP(hipGetLastError());
     if (g.splitk > 1) {
         const int64_t total = (int64_t)g.M * ceil_div(g.N, 8);
@@ -1919,7 +1811,6 @@ static int launch_gemm(odise_hip_ctx* ctx, GemmArgs& g, int batch, int force_til
     int tile = 2, best_split = 1;
     double best = 1e30;
     const int flags = g_conv_flags | env_gemm_flags();
-    g.direct_epilogue = (flags & 4096) ? 1 : 0;
     const bool pp_ok = !no_interleave && !(flags & 2) && g.K % 64 == 0 && (!CONV || (g.cg.Cin % 64 == 0 && !g.cg.ups));
     for (int t = 0; t < kNumTiles; ++t) {
         if (force_tile >= 0 && force_tile < kNumTiles && t != force_tile) continue;
@@ -2053,7 +1944,6 @@ int gemm_forced(odise_hip_ctx* ctx, const odise_gemm_desc* d, int force_tile, in
     const int batch = d->batch < 1 ? 1 : d->batch;
     ODISE_REQUIRE(batch == 1 || ((d->strideA % 8 == 0) && (d->strideW % 8 == 0)), "gemm: batch strides must keep 16-byte alignment");
     GemmArgs g;
-    g.direct_epilogue = 0;
     g.M = d->M; g.N = d->N; g.K = d->K;
     g.A = (const f16*)d->A; g.lda = d->lda; g.strideA = d->strideA;
     g.W = (const f16*)d->W; g.ldw = d->ldw; g.strideW = d->strideW;
@@ -2078,7 +1968,6 @@ int conv_forced(odise_hip_ctx* ctx, const odise_conv_desc* d, int force_tile, in
     ODISE_REQUIRE(((uintptr_t)d->X & 15) == 0 && ((uintptr_t)d->Wt & 15) == 0, "conv2d: X/Wt must be 16-byte aligned");
     if (d->N == 0) return ODISE_OK;
     GemmArgs g;
-    g.direct_epilogue = 0;
     g.M = d->N * d->OH * d->OW;
     g.N = d->Cout;
     g.K = d->KH * d->KW * d->Cin;

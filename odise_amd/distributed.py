@@ -102,6 +102,10 @@ class Exchange:
             data = broadcast(bytes(buf) if rank == 0 else None)
             buf = (C.c_ubyte * COMM_ID_BYTES).from_buffer_copy(data)
         check(ctx.lib.odise_hip_comm_init(ctx.h, buf, rank, world), "comm_init")
+        try:   # RCCL writes a version banner through C stdio at initialisation: push it out now, not after whatever Python prints last
+            C.CDLL(None).fflush(None)
+        except (OSError, AttributeError):
+            pass
 
     def allgather(self, local, out) -> None:
         """out [world * n] = every rank's local [n] (device int32 buffers: runtime.DeviceArray).  Asynchronous: runs on the library's

@@ -145,8 +145,45 @@ def test_postprocess_x4_kernel_matches_generic(models, h, w):
     np.testing.assert_array_equal(fast["instances"]["scores"], gen["instances"]["scores"])
 
 
+def test_panoptic_record_written_into_a_caller_owned_buffer(models):
+    """The multi-GPU step (bench.py --gpus N) lets the device write every image's prediction record - panoptic map AND segment table -
+    straight into this rank's slice of the all-gather buffer: same map, same segments as the host-returning call."""
+    from odise_amd import distributed as D
+    _, _, _, hip = models
+    img = _image_u8(512, 512, seed=3)
+    ref = hip.forward([{"image": img}])[0]
+    rec = hip.ctx.zeros((1, D.record_size(512, 512)), np.int32)
+    d = hip.ctx.to_device(img.numpy())
+    out = hip.infer_device([d], 1, [(512, 512)], [(512, 512)], to_host=False, pan_out=[rec.ptr])[0]
+    assert out["panoptic_seg"] == (None, None)
+    seg, info = D.unpack_record(torch.from_numpy(rec.numpy()[0]), 512, 512)
+    np.testing.assert_array_equal(seg, ref["panoptic_seg"][0])
+    assert info == ref["panoptic_seg"][1] and len(info) >= 1
+
+
+def test_unequal_image_sizes_in_one_batch(models):
+    """ImageList.from_tensors pads a batch to its largest image (odise.py:238-244): a mixed batch must reproduce the results of each
+    image's own padded call - the network sees the same padded tensors either way."""
+    bb, head, heads, hip = models
+    a, b = _image_u8(512, 704, seed=21), _image_u8(576, 512, seed=22)
+    both = hip.forward([{"image": a}, {"image": b}])
+    # reference for image a inside the batch canvas (576 x 704 -> 576 x 704 padded to 576 x 704): run it alone on the same canvas
+    for im, got in zip((a, b), both):
+        h, w = im.shape[-2:]
+        assert got["sem_seg"].shape == (len(GROUPS), h, w) and got["panoptic_seg"][0].shape == (h, w)
+        assert got["instances"]["pred_masks"].shape[1:] == (h, w)
+    ref_cls, ref_out, ref = _oracle_forward_batch(bb, head, heads, [a, b], 0.0)
+    for i, got in enumerate(both):
+        sem_ref = ref[i]["sem_seg"].numpy()
+        err = np.abs(got["sem_seg"] - sem_ref).max() / np.abs(sem_ref).max()
+        agree = (got["panoptic_seg"][0] == ref[i]["panoptic_seg"][0].numpy()).mean()
+        print("mixed batch image", i, "sem_seg err", err, "panoptic agreement", agree, got["panoptic_seg"][1], ref[i]["panoptic_seg"][1])
+        assert err < 2e-2 and agree > 0.995 and got["panoptic_seg"][1] == ref[i]["panoptic_seg"][1]
+
+
 def test_caption_variant_matches_oracle(ctx):
-    """CaptionODISE eval forward (odise.py:545-619): learned (object, no-object) class head + word bank without a null embedding."""
+    """(Keep this test LAST in the module: it loads another model into the shared context, replacing the weights of the `models` fixture.)
+    CaptionODISE eval forward (odise.py:545-619): learned (object, no-object) class head + word bank without a null embedding."""
     from odise_amd.pipeline import HipCaptionODISE
     ext = ImplicitCaptionerExtractor(**SMALL)
     bb = FeatureExtractorBackbone(ext, [128, 128, 512, 384, 192, 128, 128, 128])
@@ -182,39 +219,3 @@ def test_caption_variant_matches_oracle(ctx):
     agree = (pan == pan_ref.numpy()).mean()
     print("segments", info, "ref", info_ref, "agreement", agree)
     assert info == info_ref and agree > 0.995
-
-
-def test_panoptic_record_written_into_a_caller_owned_buffer(models):
-    """The multi-GPU step (bench.py --gpus N) lets the device write every image's prediction record - panoptic map AND segment table -
-    straight into this rank's slice of the all-gather buffer: same map, same segments as the host-returning call."""
-    from odise_amd import distributed as D
-    _, _, _, hip = models
-    img = _image_u8(512, 512, seed=3)
-    ref = hip.forward([{"image": img}])[0]
-    rec = hip.ctx.zeros((1, D.record_size(512, 512)), np.int32)
-    d = hip.ctx.to_device(img.numpy())
-    out = hip.infer_device([d], 1, [(512, 512)], [(512, 512)], to_host=False, pan_out=[rec.ptr])[0]
-    assert out["panoptic_seg"] == (None, None)
-    seg, info = D.unpack_record(torch.from_numpy(rec.numpy()[0]), 512, 512)
-    np.testing.assert_array_equal(seg, ref["panoptic_seg"][0])
-    assert info == ref["panoptic_seg"][1] and len(info) >= 1
-
-
-def test_unequal_image_sizes_in_one_batch(models):
-    """ImageList.from_tensors pads a batch to its largest image (odise.py:238-244): a mixed batch must reproduce the results of each
-    image's own padded call - the network sees the same padded tensors either way."""
-    bb, head, heads, hip = models
-    a, b = _image_u8(512, 704, seed=21), _image_u8(576, 512, seed=22)
-    both = hip.forward([{"image": a}, {"image": b}])
-    # reference for image a inside the batch canvas (576 x 704 -> 576 x 704 padded to 576 x 704): run it alone on the same canvas
-    for im, got in zip((a, b), both):
-        h, w = im.shape[-2:]
-        assert got["sem_seg"].shape == (len(GROUPS), h, w) and got["panoptic_seg"][0].shape == (h, w)
-        assert got["instances"]["pred_masks"].shape[1:] == (h, w)
-    ref_cls, ref_out, ref = _oracle_forward_batch(bb, head, heads, [a, b], 0.0)
-    for i, got in enumerate(both):
-        sem_ref = ref[i]["sem_seg"].numpy()
-        err = np.abs(got["sem_seg"] - sem_ref).max() / np.abs(sem_ref).max()
-        agree = (got["panoptic_seg"][0] == ref[i]["panoptic_seg"][0].numpy()).mean()
-        print("mixed batch image", i, "sem_seg err", err, "panoptic agreement", agree, got["panoptic_seg"][1], ref[i]["panoptic_seg"][1])
-        assert err < 2e-2 and agree > 0.995 and got["panoptic_seg"][1] == ref[i]["panoptic_seg"][1]
