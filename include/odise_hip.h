@@ -219,6 +219,15 @@ int odise_hip_head_build(odise_hip_ctx* ctx);
 int odise_hip_head_forward(odise_hip_ctx* ctx, const float* const* feats4, int B, int Cin, int H4, int W4, float* pred_masks,
                            float* mask_embed, float* mask_pooled, float* logit_scale);
 int odise_hip_maskgen_info(odise_hip_ctx* ctx, int* num_queries, int* hidden_dim, double* last_macs);
+/* the two halves of the head on their own (the reference's modules are callable one by one):
+ * MSDeformAttnPixelDecoder.forward_features (msdeformattn.py:314-358): feats4 = s2..s5 fp32 NCHW -> mask_features [B,C,H4,W4] and the three
+ * multi-scale maps [B,C,H4/8,W4/8], [B,C,H4/4,W4/4], [B,C,H4/2,W4/2] (fp32 NCHW device, any may be NULL) */
+int odise_hip_pixel_decoder_forward(odise_hip_ctx* ctx, const float* const* feats4, int B, int Cin, int H4, int W4, float* mask_features,
+                                    float* const* multi_scale3);
+/* ODISEMultiScaleMaskedTransformerDecoder.forward (odise.py:642-727): multi_scale3 = 3 fp32 NCHW maps of sizes hw3 [3][2] (HOST),
+ * mask_features [B,C,H4,W4]; outputs as odise_hip_head_forward (and kept inside for odise_hip_classify / postprocess) */
+int odise_hip_predictor_forward(odise_hip_ctx* ctx, const float* const* multi_scale3, const int* hw3, const float* mask_features, int B, int H4, int W4,
+                                float* pred_masks, float* mask_embed, float* mask_pooled, float* logit_scale);
 
 /* ---- open-vocabulary classification (odise.py:285-323; clip.py:252-361; helper.py:79-109) ---------------------------- */
 /* weights: category_head.text_proj.{weight,bias}, category_head.null_embed (ODISE ckpt) + the CLIP tower of the extractor */
@@ -231,6 +240,9 @@ int odise_hip_set_vocabulary(odise_hip_ctx* ctx, const float* cat_text, const fl
 /* image [B,3,H,W] fp32 device in [0,1]; uses the last head_forward; mask_cls [B,Q,K+1] fp32 device (log-probabilities);
  * clip_embed (optional) [B,Q,dim] fp32 device = MaskCLIP.get_mask_embed */
 int odise_hip_classify(odise_hip_ctx* ctx, const float* image, int B, int H, int W, float* mask_cls, float* clip_embed);
+/* MaskCLIP.get_mask_embed stand-alone (clip.py:325-338; the arithmetic of PoolingCLIPHead.forward, odise.py:1469-1542): image [B,3,H,W] fp32 in
+ * [0,1], pred_masks [B,Q,h,w] fp32 logits (device) -> clip_embed [B,Q,dim] fp32.  Needs the CLIP tower (odise_hip_extractor_build). */
+int odise_hip_maskclip_embed(odise_hip_ctx* ctx, const float* image, int B, int H, int W, const float* pred_masks, int Q, int h, int w, float* clip_embed);
 
 /* ---- post-processing (odise.py:326-370; maskformer_model.py:280-380) ------------------------------------------------- */
 /* fused mask upsample (x4 bilinear to pad_h x pad_w, crop img_h x img_w, bilinear to out_h x out_w) + sigmoid +

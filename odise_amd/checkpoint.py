@@ -163,6 +163,33 @@ def read_openseg_labels(path: str, invalid_name: str = "invalid_class_id") -> Li
     return out
 
 
+def default_train_labels() -> List[List[str]]:
+    """The training vocabulary PoolingCLIPHead falls back to (odise.py:1446-1447: `get_openseg_labels("coco_panoptic",
+    prompt_engineered=True)`): read from the label file the reference ships, found in `$ODISE_OPENSEG_LABELS` or in an `odise` package
+    directory on sys.path (odise/data/datasets/openseg_labels/coco_panoptic_with_prompt_eng.txt).  There is no silent substitute: the
+    seen / unseen split decides the ensemble weights (alpha for seen, beta for unseen categories)."""
+    import sys
+    name = "coco_panoptic_with_prompt_eng.txt"
+    cands = [os.path.join(os.environ["ODISE_OPENSEG_LABELS"], name)] if os.environ.get("ODISE_OPENSEG_LABELS") else []
+    cands += [os.path.join(p or ".", "odise", "data", "datasets", "openseg_labels", name) for p in sys.path]
+    for c in cands:
+        if os.path.exists(c):
+            return read_openseg_labels(c)
+    raise FileNotFoundError(f"{name} not found: pass train_labels explicitly, or point ODISE_OPENSEG_LABELS at the reference's "
+                            "odise/data/datasets/openseg_labels directory (or put the reference checkout on sys.path)")
+
+
+def ensemble_max(logits, group_sizes):
+    """helper.py:79-109 `ensemble_logits_with_labels(..., ensemble_method="max")` on a torch tensor [..., K_tot] -> [..., K]."""
+    import torch
+    out, start = [], 0
+    for n in group_sizes:
+        out.append(logits[..., start:start + n].max(dim=-1).values)
+        start += n
+    assert start == logits.shape[-1]
+    return torch.stack(out, dim=-1)
+
+
 def category_overlapping_mask(train_labels: Sequence[Sequence[str]], test_labels: Sequence[Sequence[str]]) -> np.ndarray:
     """PoolingCLIPHead.forward, odise.py:1479-1491: 1 where a test category shares a name with any training category."""
     train = {s for l in train_labels for s in l}
@@ -183,5 +210,5 @@ def build_vocabulary(test_labels: Sequence[Sequence[str]], tokenizer, text_encod
         clp = cat
     else:
         clp = enc2.build_text_embed(tokenizer(flat(prompt_labels(test_labels, clip_prompt))))
-    overlap = category_overlapping_mask(train_labels if train_labels is not None else test_labels, test_labels)
+    overlap = category_overlapping_mask(train_labels if train_labels is not None else default_train_labels(), test_labels)
     return cat, clp, sizes, overlap

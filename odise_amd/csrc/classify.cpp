@@ -361,6 +361,32 @@ extern "C" int odise_hip_instance_masks(odise_hip_ctx* ctx, int b, const int* id
     return launch_instance_masks(ctx, ho.pred_masks + (size_t)b * ho.Q * ho.h4 * ho.w4, idx, out, n, g);
 }
 
+extern "C" int odise_hip_maskclip_embed(odise_hip_ctx* ctx, const float* image, int B, int H, int W, const float* pred_masks, int Q, int h, int w,
+                                        float* clip_embed) {
+    ODISE_REQUIRE(ctx && image && pred_masks && clip_embed && B >= 1 && Q >= 1 && h >= 1 && w >= 1, "maskclip_embed: bad argument");
+    ModelStore* ms = store_of(ctx);
+    int S = 0, patch = 0, T = 0, cdim = 0;
+    if (clip_dims(ms, &S, &patch, &T, &cdim) != ODISE_OK) {
+        set_error("maskclip_embed: the CLIP tower is not built (odise_hip_extractor_build)");
+        return ODISE_ERR_STATE;
+    }
+    ODISE_TRY(ensure_arena(ctx, ms, ((size_t)1 << 30) + (size_t)B * (T + Q) * 1024 * 2 * 64));
+    Exec ex{ctx, ms};
+    ArenaScope scope(ms->arena);
+    const int64_t MQ = (int64_t)B * Q, ldm = round_up(T, 8);
+    f16* logits16 = (f16*)ex.alloc_bytes((size_t)MQ * h * w * 2);
+    f16* ce = (f16*)ex.alloc_bytes((size_t)MQ * cdim * 2);
+    uint8_t* tmask = (uint8_t*)ex.alloc_bytes((size_t)B * (T + Q) * ldm);
+    if (!logits16 || !ce || !tmask) return ODISE_ERR_NOMEM;
+    ODISE_TRY(odise_hip_cast_f32_to_f16(ctx, pred_masks, logits16, (size_t)MQ * h * w));
+    Act img;
+    ODISE_TRY(ex.alloc(img, B, S, S, 8));
+    ODISE_TRY(launch_resize_bilinear_norm(ctx, image, img.p, B, H, W, S));
+    ODISE_TRY(launch_maskclip_token_mask(ctx, logits16, tmask, B, Q, h, w, S, patch, T, ldm));
+    ODISE_TRY(clip_tower(ex, img, Q, tmask, ldm, ce));
+    return odise_hip_cast_f16_to_f32(ctx, ce, clip_embed, (size_t)MQ * cdim);
+}
+
 // ---- the three heads for a batch, decisions on the device -------------------------------------------------------------------------------
 extern "C" int odise_hip_postprocess_batch(odise_hip_ctx* ctx, const odise_post_desc* d) {
     ODISE_REQUIRE(ctx && d, "postprocess_batch: null argument");

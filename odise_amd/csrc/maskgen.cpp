@@ -393,20 +393,24 @@ static int mlp3(Exec& ex, const LinW* w, const f16* x, int64_t M, f16* t1, f16* 
     return ODISE_OK;
 }
 
-static int head_forward(odise_hip_ctx* ctx, const Act feats[4]) {
-    ModelStore* ms = store_of(ctx);
-    MaskGenModel* g = ms->maskgen;
-    Exec ex{ctx, ms};
-    const int C = g->C, B = feats[0].n, Q = g->Q;
-    const int hs[3] = {feats[3].h, feats[2].h, feats[1].h}, ws[3] = {feats[3].w, feats[2].w, feats[1].w};  // s5, s4, s3
+// Outputs of the pixel decoder handed to the predictor (all in the arena)
+struct PixDec {
+    Act ms_feat[3];   // multi_scale_features low -> high resolution (s5, s4, s3 grids), NHWC
+    Act mf;           // mask_features, pixel-major [B, HW4, C]  (W operand of the mask-logit GEMM)
+    f16* mfT = nullptr;  // mask_features, channel-major [B, C, HW4] (W operand of the pooling GEMM)
+    int h4 = 0, w4 = 0;
+};
+
+// sine positional tables of the three transformer levels (shared by the pixel decoder's encoder and the predictor)
+static int ensure_pe_tables(odise_hip_ctx* ctx, ModelStore* ms, MaskGenModel* g, const int hs[3], const int ws[3]) {
+    const int C = g->C;
     int starts[3], Lq = 0;
     for (int l = 0; l < 3; ++l) { starts[l] = Lq; Lq += hs[l] * ws[l]; }
-    // ---- tables: sine PE per level, encoder positional table -------------------------------------------------------------
     const int key = (hs[0] << 20) ^ (ws[0] << 10) ^ hs[2] ^ (ws[2] << 5);
     if (g->enc_pos_key != key || !g->enc_pos_all) {
-        std::vector<float> all((size_t)Lq * C), lvl, emb((size_t)3 * C);
+        std::vector<float> all((size_t)Lq * C), lvl, emb((size_t)3 * C, 0.f);
         ODISE_CHECK_HIP(hipStreamSynchronize(ctx->stream));
-        ODISE_CHECK_HIP(hipMemcpy(emb.data(), g->enc_level_embed, emb.size() * 4, hipMemcpyDeviceToHost));
+        if (g->enc_level_embed) ODISE_CHECK_HIP(hipMemcpy(emb.data(), g->enc_level_embed, emb.size() * 4, hipMemcpyDeviceToHost));
         for (int l = 0; l < 3; ++l) {
             sine_pe(hs[l], ws[l], C / 2, lvl);
             ODISE_TRY(upload_new(ctx, ms, lvl.data(), lvl.size() * 4, (void**)&g->pe[l]));
@@ -417,6 +421,19 @@ static int head_forward(odise_hip_ctx* ctx, const Act feats[4]) {
         ODISE_TRY(upload_new(ctx, ms, all.data(), all.size() * 4, (void**)&g->enc_pos_all));
         g->enc_pos_key = key;
     }
+    return ODISE_OK;
+}
+
+// MSDeformAttnPixelDecoder.forward_features (msdeformattn.py:314-358)
+static int pixel_decoder_forward(odise_hip_ctx* ctx, const Act feats[4], PixDec& pd) {
+    ModelStore* ms = store_of(ctx);
+    MaskGenModel* g = ms->maskgen;
+    Exec ex{ctx, ms};
+    const int C = g->C, B = feats[0].n, Q = g->Q;
+    const int hs[3] = {feats[3].h, feats[2].h, feats[1].h}, ws[3] = {feats[3].w, feats[2].w, feats[1].w};  // s5, s4, s3
+    int starts[3], Lq = 0;
+    for (int l = 0; l < 3; ++l) { starts[l] = Lq; Lq += hs[l] * ws[l]; }
+    ODISE_TRY(ensure_pe_tables(ctx, ms, g, hs, ws));
     const int64_t MT = (int64_t)B * Lq;
     // ---- pixel decoder: input_proj (1x1 + GN) into one [B, Lq, C] token matrix ----------------------------------------------
     f16* src = (f16*)ex.alloc_bytes((size_t)MT * C * 2);
@@ -458,7 +475,7 @@ static int head_forward(odise_hip_ctx* ctx, const Act feats[4]) {
         ODISE_TRY(ex.layer_norm(x1, src, MT, L.norm2, 1e-5f));
     }
     // multi-scale features (contiguous per level) = split of the encoder output
-    Act ms_feat[3];
+    Act (&ms_feat)[3] = pd.ms_feat;
     for (int l = 0; l < 3; ++l) {
         ODISE_TRY(ex.alloc(ms_feat[l], B, hs[l], ws[l], C));
         const size_t rowb = (size_t)hs[l] * ws[l] * C * 2;
@@ -467,7 +484,8 @@ static int head_forward(odise_hip_ctx* ctx, const Act feats[4]) {
     // FPN level on s2 + mask features (both layouts)
     const Act& s2 = feats[0];
     const int64_t HW4 = (int64_t)s2.h * s2.w;
-    Act lat, latn, fsum, o3, o3n, mf;
+    Act lat, latn, fsum, o3, o3n;
+    Act& mf = pd.mf;
     ODISE_TRY(ex.conv(s2, g->adapter, lat, 1, 0));
     ODISE_TRY(ex.group_norm(lat, g->adapter_gn, latn, 1e-5f, ODISE_ACT_NONE));
     ODISE_TRY(ex.alloc(fsum, B, s2.h, s2.w, C));
@@ -481,6 +499,24 @@ static int head_forward(odise_hip_ctx* ctx, const Act feats[4]) {
         LinW v; v.w = g->mask_feat_wT; v.in = C; v.out = g->mask_feat.cout; v.b = nullptr;
         ODISE_TRY(gemm_vt(ex, v, g->mask_feat.b, o3n.p, B, HW4, HW4, mfT));
     }
+    pd.mfT = mfT; pd.h4 = s2.h; pd.w4 = s2.w;
+    (void)Q;
+    return ODISE_OK;
+}
+
+// ODISEMultiScaleMaskedTransformerDecoder.forward (odise.py:642-727) + PooledMaskEmbed of the final prediction (odise.py:984-1015)
+static int predictor_forward(odise_hip_ctx* ctx, const PixDec& pd) {
+    ModelStore* ms = store_of(ctx);
+    MaskGenModel* g = ms->maskgen;
+    Exec ex{ctx, ms};
+    const int C = g->C, B = pd.ms_feat[0].n, Q = g->Q;
+    const int hs[3] = {pd.ms_feat[0].h, pd.ms_feat[1].h, pd.ms_feat[2].h}, ws[3] = {pd.ms_feat[0].w, pd.ms_feat[1].w, pd.ms_feat[2].w};
+    ODISE_TRY(ensure_pe_tables(ctx, ms, g, hs, ws));
+    const Act (&ms_feat)[3] = pd.ms_feat;
+    const Act& mf = pd.mf;
+    f16* mfT = pd.mfT;
+    struct { int h, w; } s2{pd.h4, pd.w4};
+    const int64_t HW4 = (int64_t)s2.h * s2.w;
     // ---- masked transformer decoder ----------------------------------------------------------------------------------------
     const int64_t MQ = (int64_t)B * Q;
     f16* valin[3]; f16* keyin[3];
@@ -613,6 +649,12 @@ static int head_forward(odise_hip_ctx* ctx, const Act feats[4]) {
     return ODISE_OK;
 }
 
+static int head_forward(odise_hip_ctx* ctx, const Act feats[4]) {
+    PixDec pd;
+    ODISE_TRY(pixel_decoder_forward(ctx, feats, pd));
+    return predictor_forward(ctx, pd);
+}
+
 int head_outputs(ModelStore* ms, HeadOutputs* out) {
     MaskGenModel* g = ms->maskgen;
     if (!g || !g->head_built || !g->pred_masks) {
@@ -673,6 +715,76 @@ extern "C" int odise_hip_head_forward(odise_hip_ctx* ctx, const float* const* fe
         for (int i = 0; i < 4; ++i) feats[i] = g->feats[i];
     }
     ODISE_TRY(head_forward(ctx, feats));
+    const int64_t MQ = (int64_t)g->out_B * g->Q;
+    if (pred_masks) ODISE_TRY(odise_hip_cast_f16_to_f32(ctx, g->pred_masks, pred_masks, (size_t)MQ * g->out_h * g->out_w));
+    if (mask_embed) ODISE_TRY(odise_hip_cast_f16_to_f32(ctx, g->mask_embed, mask_embed, (size_t)MQ * g->C));
+    if (mask_pooled) ODISE_TRY(odise_hip_cast_f16_to_f32(ctx, g->mask_pooled, mask_pooled, (size_t)MQ * g->C));
+    if (logit_scale) *logit_scale = g->logit_scale;
+    return ODISE_OK;
+}
+
+// MSDeformAttnPixelDecoder.forward_features stand-alone (msdeformattn.py:314-358): feats4 = s2..s5 fp32 NCHW device pointers.
+// Outputs (device fp32 NCHW, any may be NULL): mask_features [B,C,H4,W4]; multi_scale[0..2] = [B,C,H4/8,W4/8], [B,C,H4/4,W4/4],
+// [B,C,H4/2,W4/2] (low -> high resolution; the reference's `transformer_encoder_features` is multi_scale[0]).
+extern "C" int odise_hip_pixel_decoder_forward(odise_hip_ctx* ctx, const float* const* feats4, int B, int Cin, int H4, int W4, float* mask_features,
+                                               float* const* multi_scale3) {
+    ODISE_REQUIRE(ctx && feats4, "pixel_decoder_forward: null argument");
+    ModelStore* ms = store_of(ctx);
+    MaskGenModel* g = ms->maskgen;
+    if (!g || !g->head_built) {
+        set_error("pixel_decoder_forward: call odise_hip_head_build first");
+        return ODISE_ERR_STATE;
+    }
+    ODISE_REQUIRE(B >= 1 && Cin % 8 == 0 && H4 % 8 == 0 && W4 % 8 == 0, "pixel_decoder_forward: bad feature shapes");
+    Exec ex{ctx, ms};
+    ODISE_TRY(ensure_arena(ctx, ms, (size_t)B * H4 * W4 * 256 * 2 * 40 + ((size_t)512 << 20)));
+    ms->arena.reset();
+    ms->macs = 0.0;
+    Act feats[4];
+    for (int i = 0; i < 4; ++i) {
+        const int h = H4 >> i, w = W4 >> i;
+        ODISE_TRY(ex.alloc(feats[i], B, h, w, Cin));
+        ODISE_TRY(odise_hip_nchw_f32_to_nhwc_f16(ctx, feats4[i], feats[i].p, B, Cin, h, w, Cin));
+    }
+    PixDec pd;
+    ODISE_TRY(pixel_decoder_forward(ctx, feats, pd));
+    g->pred_masks = nullptr;   // the head outputs of an earlier call do not survive the arena reset
+    if (mask_features) ODISE_TRY(odise_hip_cast_f16_to_f32(ctx, pd.mfT, mask_features, (size_t)B * g->C * H4 * W4));   // channel-major = NCHW
+    for (int l = 0; l < 3 && multi_scale3; ++l)
+        if (multi_scale3[l]) ODISE_TRY(odise_hip_nhwc_f16_to_nchw_f32(ctx, pd.ms_feat[l].p, multi_scale3[l], B, g->C, pd.ms_feat[l].h, pd.ms_feat[l].w));
+    return ODISE_OK;
+}
+
+// ODISEMultiScaleMaskedTransformerDecoder.forward stand-alone (odise.py:642-727): multi_scale3 = three fp32 NCHW maps [B,C,h_l,w_l]
+// (low -> high resolution), mask_features [B,C,H4,W4] fp32 NCHW; outputs as odise_hip_head_forward.
+extern "C" int odise_hip_predictor_forward(odise_hip_ctx* ctx, const float* const* multi_scale3, const int* hw3, const float* mask_features, int B, int H4,
+                                           int W4, float* pred_masks, float* mask_embed, float* mask_pooled, float* logit_scale) {
+    ODISE_REQUIRE(ctx && multi_scale3 && hw3 && mask_features, "predictor_forward: null argument");
+    ModelStore* ms = store_of(ctx);
+    MaskGenModel* g = ms->maskgen;
+    if (!g || !g->head_built) {
+        set_error("predictor_forward: call odise_hip_head_build first");
+        return ODISE_ERR_STATE;
+    }
+    ODISE_REQUIRE(B >= 1 && H4 >= 1 && W4 >= 1 && ((int64_t)H4 * W4) % 8 == 0, "predictor_forward: bad mask feature shape");
+    Exec ex{ctx, ms};
+    ODISE_TRY(ensure_arena(ctx, ms, (size_t)B * H4 * W4 * 256 * 2 * 40 + ((size_t)512 << 20)));
+    ms->arena.reset();
+    ms->macs = 0.0;
+    const int C = g->C;
+    PixDec pd;
+    for (int l = 0; l < 3; ++l) {
+        ODISE_REQUIRE(hw3[2 * l] >= 1 && hw3[2 * l + 1] >= 1, "predictor_forward: bad level %d", l);
+        ODISE_TRY(ex.alloc(pd.ms_feat[l], B, hw3[2 * l], hw3[2 * l + 1], C));
+        ODISE_TRY(odise_hip_nchw_f32_to_nhwc_f16(ctx, multi_scale3[l], pd.ms_feat[l].p, B, C, hw3[2 * l], hw3[2 * l + 1], C));
+    }
+    ODISE_TRY(ex.alloc(pd.mf, B, H4, W4, C));
+    ODISE_TRY(odise_hip_nchw_f32_to_nhwc_f16(ctx, mask_features, pd.mf.p, B, C, H4, W4, C));
+    pd.mfT = (f16*)ex.alloc_bytes((size_t)B * C * H4 * W4 * 2);
+    if (!pd.mfT) return ODISE_ERR_NOMEM;
+    ODISE_TRY(odise_hip_cast_f32_to_f16(ctx, mask_features, pd.mfT, (size_t)B * C * H4 * W4));
+    pd.h4 = H4; pd.w4 = W4;
+    ODISE_TRY(predictor_forward(ctx, pd));
     const int64_t MQ = (int64_t)g->out_B * g->Q;
     if (pred_masks) ODISE_TRY(odise_hip_cast_f16_to_f32(ctx, g->pred_masks, pred_masks, (size_t)MQ * g->out_h * g->out_w));
     if (mask_embed) ODISE_TRY(odise_hip_cast_f16_to_f32(ctx, g->mask_embed, mask_embed, (size_t)MQ * g->C));

@@ -1,0 +1,5 @@
+"""Overlay shell of the reference's `odise` package (odise_amd.dropin): this directory first, the reference's own directory behind it."""
+from odise_amd.dropin import chain_reference
+
+__path__ = chain_reference(__name__, __path__)
+__version__ = "0.1"

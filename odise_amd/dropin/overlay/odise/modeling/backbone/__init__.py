@@ -1,0 +1,7 @@
+"""Overlay shell of the reference's `odise.modeling.backbone` package (odise_amd.dropin): this directory first, the reference's own directory behind it."""
+from odise_amd.dropin import chain_reference
+
+__path__ = chain_reference(__name__, __path__)
+from .feature_extractor import FeatureExtractorBackbone  # noqa: E402,F401
+
+__all__ = ["FeatureExtractorBackbone"]
