@@ -29,6 +29,9 @@ int odise_hip_gemm_debug(int flags);
 /* 1: the post-processing kernels never take their exact-x4-upsampling specialisations (tests assert both forms are bit-identical) */
 int odise_hip_post_generic(int on);
 
+/* 1: the feature extractor enqueues everything on one stream; 2 (default): its CLIP -> UNet branch runs on a second stream beside the VAE */
+int odise_hip_set_lanes(odise_hip_ctx* ctx, int lanes);
+
 /* probes (probe.hip): MFMA output layout, sustained MFMA rate on register-resident operands, LDS port rates */
 int odise_hip_mfma_probe(odise_hip_ctx* ctx, float* host_out);
 int odise_hip_mfma_rate(odise_hip_ctx* ctx, int variant, int iters, int blocks, int reps, float* ms_out, double* flops_out, double* mhz_out);

@@ -58,6 +58,11 @@ extern "C" int odise_hip_destroy(odise_hip_ctx* ctx) {
     odise::jpeg_release(ctx);
     odise::comm_release(ctx);
     if (ctx->ws) (void)hipFree(ctx->ws);
+    if (ctx->ws2) (void)hipFree(ctx->ws2);
+    if (ctx->ev_fork) (void)hipEventDestroy(ctx->ev_fork);
+    if (ctx->ev_mid) (void)hipEventDestroy(ctx->ev_mid);
+    if (ctx->ev_join) (void)hipEventDestroy(ctx->ev_join);
+    if (ctx->stream2) (void)hipStreamDestroy(ctx->stream2);
     if (ctx->zeros) (void)hipFree(ctx->zeros);
     if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
     if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
@@ -146,6 +151,12 @@ extern "C" int odise_hip_device_info(odise_hip_ctx* ctx, char* name_buf, int buf
     return ODISE_OK;
 }
 // ABI self-description used by tests/test_lib_abi.py to validate the ctypes mirrors
+extern "C" int odise_hip_set_lanes(odise_hip_ctx* ctx, int lanes) {
+    ODISE_REQUIRE(ctx && (lanes == 1 || lanes == 2), "set_lanes: 1 or 2");
+    ODISE_CHECK_HIP(hipStreamSynchronize(ctx->stream));
+    ctx->lanes = lanes;
+    return ODISE_OK;
+}
 extern "C" int odise_hip_sizeof_gemm_desc(void) { return (int)sizeof(odise_gemm_desc); }
 extern "C" int odise_hip_sizeof_conv_desc(void) { return (int)sizeof(odise_conv_desc); }
 extern "C" int odise_hip_sizeof_attn_desc(void) { return (int)sizeof(odise_attn_desc); }

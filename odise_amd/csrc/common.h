@@ -69,6 +69,12 @@ struct odise_hip_ctx {
     void* jpeg_dev = nullptr;
     size_t jpeg_dev_bytes = 0;
     hipEvent_t jpeg_ev = nullptr;
+    // second lane (engine.h Lane2): the feature extractor runs its two independent branches - CLIP conditioning -> UNet, and VAE encoder ->
+    // VAE decoder - on two streams with separate split-K workspaces, joined by events
+    hipStream_t stream2 = nullptr;
+    void* ws2 = nullptr;
+    hipEvent_t ev_fork = nullptr, ev_mid = nullptr, ev_join = nullptr;
+    int lanes = 2;  // 1 = everything on the one stream (tools A/B: odise_hip_set_lanes)
     void* comm = nullptr;  // odise::Comm* (comm.cpp): RCCL communicator + exchange stream, created by odise_hip_comm_init
 };
 

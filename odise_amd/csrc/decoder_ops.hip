@@ -26,6 +26,50 @@ __global__ void __launch_bounds__(256) crop_extract_kernel(const float* __restri
     }
 }
 
+// Slide windows smaller than the network input (images whose short side is below 512, feature_extractor.py:197-215): the s x s window
+// is resized to S x S with bicubic interpolation - torchvision T.Resize(BICUBIC) on a tensor = F.interpolate(mode="bicubic",
+// align_corners=False, antialias off; feature_extractor.py:69-77, 146-149): cubic convolution with A = -0.75, source coordinate
+// (dst + 0.5) * s / S - 0.5, taps clamped to the WINDOW (the resize sees the cropped tensor, not the image around it).
+__device__ __forceinline__ void cubic_coeffs(float t, float (&w)[4]) {
+    const float A = -0.75f;
+    float x = t + 1.f;
+    w[0] = ((A * x - 5.f * A) * x + 8.f * A) * x - 4.f * A;
+    x = t;
+    w[1] = ((A + 2.f) * x - (A + 3.f)) * x * x + 1.f;
+    x = 1.f - t;
+    w[2] = ((A + 2.f) * x - (A + 3.f)) * x * x + 1.f;
+    x = 2.f - t;
+    w[3] = ((A * x - 5.f * A) * x + 8.f * A) * x - 4.f * A;
+}
+__global__ void __launch_bounds__(256) crop_resize_bicubic_kernel(const float* __restrict__ img, float* __restrict__ crops, int C, int H, int W, int s,
+                                                                 int S, int K, const int* __restrict__ boxes, int64_t total) {
+    const float scale = (float)s / (float)S;
+    for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * blockDim.x) {
+        const int x = (int)(idx % S);
+        int64_t t = idx / S;
+        const int y = (int)(t % S); t /= S;
+        const int c = (int)(t % C); t /= C;
+        const int k = (int)(t % K);
+        const int64_t b = t / K;
+        const float sy = ((float)y + 0.5f) * scale - 0.5f, sx = ((float)x + 0.5f) * scale - 0.5f;
+        const int iy = (int)floorf(sy), ix = (int)floorf(sx);
+        float wy[4], wx[4];
+        cubic_coeffs(sy - (float)iy, wy);
+        cubic_coeffs(sx - (float)ix, wx);
+        const float* src = img + ((b * C + c) * H + boxes[2 * k]) * (int64_t)W + boxes[2 * k + 1];
+        float acc = 0.f;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int yy = min(max(iy - 1 + j, 0), s - 1);
+            float row = 0.f;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) row += wx[i] * src[(int64_t)yy * W + min(max(ix - 1 + i, 0), s - 1)];
+            acc += wy[j] * row;
+        }
+        crops[idx] = acc;
+    }
+}
+
 // y [N,OH,OW,C] = x [N,H,W,C] nearest (src = floor(dst * in / out))
 __global__ void __launch_bounds__(256) upsample_nearest_kernel(const f16* __restrict__ x, f16* __restrict__ y, int H, int W, int OH, int OW,
                                                               int C8, int64_t total) {
@@ -272,6 +316,12 @@ static int g1(int64_t n) { return (int)std::min<int64_t>(ceil_div(n, 256), 8192)
 int launch_crop_extract(odise_hip_ctx* ctx, const float* img, float* crops, int B, int C, int H, int W, int S, int K, const int* boxes_dev) {
     const int64_t total = (int64_t)B * K * C * S * S;
     hipLaunchKernelGGL(crop_extract_kernel, dim3(g1(total)), dim3(256), 0, ctx->stream, img, crops, C, H, W, S, K, boxes_dev, total);
+    ODISE_CHECK_HIP(hipGetLastError());
+    return ODISE_OK;
+}
+int launch_crop_resize_bicubic(odise_hip_ctx* ctx, const float* img, float* crops, int B, int C, int H, int W, int s, int S, int K, const int* boxes_dev) {
+    const int64_t total = (int64_t)B * K * C * S * S;
+    hipLaunchKernelGGL(crop_resize_bicubic_kernel, dim3(g1(total)), dim3(256), 0, ctx->stream, img, crops, C, H, W, s, S, K, boxes_dev, total);
     ODISE_CHECK_HIP(hipGetLastError());
     return ODISE_OK;
 }

@@ -26,8 +26,28 @@ void models_destroy(odise_hip_ctx* ctx) {
     classify_destroy(ms);
     for (void* p : ms->dev_allocs) (void)hipFree(p);
     if (ms->arena.base) (void)hipFree(ms->arena.base);
+    if (ms->arena2.base) (void)hipFree(ms->arena2.base);
     delete ms;
     ctx->models = nullptr;
+}
+
+int ensure_lane2(odise_hip_ctx* ctx, ModelStore* ms, size_t arena_bytes) {
+    if (!ctx->stream2) {
+        ODISE_CHECK_HIP(hipStreamCreateWithFlags(&ctx->stream2, hipStreamNonBlocking));
+        ODISE_CHECK_HIP(hipMalloc(&ctx->ws2, ctx->ws_bytes));
+        ODISE_CHECK_HIP(hipEventCreateWithFlags(&ctx->ev_fork, hipEventDisableTiming));
+        ODISE_CHECK_HIP(hipEventCreateWithFlags(&ctx->ev_mid, hipEventDisableTiming));
+        ODISE_CHECK_HIP(hipEventCreateWithFlags(&ctx->ev_join, hipEventDisableTiming));
+    }
+    if (ms->arena2.cap < arena_bytes) {
+        ODISE_CHECK_HIP(hipStreamSynchronize(ctx->stream));
+        ODISE_CHECK_HIP(hipStreamSynchronize(ctx->stream2));
+        if (ms->arena2.base) ODISE_CHECK_HIP(hipFree(ms->arena2.base));
+        ms->arena2 = Arena();
+        ODISE_CHECK_HIP(hipMalloc((void**)&ms->arena2.base, arena_bytes));
+        ms->arena2.cap = arena_bytes;
+    }
+    return ODISE_OK;
 }
 
 // ---------------------------------------------------------------------------------------------------------------

@@ -4,6 +4,7 @@
 // op-level parity tests cover is exactly what the stages run.
 #pragma once
 #include <map>
+#include <utility>
 #include <string>
 #include <vector>
 
@@ -80,6 +81,7 @@ struct ModelStore {
     std::map<std::string, HostTensor> host;
     std::vector<void*> dev_allocs;
     Arena arena;
+    Arena arena2;   // activations of the second lane (Lane2)
     UNetModel* unet = nullptr;
     struct ExtractorModel* extractor = nullptr;
     struct MaskGenModel* maskgen = nullptr;
@@ -125,6 +127,28 @@ struct Exec {
 };
 
 
+// ---- second lane ---------------------------------------------------------------------------------------------------------------------
+// While a Lane2 object lives, everything enqueued through the context goes to its second stream, allocates from the second arena and
+// uses the second split-K workspace: two independent branches of a stage can then execute concurrently (small, latency-bound launches of
+// one fill the CUs the other leaves idle) without sharing any scratch memory.  Ordering between the lanes is by events (lane2_*).
+int ensure_lane2(odise_hip_ctx* ctx, ModelStore* ms, size_t arena_bytes);
+struct Lane2 {
+    odise_hip_ctx* ctx;
+    ModelStore* ms;
+    hipStream_t s0;
+    void* w0;
+    Lane2(odise_hip_ctx* c, ModelStore* m) : ctx(c), ms(m), s0(c->stream), w0(c->ws) {
+        ctx->stream = ctx->stream2;
+        ctx->ws = ctx->ws2;
+        std::swap(ms->arena, ms->arena2);
+    }
+    ~Lane2() {
+        ctx->stream = s0;
+        ctx->ws = w0;
+        std::swap(ms->arena, ms->arena2);
+    }
+};
+
 // ---- stage entry points shared between translation units --------------------------------------------------------
 int ensure_arena(odise_hip_ctx* ctx, ModelStore* ms, size_t bytes);
 int unet_build(odise_hip_ctx* ctx, const char* prefix);
@@ -160,6 +184,7 @@ int launch_cond_inputs(odise_hip_ctx* ctx, const float* proj, const float* A1, c
 
 // decoder_ops.hip
 int launch_crop_extract(odise_hip_ctx* ctx, const float* img, float* crops, int B, int C, int H, int W, int S, int K, const int* boxes_dev);
+int launch_crop_resize_bicubic(odise_hip_ctx* ctx, const float* img, float* crops, int B, int C, int H, int W, int s, int S, int K, const int* boxes_dev);
 int launch_upsample_nearest(odise_hip_ctx* ctx, const f16* x, f16* y, int N, int H, int W, int OH, int OW, int C);
 int launch_stitch(odise_hip_ctx* ctx, const f16* feat, f16* out, float* out_nchw, int B, int K, const int* boxes_dev, int ch, int cw, int OH,
                   int OW, int C);

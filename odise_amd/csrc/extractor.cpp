@@ -432,6 +432,11 @@ static int run_clip(Exec& ex, ExtractorModel* e, const float* image, int B, int 
     return ODISE_OK;
 }
 
+static bool standalone_graph_capture(odise_hip_ctx* ctx) {
+    hipStreamCaptureStatus st = hipStreamCaptureStatusNone;
+    return hipStreamIsCapturing(ctx->stream, &st) == hipSuccess && st != hipStreamCaptureStatusNone;
+}
+
 size_t extractor_arena_bytes(int B, int H, int W) {
     // the VAE levels at full resolution dominate (128-channel maps of H x W, ~4 live at a time) + UNet + CLIP
     const size_t per = (size_t)H * W * 128 * 2 * 6 + ((size_t)900 << 20);
@@ -450,25 +455,47 @@ int extractor_launch(odise_hip_ctx* ctx, ModelStore* ms, const float* image, int
         ms->macs = 0.0;
     }
     const int lh = H / 8, lw = W / 8;
+    // Two independent branches feed the taps: [CLIP image embedding -> conditioning -> UNet] and [VAE encoder -> latent -> VAE decoder];
+    // the UNet only needs the latent of the second.  With two lanes the first branch is enqueued on the context's second stream (own arena,
+    // own split-K workspace): its many short launches (CLIP GEMMs on 148 of 256 CUs, ~540 UNet kernels) execute in the gaps of the VAE's
+    // chip-filling convolutions.  The reference runs the same modules one after the other (ldm.py:697-718, 543-621).
+    const bool two = ctx->lanes == 2 && !standalone_graph_capture(ctx);
+    if (two) {
+        // CLIP activations (16 crops: ~1.5 GB) + UNet (~6 GB) - the extractor's own estimate covers both branches
+        ODISE_TRY(ensure_lane2(ctx, ms, extractor_arena_bytes(B, H, W) / 2 + ((size_t)1 << 30)));
+        ms->arena2.reset();
+        ODISE_CHECK_HIP(hipEventRecord(ctx->ev_fork, ctx->stream));           // the crops (and everything before) are ready
+    }
     // ---- implicit captioner conditioning --------------------------------------------------------------------------
-    f16* prefix16 = (f16*)ex.alloc_bytes((size_t)B * e->clip_out * 2);
-    float* proj = (float*)ex.alloc_bytes((size_t)B * e->ctx_dim * 4);
-    float* cond_inputs = (float*)ex.alloc_bytes((size_t)B * 77 * e->ctx_dim * 4);
-    float* cond_emb = (float*)ex.alloc_bytes((size_t)B * e->ted * 4);
-    if (!prefix16 || !proj || !cond_inputs || !cond_emb) return ODISE_ERR_NOMEM;
-    ODISE_TRY(run_clip(ex, e, image, B, H, W, prefix16));
-    odise_gemm_desc d;
-    memset(&d, 0, sizeof(d));
-    d.M = B; d.N = e->ctx_dim; d.K = e->cap_proj.in;
-    d.A = prefix16; d.lda = e->cap_proj.in; d.W = e->cap_proj.w; d.ldw = e->cap_proj.in;
-    d.C = proj; d.ldc = e->ctx_dim; d.c_dtype = ODISE_F32; d.bias_n = e->cap_proj.b; d.alpha = 1.f; d.batch = 1;
-    ODISE_TRY(ex.gemm(d));
-    ODISE_TRY(launch_cond_inputs(ctx, proj, e->cap_A1, e->cap_A2, cond_inputs, B, 77, e->ctx_dim));
-    memset(&d, 0, sizeof(d));
-    d.M = B; d.N = e->ted; d.K = e->cap_time.in;
-    d.A = prefix16; d.lda = e->cap_time.in; d.W = e->cap_time.w; d.ldw = e->cap_time.in;
-    d.C = cond_emb; d.ldc = e->ted; d.c_dtype = ODISE_F32; d.bias_n = e->cap_time.b; d.alpha = 1.f; d.batch = 1;
-    ODISE_TRY(ex.gemm(d));
+    float* cond_inputs = nullptr;
+    float* cond_emb = nullptr;
+    auto conditioning = [&]() -> int {
+        f16* prefix16 = (f16*)ex.alloc_bytes((size_t)B * e->clip_out * 2);
+        float* proj = (float*)ex.alloc_bytes((size_t)B * e->ctx_dim * 4);
+        cond_inputs = (float*)ex.alloc_bytes((size_t)B * 77 * e->ctx_dim * 4);
+        cond_emb = (float*)ex.alloc_bytes((size_t)B * e->ted * 4);
+        if (!prefix16 || !proj || !cond_inputs || !cond_emb) return ODISE_ERR_NOMEM;
+        ODISE_TRY(run_clip(ex, e, image, B, H, W, prefix16));
+        odise_gemm_desc d;
+        memset(&d, 0, sizeof(d));
+        d.M = B; d.N = e->ctx_dim; d.K = e->cap_proj.in;
+        d.A = prefix16; d.lda = e->cap_proj.in; d.W = e->cap_proj.w; d.ldw = e->cap_proj.in;
+        d.C = proj; d.ldc = e->ctx_dim; d.c_dtype = ODISE_F32; d.bias_n = e->cap_proj.b; d.alpha = 1.f; d.batch = 1;
+        ODISE_TRY(ex.gemm(d));
+        ODISE_TRY(launch_cond_inputs(ctx, proj, e->cap_A1, e->cap_A2, cond_inputs, B, 77, e->ctx_dim));
+        memset(&d, 0, sizeof(d));
+        d.M = B; d.N = e->ted; d.K = e->cap_time.in;
+        d.A = prefix16; d.lda = e->cap_time.in; d.W = e->cap_time.w; d.ldw = e->cap_time.in;
+        d.C = cond_emb; d.ldc = e->ted; d.c_dtype = ODISE_F32; d.bias_n = e->cap_time.b; d.alpha = 1.f; d.batch = 1;
+        return ex.gemm(d);
+    };
+    if (two) {
+        Lane2 lane(ctx, ms);
+        ODISE_CHECK_HIP(hipStreamWaitEvent(ctx->stream, ctx->ev_fork, 0));
+        ODISE_TRY(conditioning());
+    } else {
+        ODISE_TRY(conditioning());
+    }
 
     // ---- VAE encoder ------------------------------------------------------------------------------------------------
     Act x;
@@ -515,7 +542,15 @@ int extractor_launch(odise_hip_ctx* ctx, ModelStore* ms, const float* image, int
     ODISE_TRY(ex.alloc(zdec, B, lh, lw, 8));
     ODISE_TRY(launch_latent_heads(ctx, cur.p, e->noise, xt.p, zdec.p, nullptr, B, lh * lw, e->lat));
     // ---- UNet (t = 0) -------------------------------------------------------------------------------------------------
-    ODISE_TRY(unet_launch(ctx, ms, ms->unet, nullptr, xt.p, cond_inputs, cond_emb, B, lh, lw, false));
+    if (two) {
+        ODISE_CHECK_HIP(hipEventRecord(ctx->ev_mid, ctx->stream));            // the latent is ready
+        Lane2 lane(ctx, ms);
+        ODISE_CHECK_HIP(hipStreamWaitEvent(ctx->stream, ctx->ev_mid, 0));
+        ODISE_TRY(unet_launch(ctx, ms, ms->unet, nullptr, xt.p, cond_inputs, cond_emb, B, lh, lw, false));
+        ODISE_CHECK_HIP(hipEventRecord(ctx->ev_join, ctx->stream));
+    } else {
+        ODISE_TRY(unet_launch(ctx, ms, ms->unet, nullptr, xt.p, cond_inputs, cond_emb, B, lh, lw, false));
+    }
     const Act* ut = unet_taps(ms);
     for (int i = 0; i < 4; ++i) e->taps[2 + i] = ut[i];
     // ---- VAE decoder up to the last tap ----------------------------------------------------------------------------------
@@ -535,6 +570,7 @@ int extractor_launch(odise_hip_ctx* ctx, ModelStore* ms, const float* image, int
         ODISE_TRY(run_vae_res(ex, e->dec_l2[1], m0, m1));
         e->taps[7] = m1;  // input of up block 5
     }
+    if (two) ODISE_CHECK_HIP(hipStreamWaitEvent(ctx->stream, ctx->ev_join, 0));   // join: the UNet taps are ready for whoever consumes them on the main stream
     e->last_macs = ms->macs;
     return ODISE_OK;
 }

@@ -295,17 +295,18 @@ static int backbone_forward(odise_hip_ctx* ctx, const float* image, int B, int H
         set_error("backbone_forward: call odise_hip_extractor_build and odise_hip_backbone_build first");
         return ODISE_ERR_STATE;
     }
-    ODISE_REQUIRE(image && B >= 1 && H % 64 == 0 && W % 64 == 0 && H >= 512 && W >= 512,
-                  "backbone_forward: image %dx%d must be >= 512 and a multiple of 64 (the caller pads, odise.py:238-242)", H, W);
-    const int S = 512;
-    // slide-window boxes (feature_extractor.py:197-222)
+    ODISE_REQUIRE(image && B >= 1 && H % 64 == 0 && W % 64 == 0 && H >= 64 && W >= 64,
+                  "backbone_forward: image %dx%d must be a multiple of 64 (the caller pads, odise.py:238-242)", H, W);
+    const int S = 512;                                      // backbone_in_size: what the extractor sees
+    const int cs = std::min(S, std::min(H, W));             // slide window = min(backbone_in_size, short side)  (feature_extractor.py:199-203)
+    // slide-window boxes (feature_extractor.py:197-222): stride = window, the last row / column shifted inwards
     std::vector<int> boxes;
-    const int hg = (std::max(H - S + S - 1, 0)) / S + 1, wg = (std::max(W - S + S - 1, 0)) / S + 1;
+    const int hg = (std::max(H - cs + cs - 1, 0)) / cs + 1, wg = (std::max(W - cs + cs - 1, 0)) / cs + 1;
     for (int hi = 0; hi < hg; ++hi)
         for (int wi = 0; wi < wg; ++wi) {
-            const int y2 = std::min(hi * S + S, H), x2 = std::min(wi * S + S, W);
-            boxes.push_back(std::max(y2 - S, 0));
-            boxes.push_back(std::max(x2 - S, 0));
+            const int y2 = std::min(hi * cs + cs, H), x2 = std::min(wi * cs + cs, W);
+            boxes.push_back(std::max(y2 - cs, 0));
+            boxes.push_back(std::max(x2 - cs, 0));
         }
     const int K = (int)boxes.size() / 2;
     if (g->boxes_key_h != H || g->boxes_key_w != W) {
@@ -330,11 +331,12 @@ static int backbone_forward(odise_hip_ctx* ctx, const float* image, int B, int H
     const size_t mk = ms->arena.mark();
     float* crops = (float*)ex.alloc_bytes((size_t)B * K * 3 * S * S * 4);
     if (!crops) return ODISE_ERR_NOMEM;
-    ODISE_TRY(launch_crop_extract(ctx, image, crops, B, 3, H, W, S, K, g->boxes_dev));
+    if (cs == S) ODISE_TRY(launch_crop_extract(ctx, image, crops, B, 3, H, W, S, K, g->boxes_dev));
+    else ODISE_TRY(launch_crop_resize_bicubic(ctx, image, crops, B, 3, H, W, cs, S, K, g->boxes_dev));   // windows below 512: bicubic to 512 x 512
     ODISE_TRY(extractor_launch(ctx, ms, crops, B * K, S, S, false));
     const Act* taps = extractor_taps(ms);
     for (int gi = 0; gi < 4; ++gi) {
-        const int stride = kGroupStride[gi], fs = S / stride;
+        const int stride = kGroupStride[gi], fs = cs / stride;   // features are restored to window / stride (feature_extractor.py:165-168)
         Act acc;
         bool have = false;
         for (int j = 0; j < 3 && kGroups[gi][j] >= 0; ++j) {

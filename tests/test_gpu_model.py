@@ -73,7 +73,7 @@ def _oracle_forward_batch(bb, head, heads, imgs_u8, overlap_threshold):
     return mask_cls, outputs, om.postprocess(mask_cls, outputs["pred_masks"], (Hp, Wp), sizes, sizes, len(GROUPS), THINGS, overlap_threshold)
 
 
-@pytest.mark.parametrize("h,w,oh,ow", [(512, 512, 512, 512), (512, 704, 256, 352)])
+@pytest.mark.parametrize("h,w,oh,ow", [(512, 512, 512, 512), (512, 704, 256, 352), (300, 400, 300, 400)])   # the last: short side below 512
 def test_full_forward_matches_oracle(models, h, w, oh, ow):
     bb, head, heads, hip = models
     img = _image_u8(h, w, seed=h + w)
