@@ -68,12 +68,14 @@ def normalize_only(image):   # clip_preprocess on an image that already has the 
     return (image - mean) / std
 
 
-def case(name, seed, sizes, out_sizes, labels, things, train_labels, in_channels=32, topk=30, overlap_threshold=0.8, caption=False):
+def case(name, seed, sizes, out_sizes, labels, things, train_labels, in_channels=32, topk=30, overlap_threshold=0.8, caption=False, spread=False,
+         branch_gain=1.0, null_bias=0.05):
     """caption=True: `CaptionODISE.forward` (odise.py:545-619) with `WordEmbed.forward` eval (1206-1216) and the learned 2-way
     `class_embed` of the decoder (mask_generator_with_caption.py) instead of `CategoryODISE` / `CategoryEmbed` / `PseudoClassEmbed`."""
     K = len(labels)
     group_sizes = [len(l) for l in labels]
-    head_o = init_synthetic_(SemSegHead(small=True, num_classes=1 if caption else K, in_channels=in_channels, learned_class_embed=caption), seed=seed)
+    head_o = init_synthetic_(SemSegHead(small=True, num_classes=1 if caption else K, in_channels=in_channels, learned_class_embed=caption), seed=seed,
+                             branch_gain=branch_gain)
     clip_o = clip_vit.init_synthetic_(clip_vit.CLIPVisual(image_size=56, patch_size=14, width=128, layers=2, heads=2, output_dim=48), seed=seed + 5).eval()
     overlap = [int(not {s for l in train_labels for s in l}.isdisjoint(set(l))) for l in labels]
     heads_o = om.OpenVocabHeads(clip_o, group_sizes, projection_dim=64, seed=seed + 7, overlap=overlap, alpha=0.35, beta=0.65)
@@ -84,6 +86,21 @@ def case(name, seed, sizes, out_sizes, labels, things, train_labels, in_channels
     g = torch.Generator().manual_seed(seed + 1)
     feats = {f"s{i}": torch.randn(B, in_channels, Hp >> i, Wp >> i, generator=g) for i in (2, 3, 4, 5)}
     images = [torch.randint(0, 256, (3, h, w), generator=g, dtype=torch.uint8) for h, w in sizes]
+
+    if spread:
+        # text banks that spread the labels over the queries (tests/fullsize.spread_vocabulary): several categories per image, things and
+        # stuff, several queries per stuff class (the merging branch of maskformer_model.py:327-333), null-labelled queries.  The banks are
+        # INPUTS of the stages pinned; they are stored in the fixture.
+        sys.path.insert(0, os.path.join(HERE, ".."))
+        from fullsize import spread_vocabulary
+        den = torch.zeros(B, 3, H, W)
+        for i, im in enumerate(images):
+            den[i, :, :im.shape[-2], :im.shape[-1]] = im.float() / 255.0
+        with torch.no_grad():
+            out_o = head_o(feats)
+            ce_o = om.mask_clip_embed(clip_o, den, out_o["pred_masks"])
+            head_o.predictor.post_mask_embed.logit_scale.fill_(float(np.log(100.0)))
+        spread_vocabulary(heads_o, out_o["mask_embed"][0], ce_o[0], seed=seed + 11, null_queries=3, null_bias=null_bias)
 
     ref_head = reference_head(1 if caption else K, in_channels, 64, 64, 2, 128, 64, 20, 128, 3, learned_class_embed=caption)
     ref_head.load_state_dict(head_o.state_dict(), strict=True)
@@ -132,7 +149,10 @@ def case(name, seed, sizes, out_sizes, labels, things, train_labels, in_channels
     arrays = {f"feat_{k}": v.numpy() for k, v in feats.items()}
     arrays.update(seed=np.int64(seed), in_channels=np.int64(in_channels), group_sizes=np.array(group_sizes), things=np.array(sorted(things)),
                   overlap=np.array(overlap), topk=np.int64(topk), overlap_threshold=np.float64(overlap_threshold), caption=np.int64(caption),
-                  sizes=np.array(sizes), out_sizes=np.array(out_sizes))
+                  sizes=np.array(sizes), out_sizes=np.array(out_sizes), branch_gain=np.float64(branch_gain))
+    if spread:
+        arrays.update(text_embed=heads_o.text_embed.numpy(), clip_text_embed=heads_o.clip_text_embed.numpy(), null_embed=heads_o.null_embed.detach().numpy(),
+                      logit_scale_param=np.float64(np.log(100.0)))
     for b, (im, r) in enumerate(zip(images, results)):
         pan, info = r["panoptic_seg"]
         inst = r["instances"]
@@ -154,4 +174,8 @@ if __name__ == "__main__":
     case("c", seed=55, sizes=[(192, 128)], out_sizes=[(192, 128)], labels=LABELS, things={0, 3, 6}, train_labels=TRAIN, overlap_threshold=0.0, topk=40)
     case("e_caption", seed=55, sizes=[(128, 192)], out_sizes=[(96, 144)], labels=LABELS, things={0, 3, 6}, train_labels=TRAIN, overlap_threshold=0.0,
          topk=25, caption=True)
+    case("f_diverse", seed=91, sizes=[(192, 128), (128, 192)], out_sizes=[(192, 128), (96, 144)], labels=LABELS, things={0, 3, 6}, train_labels=TRAIN,
+         overlap_threshold=0.0, topk=40, spread=True, branch_gain=0.3)
+    case("g_diverse", seed=92, sizes=[(192, 192)], out_sizes=[(192, 192)], labels=LABELS, things={0, 3, 6}, train_labels=TRAIN, overlap_threshold=0.5, topk=30,
+         spread=True, branch_gain=0.3, null_bias=0.08)
     case("d", seed=56, sizes=[(192, 128)], out_sizes=[(144, 96)], labels=LABELS, things={0, 3, 6}, train_labels=TRAIN, overlap_threshold=0.0, topk=40)

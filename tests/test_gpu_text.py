@@ -63,3 +63,17 @@ def test_uncond_inputs_from_hf_named_weights(ctx):
     err = np.abs(got - ref).max() / np.abs(ref).max()
     print("uncond_inputs err", err)
     assert got.shape == (1, 77, 128) and err < 3e-3
+
+
+def test_reference_generated_text_fixture_on_device(ctx):
+    """tests/golden/text_encode.npz was written by the REFERENCE's `ClipAdapter._encode_text` (clip.py:148-162) walking the oracle's seeded text
+    tower (tests/golden/make_golden_text.py); the device tower with the same weights must reproduce it."""
+    import os
+    z = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "text_encode.npz"))
+    m = init_synthetic_(CLIPText(vocab_size=49408, context_length=77, width=64, layers=2, heads=2, output_dim=32), seed=7).eval()
+    enc = HipTextEncoder(ctx, {k: v for k, v in m.state_dict().items()}, heads=2)
+    emb, hid = enc.build_text_embed(z["tokens"]), enc.hidden(z["tokens"])
+    e1 = np.abs(hid - z["hidden"].astype(np.float32)).max() / np.abs(z["hidden"]).max()
+    e2 = np.abs(emb - z["embed"]).max() / np.abs(z["embed"]).max()
+    print("reference text fixture on the device: hidden err", e1, "embed err", e2)
+    assert e1 < 4e-3 and e2 < 4e-3

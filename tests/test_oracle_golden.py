@@ -45,18 +45,17 @@ def test_classification_and_postprocessing_match_reference_forward(path):
     null merge, upsampling, sem_seg_postprocess, semantic / panoptic / instance inference) replayed through oracle/odise_model.py."""
     from oracle import clip_vit, odise_model as om
     z = np.load(path)
-    seed, C = int(z["seed"]), int(z["in_channels"])
-    groups, things = z["group_sizes"].tolist(), set(z["things"].tolist())
+    from golden_heads import build
+    head, clip, heads, groups, things, caption = build(z)
     K = len(groups)
-    caption = bool(int(z["caption"]))                                      # CaptionODISE.forward + WordEmbed + the learned 2-way class_embed
-    head = init_synthetic_(SemSegHead(small=True, num_classes=1 if caption else K, in_channels=C, learned_class_embed=caption), seed=seed)
-    clip = clip_vit.init_synthetic_(clip_vit.CLIPVisual(image_size=56, patch_size=14, width=128, layers=2, heads=2, output_dim=48), seed=seed + 5).eval()
-    heads = om.OpenVocabHeads(clip, groups, projection_dim=64, seed=seed + 7, overlap=z["overlap"].tolist(), alpha=0.35, beta=0.65)
     feats = {k[5:]: torch.from_numpy(z[k]) for k in z.files if k.startswith("feat_")}
     sizes, out_sizes = [tuple(s) for s in z["sizes"].tolist()], [tuple(s) for s in z["out_sizes"].tolist()]
     B = len(sizes)
-    assert len(set(sizes)) == 1
-    images01 = torch.stack([torch.from_numpy(z[f"image_{b}"]).float() / 255.0 for b in range(B)])
+    H, W = max(s[0] for s in sizes), max(s[1] for s in sizes)          # ImageList.from_tensors pads to the batch maximum (odise.py:242-244)
+    images01 = torch.zeros(B, 3, H, W)
+    for b in range(B):
+        im = torch.from_numpy(z[f"image_{b}"]).float() / 255.0
+        images01[b, :, :im.shape[-2], :im.shape[-1]] = im
     Hp, Wp = feats["s2"].shape[-2] * 4, feats["s2"].shape[-1] * 4
     with torch.no_grad():
         outputs = head(feats)
