@@ -273,7 +273,7 @@ constexpr int epi_wave_rows(int BM, int BN, int WAVES_M, int lds_bytes) {
 }
 constexpr int epi_lds_bytes(int BM, int BN, int WAVES_M, int WG) { return WG * (BM / WAVES_M) * (BN + 4) * 4; }
 
-template <int BM, int BN, int WAVES_M, int WAVES_N, int WG, bool HALO = false, bool STATS = false>
+template <int BM, int BN, int WAVES_M, int WAVES_N, int WG, bool HALO = false, bool STATS = false, bool PAIRS = true>
 __device__ __forceinline__ void gemm_epilogue(const GemmArgs& g, f32x16 (&acc)[BM / WAVES_M / 32][BN / WAVES_N / 32], char* smem, int m0, int n0,
                                               int z, int zb, bool split) {
     constexpr int NT = 64 * WAVES_M * WAVES_N;
@@ -292,9 +292,9 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& g, f32x16 (&acc)[B
     // (sum, sum of squares) over its rows in registers; the block folds the NT / CH row lanes in LDS in a fixed order afterwards
     // (STATS is only instantiated for the conv kernels that feed GroupNorms: the 16 accumulators cost registers in a 128-accumulator epilogue)
     const bool stats = STATS && (NT % CH == 0) && g.epi.gn_stats != nullptr && !split;
-    float s8[8], q8[8], bn8[8];
+    float s8[8], q8[8];
 #pragma unroll
-    for (int i = 0; i < 8; ++i) s8[i] = q8[i] = bn8[i] = 0.f;
+    for (int i = 0; i < 8; ++i) s8[i] = q8[i] = 0.f;
 #pragma unroll
     for (int gp = 0; gp < WAVES_M / WG; ++gp) {
         if (gp > 0) lds_barrier();  // staging reads of the previous pass are done (global stores may still fly)
@@ -320,30 +320,37 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& g, f32x16 (&acc)[B
         if constexpr ((NT % CH == 0) && ((ROWS * CH) % NT == 0)) {
             if (g.epi.fast && !split && n0 + BN <= g.N && !ODISE_ABLATE(g, 8 | 32)) {   // tools: ODISE_EPI_OLD=1 (bit 32) keeps the previous form for A/B runs
                 constexpr int IT = (ROWS * CH) / NT, RSTEP = NT / CH;
-                constexpr int U = IT % 2 == 0 ? 2 : 1;   // 4 spills: half the waves still hold 128 accumulators during the first pass
+                // rows in pairs where the registers allow it: kernels that also carry the GroupNorm statistics (16 accumulators) or the plain
+                // kernel's wider address state would spill to scratch (measured as +144 MB of HBM writes per launch on the dominant conv)
+                constexpr int U = (IT % 2 == 0 && PAIRS && !STATS && !HALO) ? 2 : 1;
                 const GemmEpi& e = g.epi;
                 const int c8 = tid % CH, row0 = tid / CH;
                 const int n = n0 + c8 * 8;
-                if (gp == 0 && e.bias_n) {
-                    const float4 b0 = *reinterpret_cast<const float4*>(e.bias_n + n);
-                    const float4 b1 = *reinterpret_cast<const float4*>(e.bias_n + n + 4);
-                    bn8[0] = b0.x; bn8[1] = b0.y; bn8[2] = b0.z; bn8[3] = b0.w; bn8[4] = b1.x; bn8[5] = b1.y; bn8[6] = b1.z; bn8[7] = b1.w;
-                }
-                // the per-image vector (time-embedding term) of the pass's first row: almost always the group of every row of the pass
+                // bias_n plus the per-image vector (time-embedding term) of the pass's first row - almost always the group of every row of the
+                // pass - kept across the rows where the registers allow it (HOIST); otherwise every row fetches its own (L1-resident) copy
+                constexpr bool HOIST = (U == 2);
                 float bg8[8];
                 unsigned grp0 = 0xffffffffu;
+                auto load_bias_group = [&](float (&b)[8], unsigned grp, bool with_group) {
 #pragma unroll
-                for (int i = 0; i < 8; ++i) bg8[i] = bn8[i];
-                if (e.rowgroup_add) {
-                    int mf = m0 + gp * ROWS + row0;
-                    if (HALO) mf = -1;   // patch rows are not consecutive pixels: look the group up per row below
-                    if (mf >= 0 && mf < g.M) {
-                        grp0 = (unsigned)mf / (unsigned)e.rows_per_group;
-                        const float* rg = e.rowgroup_add + (int64_t)grp0 * e.ldg + n;
+                    for (int i = 0; i < 8; ++i) b[i] = 0.f;
+                    if (e.bias_n) {
+                        const float4 b0 = *reinterpret_cast<const float4*>(e.bias_n + n);
+                        const float4 b1 = *reinterpret_cast<const float4*>(e.bias_n + n + 4);
+                        b[0] = b0.x; b[1] = b0.y; b[2] = b0.z; b[3] = b0.w; b[4] = b1.x; b[5] = b1.y; b[6] = b1.z; b[7] = b1.w;
+                    }
+                    if (with_group) {
+                        const float* rg = e.rowgroup_add + (int64_t)grp * e.ldg + n;
                         const float4 r0 = *reinterpret_cast<const float4*>(rg);
                         const float4 r1 = *reinterpret_cast<const float4*>(rg + 4);
-                        bg8[0] += r0.x; bg8[1] += r0.y; bg8[2] += r0.z; bg8[3] += r0.w; bg8[4] += r1.x; bg8[5] += r1.y; bg8[6] += r1.z; bg8[7] += r1.w;
+                        b[0] += r0.x; b[1] += r0.y; b[2] += r0.z; b[3] += r0.w; b[4] += r1.x; b[5] += r1.y; b[6] += r1.z; b[7] += r1.w;
                     }
+                };
+                if (HOIST) {
+                    const int mf = m0 + gp * ROWS + row0;
+                    const bool have = e.rowgroup_add && mf < g.M;
+                    if (have) grp0 = (unsigned)mf / (unsigned)e.rows_per_group;
+                    load_bias_group(bg8, grp0, have);
                 }
 #pragma unroll
                 for (int it0 = 0; it0 < IT; it0 += U) {
@@ -374,17 +381,15 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& g, f32x16 (&acc)[B
                         if (m >= g.M) continue;
                         float v[8] = {t0[u].x, t0[u].y, t0[u].z, t0[u].w, t1[u].x, t1[u].y, t1[u].z, t1[u].w};
                         float b[8];
+                        if (HOIST) {
 #pragma unroll
-                        for (int i = 0; i < 8; ++i) b[i] = bg8[i];
-                        if (e.rowgroup_add) {
-                            const unsigned grp = (unsigned)m / (unsigned)e.rows_per_group;
-                            if (grp != grp0) {   // a pass that straddles two images (or a halo patch): this row's own vector
-                                const float* rg = e.rowgroup_add + (int64_t)grp * e.ldg + n;
-                                const float4 r0 = *reinterpret_cast<const float4*>(rg);
-                                const float4 r1 = *reinterpret_cast<const float4*>(rg + 4);
-                                b[0] = bn8[0] + r0.x; b[1] = bn8[1] + r0.y; b[2] = bn8[2] + r0.z; b[3] = bn8[3] + r0.w;
-                                b[4] = bn8[4] + r1.x; b[5] = bn8[5] + r1.y; b[6] = bn8[6] + r1.z; b[7] = bn8[7] + r1.w;
+                            for (int i = 0; i < 8; ++i) b[i] = bg8[i];
+                            if (e.rowgroup_add) {
+                                const unsigned grp = (unsigned)m / (unsigned)e.rows_per_group;
+                                if (grp != grp0) load_bias_group(b, grp, true);   // a pass that straddles two images: this row's own vector, same order of additions
                             }
+                        } else {
+                            load_bias_group(b, e.rowgroup_add ? (unsigned)m / (unsigned)e.rows_per_group : 0u, e.rowgroup_add != nullptr);
                         }
                         float alpha = e.alpha;
                         if (e.scale_m) alpha *= e.scale_m[m];
@@ -727,7 +732,7 @@ __global__ void __launch_bounds__(64 * WAVES_M * WAVES_N) gemm_kernel(GemmArgs g
     __syncthreads();  // every wave is done with the operand tiles before the staging buffer is reused
     if (ODISE_ABLATE(g, 4)) return;  // ablation: main loop only
 
-    gemm_epilogue<BM, BN, WAVES_M, WAVES_N, epi_wave_rows(BM, BN, WAVES_M, plain_lds_bytes(BM, BN, WAVES_M))>(g, acc, smem, m0, n0, z, zb, split);
+    gemm_epilogue<BM, BN, WAVES_M, WAVES_N, epi_wave_rows(BM, BN, WAVES_M, plain_lds_bytes(BM, BN, WAVES_M)), false, false, (BM * BN < 256 * 256)>(g, acc, smem, m0, n0, z, zb, split);
 }
 
 template <int N>
