@@ -39,12 +39,18 @@ def image_u8(h, w, seed=0):
     return (x[0] * 255).round().to(torch.uint8)
 
 
+_MEMO = {}     # one oracle pass per pytest session: test_gpu_fullsize.py and test_gpu_dropin.py share it
+
+
 def build_models(num_classes):
+    if ("models", num_classes) in _MEMO:
+        return _MEMO[("models", num_classes)]
     ext = ImplicitCaptionerExtractor()
     bb = FeatureExtractorBackbone(ext, FEATURE_DIMS)
     head = init_synthetic_(SemSegHead(num_classes=num_classes), branch_gain=0.3)
     with torch.no_grad():   # the learned temperature at its clamp (odise.py:1013 clamps exp(logit_scale) at 100): class distributions as peaked as a trained model's
         head.predictor.post_mask_embed.logit_scale.fill_(math.log(100.0))
+    _MEMO[("models", num_classes)] = (ext, bb, head)
     return ext, bb, head
 
 
@@ -121,6 +127,9 @@ def _cache_path(tag):
 def reference(bb, head, ext, size, num_classes, num_strings, seed=0, use_cache=True):
     """Oracle pass over one size x size image: features, head outputs, MaskCLIP embedding; then the spread vocabulary and mask_cls.
     Returns (img_u8, heads, dict of torch tensors)."""
+    key = ("ref", id(head), size, num_classes, num_strings, seed)
+    if key in _MEMO:
+        return _MEMO[key]
     img = image_u8(size, size, seed)
     cat, clp, sizes, overlap = synthetic_vocabulary(num_classes, num_strings, 768)
     heads = om.OpenVocabHeads(ext.clip, [int(s) for s in sizes], projection_dim=256, overlap=torch.from_numpy(overlap.astype(bool)))
@@ -159,6 +168,7 @@ def reference(bb, head, ext, size, num_classes, num_strings, seed=0, use_cache=T
         clip_logits = om.mask_clip_pred_logits(r["clip_embed"], heads.clip_text_embed, heads.group_sizes)
         open_logits = om.pooling_clip_head(pred_logits[..., :-1], clip_logits, heads.category_overlapping_mask, heads.alpha, heads.beta)
         r["mask_cls"] = om.merge_with_null(pred_logits, open_logits)
+    _MEMO[key] = (img, heads, r)
     return img, heads, r
 
 
