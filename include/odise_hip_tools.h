@@ -23,6 +23,11 @@ int odise_hip_sizeof_infer_desc(void);
  * (tile ids: gemm.hip kTileBM / kTileBN; -1 / 0 = automatic) */
 int odise_hip_gemm_forced(odise_hip_ctx* ctx, const odise_gemm_desc* d, int tile, int splitk);
 int odise_hip_conv2d_forced(odise_hip_ctx* ctx, const odise_conv_desc* d, int tile, int splitk);
+/* the conv -> GroupNorm pair of the ResBlocks with the conv's tile forced: the conv epilogue reduces the GroupNorm statistics (per channel and
+ * row block) into stats_scratch [N * ceil(OH*OW/64) * Cout * 2] and the GroupNorm only finalises + applies; y_norm = act(gn(conv(x))) (f16).
+ * *stats_blocks = row blocks per image (0: this kernel declined the fusion, the stand-alone GroupNorm ran) */
+int odise_hip_conv2d_gn_forced(odise_hip_ctx* ctx, const odise_conv_desc* d, int tile, int splitk, const float* gamma, const float* beta,
+                               int groups, float eps, int act, void* y_norm, float* stats_scratch, int* stats_blocks);
 /* process-wide kernel-selection switches for A/B measurements (bits: gemm.hip launch_gemm) */
 int odise_hip_gemm_debug(int flags);
 

@@ -176,7 +176,7 @@ int launch_image_to_nhwc(odise_hip_ctx* ctx, const float* x, f16* y, int N, int 
 int launch_clip_preprocess(odise_hip_ctx* ctx, const float* x, f16* y, int N, int H, int W, int S);
 int launch_softmax_rows(odise_hip_ctx* ctx, const f16* x, f16* y, int64_t rows, int cols, int64_t ld, float scale);
 int launch_clip_assemble(odise_hip_ctx* ctx, const f16* patches, const float* cls, const float* pos, f16* tok, int B, int T, int extra,
-                         int Cw);
+                         int TP, int Cw);
 int clip_tower(Exec& ex, const Act& img, int extra, const uint8_t* mask, int64_t ldm, f16* out);
 int clip_dims(ModelStore* ms, int* image, int* patch, int* tokens, int* out_dim);
 int launch_cond_inputs(odise_hip_ctx* ctx, const float* proj, const float* A1, const float* A2, float* out, int B, int T, int Cw);

@@ -260,7 +260,8 @@ constexpr int pp_lds_bytes(int BM, int BN, int WAVES_M) {
 }
 constexpr int halo_lds_bytes(int BN) {
     const int layout = 2 * BN * 64 * 2 + 2 * (41 + 1) * 1024;  // two B stages + two halo buffers (41 groups + a dummy one)
-    const int epi = 128 * (BN + 4) * 4;                        // two wave-rows per epilogue pass
+    const int all = 256 * (BN + 4) * 4;                        // the whole 256-row tile staged in one epilogue pass when that fits (BN = 128) ...
+    const int epi = all <= 160 * 1024 ? all : all / 2;         // ... else two wave-rows per pass
     return layout > epi ? layout : epi;
 }
 constexpr int epi_wave_rows(int BM, int BN, int WAVES_M, int lds_bytes) {
@@ -295,6 +296,34 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& g, f32x16 (&acc)[B
     float s8[8], q8[8];
 #pragma unroll
     for (int i = 0; i < 8; ++i) s8[i] = q8[i] = 0.f;
+    // Residual prefetch.  The read phase below fetches the residual tile row by row, one HBM round trip per row group: measured, a conv
+    // with a residual runs 10-21 % longer than the same conv without (K = 1152: 1.85 -> 2.25 ms), i.e. those round trips are exposed.
+    // Touch every 128-byte line of the block's residual tile NOW (one dword per lane and line, 2-3 loads per thread); the lines travel to
+    // the L2 while the accumulators are staged, and the fake use after the first staging barrier retires the loads before the read phase.
+    // Measured (tools/halo512_probe.py, same box): -5..9 % on the VAE convolutions that carry a residual.
+    constexpr int LPR = (BN * 2 + 127) / 128;                 // lines per tile row
+    constexpr int NPF = (BM * LPR + NT - 1) / NT;             // prefetch loads per thread
+    unsigned pf[NPF];
+    const bool prefetch = g.epi.residual != nullptr && !split && !ODISE_ABLATE(g, 64);   // tools: ODISE_NO_RES_PREFETCH=1 (bit 64) for A/B runs
+    if (prefetch) {
+#pragma unroll
+        for (int i = 0; i < NPF; ++i) {
+            const int li = tid + i * NT;
+            const int rt = li / LPR, seg = li - rt * LPR;
+            int m = m0 + rt;
+            if (HALO) {
+                const int patch = m0 / BM;
+                const int per_img = g.cg.halo_tx * g.cg.halo_ty;
+                const int img = patch / per_img, pr = patch - img * per_img;
+                const int oy = (pr / g.cg.halo_tx) * 16 + (rt >> 4), ox = (pr % g.cg.halo_tx) * 16 + (rt & 15);
+                m = (oy < g.cg.OH && ox < g.cg.OW) ? (img * g.cg.OH + oy) * g.cg.OW + ox : g.M;
+            }
+            pf[i] = 0u;
+            if (rt < BM && m < g.M && n0 + seg * 64 + 2 <= g.N)
+                pf[i] = *reinterpret_cast<const unsigned*>(g.epi.residual + (int64_t)zb * g.epi.strideR + (int64_t)m * g.epi.ldr + n0 + seg * 64);
+        }
+        asm volatile("" ::: "memory");  // keep the loads ahead of the staging writes
+    }
 #pragma unroll
     for (int gp = 0; gp < WAVES_M / WG; ++gp) {
         if (gp > 0) lds_barrier();  // staging reads of the previous pass are done (global stores may still fly)
@@ -312,6 +341,10 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& g, f32x16 (&acc)[B
                 }
         }
         lds_barrier();
+        if (gp == 0 && prefetch) {
+#pragma unroll
+            for (int i = 0; i < NPF; ++i) asm volatile("" ::"v"(pf[i]));  // the prefetched lines have landed (in the L2, too); registers free again
+        }
         // ---- read phase.  Common case (lean epilogue, whole column chunks, NT % CH == 0): a thread keeps ONE 8-column chunk over the pass
         // and walks rows row0, row0 + NT/CH, ... - the trip count is a compile-time constant, so the rows are processed in groups of U with
         // every load of the group (staged accumulators, residual, per-image vector) issued before the first dependent instruction; bias_n is
@@ -1771,13 +1804,18 @@ static const TileCost kTileCost[kNumTiles] = {
     {1.42, 6.0, 1},   // 256x128
     {2.25, 12.0, 1},  // 512x128 (ping-pong kernel only)
     {1.92, 12.0, 1},  // halo 256 pixels x 256 channels (measured 7 % under the im2col ping-pong tile on the 512-channel VAE layers)
-    {1.32, 10.0, 1},  // halo 256 pixels x 128 channels (wins over 512x128 when that tile cannot fill the CUs)
+    {1.12, 9.0, 1},   // halo 256 pixels x 128 channels (re-fitted in round 2: 28 us per block of 18 K-tiles on the 128-channel VAE level, where
+                      // the im2col 512x128 tile takes 65 us per block of twice the size: 1.80 vs 2.07 ms per launch, tools/halo512_probe.py)
 };
 // the 256-row tiles as run by the ping-pong kernel (K % 64 == 0; conv: Cin % 64 == 0, no fused upsample)
 static const TileCost kTileCostPP[2] = {
     {2.55, 16.0, 1},  // 256x320
     {2.10, 12.0, 1},  // 256x256
 };
+// the 512x128 tile on implicit-GEMM convolutions: every input pixel passes the LDS-DMA path nine times (measured 61-65 us per block of
+// 18 K-tiles on the 128-channel VAE level; the dense fit above says 52 us).  Still ahead of the plain 256x128 tile on the stride-2 conv
+// of that level (622 vs 651 us), behind the halo tile on the stride-1 ones.
+static const TileCost kTileCostConv512 = {2.5, 16.0, 1};
 // previous fit (before the lean epilogue / ping-pong kernel), kept selectable for A/B runs: ODISE_GEMM_FLAGS=8
 static const TileCost kTileCostOld[kNumTiles] = {{1.68, 9.5, 2}, {1.58, 4.1, 3}, {1.28, 2.4, 4}, {3.04, 29.0, 1}, {2.58, 22.0, 1},
                                                  {1.75, 10.6, 1}, {2.25, 12.0, 1}, {1.92, 12.0, 1}, {1.32, 10.0, 1}};
@@ -1821,7 +1859,7 @@ static int launch_gemm(odise_hip_ctx* ctx, GemmArgs& g, int batch, int force_til
         if (force_tile >= 0 && force_tile < kNumTiles && t != force_tile) continue;
         if (t == 6 && (!pp_ok || (flags & 16))) continue;
         if (t >= 7 && (!halo_ok || !pp_ok || (flags & 64))) continue;  // ODISE_GEMM_FLAGS=64: never use the halo kernel
-        const TileCost& tc = (flags & 8) ? kTileCostOld[t] : (pp_ok && (t == 3 || t == 4)) ? kTileCostPP[t - 3] : kTileCost[t];
+        const TileCost& tc = (flags & 8) ? kTileCostOld[t] : (pp_ok && (t == 3 || t == 4)) ? kTileCostPP[t - 3] : (CONV && t == 6) ? kTileCostConv512 : kTileCost[t];
         if (force_tile < 0) {
             if (kTileBM[t] > 64 && g.M <= kTileBM[t] / 2) continue;            // mostly-empty row tiles
             if (kTileBN[t] > 64 && g.N <= kTileBN[t] / 2 && t != 2) continue;  // mostly-empty column tiles
@@ -1891,7 +1929,7 @@ static int launch_gemm(odise_hip_ctx* ctx, GemmArgs& g, int batch, int force_til
     }
     g.zeros = (const f16*)ctx->zeros;
 #ifdef ODISE_TOOLS
-    static const int freeze_k = (getenv("ODISE_GEMM_FREEZE_K") ? 16 : 0) | (getenv("ODISE_EPI_OLD") ? 32 : 0);
+    static const int freeze_k = (getenv("ODISE_GEMM_FREEZE_K") ? 16 : 0) | (getenv("ODISE_EPI_OLD") ? 32 : 0) | (getenv("ODISE_NO_RES_PREFETCH") ? 64 : 0);
     g.dbg = g_gemm_debug | freeze_k;
 #else
     g.dbg = 0;
@@ -2005,6 +2043,10 @@ int conv_forced(odise_hip_ctx* ctx, const odise_conv_desc* d, int force_tile, in
     return rc;
 }
 
+// norm.hip
+int group_norm_from_colpart(odise_hip_ctx* ctx, const void* x, void* y, const float* gamma, const float* beta, int N, int HW, int C, int groups,
+                            float eps, int act, const float* colpart, int nblk);
+
 }  // namespace odise
 
 extern "C" int odise_hip_gemm_debug(int flags) { odise::g_gemm_debug = flags & 15; odise::g_conv_flags = flags >> 4; return 0; }
@@ -2016,4 +2058,16 @@ extern "C" int odise_hip_gemm_forced(odise_hip_ctx* ctx, const odise_gemm_desc* 
 }
 extern "C" int odise_hip_conv2d_forced(odise_hip_ctx* ctx, const odise_conv_desc* d, int tile, int splitk) {
     return odise::conv_forced(ctx, d, tile, splitk);
+}
+// conv (forced tile) whose epilogue also reduces the GroupNorm statistics, then the GroupNorm that consumes them: the pair the VAE / UNet
+// ResBlocks run (engine.cpp Exec::conv -> Exec::group_norm).  *stats_blocks = 0 reports that the chosen kernel declined the fusion and
+// the stand-alone GroupNorm ran instead.  stats_scratch: N * ceil(OH*OW / 64) * Cout * 2 floats.
+extern "C" int odise_hip_conv2d_gn_forced(odise_hip_ctx* ctx, const odise_conv_desc* d, int tile, int splitk, const float* gamma, const float* beta,
+                                          int groups, float eps, int act, void* y_norm, float* stats_scratch, int* stats_blocks) {
+    ODISE_REQUIRE(ctx && d && gamma && beta && y_norm && stats_scratch && stats_blocks, "conv2d_gn_forced: null argument");
+    ODISE_REQUIRE(d->y_dtype == ODISE_F16, "conv2d_gn_forced: f16 output only");
+    if (int rc = odise::conv_forced(ctx, d, tile, splitk, stats_scratch, stats_blocks)) return rc;
+    if (*stats_blocks > 0)
+        return odise::group_norm_from_colpart(ctx, d->Y, y_norm, gamma, beta, d->N, d->OH * d->OW, d->Cout, groups, eps, act, stats_scratch, *stats_blocks);
+    return odise_hip_group_norm(ctx, d->Y, y_norm, gamma, beta, d->N, d->OH * d->OW, d->Cout, groups, eps, act);
 }

@@ -134,19 +134,22 @@ __global__ void __launch_bounds__(256) softmax_rows_kernel(const f16* __restrict
     }
 }
 
-// tok[b, t, :] = (t == 0 ? cls : patches[b, t-1, :]) + pos[t, :]     (f16 out)
+// tok[b, t, :] = (t == 0 ? cls : patches[b, t-1, :]) + pos[t, :]     (f16 out); every image owns TP >= T + extra rows, the tail rows are zero
 __global__ void __launch_bounds__(256) clip_assemble_kernel(const f16* __restrict__ patches, const float* __restrict__ cls,
-                                                           const float* __restrict__ pos, f16* __restrict__ tok, int T, int extra,
+                                                           const float* __restrict__ pos, f16* __restrict__ tok, int T, int extra, int TP,
                                                            int Cw, int64_t total8) {
     const int C8 = Cw >> 3;
     const int TA = T + extra;  // tokens T..TA-1 are MaskCLIP mask tokens = copies of the class token (clip.py:268-270)
     for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total8; idx += (int64_t)gridDim.x * blockDim.x) {
         const int c = (int)(idx % C8) * 8;
         const int64_t bt = idx / C8;
-        const int t = (int)(bt % TA);
-        const int64_t b = bt / TA;
+        const int t = (int)(bt % TP);
+        const int64_t b = bt / TP;
         f16x8 o;
-        if (t == 0 || t >= T) {
+        if (t >= TA) {
+#pragma unroll
+            for (int i = 0; i < 8; ++i) o[i] = (f16)0.f;
+        } else if (t == 0 || t >= T) {
 #pragma unroll
             for (int i = 0; i < 8; ++i) o[i] = (f16)(cls[c + i] + pos[c + i]);
         } else {
@@ -236,9 +239,10 @@ int launch_softmax_rows(odise_hip_ctx* ctx, const f16* x, f16* y, int64_t rows, 
 }
 
 int launch_clip_assemble(odise_hip_ctx* ctx, const f16* patches, const float* cls, const float* pos, f16* tok, int B, int T, int extra,
-                         int Cw) {
-    const int64_t total8 = (int64_t)B * (T + extra) * (Cw / 8);
-    hipLaunchKernelGGL(clip_assemble_kernel, dim3(grid1d(total8)), dim3(256), 0, ctx->stream, patches, cls, pos, tok, T, extra, Cw, total8);
+                         int TP, int Cw) {
+    ODISE_REQUIRE(TP >= T + extra, "clip_assemble: %d rows per image < %d tokens", TP, T + extra);
+    const int64_t total8 = (int64_t)B * TP * (Cw / 8);
+    hipLaunchKernelGGL(clip_assemble_kernel, dim3(grid1d(total8)), dim3(256), 0, ctx->stream, patches, cls, pos, tok, T, extra, TP, Cw, total8);
     ODISE_CHECK_HIP(hipGetLastError());
     return ODISE_OK;
 }

@@ -215,6 +215,31 @@ class Context:
             check(self.lib.odise_hip_conv2d(self.h, C.byref(d)), "conv2d")
         return out
 
+    def conv2d_gn(self, X: DeviceArray, Wt: DeviceArray, gamma: DeviceArray, beta: DeviceArray, *, bias=None, groups=32, eps=1e-5, act=ACT_NONE,
+                  force_tile=-1, force_split=0):
+        """3x3 / 1x1 stride-1 conv whose epilogue reduces the GroupNorm statistics, then that GroupNorm (developer hook
+        odise_hip_conv2d_gn_forced): returns (conv output, normalised output, row blocks per image; 0 = fusion declined)."""
+        N, H, W, Cin = X.shape
+        Cout, KH, KW, _ = Wt.shape
+        y = self.empty((N, H, W, Cout), np.float16)
+        yn = self.empty((N, H, W, Cout), np.float16)
+        scratch = self.empty((N * ((H * W + 63) // 64) * Cout * 2,), np.float32)
+        d = ConvDesc()
+        d.N, d.H, d.W, d.Cin = N, H, W, Cin
+        d.Cout, d.KH, d.KW, d.stride = Cout, KH, KW, 1
+        d.pad_t, d.pad_l, d.OH, d.OW = KH // 2, KW // 2, H, W
+        d.X, d.Wt, d.Y = X.ptr, Wt.ptr, y.ptr
+        d.y_dtype = F16
+        d.bias = bias.ptr if bias is not None else None
+        d.act = ACT_NONE
+        blocks = C.c_int(0)
+        check(self.lib.odise_hip_conv2d_gn_forced(self.h, C.byref(d), int(force_tile), int(force_split), _p(gamma), _p(beta), int(groups),
+                                                  C.c_float(eps), int(act), C.c_void_p(yn.ptr), C.c_void_p(scratch.ptr), C.byref(blocks)),
+              "conv2d_gn_forced")
+        self.sync()
+        scratch.free()
+        return y, yn, blocks.value
+
     def group_norm(self, x: DeviceArray, gamma: Optional[DeviceArray], beta: Optional[DeviceArray], groups=32, eps=1e-5,
                    act=ACT_NONE) -> DeviceArray:
         """x [N, ..., C] f16 channels-last."""

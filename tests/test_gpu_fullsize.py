@@ -156,8 +156,13 @@ def test_end_to_end_contract(full, overlap_threshold):
     # ---- semantic
     sem_ref = ref["sem_seg"].numpy()
     serr = np.abs(got["sem_seg"] - sem_ref).max() / np.abs(sem_ref).max()
-    sagree = (got["sem_seg"].argmax(0) == sem_ref.argmax(0)).mean()
-    print("sem_seg max-err/scale", serr, "argmax agreement", sagree)
+    same = got["sem_seg"].argmax(0) == sem_ref.argmax(0)
+    sagree = same.mean()
+    # the label may only change where the reference's own top-2 margin is inside the measured error: 2 * max-err bounds how far two scores can move apart
+    top2 = np.partition(sem_ref, -2, axis=0)[-2:]
+    decided = (top2[1] - top2[0]) > 2.0 * np.abs(got["sem_seg"] - sem_ref).max()
+    print("sem_seg max-err/scale", serr, "argmax agreement", sagree, "pixels whose reference margin exceeds twice the max error", decided.mean(),
+          "agreement there", same[decided].mean() if decided.any() else 1.0)
     # ---- instances: the same (query, class) entries wherever the k-th score is separated; matching entries have the same masks and scores
     inst_ref, inst = ref["instances"], got["instances"]
     s_ref = inst_ref["scores"].numpy()
@@ -177,7 +182,9 @@ def test_end_to_end_contract(full, overlap_threshold):
     print("instances", len(key_got), "ref", len(key_ref), "in common", len(common), "k-th class score", kth, "worst mask IoU", worst, "worst score diff", worst_score)
     assert info == info_ref, (info, info_ref)
     assert agree > 0.995
-    assert serr < TAU_PROB and sagree > 0.995        # sem_seg = sum_q P[q,k] sigmoid(mask_q): carries the class-probability error
+    # sem_seg = sum_q P[q,k] sigmoid(mask_q) carries the class-probability error; its per-pixel argmax is identical wherever the reference decides by
+    # more than that error, and the undecided rest (near-ties between two of the 133 scores) stays a small fraction
+    assert serr < TAU_PROB and same[decided].all() and sagree > 0.98
     assert inst["pred_masks"].shape[1:] == (1024, 1024)
     for q, c in set(key_ref) ^ set(key_got):    # entries may only differ at the selection boundary of the top-k
         assert abs(float(scores_flat[q * K + c]) - kth) < TAU_PROB, (q, c)

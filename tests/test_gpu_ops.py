@@ -189,6 +189,50 @@ def test_conv3x3_and_1x1(ctx, N, H, W, Cin, Cout, k, tile, split):
     close(out, ref.numpy(), what=f"conv{k}x{k} {N}x{H}x{W}x{Cin}->{Cout}")
 
 
+# the halo kernels (3x3 / stride 1 / pad 1, Cin % 64 == 0; tile ids 7: 16x16 pixels x 256 channels, 8: 16x16 x 128), forced: whole patches,
+# ragged image sizes (partial patches in both directions), several 64-channel chunks, split-K over whole chunks, a Cout that is not a
+# multiple of the column tile
+@pytest.mark.parametrize("N,H,W,Cin,Cout,tile,split", [
+    (2, 32, 32, 128, 128, 8, 0), (1, 64, 48, 128, 128, 8, 0), (2, 40, 24, 128, 128, 8, 0), (1, 33, 17, 64, 128, 8, 0), (1, 16, 16, 192, 256, 8, 0),
+    (1, 32, 32, 256, 128, 8, 2), (1, 8, 8, 128, 72, 8, 0), (3, 96, 32, 128, 128, 8, 0), (1, 33, 17, 192, 128, 8, 3),
+    (1, 40, 24, 128, 256, 7, 0), (1, 16, 48, 256, 512, 7, 2), (2, 32, 32, 64, 320, 7, 0),
+])
+def test_conv3x3_halo_tiles(ctx, N, H, W, Cin, Cout, tile, split):
+    g = torch.Generator().manual_seed(N + H + W + Cin + Cout + tile)
+    x = h(torch.randn(N, H, W, Cin, generator=g))
+    w = h(torch.randn(Cout, 3, 3, Cin, generator=g) / (9 * Cin) ** 0.5)
+    b = torch.randn(Cout, generator=g)
+    res = h(torch.randn(N, H, W, Cout, generator=g))
+    ref = _conv_ref(x, w, 1, 1, b) + res
+    dx, dw, db, dr = ctx.to_device(x.half().numpy()), ctx.to_device(w.half().numpy()), ctx.to_device(b), ctx.to_device(res.half().numpy())
+    out = ctx.conv2d(dx, dw, bias=db, residual=dr, force_tile=tile, force_split=split).numpy()   # split 0: the cost model's own choice
+    close(out, ref.numpy(), what=f"halo tile {tile} conv {N}x{H}x{W}x{Cin}->{Cout} split {split}")
+    # same fp32 summation order (chunk-major) in both halo tiles: without split-K they are bit-identical
+    one = ctx.conv2d(dx, dw, bias=db, residual=dr, force_tile=tile, force_split=1).numpy()
+    other = ctx.conv2d(dx, dw, bias=db, residual=dr, force_tile=15 - tile, force_split=1).numpy()
+    assert np.array_equal(one, other), f"tile {tile} differs bitwise from tile {15 - tile}"
+
+
+@pytest.mark.parametrize("N,H,W,Cin,Cout,tile", [(2, 64, 64, 128, 128, 8), (1, 40, 24, 128, 128, 8), (1, 48, 32, 128, 256, 7), (1, 33, 20, 64, 512, 7),
+                                                 (1, 64, 32, 128, 128, 6), (1, 32, 32, 128, 256, 4)])
+def test_conv_fused_groupnorm_statistics(ctx, N, H, W, Cin, Cout, tile):
+    """The conv -> GroupNorm pair of the ResBlocks (ldm ResnetBlock: conv1 -> norm2 -> swish): the conv epilogue reduces the statistics,
+    the GroupNorm only finalises and applies.  Compared with torch conv2d -> group_norm -> silu."""
+    g = torch.Generator().manual_seed(H + W + Cout + tile)
+    x = h(torch.randn(N, H, W, Cin, generator=g))
+    w = h(torch.randn(Cout, 3, 3, Cin, generator=g) / (9 * Cin) ** 0.5 * 2.0)
+    b = torch.randn(Cout, generator=g)
+    gamma, beta = torch.randn(Cout, generator=g), torch.randn(Cout, generator=g)
+    y, yn, blocks = ctx.conv2d_gn(ctx.to_device(x.half().numpy()), ctx.to_device(w.half().numpy()), ctx.to_device(gamma), ctx.to_device(beta),
+                                  bias=ctx.to_device(b), eps=1e-6, act=1, force_tile=tile, force_split=1)
+    assert blocks > 0, "the forced kernel declined the statistics fusion"
+    ref = _conv_ref(x, w, 1, 1, b)
+    close(y.numpy(), ref.numpy(), what=f"conv (tile {tile})")
+    y16 = torch.from_numpy(y.numpy().astype(np.float32))   # GroupNorm of the f16 tensor the conv actually wrote
+    refn = F.silu(F.group_norm(y16.permute(0, 3, 1, 2), 32, gamma, beta, eps=1e-6)).permute(0, 2, 3, 1)
+    close(yn.numpy(), refn.numpy(), rtol=3e-3, what=f"group_norm from fused statistics (tile {tile}, {blocks} row blocks)")
+
+
 def test_conv_stride2_variants(ctx):
     g = torch.Generator().manual_seed(3)
     x = h(torch.randn(2, 16, 16, 64, generator=g))

@@ -33,6 +33,8 @@ def t(fn):
 shapes = [(9232, 1024, 1024), (9232, 3072, 1024), (9232, 4096, 1024), (9232, 1024, 4096), (2708, 1024, 1024), (2708, 3072, 1024), (2708, 4096, 1024),
           (2708, 1024, 4096), (65536, 320, 320), (65536, 960, 320), (16384, 640, 640), (16384, 1920, 640), (4096, 1280, 1280), (4096, 3840, 1280),
           (21504, 256, 256), (21504, 1024, 256), (21504, 256, 1024)]
+if len(sys.argv) > 1:  # tile_probe.py M,N,K [M,N,K ...]
+    shapes = [tuple(int(v) for v in a.split(",")) for a in sys.argv[1:]]
 for (M, N, K) in shapes:
     A, W, O = f16((M, K)), f16((N, K), K ** -0.5), ctx.empty((M, N), np.float16)
     b = ctx.to_device(rng.standard_normal(N, dtype=np.float32))
