@@ -213,13 +213,13 @@ __device__ __forceinline__ void epi_fast8(const GemmEpi& e, float (&v)[8], int m
     if (e.residual) r = *reinterpret_cast<const f16x8*>(e.residual + (int64_t)z * e.strideR + (int64_t)m * e.ldr + n);
     if (e.act == ODISE_ACT_SILU) {
 #pragma unroll
-        for (int i = 0; i < 8; ++i) v[i] = v[i] / (1.0f + __expf(-v[i]));
+        for (int i = 0; i < 8; ++i) v[i] = mul_sigmoid(v[i], v[i]);
     } else if (e.act == ODISE_ACT_RELU) {
 #pragma unroll
         for (int i = 0; i < 8; ++i) v[i] = v[i] > 0.f ? v[i] : 0.f;
     } else if (e.act == ODISE_ACT_QUICKGELU) {
 #pragma unroll
-        for (int i = 0; i < 8; ++i) v[i] = v[i] / (1.0f + __expf(-1.702f * v[i]));
+        for (int i = 0; i < 8; ++i) v[i] = mul_sigmoid(v[i], 1.702f * v[i]);
     } else if (e.act == ODISE_ACT_GELU) {
 #pragma unroll
         for (int i = 0; i < 8; ++i) v[i] = gelu_exact(v[i]);
@@ -450,13 +450,13 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& g, f32x16 (&acc)[B
                         }
                         if (e.act == ODISE_ACT_SILU) {
 #pragma unroll
-                            for (int i = 0; i < 8; ++i) v[i] = v[i] / (1.0f + __expf(-v[i]));
+                            for (int i = 0; i < 8; ++i) v[i] = mul_sigmoid(v[i], v[i]);
                         } else if (e.act == ODISE_ACT_RELU) {
 #pragma unroll
                             for (int i = 0; i < 8; ++i) v[i] = v[i] > 0.f ? v[i] : 0.f;
                         } else if (e.act == ODISE_ACT_QUICKGELU) {
 #pragma unroll
-                            for (int i = 0; i < 8; ++i) v[i] = v[i] / (1.0f + __expf(-1.702f * v[i]));
+                            for (int i = 0; i < 8; ++i) v[i] = mul_sigmoid(v[i], 1.702f * v[i]);
                         } else if (e.act == ODISE_ACT_GELU) {
 #pragma unroll
                             for (int i = 0; i < 8; ++i) v[i] = gelu_exact(v[i]);

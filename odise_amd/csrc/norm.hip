@@ -214,7 +214,7 @@ __global__ void __launch_bounds__(256) gn_apply_kernel(const f16* __restrict__ x
             for (int i = 0; i < 8; ++i) t[i] = (float)v[u][i] * sc[i] + sh[i] + (float)r[u][i];  // y = act(gn(x) + residual) + accum
             if (act == ODISE_ACT_SILU) {
 #pragma unroll
-                for (int i = 0; i < 8; ++i) t[i] = t[i] / (1.0f + __expf(-t[i]));
+                for (int i = 0; i < 8; ++i) t[i] = mul_sigmoid(t[i], t[i]);
             } else if (act != ODISE_ACT_NONE) {
 #pragma unroll
                 for (int i = 0; i < 8; ++i) t[i] = act_apply(t[i], act);
