@@ -89,8 +89,6 @@ __device__ __forceinline__ void glds16(const void* gsrc, void* lds_base) {
                                      (__attribute__((address_space(3))) void*)lds_base, 16, 0, 0);
 }
 
-__device__ __forceinline__ float gelu_exact(float v) { return 0.5f * v * (1.0f + erff(v * 0.70710678118654752f)); }
-
 // Applies the epilogue to 8 consecutive columns (n..n+7) of row m and stores them.
 __device__ __forceinline__ void epi_store8(const GemmEpi& e, float (&v)[8], int m, int n, int N, int z) {
     const int nvalid = (N - n) < 8 ? (N - n) : 8;
@@ -110,7 +108,7 @@ __device__ __forceinline__ void epi_store8(const GemmEpi& e, float (&v)[8], int 
         // columns are (a, gate) pairs; output has N/2 columns
         float o[4];
 #pragma unroll
-        for (int i = 0; i < 4; ++i) o[i] = v[2 * i] * gelu_exact(v[2 * i + 1]);
+        for (int i = 0; i < 4; ++i) o[i] = v[2 * i] * gelu_erf(v[2 * i + 1]);
         const int no = n >> 1;
         const int nov = nvalid >> 1;
         if (e.c_dtype == ODISE_F16) {
@@ -197,7 +195,7 @@ __device__ __forceinline__ void epi_fast8(const GemmEpi& e, float (&v)[8], int m
         // columns are (a, gate) pairs; the output has N/2 columns (no activation / residual on this path)
         float o[4];
 #pragma unroll
-        for (int i = 0; i < 4; ++i) o[i] = v[2 * i] * gelu_exact(v[2 * i + 1]);
+        for (int i = 0; i < 4; ++i) o[i] = v[2 * i] * gelu_erf(v[2 * i + 1]);
         const int64_t off = (int64_t)z * e.strideC + (int64_t)m * e.ldc + (n >> 1);
         if (e.c_dtype == ODISE_F16) {
             f16x4 t;
@@ -222,7 +220,7 @@ __device__ __forceinline__ void epi_fast8(const GemmEpi& e, float (&v)[8], int m
         for (int i = 0; i < 8; ++i) v[i] = mul_sigmoid(v[i], 1.702f * v[i]);
     } else if (e.act == ODISE_ACT_GELU) {
 #pragma unroll
-        for (int i = 0; i < 8; ++i) v[i] = gelu_exact(v[i]);
+        for (int i = 0; i < 8; ++i) v[i] = gelu_erf(v[i]);
     }
     const int64_t off = (int64_t)z * e.strideC + (int64_t)m * e.ldc + n;
     if (e.c_dtype == ODISE_F16) {
@@ -436,7 +434,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& g, f32x16 (&acc)[B
                         if (e.geglu) {
                             float o[4];
 #pragma unroll
-                            for (int i = 0; i < 4; ++i) o[i] = v[2 * i] * gelu_exact(v[2 * i + 1]);
+                            for (int i = 0; i < 4; ++i) o[i] = v[2 * i] * gelu_erf(v[2 * i + 1]);
                             const int64_t off = (int64_t)zb * e.strideC + (int64_t)m * e.ldc + (n >> 1);
                             if (e.c_dtype == ODISE_F16) {
                                 f16x4 t;
@@ -459,7 +457,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& g, f32x16 (&acc)[B
                             for (int i = 0; i < 8; ++i) v[i] = mul_sigmoid(v[i], 1.702f * v[i]);
                         } else if (e.act == ODISE_ACT_GELU) {
 #pragma unroll
-                            for (int i = 0; i < 8; ++i) v[i] = gelu_exact(v[i]);
+                            for (int i = 0; i < 8; ++i) v[i] = gelu_erf(v[i]);
                         }
                         const int64_t off = (int64_t)zb * e.strideC + (int64_t)m * e.ldc + n;
                         if (e.c_dtype == ODISE_F16) {
