@@ -444,11 +444,15 @@ extern "C" int odise_hip_postprocess_batch(odise_hip_ctx* ctx, const odise_post_
     if (want_pan && ctx->comm) ODISE_TRY(odise_hip_comm_wait(ctx, 0));
     ODISE_TRY(launch_post_decide(ctx, d->mask_cls, kscore, label, semT, probs, B, Q, Qpad, K, d->object_mask_threshold));
     Exec ex{ctx, ms};
-    for (int b = 0; b < B; ++b) {
+    auto geometry = [&](int b) {
         PostGeom g;
         g.h4 = ho.h4; g.w4 = ho.w4; g.ph = d->pad_h; g.pw = d->pad_w; g.ih = d->img_hw[2 * b]; g.iw = d->img_hw[2 * b + 1];
         g.oh = d->out_hw ? d->out_hw[2 * b] : g.ih; g.ow = d->out_hw ? d->out_hw[2 * b + 1] : g.iw;
         g.Q = Q; g.Qpad = Qpad;
+        return g;
+    };
+    for (int b = 0; b < B; ++b) {
+        const PostGeom g = geometry(b);
         const int npix = g.oh * g.ow;
         const f16* logits = ho.pred_masks + (size_t)b * Q * ho.h4 * ho.w4;
         float* sem = (want_sem && d->sem_seg) ? d->sem_seg[b] : nullptr;
@@ -473,12 +477,14 @@ extern "C" int odise_hip_postprocess_batch(odise_hip_ctx* ctx, const odise_post_
                                              pan + npix, Q, K, d->overlap_threshold, ODISE_MAX_SEGMENTS, stuff));
             ODISE_TRY(launch_panoptic_write(ctx, ids, map + (size_t)b * Q, pan, npix));
         }
-        if (inst) {
+    }
+    if (want_inst) {   // the top-k selection of every image in one launch (one block per image), then the selected masks
+        ODISE_TRY(launch_instance_topk(ctx, probs, stats, thing, d->inst_table, d->inst_scores, B, Q, Qpad, K, topk, d->panoptic_on ? 1 : 0));
+        for (int b = 0; b < B && d->inst_masks; ++b) {
+            if (!d->inst_masks[b]) continue;
             int* tb = d->inst_table + (size_t)b * (1 + 2 * topk);
-            ODISE_TRY(launch_instance_topk(ctx, probs + (size_t)b * Q * K, stats + (size_t)b * 2 * Qpad, thing, tb, d->inst_scores + (size_t)b * topk, Q, Qpad,
-                                           K, topk, d->panoptic_on ? 1 : 0));
-            if (d->inst_masks && d->inst_masks[b])
-                ODISE_TRY(launch_instance_masks(ctx, logits, tb + 1, d->inst_masks[b], std::min(topk, Q * K), g, tb));
+            const f16* logits = ho.pred_masks + (size_t)b * Q * ho.h4 * ho.w4;
+            ODISE_TRY(launch_instance_masks(ctx, logits, tb + 1, d->inst_masks[b], std::min(topk, Q * K), geometry(b), tb));
         }
     }
     return ODISE_OK;

@@ -520,14 +520,18 @@ __global__ void panoptic_decide_kernel(const int* __restrict__ cnt, const float*
     }
 }
 
-// Instance head (maskformer_model.py:344-380): one block per image selects the top-k of the Q*K class probabilities (radix select on
+// Instance head (maskformer_model.py:344-380): one block per image (blockIdx.x; one launch for the batch) selects the top-k of the Q*K class probabilities (radix select on
 // the float bits - probabilities are non-negative, so unsigned order = float order), sorts them (score descending, flat index
 // ascending on ties), keeps "thing" classes when the panoptic head is on (:363-369) and multiplies with the mask score
 // sum(sigmoid * [logit > 0]) / (count + 1e-6) (:376-377) from the per-pixel pass.
 //   table [1 + 2*topk] int32: n | query index x topk | class x topk ;  scores [topk] f32 (entries >= n are zero)
-__global__ void __launch_bounds__(1024) instance_topk_kernel(const float* __restrict__ probs, const float* __restrict__ inst_stats,
-                                                            const uint8_t* __restrict__ isthing, int* __restrict__ table, float* __restrict__ scores,
+__global__ void __launch_bounds__(1024) instance_topk_kernel(const float* __restrict__ probs_all, const float* __restrict__ inst_stats_all,
+                                                            const uint8_t* __restrict__ isthing, int* __restrict__ table_all, float* __restrict__ scores_all,
                                                             int Q, int Qpad, int K, int topk, int things_only) {
+    const float* probs = probs_all + (size_t)blockIdx.x * Q * K;
+    const float* inst_stats = inst_stats_all + (size_t)blockIdx.x * 2 * Qpad;
+    int* table = table_all + (size_t)blockIdx.x * (1 + 2 * topk);
+    float* scores = scores_all + (size_t)blockIdx.x * topk;
     extern __shared__ unsigned int sm_u[];
     unsigned int* hist = sm_u;                 // [256]
     unsigned int* sel_key = sm_u + 256;        // [topk]
@@ -773,11 +777,12 @@ int launch_panoptic_decide(odise_hip_ctx* ctx, const int* counts, const float* k
     ODISE_CHECK_HIP(hipGetLastError());
     return ODISE_OK;
 }
-int launch_instance_topk(odise_hip_ctx* ctx, const float* probs, const float* inst_stats, const uint8_t* isthing, int* table, float* scores, int Q,
-                         int Qpad, int K, int topk, int things_only) {
+int launch_instance_topk(odise_hip_ctx* ctx, const float* probs, const float* inst_stats, const uint8_t* isthing, int* table, float* scores, int B,
+                         int Q, int Qpad, int K, int topk, int things_only) {
     ODISE_REQUIRE(topk >= 1 && topk <= 4096, "instance_topk: topk %d out of range", topk);
     const size_t lds = (256 + 2 * (size_t)topk) * sizeof(unsigned int);
-    hipLaunchKernelGGL(instance_topk_kernel, dim3(1), dim3(1024), lds, ctx->stream, probs, inst_stats, isthing, table, scores, Q, Qpad, K, topk,
+    // probs [B][Q*K], inst_stats [B][2*Qpad], table [B][1 + 2*topk], scores [B][topk]
+    hipLaunchKernelGGL(instance_topk_kernel, dim3((unsigned)B), dim3(1024), lds, ctx->stream, probs, inst_stats, isthing, table, scores, Q, Qpad, K, topk,
                        things_only);
     ODISE_CHECK_HIP(hipGetLastError());
     return ODISE_OK;

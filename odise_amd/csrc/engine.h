@@ -219,8 +219,8 @@ int launch_post_decide(odise_hip_ctx* ctx, const float* mask_cls, float* kscore,
                        float object_mask_threshold);
 int launch_panoptic_decide(odise_hip_ctx* ctx, const int* counts, const float* kscore, const int* label, const uint8_t* isthing, int* map, int* table,
                            int Q, int K, double overlap_threshold, int max_segments, int* stuff_scratch);
-int launch_instance_topk(odise_hip_ctx* ctx, const float* probs, const float* inst_stats, const uint8_t* isthing, int* table, float* scores, int Q,
-                         int Qpad, int K, int topk, int things_only);
+int launch_instance_topk(odise_hip_ctx* ctx, const float* probs, const float* inst_stats, const uint8_t* isthing, int* table, float* scores, int B,
+                         int Q, int Qpad, int K, int topk, int things_only);
 int launch_image_pad(odise_hip_ctx* ctx, const void* src, int layout, int h, int w, float* dst, int Hp, int Wp);
 int launch_semantic_argmax(odise_hip_ctx* ctx, const f16* S, const f16* PT, int* out, int npix, int Qpad, int K);
 // maskgen.cpp accessors used by classify.cpp

@@ -10,6 +10,7 @@
 //      scale/shift in LDS and streams x -> act(x*scale+shift) with 16-byte loads/stores.
 // LayerNorm keeps a row in registers (one wavefront per row, <= 3 vectors per lane) so x is read once.
 #include "common.h"
+#include <stdlib.h>
 
 namespace odise {
 
@@ -386,7 +387,11 @@ extern "C" int odise_hip_layer_norm(odise_hip_ctx* ctx, const void* x, void* y, 
         const dim3 grid((unsigned)ceil_div(rows, 4 * R));
         hipLaunchKernelGGL(kern, grid, dim3(256), 0, ctx->stream, (const f16*)x, (f16*)y, gamma, beta, rows, C, eps);
     };
-    const bool many = rows >= 8192;  // enough rows to keep every CU busy with 4 rows per wavefront
+    int many_rows = 2048;  // four rows per wavefront (all loads in flight first) from here on; measured on the step: never -2.1 ms, from 8192 rows -0.2 ms
+#ifdef ODISE_TOOLS
+    if (const char* e = getenv("ODISE_LN_MANY_ROWS")) many_rows = atoi(e);   // A/B of the rows-per-wavefront switch
+#endif
+    const bool many = rows >= many_rows;
     if (C <= 512) { if (many) launch(layer_norm_kernel<1, 4>, 4); else launch(layer_norm_kernel<1, 1>, 1); }
     else if (C <= 1024) { if (many) launch(layer_norm_kernel<2, 4>, 4); else launch(layer_norm_kernel<2, 1>, 1); }
     else if (C <= 2048) { if (many) launch(layer_norm_kernel<4, 2>, 2); else launch(layer_norm_kernel<4, 1>, 1); }
