@@ -57,7 +57,8 @@ def small_models(ctx):
     return bb, head, hip
 
 
-@pytest.mark.parametrize("h,w", [(512, 512), (1024, 512), (768, 640), (320, 448), (256, 256), (384, 1024)])   # the last three: windows below 512 (bicubic)
+# (1280, 1280): the nine overlapping 512-windows of BASELINE configs[4] (starts 0, 512, 768); the last three: windows below 512 (bicubic)
+@pytest.mark.parametrize("h,w", [(512, 512), (1024, 512), (768, 640), (1280, 1280), (320, 448), (256, 256), (384, 1024)])
 def test_small_backbone_slide_forward(small_models, h, w):
     bb, _, hip = small_models
     img = _image(1 if (h, w) != (512, 512) else 2, h, w, seed=h + w)
