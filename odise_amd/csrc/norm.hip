@@ -223,7 +223,7 @@ __global__ void __launch_bounds__(256) gn_apply_kernel(const f16* __restrict__ x
             f16x8 o;
 #pragma unroll
             for (int i = 0; i < 8; ++i) o[i] = (f16)(t[i] + (float)a[u][i]);
-            *reinterpret_cast<f16x8*>(yb + (int64_t)idx * 8) = o;
+            __builtin_nontemporal_store(o, reinterpret_cast<f16x8*>(yb + (int64_t)idx * 8));  // streamed once: keep it out of the way of the L2-resident operands of the next conv
         }
     }
 }
