@@ -1892,7 +1892,7 @@ static int launch_gemm(odise_hip_ctx* ctx, GemmArgs& g, int batch, int force_til
         g.splitk = (int)ceil_div(nk, g.ktiles_per_split);
         ODISE_REQUIRE((size_t)g.splitk * g.M * g.N * sizeof(float) <= ctx->ws_bytes, "gemm: split-K workspace too small");
     }
-    if (flags & 32) {  // ODISE_GEMM_FLAGS=32: log every launch (tools/shape_log.py aggregates)
+    if (flags & 32) {  // ODISE_GEMM_FLAGS=32: log every launch (tools/gemm_eff.py joins the log with a rocprofv3 kernel trace: per-shape TFLOP/s)
         fprintf(stderr, "GEMMLOG conv=%d M=%d N=%d K=%d batch=%d cin=%d kh=%d h=%d w=%d stride=%d ups=%d tile=%d split=%d pp=%d\n", (int)CONV, g.M, g.N,
                 g.K, batch, g.cg.Cin, g.cg.KH, g.cg.H, g.cg.W, g.cg.stride, g.cg.ups, tile, best_split, (int)pp_ok);
     }
