@@ -1,0 +1,40 @@
+"""The bench line the driver parses: every committed `profiles/r02_bench_*.json` (rank 0's one JSON line of a `bench.py` run on an MI355X)
+carries the keys of the measurement contract, with consistent arithmetic.  CPU only: guards the format, not the numbers."""
+import glob
+import json
+import os
+
+import pytest
+
+ROOT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..")
+LINES = sorted(glob.glob(os.path.join(ROOT, "profiles", "r02_bench_*.json")))
+
+
+@pytest.mark.parametrize("path", LINES, ids=[os.path.basename(p) for p in LINES])
+def test_bench_line_contract(path):
+    d = json.load(open(path))
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data", "config"):
+        assert k in d, k
+    assert d["n_gpus"] == 1 and d["higher_is_better"] is True and d["scaling"] == "weak" and d["vs_baseline"] is None
+    assert d["dtype"] == "f16" and d["data"] == "synthetic" and "workload" in d["config"] and "model" not in d["config"]
+    units = d["config"]["units_per_step_per_gpu"]
+    assert abs(d["value"] - units * 1e3 / d["ms_per_step"]) < 1e-6 * d["value"]          # whole-job throughput = units / step time
+    r = d["roofline"]
+    for k in ("bound", "achieved", "peak", "unit", "frac", "traffic"):
+        assert k in r, k
+    assert r["bound"] == "mfma" and r["unit"] == "TFLOP/s" and r["peak"] == 2500.0 and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-9
+    if "launch_us" in r:   # the dominant kernel: algorithmic FLOPs per launch / live launch time
+        assert abs(r["achieved"] - r["algorithmic_flops_per_launch"] / (r["launch_us"] * 1e-6) / 1e12) < 1e-6 * r["achieved"]
+        assert r["traffic"] > 541e6                                                      # HBM bytes per launch >= the algorithmic bytes
+        assert 0.0 < r["step_frac"] < r["frac"] < 1.0
+
+
+def test_headline_line_has_the_cpu_baseline():
+    d = json.load(open(os.path.join(ROOT, "profiles", "r02_bench_full_b4_1024.json")))
+    assert d["metric"] == "panoptic-inference images/sec @1024x1024" and d["unit"] == "images/s"
+    assert d["config"]["workload"].startswith("BASELINE configs[2]") and d["config"]["units_per_step_per_gpu"] == 4
+    c = d["cpu_baseline"]
+    for k in ("value", "unit", "cores", "kind", "sample"):
+        assert k in c, k
+    assert c["kind"] == "port" and c["unit"] == "images/s" and c["cores"] >= 1 and len(c["crop_seconds_live"]) >= 3
+    assert 0 < c["value"] < d["value"]
