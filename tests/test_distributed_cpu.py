@@ -108,3 +108,90 @@ def test_confusion_matrix_allreduce_gloo_world2():
         ref += semantic_confusion(rng.standard_normal((4, 6, 7)).astype(np.float32), rng.integers(0, 4, (6, 7)))
     for r in range(world):
         np.testing.assert_array_equal(results[r], ref)
+
+
+# ---- the launcher side of the library-owned exchange (odise_amd.distributed.Exchange) at world size 2, with the library replaced by a
+# recorder: rank 0 alone asks for the communicator id, the id travels over the CPU rendezvous (gloo_broadcast, as bench.py does for
+# --gpus N), every rank initialises the communicator with the SAME 128 bytes and its own rank; the collectives hand the library the
+# element counts it expects.  (The RCCL half of the path runs in tests/test_gpu_exchange.py with a one-rank communicator.)
+class _FakeLib:
+    def __init__(self, rank, log):
+        self.rank, self.log = rank, log
+
+    def odise_hip_comm_unique_id(self, buf):
+        self.log.append(("unique_id", self.rank))
+        for i in range(len(buf)):
+            buf[i] = (i * 7 + 3) % 256
+        return 0
+
+    def odise_hip_comm_init(self, h, buf, rank, world):
+        self.log.append(("init", bytes(buf), rank, world))
+        return 0
+
+    def odise_hip_allgather_predictions(self, h, local, n, out):
+        self.log.append(("allgather", int(n)))
+        return 0
+
+    def odise_hip_allreduce_sum_i64(self, h, data, n):
+        self.log.append(("allreduce", int(n)))
+        return 0
+
+    def odise_hip_comm_wait(self, h, host):
+        self.log.append(("wait", int(host)))
+        return 0
+
+    def odise_hip_comm_destroy(self, h):
+        self.log.append(("destroy",))
+        return 0
+
+
+class _FakeArray:
+    def __init__(self, shape, dtype):
+        self.shape, self.dtype, self.ptr = shape, np.dtype(dtype), 0x1000
+
+
+def _exchange_worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    log = []
+
+    class Ctx:
+        lib = _FakeLib(rank, log)
+        h = 1
+
+    ex = D.Exchange(Ctx, rank, world, D.gloo_broadcast)
+    B, rec = 3, D.record_size(4, 5)
+    ex.allgather(_FakeArray((B, rec), np.int32), _FakeArray((world * B, rec), np.int32))
+    ex.allreduce_sum_i64(_FakeArray((5, 5), np.int64))
+    ex.wait(True)
+    ex.close()
+    q.put((rank, log))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_exchange_launcher_side_world2():
+    world, port = 2, _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_exchange_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    logs = dict(q.get(timeout=120) for _ in range(world))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert [e for e in logs[0] if e[0] == "unique_id"] == [("unique_id", 0)] and not [e for e in logs[1] if e[0] == "unique_id"]
+    inits = {r: [e for e in logs[r] if e[0] == "init"][0] for r in range(world)}
+    assert inits[0][1] == inits[1][1] == bytes((i * 7 + 3) % 256 for i in range(128))     # the same id everywhere
+    assert (inits[0][2], inits[0][3]) == (0, 2) and (inits[1][2], inits[1][3]) == (1, 2)
+    for r in range(world):
+        assert ("allgather", 3 * D.record_size(4, 5)) in logs[r] and ("allreduce", 25) in logs[r] and ("wait", 1) in logs[r] and logs[r][-1] == ("destroy",)
+
+
+def test_exchange_needs_a_broadcast_beyond_one_rank():
+    class Ctx:
+        lib = _FakeLib(0, [])
+        h = 1
+    with pytest.raises(ValueError):
+        D.Exchange(Ctx, 0, 2, None)
