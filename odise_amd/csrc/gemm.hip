@@ -330,11 +330,16 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& g, f32x16 (&acc)[B
             for (int p = 0; p < TM; ++p)
 #pragma unroll
                 for (int j = 0; j < TN; ++j) {
+                    // The kernels multiply with the operands swapped - acc = mfma(b_frag, a_frag, acc), same products and k order, i.e. the same
+                    // bits - so the 32x32 tile sits TRANSPOSED in the registers: lane l owns row l & 31 and, per register quad q, the four
+                    // consecutive columns 8q + 4(l >> 5) + (0..3).  A quad is one 16-byte staging write (32 ds_write_b128 per wave and tile
+                    // instead of 128 ds_write_b32); eight consecutive rows of the padded staging image hit all 32 banks once ((BN + 4) % 32 == 4).
+                    const int row = (wm % WG) * WTM + p * 32 + l31;
 #pragma unroll
-                    for (int r = 0; r < 16; ++r) {
-                        const int row = (wm % WG) * WTM + p * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
-                        const int col = wn * WTN + j * 32 + l31;
-                        stg[row * LDS_LD + col] = acc[p][j][r];
+                    for (int q = 0; q < 4; ++q) {
+                        const int col = wn * WTN + j * 32 + 8 * q + 4 * hi;
+                        *reinterpret_cast<float4*>(&stg[row * LDS_LD + col]) =
+                            make_float4(acc[p][j][4 * q], acc[p][j][4 * q + 1], acc[p][j][4 * q + 2], acc[p][j][4 * q + 3]);
                     }
                 }
         }
@@ -747,7 +752,7 @@ __global__ void __launch_bounds__(64 * WAVES_M * WAVES_N) gemm_kernel(GemmArgs g
             for (int i = 0; i < TM; ++i)
 #pragma unroll
                 for (int j = 0; j < TN; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[i], bf[j], acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bf[j], af[i], acc[i][j], 0, 0, 0);  // operands swapped: transposed tile (see gemm_epilogue)
             if (INTERLEAVE) {
                 // next tile's LDS-DMA loads are issued in the shadow of this k-step's MFMAs (the matrix pipe keeps
                 // draining the queued MFMAs while the wave issues address math + global_load_lds)
@@ -1078,7 +1083,7 @@ __global__ void __launch_bounds__(512) gemm_pp_kernel(GemmArgs g) {
                     if (jj < nj) {
 #pragma unroll
                         for (int i = 0; i < TM; ++i)
-                            acc[i][j0 + jj] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[i][s], bf[jj][s], acc[i][j0 + jj], 0, 0, 0);
+                            acc[i][j0 + jj] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bf[jj][s], af[i][s], acc[i][j0 + jj], 0, 0, 0);  // transposed tile (see gemm_epilogue)
                     }
             __builtin_amdgcn_s_setprio(0);
             __builtin_amdgcn_sched_barrier(0);
@@ -1386,7 +1391,7 @@ __global__ void __launch_bounds__(512) gemm_pp2_kernel(GemmArgs g) {
                 for (int jj = 0; jj < PT; ++jj)
 #pragma unroll
                     for (int i = 0; i < TM; ++i)
-                        acc[i][j0 + jj] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[i][s], bf[jj][s], acc[i][j0 + jj], 0, 0, 0);
+                        acc[i][j0 + jj] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bf[jj][s], af[i][s], acc[i][j0 + jj], 0, 0, 0);  // transposed tile (see gemm_epilogue)
                 if (have_next) {
                     if (!next_in_tile) {
 #pragma unroll
@@ -1630,7 +1635,7 @@ __global__ void __launch_bounds__(512) conv3_halo_kernel(GemmArgs g) {
                 for (int jj = 0; jj < PT; ++jj)
 #pragma unroll
                     for (int i = 0; i < TM; ++i)
-                        acc[i][j0 + jj] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[i][s], bf[jj][s], acc[i][j0 + jj], 0, 0, 0);
+                        acc[i][j0 + jj] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bf[jj][s], af[i][s], acc[i][j0 + jj], 0, 0, 0);  // transposed tile (see gemm_epilogue)
                 if (have_next) {
                     if (!next_in_tile) read_a(t1, s, af);
 #pragma unroll
