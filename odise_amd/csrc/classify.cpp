@@ -40,7 +40,7 @@ struct ClassifyModel {
     // 1281-1288): OpenPanopticInference swaps the vocabulary in and out around EVERY call (pano_wrapper.py:62-66), which must not cost
     // allocations, uploads or a synchronisation
     struct Bank {
-        uint64_t key = 0;
+        uint64_t key = 0, key2 = 0;
         int K = 0, Ktot = 0;
         f16* T1 = nullptr;
         f16* T2 = nullptr;
@@ -130,6 +130,8 @@ using namespace odise;
 
 extern "C" int odise_hip_classify_build(odise_hip_ctx* ctx) {
     ODISE_REQUIRE(ctx, "classify_build: null context");
+    ODISE_CHECK_HIP(hipSetDevice(ctx->device));
+    ODISE_CHECK_HIP(hipStreamSynchronize(ctx->stream));   // a REbuild frees the previous head's banks and scratch: queued kernels may still read them
     return classify_build(ctx);
 }
 
@@ -151,11 +153,24 @@ extern "C" int odise_hip_set_vocabulary(odise_hip_ctx* ctx, const float* cat_tex
     }
     ODISE_REQUIRE(seg[K] == K_tot, "set_vocabulary: group sizes sum to %d, expected %d", seg[K], K_tot);
     ODISE_CHECK_HIP(hipSetDevice(ctx->device));
-    // ---- cached? (FNV-1a over every input byte)
-    uint64_t key = 1469598103934665603ull;
+    // ---- cached?  The key is 128 bits - two independent multiply-xorshift hashes over the inputs, eight bytes per step (~1 ms for the
+    // 9 MB of a 1.5k-string vocabulary; the byte-wise FNV used before took ~10 ms per call) - so that a collision activating the wrong
+    // bank is out of reach; the Python side short-circuits repeated label tuples before getting here.
+    uint64_t key = 1469598103934665603ull, key2 = 0x9E3779B97F4A7C15ull;
     auto mix = [&](const void* p, size_t n) {
         const unsigned char* b = (const unsigned char*)p;
-        for (size_t i = 0; i < n; ++i) { key ^= b[i]; key *= 1099511628211ull; }
+        size_t i = 0;
+        for (; i + 8 <= n; i += 8) {
+            uint64_t w;
+            memcpy(&w, b + i, 8);
+            key = (key ^ w) * 1099511628211ull; key ^= key >> 29;
+            key2 = (key2 + w) * 0xD6E8FEB86659FD93ull; key2 ^= key2 >> 32;
+        }
+        uint64_t w = 0;
+        if (i < n) memcpy(&w, b + i, n - i);
+        w ^= (uint64_t)n << 56;
+        key = (key ^ w) * 1099511628211ull; key ^= key >> 29;
+        key2 = (key2 + w) * 0xD6E8FEB86659FD93ull; key2 ^= key2 >> 32;
     };
     mix(cat_text, (size_t)K_tot * dim * 4); mix(clip_text, (size_t)K_tot * dim * 4); mix(group_sizes, (size_t)K * 4); mix(overlap, (size_t)K * 4);
     mix(&alpha, 4); mix(&beta, 4); mix(&K_tot, 4);
@@ -166,7 +181,7 @@ extern "C" int odise_hip_set_vocabulary(odise_hip_ctx* ctx, const float* cat_tex
         c->has_vocab = true;
     };
     for (auto& bk : c->banks)
-        if (bk.key == key && bk.K == K && bk.Ktot == K_tot) { activate(bk); return ODISE_OK; }
+        if (bk.key == key && bk.key2 == key2 && bk.K == K && bk.Ktot == K_tot) { activate(bk); return ODISE_OK; }
     ODISE_CHECK_HIP(hipStreamSynchronize(ctx->stream));   // a new bank: queued work may still read the one about to be evicted
     if (c->banks.size() >= 8) {
         size_t lru = 0;
@@ -180,7 +195,7 @@ extern "C" int odise_hip_set_vocabulary(odise_hip_ctx* ctx, const float* cat_tex
     for (size_t i = 0; i < (size_t)K_tot * dim; ++i) in16[i] = (f16)cat_text[i];
     for (int i = 0; i < dim; ++i) in16[(size_t)K_tot * dim + i] = (f16)c->null_embed[i];
     ClassifyModel::Bank bk;
-    bk.key = key; bk.K = K; bk.Ktot = K_tot; bk.alpha = alpha; bk.beta = beta;
+    bk.key = key; bk.key2 = key2; bk.K = K; bk.Ktot = K_tot; bk.alpha = alpha; bk.beta = beta;
     f16* d_in = nullptr;
     float* d_proj = nullptr;
     float* d_clip = nullptr;
@@ -370,7 +385,14 @@ extern "C" int odise_hip_maskclip_embed(odise_hip_ctx* ctx, const float* image, 
         set_error("maskclip_embed: the CLIP tower is not built (odise_hip_extractor_build)");
         return ODISE_ERR_STATE;
     }
-    ODISE_TRY(ensure_arena(ctx, ms, ((size_t)1 << 30) + (size_t)B * (T + Q) * 1024 * 2 * 64));
+    {
+        // this path allocates ABOVE whatever an earlier head call left in the arena (its outputs stay valid for a later classify /
+        // post-processing call), so the requirement counts from the current mark; if the arena has to grow it is reallocated, and the
+        // head outputs that pointed into the old one are invalidated instead of dangling
+        const char* base0 = ms->arena.base;
+        ODISE_TRY(ensure_arena(ctx, ms, ms->arena.off + ((size_t)1 << 30) + (size_t)B * (T + Q) * 1024 * 2 * 64));
+        if (ms->arena.base != base0) maskgen_invalidate_outputs(ms);
+    }
     Exec ex{ctx, ms};
     ArenaScope scope(ms->arena);
     const int64_t MQ = (int64_t)B * Q, ldm = round_up(T, 8);

@@ -106,14 +106,10 @@ extern "C" int odise_hip_comm_unique_id(void* id128) {
     return ODISE_OK;
 }
 
-extern "C" int odise_hip_comm_init(odise_hip_ctx* ctx, const void* id128, int rank, int world) {
-    ODISE_REQUIRE(ctx && id128, "comm_init: null argument");
-    ODISE_REQUIRE(world >= 1 && rank >= 0 && rank < world, "comm_init: rank %d / world %d", rank, world);
-    if (int rc = rccl_load()) return rc;
-    comm_release(ctx);
+static int comm_init_impl(odise_hip_ctx* ctx, const void* id128, int rank, int world) {
     ODISE_CHECK_HIP(hipSetDevice(ctx->device));
     Comm* c = new Comm();
-    ctx->comm = c;
+    ctx->comm = c;   // owned by the context from here on: the caller releases it on any failure below
     c->rank = rank;
     c->world = world;
     ODISE_CHECK_HIP(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
@@ -123,6 +119,16 @@ extern "C" int odise_hip_comm_init(odise_hip_ctx* ctx, const void* id128, int ra
     memcpy(&id, id128, sizeof(id));
     ODISE_CHECK_NCCL(g_rccl.CommInitRank(&c->comm, world, id, rank));
     return ODISE_OK;
+}
+
+extern "C" int odise_hip_comm_init(odise_hip_ctx* ctx, const void* id128, int rank, int world) {
+    ODISE_REQUIRE(ctx && id128, "comm_init: null argument");
+    ODISE_REQUIRE(world >= 1 && rank >= 0 && rank < world, "comm_init: rank %d / world %d", rank, world);
+    if (int rc = rccl_load()) return rc;
+    comm_release(ctx);
+    const int rc = comm_init_impl(ctx, id128, rank, world);
+    if (rc != ODISE_OK) comm_release(ctx);   // never leave a half-built communicator behind: comm_of() only tests ctx->comm
+    return rc;
 }
 
 extern "C" int odise_hip_comm_destroy(odise_hip_ctx* ctx) {

@@ -232,6 +232,7 @@ struct HeadOutputs {
     const float* class_logits;  // [B, Q, 2] learned (object, no-object) logits of the caption variant's class_embed, or nullptr
 };
 int head_outputs(ModelStore* ms, HeadOutputs* out);
+void maskgen_invalidate_outputs(ModelStore* ms);   // the arena was reallocated: outputs of earlier backbone / head calls are gone
 
 // gemm.hip / norm.hip internals used by Exec
 int conv_forced(odise_hip_ctx* ctx, const odise_conv_desc* d, int force_tile, int force_split, float* gn_stats, int* stats_blocks);

@@ -59,13 +59,36 @@ struct MaskGenModel {
     NormW pool_ln, post_ln;
     float logit_scale = 0.f;
     int Q = 100, dec_heads = 8;
-    // caches keyed by feature-map shape
-    int pe_h[4] = {0, 0, 0, 0}, pe_w[4] = {0, 0, 0, 0};
-    float* pe[4] = {nullptr, nullptr, nullptr, nullptr};  // sine PE [h*w, C] for the 3 transformer levels (+ spare)
+    // Per-size device tables, kept in small LRU caches keyed by the EXACT shapes: a dataset evaluation sees many aspect ratios, and every
+    // size used to cost a fresh hipMalloc that was never freed (40 MB of positional tables per size change at 1024^2).  A hit costs nothing;
+    // a miss uploads one set and, beyond kSizeCache entries, frees the least recently used one (after a stream sync: queued kernels may
+    // still read it).  `pe` / `enc_pos_all` / `boxes_dev` point into the active entries.
+    static const int kSizeCache = 8;
+    struct PeEntry {
+        int hs[3] = {0, 0, 0}, ws[3] = {0, 0, 0};
+        float* pe[3] = {nullptr, nullptr, nullptr};
+        float* all = nullptr;
+        uint64_t stamp = 0;
+    };
+    struct BoxEntry {
+        int H = 0, W = 0, K = 0;
+        int* dev = nullptr;
+        uint64_t stamp = 0;
+    };
+    std::vector<PeEntry> pe_cache;
+    std::vector<BoxEntry> box_cache;
+    uint64_t size_clock = 0;
+    float* pe[4] = {nullptr, nullptr, nullptr, nullptr};  // sine PE [h*w, C] for the 3 transformer levels (+ spare) of the active entry
     float* enc_pos_all = nullptr;                         // [Lq, C] = PE + encoder level_embed
-    int enc_pos_key = 0;
     int* boxes_dev = nullptr;  // [4 groups + image][K][2]
-    int boxes_key_h = 0, boxes_key_w = 0, boxes_K = 0;
+    int boxes_K = 0;
+    void drop_size_caches() {   // the tables derive from the weights (level_embed): a rebuilt model starts empty
+        for (auto& e : pe_cache) { for (float* p : e.pe) (void)hipFree(p); (void)hipFree(e.all); }
+        for (auto& e : box_cache) (void)hipFree(e.dev);
+        pe_cache.clear(); box_cache.clear();
+        pe[0] = pe[1] = pe[2] = pe[3] = nullptr; enc_pos_all = nullptr; boxes_dev = nullptr; boxes_K = 0;
+    }
+    ~MaskGenModel() { drop_size_caches(); }
     // outputs of the last calls (arena)
     Act feats[4];              // s2..s5 NHWC fp16
     f16* pred_masks = nullptr;   // [B, Q, H4*W4] logits
@@ -153,7 +176,8 @@ static int maskgen_build_head(odise_hip_ctx* ctx) {
     g->C = g->in_proj[0].cout;
     const int C = g->C;
     ODISE_TRY(pk.vec_f32("transformer.level_embed", &g->enc_level_embed, 3 * C));
-    g->enc_pos_key = 0;  // PE + level_embed table is derived from these weights: a rebuilt head must not reuse the previous model's
+    ODISE_CHECK_HIP(hipStreamSynchronize(ctx->stream));
+    g->drop_size_caches();  // PE + level_embed tables are derived from these weights: a rebuilt head must not reuse the previous model's
     g->enc_layers.clear();
     for (int i = 0;; ++i) {
         const std::string k = "transformer.encoder.layers." + std::to_string(i);
@@ -254,14 +278,6 @@ static void sine_pe(int h, int w, int npf, std::vector<float>& out) {
         }
 }
 
-static int upload_new(odise_hip_ctx* ctx, ModelStore* ms, const void* host, size_t bytes, void** dev) {
-    ODISE_CHECK_HIP(hipStreamSynchronize(ctx->stream));
-    ODISE_CHECK_HIP(hipMalloc(dev, bytes));
-    ms->dev_allocs.push_back(*dev);
-    ODISE_CHECK_HIP(hipMemcpy(*dev, host, bytes, hipMemcpyHostToDevice));
-    return ODISE_OK;
-}
-
 // ---- BottleneckBlock: 1x1+GN+ReLU -> 3x3+GN+ReLU -> 1x1+GN ; ReLU(out + shortcut) (+ accum of the stride group) ----------
 static int run_bottleneck(Exec& ex, const BottleneckW& w, const Act& x, const Act* accum, Act& out) {
     ODISE_TRY(ex.alloc(out, x.n, x.h, x.w, w.c3.cout));
@@ -309,13 +325,36 @@ static int backbone_forward(odise_hip_ctx* ctx, const float* image, int B, int H
             boxes.push_back(std::max(x2 - cs, 0));
         }
     const int K = (int)boxes.size() / 2;
-    if (g->boxes_key_h != H || g->boxes_key_w != W) {
-        std::vector<int> all;  // [5][K][2]: image pixels, then s2..s5 feature pixels
-        for (int k = 0; k < 2 * K; ++k) all.push_back(boxes[k]);
-        for (int gi = 0; gi < 4; ++gi)
-            for (int k = 0; k < 2 * K; ++k) all.push_back(boxes[k] / kGroupStride[gi]);
-        ODISE_TRY(upload_new(ctx, ms, all.data(), all.size() * sizeof(int), (void**)&g->boxes_dev));
-        g->boxes_key_h = H; g->boxes_key_w = W; g->boxes_K = K;
+    {
+        MaskGenModel::BoxEntry* hit = nullptr;
+        for (auto& e : g->box_cache)
+            if (e.H == H && e.W == W) hit = &e;
+        if (!hit) {
+            std::vector<int> all;  // [5][K][2]: image pixels, then s2..s5 feature pixels
+            for (int k = 0; k < 2 * K; ++k) all.push_back(boxes[k]);
+            for (int gi = 0; gi < 4; ++gi)
+                for (int k = 0; k < 2 * K; ++k) all.push_back(boxes[k] / kGroupStride[gi]);
+            ODISE_CHECK_HIP(hipStreamSynchronize(ctx->stream));   // queued kernels may still read the entry about to be evicted
+            if ((int)g->box_cache.size() >= MaskGenModel::kSizeCache) {
+                size_t lru = 0;
+                for (size_t i = 1; i < g->box_cache.size(); ++i) if (g->box_cache[i].stamp < g->box_cache[lru].stamp) lru = i;
+                (void)hipFree(g->box_cache[lru].dev);
+                g->box_cache.erase(g->box_cache.begin() + lru);
+            }
+            MaskGenModel::BoxEntry e;
+            e.H = H; e.W = W; e.K = K;
+            ODISE_CHECK_HIP(hipMalloc((void**)&e.dev, all.size() * sizeof(int)));
+            if (hipMemcpy(e.dev, all.data(), all.size() * sizeof(int), hipMemcpyHostToDevice) != hipSuccess) {
+                (void)hipFree(e.dev);
+                set_error("backbone_forward: uploading the window table failed");
+                return ODISE_ERR_HIP;
+            }
+            g->box_cache.push_back(e);
+            hit = &g->box_cache.back();
+        }
+        hit->stamp = ++g->size_clock;
+        g->boxes_dev = hit->dev;
+        g->boxes_K = hit->K;
     }
     ODISE_TRY(unet_prepare_timestep(ctx, ms, ms->unet, B * K, 0));
     size_t need = extractor_arena_bytes(B * K, S, S) + (size_t)B * K * 3 * S * S * 4;
@@ -405,24 +444,50 @@ struct PixDec {
 
 // sine positional tables of the three transformer levels (shared by the pixel decoder's encoder and the predictor)
 static int ensure_pe_tables(odise_hip_ctx* ctx, ModelStore* ms, MaskGenModel* g, const int hs[3], const int ws[3]) {
+    (void)ms;
     const int C = g->C;
-    int starts[3], Lq = 0;
-    for (int l = 0; l < 3; ++l) { starts[l] = Lq; Lq += hs[l] * ws[l]; }
-    const int key = (hs[0] << 20) ^ (ws[0] << 10) ^ hs[2] ^ (ws[2] << 5);
-    if (g->enc_pos_key != key || !g->enc_pos_all) {
+    MaskGenModel::PeEntry* hit = nullptr;
+    for (auto& e : g->pe_cache) {
+        bool same = true;
+        for (int l = 0; l < 3; ++l) same = same && e.hs[l] == hs[l] && e.ws[l] == ws[l];
+        if (same) hit = &e;
+    }
+    if (!hit) {
+        int starts[3], Lq = 0;
+        for (int l = 0; l < 3; ++l) { starts[l] = Lq; Lq += hs[l] * ws[l]; }
         std::vector<float> all((size_t)Lq * C), lvl, emb((size_t)3 * C, 0.f);
-        ODISE_CHECK_HIP(hipStreamSynchronize(ctx->stream));
+        ODISE_CHECK_HIP(hipStreamSynchronize(ctx->stream));   // also: queued kernels may still read the entry about to be evicted
         if (g->enc_level_embed) ODISE_CHECK_HIP(hipMemcpy(emb.data(), g->enc_level_embed, emb.size() * 4, hipMemcpyDeviceToHost));
+        if ((int)g->pe_cache.size() >= MaskGenModel::kSizeCache) {
+            size_t lru = 0;
+            for (size_t i = 1; i < g->pe_cache.size(); ++i) if (g->pe_cache[i].stamp < g->pe_cache[lru].stamp) lru = i;
+            for (float* p : g->pe_cache[lru].pe) (void)hipFree(p);
+            (void)hipFree(g->pe_cache[lru].all);
+            g->pe_cache.erase(g->pe_cache.begin() + lru);
+        }
+        MaskGenModel::PeEntry e;
+        auto fail = [&](const char* what) {
+            for (float* p : e.pe) (void)hipFree(p);
+            (void)hipFree(e.all);
+            set_error("positional tables: %s failed", what);
+            return ODISE_ERR_HIP;
+        };
         for (int l = 0; l < 3; ++l) {
+            e.hs[l] = hs[l]; e.ws[l] = ws[l];
             sine_pe(hs[l], ws[l], C / 2, lvl);
-            ODISE_TRY(upload_new(ctx, ms, lvl.data(), lvl.size() * 4, (void**)&g->pe[l]));
-            g->pe_h[l] = hs[l]; g->pe_w[l] = ws[l];
+            if (hipMalloc((void**)&e.pe[l], lvl.size() * 4) != hipSuccess) return fail("hipMalloc");
+            if (hipMemcpy(e.pe[l], lvl.data(), lvl.size() * 4, hipMemcpyHostToDevice) != hipSuccess) return fail("hipMemcpy");
             for (size_t p = 0; p < (size_t)hs[l] * ws[l]; ++p)
                 for (int c = 0; c < C; ++c) all[((size_t)starts[l] + p) * C + c] = lvl[p * C + c] + emb[(size_t)l * C + c];
         }
-        ODISE_TRY(upload_new(ctx, ms, all.data(), all.size() * 4, (void**)&g->enc_pos_all));
-        g->enc_pos_key = key;
+        if (hipMalloc((void**)&e.all, all.size() * 4) != hipSuccess) return fail("hipMalloc");
+        if (hipMemcpy(e.all, all.data(), all.size() * 4, hipMemcpyHostToDevice) != hipSuccess) return fail("hipMemcpy");
+        g->pe_cache.push_back(e);
+        hit = &g->pe_cache.back();
     }
+    hit->stamp = ++g->size_clock;
+    for (int l = 0; l < 3; ++l) g->pe[l] = hit->pe[l];
+    g->enc_pos_all = hit->all;
     return ODISE_OK;
 }
 
@@ -668,6 +733,13 @@ int head_outputs(ModelStore* ms, HeadOutputs* out) {
     out->logit_scale = g->logit_scale;
     out->class_logits = g->class_logits;
     return ODISE_OK;
+}
+
+void maskgen_invalidate_outputs(ModelStore* ms) {
+    MaskGenModel* g = ms->maskgen;
+    if (!g) return;
+    g->pred_masks = nullptr; g->mask_embed = nullptr; g->mask_pooled = nullptr; g->class_logits = nullptr;
+    for (Act& f : g->feats) f.p = nullptr;
 }
 
 }  // namespace odise

@@ -45,6 +45,11 @@ class FeatureExtractorBackbone(nn.Module):
         super().__init__()
         if isinstance(backbone_in_size, int) or tuple(backbone_in_size) != (512, 512) or num_res_blocks != 1 or (min_stride, max_stride) != (4, 32):
             raise NotImplementedError("libodise_hip implements the released configuration: 512x512 slide windows, one BottleneckBlock per tap, strides 4..32")
+        if not slide_training:
+            # feature_extractor.py:197-203: without slide_training the inference window is the image's uncapped short side, resized down to
+            # 512x512 (one huge window for a 1024x1024 picture) - different features from the window = min(512, short side) rule the library
+            # implements; both released configurations set slide_training=True (configs/common/models/odise_with_label.py:28)
+            raise NotImplementedError("libodise_hip implements slide_training=True (window = min(512, short side)), the released configurations' setting")
         self.feature_extractor = feature_extractor
         self.use_checkpoint = use_checkpoint
         self.feature_projections = nn.ModuleList(nn.Sequential(_Bottleneck(d, projection_dim, projection_dim // 4)) for d in feature_extractor.feature_dims)

@@ -44,6 +44,7 @@ class HipFeatureExtractor:
         check(lib.odise_hip_extractor_build(ctx.h), "extractor_build")
         check(lib.odise_hip_clear_host_weights(ctx.h), "clear_host_weights")
         self.num_tensors = n
+        ctx.model_owner = self
 
     def run_nhwc(self, image: DeviceArray):
         """Hot-path call: image [B,3,H,W] f32 on the device; returns ([ptr]*8, [(n,c,h,w)]*8) of fp16 NHWC taps in the arena."""

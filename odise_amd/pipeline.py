@@ -52,6 +52,7 @@ class HipODISE:
         q, c = C.c_int(), C.c_int()
         check(lib.odise_hip_maskgen_info(ctx.h, C.byref(q), C.byref(c), None), "maskgen_info")
         self.num_queries, self.hidden_dim = q.value, c.value
+        ctx.model_owner = self
 
     # ---- FeatureExtractorBackbone.forward -----------------------------------------------------------------------------------
     def backbone_device(self, image: DeviceArray, want_outputs: bool = True):
@@ -105,16 +106,7 @@ class HipCategoryODISE(HipODISE):
     def __init__(self, ctx: Context, state, semantic_on=True, panoptic_on=True, instance_on=True, object_mask_threshold=0.0,
                  overlap_threshold=0.8, test_topk_per_image=100, size_divisibility=64):
         super().__init__(ctx, {k: v for k, v in state.items()})
-        # category_head weights are loaded through the same store: re-register them (the store was cleared after build)
-        for key in self.HEAD_KEYS:
-            val = state[key]
-            if hasattr(val, "detach"):
-                val = val.detach().cpu().numpy()
-            arr = np.ascontiguousarray(val, dtype=np.float32)
-            shape = (C.c_int64 * max(arr.ndim, 1))(*arr.shape)
-            check(ctx.lib.odise_hip_load_weight(ctx.h, key.encode(), arr.ctypes.data_as(C.POINTER(C.c_float)), shape, arr.ndim), key)
-        check(ctx.lib.odise_hip_classify_build(ctx.h), "classify_build")
-        check(ctx.lib.odise_hip_clear_host_weights(ctx.h), "clear_host_weights")
+        self.load_category_head(state)
         self.semantic_on, self.panoptic_on, self.instance_on = semantic_on, panoptic_on, instance_on
         self.semantic_argmax = False          # True: "sem_seg_argmax" int32 [h,w] instead of "sem_seg" [K,h,w] (never materialised)
         self.object_mask_threshold, self.overlap_threshold = object_mask_threshold, overlap_threshold
@@ -126,6 +118,22 @@ class HipCategoryODISE(HipODISE):
         self._alpha, self._beta = 0.3, 0.7
         self._banks, self._vocab_cache = None, {}
         self._pool = {}
+
+    def load_category_head(self, state) -> None:
+        """(Re)load the classification head's own weights - `category_head.text_proj.*`, `category_head.null_embed` (CaptionODISE:
+        `word_head.text_proj.*`) - and rebuild the stage; the mask generator and the frozen towers are untouched.  The device text banks
+        are derived from these weights, so the active vocabulary has to be set again afterwards."""
+        ctx = self.ctx
+        for key in self.HEAD_KEYS:
+            val = state[key]
+            if hasattr(val, "detach"):
+                val = val.detach().cpu().numpy()
+            arr = np.ascontiguousarray(val, dtype=np.float32)
+            shape = (C.c_int64 * max(arr.ndim, 1))(*arr.shape)
+            check(ctx.lib.odise_hip_load_weight(ctx.h, key.encode(), arr.ctypes.data_as(C.POINTER(C.c_float)), shape, arr.ndim), key)
+        check(ctx.lib.odise_hip_classify_build(ctx.h), "classify_build")
+        check(ctx.lib.odise_hip_clear_host_weights(ctx.h), "clear_host_weights")
+        self.num_classes, self._banks, self.test_labels = 0, None, None
 
     def set_vocabulary(self, cat_text, clip_text, group_sizes, overlap, thing_ids, alpha=0.3, beta=0.7):
         """cat_text / clip_text: [K_tot, dim] CLIP text embeddings of the category_head / clip_head prompt sets."""

@@ -80,6 +80,9 @@ class Context:
         check(self.lib.odise_hip_create(C.c_int(device), C.byref(h)), "create")
         self.h = h
         self.device = device
+        # A context holds ONE model (the library's weight store is per context): the host wrapper that loaded weights last registers itself
+        # here, so long-lived holders of a wrapper (test fixtures, servers swapping models) can tell whether theirs is still the resident one.
+        self.model_owner = None
 
     def close(self):
         if self.h:

@@ -43,6 +43,7 @@ class HipUNet:
         check(lib.odise_hip_unet_build(ctx.h), "unet_build")
         check(lib.odise_hip_clear_host_weights(ctx.h), "clear_host_weights")
         self.num_tensors = n
+        ctx.model_owner = self
         if use_graph:
             self.use_graph(True)
 

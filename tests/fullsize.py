@@ -9,8 +9,12 @@ query's embedding minus the mean embedding (plus seeded noise), mapped back thro
 the null embedding points at a handful of queries.  Labels then spread over ~65 classes, things and stuff, a third of the queries
 labelled null, several queries per stuff class, and the top-2 margins cover 0.01 .. 0.9.  Everything is seeded and a function of the oracle alone.
 
-The oracle results can be cached under tests/.oracle_cache (git-ignored; travels with gpurun snapshots) - the cache only saves CPU
-minutes, tests recompute when it is absent."""
+One head serves every size and vocabulary: its mask logits are centred ONCE, on the 1024x1024 reference image (build_models), so
+tests of different sizes / vocabularies may share one device model and no later call mutates the weights.
+
+The oracle passes can be cached under tests/.oracle_cache (a developer convenience: git-ignored AND gpurun-ignored, so the GPU box always
+recomputes the oracle itself).  Every cache file carries a digest of the input image and of the weights it was computed with; a file whose
+digest does not match the current inputs is ignored and recomputed."""
 import hashlib
 import math
 import os
@@ -27,7 +31,7 @@ from oracle.m2f import SemSegHead, init_synthetic_
 
 FEATURE_DIMS = [512, 512, 2560, 1920, 960, 640, 512, 512]   # enc5, enc7, u2, u5, u8, u11, dec2, dec5 (ldm.py:284-346)
 CACHE = os.path.join(os.path.dirname(os.path.abspath(__file__)), ".oracle_cache")
-VERSION = "v6"
+VERSION = "v7"
 
 
 def image_u8(h, w, seed=0):
@@ -39,23 +43,85 @@ def image_u8(h, w, seed=0):
     return (x[0] * 255).round().to(torch.uint8)
 
 
-_MEMO = {}     # one oracle pass per pytest session: test_gpu_fullsize.py and test_gpu_dropin.py share it
+_MEMO = {}     # one oracle pass per pytest session: test_gpu_fullsize*.py and test_gpu_dropin.py share it
 
 
-def build_models(num_classes):
-    if ("models", num_classes) in _MEMO:
-        return _MEMO[("models", num_classes)]
+def _sample_digest(h, name, t):
+    a = t.detach().reshape(-1)
+    h.update(name.encode())
+    h.update(str(tuple(t.shape)).encode())
+    h.update(a[:: max(1, a.numel() // 4096)].double().numpy().tobytes())
+
+
+def weights_digest(ext, bb, head):
+    """sha256 over (name, shape, ~4096 strided samples) of every tensor the oracle pass depends on."""
+    h = hashlib.sha256()
+    for k, v in sorted(ext.export_state().items()):
+        _sample_digest(h, k, torch.as_tensor(v))
+    for k, v in sorted(bb.feature_projections.state_dict().items()):
+        _sample_digest(h, "proj." + k, v)
+    for k, v in sorted(head.state_dict().items()):
+        _sample_digest(h, "head." + k, v)
+    return h.hexdigest()
+
+
+def _cached(tag, digest, fn, use_cache=True):
+    """Memo -> (digest-checked) file cache -> compute.  `digest` binds the entry to its inputs and weights."""
+    key = ("cache", tag, digest)
+    if key in _MEMO:
+        return _MEMO[key]
+    path = os.path.join(CACHE, f"{tag}_{VERSION}.npz")
+    out = None
+    if use_cache and os.path.exists(path):
+        z = np.load(path)
+        if "__digest__" in z.files and str(z["__digest__"]) == digest:
+            out = {k: torch.from_numpy(z[k]) for k in z.files if k != "__digest__"}
+    if out is None:
+        with torch.no_grad():
+            out = fn()
+        if use_cache and os.environ.get("ODISE_ORACLE_CACHE_WRITE"):
+            os.makedirs(CACHE, exist_ok=True)
+            np.savez(path, __digest__=np.asarray(digest), **{k: v.numpy() for k, v in out.items()})
+    _MEMO[key] = out
+    return out
+
+
+def features(ext, bb, size, seed=0):
+    """Oracle backbone features of the seeded size x size image (size is a multiple of 64: no padding)."""
+    if ("wd_bb",) not in _MEMO:   # the backbone's weights never change: digest once
+        h = hashlib.sha256()
+        for k, v in sorted(ext.export_state().items()):
+            _sample_digest(h, k, torch.as_tensor(v))
+        for k, v in sorted(bb.feature_projections.state_dict().items()):
+            _sample_digest(h, "proj." + k, v)
+        _MEMO[("wd_bb",)] = h.hexdigest()
+    img = image_u8(size, size, seed)
+    digest = hashlib.sha256(_MEMO[("wd_bb",)].encode() + img.numpy().tobytes()).hexdigest()
+    return img, _cached(f"feats_{size}_{seed}", digest, lambda: bb(img.float()[None] / 255.0))
+
+
+def build_models(num_classes=133):
+    """-> (extractor, backbone, head) of the full-size model, seeded.  `num_classes` is accepted for call-site symmetry only: no weight
+    of the label model depends on it (the class head is the parameter-free PseudoClassEmbed, odise.py:1273-1307)."""
+    if "models" in _MEMO:
+        return _MEMO["models"]
     ext = ImplicitCaptionerExtractor()
     bb = FeatureExtractorBackbone(ext, FEATURE_DIMS)
-    head = init_synthetic_(SemSegHead(num_classes=num_classes), branch_gain=0.3)
+    head = init_synthetic_(SemSegHead(num_classes=133), branch_gain=0.3)
     with torch.no_grad():   # the learned temperature at its clamp (odise.py:1013 clamps exp(logit_scale) at 100): class distributions as peaked as a trained model's
         head.predictor.post_mask_embed.logit_scale.fill_(math.log(100.0))
-    _MEMO[("models", num_classes)] = (ext, bb, head)
+    _, feats = features(ext, bb, 1024, 0)
+    with torch.no_grad():
+        centre_mask_logits(head, feats)
+    _MEMO["models"] = (ext, bb, head)
     return ext, bb, head
 
 
-def spread_vocabulary(heads: om.OpenVocabHeads, mask_embed, clip_embed, seed=5, null_queries=6, null_bias=0.07):
-    """Overwrite the text banks / null embedding of `heads` (see the module docstring).  mask_embed [Q,256], clip_embed [Q,768]."""
+def spread_vocabulary(heads: om.OpenVocabHeads, mask_embed, clip_embed, seed=5, null_queries=6, null_bias=0.07, anchored=None):
+    """Overwrite the text banks / null embedding of `heads` (see the module docstring).  mask_embed [Q,256], clip_embed [Q,768].
+    `anchored`: number of classes that point at a query (None = all).  A vocabulary much larger than the number of queries (A-847) would
+    otherwise put ~9 near-identical classes on every query - every decision a near-tie; like in a real image, most of its classes are then
+    absent: a seeded subset spread over the whole id range is anchored, the other classes' strings are unrelated directions."""
     g = torch.Generator().manual_seed(seed)
     Q = mask_embed.shape[0]
     sizes = heads.group_sizes
@@ -74,11 +140,22 @@ def spread_vocabulary(heads: om.OpenVocabHeads, mask_embed, clip_embed, seed=5, 
     anchor1 = torch.tensor([int(perm[(k * 3) % (Q - null_queries)]) for k in range(Kc)])      # the last `null_queries` of perm anchor no class
     other = perm[torch.randint(0, Q - null_queries, (Kc,), generator=g)]
     anchor2 = torch.where(torch.rand(Kc, generator=g) < 0.7, anchor1, other)
+    present = torch.ones(Kc, dtype=torch.bool)
+    if anchored is not None and anchored < Kc:
+        present[:] = False
+        chosen = torch.randperm(Kc, generator=g)[:anchored]
+        present[chosen] = True
+        for j, k in enumerate(sorted(chosen.tolist())):                                       # the present classes share the queries evenly
+            anchor1[k] = int(perm[(j * 3) % (Q - null_queries)])
+            if anchor2[k] != other[k]:
+                anchor2[k] = anchor1[k]
     t1, t2 = [], []
     for k, n in enumerate(sizes):
         for _ in range(n):
-            t1.append(d1[anchor1[k]] + 0.5 * torch.randn(d1.shape[1], generator=g, dtype=torch.float64) / d1.shape[1] ** 0.5)
-            t2.append(d2[anchor2[k]] + 0.5 * torch.randn(d2.shape[1], generator=g, dtype=torch.float64) / d2.shape[1] ** 0.5)
+            n1 = torch.randn(d1.shape[1], generator=g, dtype=torch.float64) / d1.shape[1] ** 0.5
+            n2 = torch.randn(d2.shape[1], generator=g, dtype=torch.float64) / d2.shape[1] ** 0.5
+            t1.append(d1[anchor1[k]] + 0.5 * n1 if present[k] else 1.1 * n1)
+            t2.append(d2[anchor2[k]] + 0.5 * n2 if present[k] else 1.1 * n2)
     t1, t2 = off_mean(torch.stack(t1), mu1), off_mean(torch.stack(t2), mu2)
     nullq = perm[-null_queries:]
     tn = off_mean(F.normalize(d1[nullq].sum(0), dim=0)[None], mu1) + null_bias * mu1   # a share of the mean direction lifts the null logit of EVERY query
@@ -110,44 +187,28 @@ def centre_mask_logits(head, feats, positive_fraction=0.15, rounds=2):
         hook.remove()
 
 
+def category_head_state(heads):
+    """The classification head's own weights (odise.py:1236-1241).  The null embedding depends on the image the vocabulary was spread over
+    (spread_vocabulary), not on the vocabulary's size."""
+    return {"category_head.text_proj.weight": heads.text_proj.weight.detach(), "category_head.text_proj.bias": heads.text_proj.bias.detach(),
+            "category_head.null_embed": heads.null_embed.detach()}
+
+
 def export_state(ext, bb, head, heads):
     state = ext.export_state()
     state.update({"backbone.feature_projections." + k: v for k, v in bb.feature_projections.state_dict().items()})
     state.update({"sem_seg_head." + k: v for k, v in head.state_dict().items()})
-    state["category_head.text_proj.weight"] = heads.text_proj.weight.detach()
-    state["category_head.text_proj.bias"] = heads.text_proj.bias.detach()
-    state["category_head.null_embed"] = heads.null_embed.detach()
+    state.update(category_head_state(heads))
     return state
 
 
-def _cache_path(tag):
-    return os.path.join(CACHE, f"{tag}_{VERSION}.npz")
-
-
-def reference(bb, head, ext, size, num_classes, num_strings, seed=0, use_cache=True):
-    """Oracle pass over one size x size image: features, head outputs, MaskCLIP embedding; then the spread vocabulary and mask_cls.
-    Returns (img_u8, heads, dict of torch tensors)."""
-    key = ("ref", id(head), size, num_classes, num_strings, seed)
-    if key in _MEMO:
-        return _MEMO[key]
-    img = image_u8(size, size, seed)
-    cat, clp, sizes, overlap = synthetic_vocabulary(num_classes, num_strings, 768)
-    heads = om.OpenVocabHeads(ext.clip, [int(s) for s in sizes], projection_dim=256, overlap=torch.from_numpy(overlap.astype(bool)))
+def head_reference(bb, head, ext, size, seed=0, use_cache=True):
+    """Vocabulary-independent part of the oracle pass over one size x size image: backbone features, head outputs, MaskCLIP embedding."""
+    img, feats = features(ext, bb, size, seed)
+    if ("wd",) not in _MEMO:
+        _MEMO[("wd",)] = weights_digest(ext, bb, head)
+    digest = hashlib.sha256(_MEMO[("wd",)].encode() + img.numpy().tobytes()).hexdigest()
     img01 = img.float()[None] / 255.0
-
-    def cached(tag, fn):
-        path = _cache_path(tag)
-        if use_cache and os.path.exists(path):
-            z = np.load(path)
-            return {k: torch.from_numpy(z[k]) for k in z.files}
-        out = fn()
-        if use_cache and os.environ.get("ODISE_ORACLE_CACHE_WRITE"):
-            os.makedirs(CACHE, exist_ok=True)
-            np.savez(path, **{k: v.numpy() for k, v in out.items()})
-        return out
-
-    feats = cached(f"feats_{size}_{seed}", lambda: bb(img01))                 # size is a multiple of 64: no padding
-    centre_mask_logits(head, feats)
 
     def run_head():
         out = head(feats)
@@ -155,25 +216,30 @@ def reference(bb, head, ext, size, num_classes, num_strings, seed=0, use_cache=T
         return {"pred_masks": out["pred_masks"], "mask_embed": out["mask_embed"], "mask_pooled_features": out["mask_pooled_features"],
                 "pred_logits": out["pred_logits"], "logit_scale": torch.as_tensor(float(out["logit_scale"])), "clip_embed": ce}
 
-    r = cached(f"head_{size}_{num_classes}_{seed}", run_head)
-    r = {**feats, **r}
+    r = dict(_cached(f"head_{size}_{seed}", digest, run_head, use_cache))
+    r.update(feats)
     r["logit_scale"] = float(r["logit_scale"])
-    spread_vocabulary(heads, r["mask_embed"][0], r["clip_embed"][0])
-    out = {"mask_embed": r["mask_embed"], "pred_masks": r["pred_masks"], "logit_scale": r["logit_scale"], "pred_logits": r["pred_logits"]}
-    # CategoryODISE.forward after the head (odise.py:285-323) with the MaskCLIP embedding computed above
+    return img, r
+
+
+def reference(bb, head, ext, size, num_classes, num_strings, seed=0, use_cache=True):
+    """Oracle pass over one size x size image (head_reference), then the spread vocabulary of `num_classes` classes / `num_strings` prompt
+    strings and CategoryODISE.forward after the head (odise.py:285-323).  Returns (img_u8, heads, dict of torch tensors incl. mask_cls)."""
+    key = ("ref", size, num_classes, num_strings, seed)
+    if key in _MEMO:
+        return _MEMO[key]
+    img, r = head_reference(bb, head, ext, size, seed, use_cache)
+    r = dict(r)
+    cat, clp, sizes, overlap = synthetic_vocabulary(num_classes, num_strings, 768)
+    heads = om.OpenVocabHeads(ext.clip, [int(s) for s in sizes], projection_dim=256, overlap=torch.from_numpy(overlap.astype(bool)))
+    # at most ~2 present classes per (non-null) query: all of COCO-133 / ADE-150, a subset of the 847
+    spread_vocabulary(heads, r["mask_embed"][0], r["clip_embed"][0], anchored=None if num_classes <= 200 else 188)
     with torch.no_grad():
         text_embed = heads.text_proj(heads.text_embed)
         null_embed = heads.text_proj(heads.null_embed)
-        pred_logits = om.cal_pred_logits(out["mask_embed"], text_embed, null_embed, out["logit_scale"], heads.group_sizes)
+        pred_logits = om.cal_pred_logits(r["mask_embed"], text_embed, null_embed, r["logit_scale"], heads.group_sizes)
         clip_logits = om.mask_clip_pred_logits(r["clip_embed"], heads.clip_text_embed, heads.group_sizes)
         open_logits = om.pooling_clip_head(pred_logits[..., :-1], clip_logits, heads.category_overlapping_mask, heads.alpha, heads.beta)
         r["mask_cls"] = om.merge_with_null(pred_logits, open_logits)
     _MEMO[key] = (img, heads, r)
     return img, heads, r
-
-
-def state_digest(state):
-    h = hashlib.sha256()
-    for k in sorted(state):
-        h.update(k.encode())
-    return h.hexdigest()[:12]

@@ -23,8 +23,7 @@ import numpy as np
 import pytest
 import torch
 
-from fullsize import build_models, export_state, reference
-from odise_amd.pipeline import HipCategoryODISE
+from fullsize import build_models, category_head_state, reference
 from oracle import odise_model as om
 
 pytestmark = pytest.mark.gpu
@@ -32,20 +31,43 @@ torch.set_num_threads(min(32, torch.get_num_threads()))
 
 K, K_TOT = 133, 254
 THINGS = set(range(80))                     # COCO panoptic: contiguous ids 0..79 are things
+# vocabulary shapes of BASELINE configs[2] (COCO panoptic) and configs[3] (ADE20K-150: 150 classes / 403 prompt strings, 100 things)
+VOCABS = {"coco133": (133, 254, set(range(80))), "ade150": (150, 403, set(range(100)))}
 TAU_MASK = 2.5e-2    # bound on a REGULAR query's mask-logit error as a fraction of max|logit| (head alone: worst query 1.8e-2, 98 of 100 below 5.3e-3; see _mask_report)
 TAU_PROB = 3e-2      # bound on a class-probability error, absolute (measured 1.9e-2 at logit scale 100)
 
 
+def use_vocabulary(full, name):
+    """Switch the device model to vocabulary `name` (same image, same head outputs: only the text banks change - the null embedding, which
+    belongs to the model's weights, is identical for every vocabulary built by tests/fullsize.py on one image) and return
+    (heads, mask_cls reference, things, K)."""
+    k, k_tot, things = VOCABS[name]
+    ext, bb, head = build_models(k)
+    _, heads, r = reference(bb, head, ext, 1024, k, k_tot)
+    assert np.array_equal(heads.null_embed.detach().numpy(), full["heads"].null_embed.detach().numpy())
+    full["hip"].set_vocabulary(heads.text_embed.numpy(), heads.clip_text_embed.numpy(), heads.group_sizes, heads.category_overlapping_mask.numpy(), things,
+                               heads.alpha, heads.beta)
+    return heads, r["mask_cls"], things, k
+
+
 @pytest.fixture(scope="module")
-def full(ctx):
+def full(ctx, fullsize_model):
     ext, bb, head = build_models(K)
     img, heads, r = reference(bb, head, ext, 1024, K, K_TOT)
-    hip = HipCategoryODISE(ctx, export_state(ext, bb, head, heads), overlap_threshold=0.8)
+    hip = fullsize_model
+    hip.load_category_head(category_head_state(heads))
     hip.set_vocabulary(heads.text_embed.numpy(), heads.clip_text_embed.numpy(), heads.group_sizes, heads.category_overlapping_mask.numpy(), THINGS,
                        heads.alpha, heads.beta)
     feats = {k: r[k] for k in ("s2", "s3", "s4", "s5")}
     post = {ot: om.postprocess(r["mask_cls"], r["pred_masks"], (1024, 1024), [(1024, 1024)], [(1024, 1024)], K, THINGS, ot)[0] for ot in (0.8, 0.0)}
     return dict(heads=heads, hip=hip, img=img, ref=(feats, r, r["mask_cls"], post))
+
+
+@pytest.fixture()
+def coco(full):
+    """Tests that read the fixture's COCO-133 references run with that vocabulary active, whatever ran before them."""
+    use_vocabulary(full, "coco133")
+    return full
 
 
 def _rel(got, ref):
@@ -123,7 +145,8 @@ def test_head_full_size_from_reference_features(full):
     assert rep["iou_min"] > 0.93 and rep["iou_med"] > 0.985
 
 
-def test_classification_full_size(full, ctx):
+def test_classification_full_size(coco, ctx):
+    full = coco
     """CategoryEmbed + MaskCLIP (ViT-L/14@336, 100 mask tokens + 577 image tokens) + ensemble + null merge at K = 133 / 254 strings,
     on the ORACLE's backbone features replayed through the device head."""
     hip, img = full["hip"], full["img"]
@@ -149,25 +172,28 @@ def test_classification_full_size(full, ctx):
     assert decided.sum() >= 60 and same.sum() >= 95
 
 
-@pytest.mark.parametrize("overlap_threshold", [0.8, 0.0])   # evaluation config / demo config (demo.py:316-318)
-def test_end_to_end_contract(full, overlap_threshold):
+@pytest.mark.parametrize("vocab,overlap_threshold", [("coco133", 0.8), ("coco133", 0.0), ("ade150", 0.8)])   # evaluation config / demo config (demo.py:316-318) / configs[3] vocabulary
+def test_end_to_end_contract(full, vocab, overlap_threshold):
     """One `model(batched_inputs)` call at 1024x1024 against the oracle's: identical segments_info, labels / masks as in the module docstring."""
     hip, img = full["hip"], full["img"]
-    _, out_ref, cls_ref, post = full["ref"]
-    ref = post[overlap_threshold]
+    _, out_ref, _, _ = full["ref"]
+    heads, cls_ref, things, k = use_vocabulary(full, vocab)
+    ref = om.postprocess(cls_ref, out_ref["pred_masks"], (1024, 1024), [(1024, 1024)], [(1024, 1024)], k, things, overlap_threshold)[0]
     hip.overlap_threshold = overlap_threshold
     try:
         got = hip.forward([{"image": img, "height": 1024, "width": 1024}])[0]
     finally:
         hip.overlap_threshold = 0.8
+        use_vocabulary(full, "coco133")
     # ---- panoptic
     pan_ref, info_ref = ref["panoptic_seg"]
     pan, info = got["panoptic_seg"]
     agree = (pan == pan_ref.numpy()).mean()
-    print("segments", len(info), "ref", len(info_ref), "classes", sorted({s["category_id"] for s in info_ref}), "stuff", sum(not s["isthing"] for s in info_ref),
-          "panoptic pixel agreement", agree)
+    print("vocabulary", vocab, "segments", len(info), "ref", len(info_ref), "classes", sorted({s["category_id"] for s in info_ref}), "stuff",
+          sum(not s["isthing"] for s in info_ref), "panoptic pixel agreement", agree)
     # ---- semantic
     sem_ref = ref["sem_seg"].numpy()
+    assert got["sem_seg"].shape == sem_ref.shape == (k, 1024, 1024)
     serr = np.abs(got["sem_seg"] - sem_ref).max() / np.abs(sem_ref).max()
     same = got["sem_seg"].argmax(0) == sem_ref.argmax(0)
     sagree = same.mean()
@@ -181,8 +207,8 @@ def test_end_to_end_contract(full, overlap_threshold):
     s_ref = inst_ref["scores"].numpy()
     scores_flat = torch.softmax(cls_ref[0], -1)[:, :-1].flatten()
     top = scores_flat.topk(100, sorted=False).indices
-    q_ref, c_ref = (top // K).numpy(), (top % K).numpy()
-    keep = np.array([int(c) in THINGS for c in c_ref])
+    q_ref, c_ref = (top // k).numpy(), (top % k).numpy()
+    keep = np.array([int(c) in things for c in c_ref])
     key_ref = {(int(q), int(c)): i for i, (q, c) in enumerate(zip(q_ref[keep], c_ref[keep]))}
     key_got = {(int(q), int(c)): i for i, (q, c) in enumerate(zip(inst["query_index"], inst["pred_classes"]))}
     common = sorted(set(key_ref) & set(key_got))
@@ -196,11 +222,11 @@ def test_end_to_end_contract(full, overlap_threshold):
     assert info == info_ref, (info, info_ref)
     assert agree > 0.995
     # sem_seg = sum_q P[q,k] sigmoid(mask_q) carries the class-probability error; its per-pixel argmax is identical wherever the reference decides by
-    # more than that error, and the undecided rest (near-ties between two of the 133 scores) stays a small fraction
+    # more than that error, and the undecided rest (near-ties between two of the class scores) stays a small fraction
     assert serr < TAU_PROB and same[decided].all() and sagree > 0.98
     assert inst["pred_masks"].shape[1:] == (1024, 1024)
     for q, c in set(key_ref) ^ set(key_got):    # entries may only differ at the selection boundary of the top-k
-        assert abs(float(scores_flat[q * K + c]) - kth) < TAU_PROB, (q, c)
+        assert abs(float(scores_flat[q * k + c]) - kth) < TAU_PROB, (q, c)
     assert len(common) >= 0.9 * len(key_ref) and worst > 0.93 and worst_score < 2 * TAU_PROB
 
 

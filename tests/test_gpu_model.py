@@ -12,6 +12,7 @@ from oracle import odise_model as om
 from oracle.backbone import FeatureExtractorBackbone
 from oracle.ldm_extractor import ImplicitCaptionerExtractor
 from oracle.m2f import SemSegHead, init_synthetic_
+from margins import instance_keys
 
 pytestmark = pytest.mark.gpu
 torch.set_num_threads(min(16, torch.get_num_threads()))
@@ -96,19 +97,26 @@ def test_full_forward_matches_oracle(models, h, w, oh, ow):
     agree = (pan == pan_ref.numpy()).mean()
     print("panoptic pixel agreement", agree)
     assert agree > 0.995
-    # instances: compare by (class, query) key
-    inst_ref = ref["instances"]
-    assert got["instances"]["pred_masks"].shape[1:] == (oh, ow)
-    # top-k over Q*K near-tied synthetic scores: entries at the selection boundary may legitimately swap, so compare the class
-    # histogram with a small slack and the sorted score profile on the common length
-    from collections import Counter
-    cg, cr = Counter(got["instances"]["pred_classes"].tolist()), Counter(inst_ref["pred_classes"].tolist())
-    diff = sum((cg - cr).values()) + sum((cr - cg).values())
-    print("instances", sum(cg.values()), "ref", sum(cr.values()), "class histogram difference", diff)
-    assert diff <= max(2, 0.1 * sum(cr.values()))
-    sg, sr = np.sort(got["instances"]["scores"])[::-1], np.sort(inst_ref["scores"].numpy())[::-1]
-    n = min(len(sg), len(sr))
-    np.testing.assert_allclose(sg[:n], sr[:n], rtol=5e-2, atol=2e-3)
+    # instances (maskformer_model.py:344-380) by (query, class) key: the same entries as the reference's top-k wherever the k-th score is
+    # separated; an entry may only be missing / extra at the selection boundary; common entries carry the same mask and score
+    inst_ref, inst = ref["instances"], got["instances"]
+    assert inst["pred_masks"].shape[1:] == (oh, ow)
+    K = len(GROUPS)
+    key_ref, kth, scores_flat = instance_keys(ref_cls[0], K, THINGS, hip.test_topk_per_image)
+    key_got = {(int(q), int(c)): i for i, (q, c) in enumerate(zip(inst["query_index"], inst["pred_classes"]))}
+    assert len(key_got) == len(inst["query_index"]), "duplicate (query, class) entries"
+    common = sorted(set(key_ref) & set(key_got))
+    s_ref = inst_ref["scores"].numpy()
+    worst_iou, worst_score = 1.0, 0.0
+    for kk in common:
+        a, b = inst["pred_masks"][key_got[kk]] > 0.5, inst_ref["pred_masks"][key_ref[kk]].numpy() > 0.5
+        worst_iou = min(worst_iou, (a & b).sum() / max((a | b).sum(), 1))
+        worst_score = max(worst_score, abs(float(inst["scores"][key_got[kk]]) - float(s_ref[key_ref[kk]])))
+    boundary = [abs(float(scores_flat[q * K + c]) - kth) for q, c in set(key_ref) ^ set(key_got)]
+    print("instances", len(key_got), "ref", len(key_ref), "in common", len(common), "k-th class score", kth, "entries off the common set", len(boundary),
+          "their distance to the k-th score", max(boundary, default=0.0), "worst mask IoU", worst_iou, "worst score diff", worst_score)
+    assert all(d < 2e-2 for d in boundary), "an instance entry differs away from the selection boundary of the top-k"
+    assert len(common) >= 0.8 * len(key_ref) and worst_iou > 0.97 and worst_score < 2e-2
 
 
 def test_classification_stage(models, ctx):
@@ -143,6 +151,27 @@ def test_postprocess_x4_kernel_matches_generic(models, h, w):
     np.testing.assert_array_equal(fast["sem_seg"], gen["sem_seg"])
     np.testing.assert_array_equal(fast["instances"]["pred_masks"], gen["instances"]["pred_masks"])
     np.testing.assert_array_equal(fast["instances"]["scores"], gen["instances"]["scores"])
+
+
+@pytest.mark.parametrize("h,w,oh,ow", [(512, 512, 512, 512), (500, 502, 500, 502), (512, 704, 256, 352), (300, 400, 450, 600)])
+def test_fused_semantic_argmax_equals_argmax_of_the_score_tensor(models, h, w, oh, ow):
+    """`semantic_argmax_kernel` (the [K,h,w]-free form of maskformer_model.py:280-284 + the evaluator's `.argmax(0)`, what
+    `bench.py --semantic-only` runs) against the arg-max of the device's own score tensor: the same fp16 operands through the same MFMA
+    k order, so every pixel must agree bit for bit - x4 and generic resampling geometries, ragged widths, K not a multiple of 32, and the
+    first-maximum tie rule of `argmax`."""
+    _, _, _, hip = models
+    img = _image_u8(h, w, seed=5 + h)
+    batch = [{"image": img, "height": oh, "width": ow}]
+    scores = hip.forward(batch)[0]["sem_seg"]
+    hip.semantic_argmax = True
+    try:
+        fused = hip.forward(batch)[0]
+    finally:
+        hip.semantic_argmax = False
+    assert "sem_seg" not in fused and fused["sem_seg_argmax"].shape == (oh, ow) and fused["sem_seg_argmax"].dtype == np.int32
+    want = scores.argmax(0)
+    print("fused semantic arg-max", (oh, ow), "labels", np.unique(want).tolist(), "mismatches", int((fused["sem_seg_argmax"] != want).sum()))
+    np.testing.assert_array_equal(fused["sem_seg_argmax"], want)
 
 
 def test_panoptic_record_written_into_a_caller_owned_buffer(models):
