@@ -10,7 +10,11 @@ resident in HBM as uint8 [H,W,3] when the timed region starts; one "step" = one 
 instance tables (the API edge of the reference's model call) and the exchange step: every image's prediction record is all-gathered
 over RCCL by the library's own communicator on a second stream (a communicator of ONE rank at --gpus 1: the same code path).
 Weights are random-init tensors of the real architectures (SD-v1 UNet 859.5M, AutoencoderKL, CLIP ViT-L/14@336, ODISE heads 28M; no
-network for checkpoints); the vocabulary is a seeded random text bank of the real shape.
+network for checkpoints).  Random weights as drawn collapse the 100 queries onto one mask and one label, which would leave the decision
+kernels an empty table; before the timed region the set-up of the full-size parity tests is applied (odise_amd/synthetic.py: residual-
+branch gain 0.3 in the masked decoder, mask logits centred so that ~15 % are positive, text banks of the real shape spread over the
+queries' own embeddings as the device computes them on the first image), so that every image yields segments and instances - the run
+FAILS if it does not.
 
     python bench.py [--gpus N] [--steps K] [--warmup W] [--images B] [--size S] [--vocab coco133|ade150|ade847] [--semantic-only]
                     [--stage full|unet] [--no-cpu-baseline] [--no-inclusive]
@@ -18,9 +22,12 @@ network for checkpoints); the vocabulary is a seeded random text bank of the rea
 `--stage unet` runs BASELINE configs[1] (SD-UNet single-step feature extraction, `--images` = crops of 512x512).
 `--vocab ade150` = configs[3] shape (K=150 / 403 strings), `--vocab ade847 --size 1280 --semantic-only` = configs[4] (K=847 / 1342
 strings, 9 crops, semantic head only with the fused per-pixel argmax instead of the 5.5 GB [847,1280,1280] tensor).
-Multi-GPU: one process per GPU (torch.distributed.run); images are independent units sharded across ranks, no collective inside the
-model forward, one RCCL all-gather of prediction records per step inside the timed region; torch.distributed (gloo, CPU) only carries
-the communicator id, the barriers and the max-over-ranks of the timings.  Weak scaling: fixed images per GPU.  ONE JSON line on rank 0.
+Multi-GPU: one process per GPU; images are independent units sharded across ranks, no collective inside the model forward, one RCCL
+all-gather of prediction records per step inside the timed region; torch.distributed (gloo, CPU) only carries the communicator id, the
+barriers and the max-over-ranks of the timings.  `--gpus N` outside a launcher starts its N ranks itself (odise_amd/launch.py, like
+tools/train_net.py:390-399 does through detectron2's launch) and exits non-zero if any rank fails; under the driver's own
+`torch.distributed.run` the world size must equal N.  The line reports the RCCL communicator's size (`config.rccl_ranks`).  Weak scaling:
+fixed images per GPU.  ONE JSON line on rank 0's stdout (everything else - RCCL's own prints included - goes to stderr).
 """
 import argparse
 import json
@@ -79,33 +86,52 @@ def image_u8(size, seed):
 
 
 def cpu_baseline_full():
-    """Oracle restatement (kind='port') on the host cores, SURVEY.md 8d convention (1 warm-up + 3 timed passes), on a bounded sample:
-    ONE 512x512 crop through the feature extractor (CLIP + VAE encoder + UNet + truncated VAE decoder = 2.86 of the 3.10 TFLOP a crop
-    costs end to end; an image = 4 crops).  Two variants: `live` (the work whose results are used, what the device path executes) and
-    `literal` (the reference's forward as written, including the discarded UNet output block / VAE decoder tail, ldm.py:485-491,
-    515-516).  images/s = 1 / (4 x crop time): an upper bound of the CPU rate, heads and post-processing excluded."""
+    """Oracle restatement (kind='port') on the host cores over WHOLE 1024x1024 images, heads included: FeatureExtractorBackbone
+    (4 crops through CLIP + VAE encoder + UNet + truncated VAE decoder, projections, stitching) -> MaskFormerHead -> category logits +
+    MaskCLIP + ensemble -> semantic / panoptic / instance inference, fp32 torch.  One warm-up crop (allocator, thread pool), then two timed
+    whole-image passes of the LIVE path (the work whose results are used, what the device path executes); the LITERAL variant - the
+    reference's forward as written, including the discarded UNet output block / VAE decoder tail (ldm.py:485-491, 515-516) - is one timed
+    literal crop, scaled: literal image = live image + 4 x (literal crop - live crop)."""
     import torch
+    from odise_amd.synthetic import synthetic_vocabulary
+    from oracle import odise_model as om
+    from oracle.backbone import FeatureExtractorBackbone
     from oracle.ldm_extractor import ImplicitCaptionerExtractor
+    from oracle.m2f import SemSegHead, init_synthetic_
     cores = _threads()
     torch.set_num_threads(cores)
     ext = ImplicitCaptionerExtractor()
-    img = torch.from_numpy(image_u8(512, 0).transpose(2, 0, 1).astype(np.float32) / 255.0)[None]
-    with torch.no_grad():
-        ext(img)  # warm-up (allocator, thread pool)
-        t = []
-        for _ in range(3):
-            t0 = time.perf_counter()
-            ext(img)
-            t.append(time.perf_counter() - t0)
+    bb = FeatureExtractorBackbone(ext, [512, 512, 2560, 1920, 960, 640, 512, 512])
+    head = init_synthetic_(SemSegHead(num_classes=133), branch_gain=0.3)
+    _, _, sizes, overlap = synthetic_vocabulary(133, 254, 768)
+    heads = om.OpenVocabHeads(ext.clip, [int(v) for v in sizes], projection_dim=256, overlap=torch.from_numpy(overlap.astype(bool)))
+    things = set(range(80))
+    crop = torch.from_numpy(image_u8(512, 0).transpose(2, 0, 1).astype(np.float32) / 255.0)[None]
+
+    def whole_image(seed):
+        img = torch.from_numpy(image_u8(1024, seed).transpose(2, 0, 1).astype(np.float32) / 255.0)[None]
         t0 = time.perf_counter()
-        ext(img, run_dead_code=True)
-        t_lit = time.perf_counter() - t0
-    live = float(np.median(t))
-    return {"value": 1.0 / (4 * live), "unit": "images/s", "cores": cores, "kind": "port", "crop_seconds_live": t, "crop_seconds_literal": t_lit,
-            "value_literal": 1.0 / (4 * t_lit),
-            "sample": "one 512x512 crop (a quarter of a 1024x1024 image) through the fp32 torch CPU oracle of LdmImplicitCaptionerExtractor "
-                      "(92% of an image's work): 1 warm-up + 3 timed live passes (median) + 1 literal pass incl. the reference's dead code; "
-                      "images/s = 1 / (4 x crop time); heads and post-processing excluded"}
+        out = head(bb(img))
+        mask_cls = heads.classify(out, img)
+        res = om.postprocess(mask_cls, out["pred_masks"], (1024, 1024), [(1024, 1024)], [(1024, 1024)], 133, things, 0.8)[0]
+        return time.perf_counter() - t0, len(res["panoptic_seg"][1])
+
+    with torch.no_grad():
+        ext(crop)                                    # warm-up (allocator, thread pool)
+        t0 = time.perf_counter()
+        ext(crop)                                    # the live crop time the literal variant is scaled from
+        t_crop_live = time.perf_counter() - t0
+        t0 = time.perf_counter()
+        ext(crop, run_dead_code=True)
+        t_crop_lit = time.perf_counter() - t0
+        t_img = [whole_image(seed)[0] for seed in (0, 1)]
+    live = float(np.mean(t_img))
+    literal = live + 4.0 * max(0.0, t_crop_lit - t_crop_live)
+    return {"value": 1.0 / live, "unit": "images/s", "cores": cores, "kind": "port", "image_seconds_live": t_img, "crop_seconds_live": t_crop_live,
+            "crop_seconds_literal": t_crop_lit, "value_literal": 1.0 / literal,
+            "sample": "two whole 1024x1024 images (4 crops each), heads and post-processing included, through the fp32 torch CPU oracle of the "
+                      "live path (mean); one warm-up crop pair before; literal variant (incl. the reference's dead code) = live image + 4 x "
+                      "(literal crop - live crop) from one timed literal crop"}
 
 
 def cpu_baseline_unet():
@@ -147,7 +173,7 @@ def dominant_kernel(ctx):
     us = ctx.timer_stop() / it * 1e3
     flops = 2.0 * n * hw * hw * cout * 9 * cin
     traffic = None
-    for name in ("r02_dominant_conv_traffic.json", "r01_dominant_conv_traffic.json"):
+    for name in ("r03_dominant_conv_traffic.json", "r02_dominant_conv_traffic.json", "r01_dominant_conv_traffic.json"):
         tp = os.path.join(ROOT, "profiles", name)
         if os.path.exists(tp):
             with open(tp) as f:
@@ -193,16 +219,48 @@ def inclusive_rates(ctx, hip, u8, S, B, sizes, steps):
     return out
 
 
+def calibrated_model(ctx, first_image_u8, S, K, K_TOT, things, anchored):
+    """HipCategoryODISE on synthetic weights with NON-DEGENERATE decisions (module docstring; odise_amd/synthetic.py): branch gain, mask
+    logits centred from the device's own head outputs on `first_image_u8` (two rounds, each a reload of the 28 M-parameter head), text
+    banks spread over the device's own mask / MaskCLIP embeddings.  Everything here happens before the timed region."""
+    from odise_amd import synthetic as syn
+    from odise_amd.pipeline import HipCategoryODISE
+    state = syn.synthetic_state()
+    syn.apply_branch_gain(state)
+    hip = HipCategoryODISE(ctx, state, overlap_threshold=0.8)
+    state = {k: v for k, v in state.items() if k.startswith(("sem_seg_head.", "category_head."))}   # the frozen towers are on the device now
+    cat, clp, sizes, overlap = syn.synthetic_vocabulary(K, K_TOT, 768)
+    hip.set_vocabulary(cat, clp, sizes, overlap, things, 0.3, 0.7)              # provisional (random) banks: the calibration pass needs one
+    img01 = ctx.to_device(np.ascontiguousarray(first_image_u8.transpose(2, 0, 1)[None].astype(np.float32) / 255.0))
+
+    def head_pass():
+        hip.backbone_device(img01, want_outputs=False)
+        pm, me, _, _ = hip.head_device(None, 1, S // 4, S // 4)
+        return pm.numpy()[0], me.numpy()[0]
+
+    for _ in range(2):
+        pm, me = head_pass()
+        state["sem_seg_head.pixel_decoder.mask_features.bias"] = (state["sem_seg_head.pixel_decoder.mask_features.bias"]
+                                                                 + syn.mask_bias_shift(me, pm)).astype(np.float32)
+        hip.reload_head(state)
+    pm, me = head_pass()
+    _, ce = hip.classify_device(img01, want_clip_embed=True)
+    t1, t2, null = syn.spread_vocabulary(me, ce.numpy()[0], sizes, state["category_head.text_proj.weight"], state["category_head.text_proj.bias"],
+                                         anchored=anchored)
+    state["category_head.null_embed"] = null
+    hip.load_category_head(state)
+    hip.set_vocabulary(t1, t2, sizes, overlap, things, 0.3, 0.7)
+    img01.free()
+    return hip, float((pm > 0).mean())
+
+
 def main():
     args = parse()
-    # RCCL prints a version banner on stdout at communicator creation when NCCL_DEBUG asks for it (C stdio: it would land AFTER the JSON
-    # line at exit); this program's stdout carries exactly one line
+    from odise_amd import launch
+    launch.ensure_world(args.gpus)             # --gpus N outside a launcher: re-executes itself as N ranks and exits with their status
+    out_stream = launch.protect_stdout()       # fd 1 -> stderr from here on (RCCL prints through C stdio); the JSON line goes to out_stream
     os.environ["NCCL_DEBUG"] = os.environ.get("ODISE_NCCL_DEBUG", "WARN")
-    rank = int(os.environ.get("RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world > 1 and world != args.gpus:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    rank, world, local_rank = launch.world_from_env()
 
     import torch
     torch.set_num_threads(_threads())
@@ -217,8 +275,9 @@ def main():
 
     # Weights: random tensors of the real architecture's shapes (odise_amd/synthetic.py; no checkpoints, no network).  The oracle is
     # imported only by the cpu_baseline leg below.
-    from odise_amd.synthetic import synthetic_state, synthetic_vocabulary
+    from odise_amd.synthetic import synthetic_state
     check_exchange = None
+    rccl_ranks, positive_fraction = None, None
     if args.stage == "unet":
         from odise_amd.unet import HipUNet
         hip = HipUNet(ctx, synthetic_state(["model.diffusion_model."], strip="model.diffusion_model."), use_graph=True)
@@ -241,19 +300,23 @@ def main():
         from odise_amd.pipeline import HipCategoryODISE
         S = args.size
         K, K_TOT, N_THINGS = VOCABS[args.vocab]
-        state = synthetic_state()
-        hip = HipCategoryODISE(ctx, state, overlap_threshold=0.8)
+        u8 = [image_u8(S, rank * B + b) for b in range(B)]               # images shard across ranks: each rank has its own
+        # every rank calibrates on the SAME picture (seed 0): identical weights and text banks on all ranks, like a loaded checkpoint
+        hip, positive_fraction = calibrated_model(ctx, u8[0] if rank == 0 else image_u8(S, 0), S, K, K_TOT, set(range(N_THINGS)),
+                                                  None if K <= 200 else 188)
         if args.semantic_only:   # configs[4]: pano_open_d2_eval.py:127-133 switches the other heads off; the evaluator keeps argmax(0)
             hip.panoptic_on = hip.instance_on = False
             hip.semantic_argmax = True
-        cat, clp, sizes, overlap = synthetic_vocabulary(K, K_TOT, 768)
-        hip.set_vocabulary(cat, clp, sizes, overlap, set(range(N_THINGS)), 0.3, 0.7)
-        del state
-        u8 = [image_u8(S, rank * B + b) for b in range(B)]               # images shard across ranks: each rank has its own
         d_img = [ctx.to_device(u) for u in u8]
         hw = [(S, S)] * B
         rec = D.record_size(S, S)
         exchange = D.Exchange(ctx, rank, world, D.gloo_broadcast if world > 1 else None)
+        import ctypes
+        cw = ctypes.c_int(0)
+        ctx.lib.odise_hip_comm_info(ctx.h, None, ctypes.byref(cw))
+        if cw.value != args.gpus:                                        # the line must never report more GPUs than the communicator spans
+            raise SystemExit(f"RCCL communicator spans {cw.value} ranks, --gpus {args.gpus}")
+        rccl_ranks = cw.value
         local = ctx.zeros((B, rec), np.int32)                            # this rank's prediction records, written by the kernels
         allrec = ctx.zeros((world * B, rec), np.int32)
         pan_out = [local.ptr + b * rec * 4 for b in range(B)] if hip.panoptic_on else None
@@ -267,17 +330,34 @@ def main():
                 exchange.allgather(local, allrec)
 
         def check_exchange():
-            """After the timed region: this rank's slice of the gathered buffer must hold its own records, with a plausible table."""
+            """After the timed region: this rank's slice of the gathered buffer must hold its own records, and EVERY image's record a
+            well-formed, NON-EMPTY segment table (an empty one means the timed decision kernels ran on nothing)."""
+            res = last["res"]
+            report = {}
+            if hip.instance_on:
+                report["instances_per_image"] = [int(len(r["instances"]["scores"])) for r in res]
+                assert min(report["instances_per_image"]) > 0, f"an image has no instances: {report['instances_per_image']}"
+            if hip.semantic_argmax:
+                lab = res[0]["sem_seg_argmax"].numpy()
+                report["semantic_labels_image0"] = int(len(np.unique(lab)))
+                assert report["semantic_labels_image0"] > 1, "the semantic arg-max is one constant label"
             if not hip.panoptic_on:
-                return None
+                return report
             exchange.wait(True)
             mine = allrec.view((B, rec), np.int32, rank * B * rec * 4).numpy()
             own = local.numpy()
             assert np.array_equal(mine, own), "all-gather: this rank's slice differs from its local records"
-            seg, info = D.unpack_record(torch.from_numpy(own[0]), S, S)
-            ids = sorted({s["id"] for s in info})
-            assert ids == list(range(1, len(info) + 1)) and set(np.unique(seg)) <= set([0] + ids), "bad prediction record"
-            return {"segments_image0": len(info), "records_bytes_per_rank": int(B * rec * 4)}
+            counts = []
+            for b in range(B):
+                seg, info = D.unpack_record(torch.from_numpy(own[b]), S, S)
+                ids = sorted({s["id"] for s in info})
+                assert ids == list(range(1, len(info) + 1)) and set(np.unique(seg)) <= set([0] + ids), "bad prediction record"
+                counts.append(len(info))
+            # the vocabulary is spread over the FIRST image's queries: that image must produce segments (the other pictures of the batch are
+            # reported; at overlap threshold 0.8 a picture with every mask contested can legitimately keep none)
+            assert counts[0] > 0 and sum(counts) > 0, f"empty segment tables: {counts} (degenerate decisions)"
+            report.update({"segments_per_image": counts, "segments_image0": counts[0], "records_bytes_per_rank": int(B * rec * 4)})
+            return report
         ncrops = (-(-S // 512)) ** 2                                       # slide windows of 512 (feature_extractor.py:197-222): 4 at 1024, 9 at 1280
         flops_per_unit = ncrops * CROP_FLOPS + (FLOPS_PER_IMAGE_1024 - 4 * CROP_FLOPS) * (S / 1024.0) ** 2
         unit, metric = "images/s", f"panoptic-inference images/sec @{S}x{S}"
@@ -285,8 +365,9 @@ def main():
         workload = (f"{cfg}: full ODISE(label) inference (CategoryODISE eval forward: {ncrops} crops/image through "
                     f"CLIP+VAE+UNet, projections, MSDeformAttn pixel decoder, 9-layer masked decoder, MaskCLIP, "
                     f"{'semantic head with fused argmax' if args.semantic_only else 'semantic+panoptic+instance heads decided on the device'}), "
-                    f"bs={B} x {S}x{S} uint8 per GPU resident in HBM, vocabulary {K} classes/{K_TOT} strings; synthetic weights of the real shapes, "
-                    f"random text bank; seeded box-filtered uint8 inputs (SURVEY 8d)")
+                    f"bs={B} x {S}x{S} uint8 per GPU resident in HBM, vocabulary {K} classes/{K_TOT} strings; synthetic weights of the real shapes "
+                    f"calibrated for non-degenerate decisions (branch gain 0.3, {positive_fraction:.0%} positive mask logits, text banks spread over "
+                    f"the queries); seeded box-filtered uint8 inputs (SURVEY 8d)")
         baseline = cpu_baseline_full
         gather = True
 
@@ -341,7 +422,8 @@ def main():
             "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f16", "data": "synthetic",
             "config": {"workload": workload, "units_per_step_per_gpu": B, "device": dev_name, "compute_units": cus,
                        "parallelism": (f"dp{world} (independent images, one RCCL all-gather of prediction records per step on the library's "
-                                       f"exchange stream)") if gather else f"dp{world}"},
+                                       f"exchange stream)") if gather else f"dp{world}",
+                       "rccl_ranks": rccl_ranks},
             "roofline": {"bound": "mfma", "achieved": achieved, "peak": MFMA_F16_PEAK / 1e12, "unit": "TFLOP/s", "frac": achieved * 1e12 / MFMA_F16_PEAK,
                          "traffic": None,
                          "kernel": "whole step (all kernels; per-kernel times in profiles/)",
@@ -363,7 +445,7 @@ def main():
                 out["cpu_baseline"] = baseline()
             except Exception as exc:
                 out["cpu_baseline"] = {"value": None, "error": f"{type(exc).__name__}: {exc}"}
-        print(json.dumps(out), flush=True)
+        print(json.dumps(out), file=out_stream, flush=True)
     if dist is not None:
         dist.barrier()
     if args.stage == "full":

@@ -54,6 +54,13 @@ class HipODISE:
         self.num_queries, self.hidden_dim = q.value, c.value
         ctx.model_owner = self
 
+    def reload_head(self, state: Dict[str, "np.ndarray"]) -> None:
+        """(Re)load `sem_seg_head.*` (pixel decoder + masked transformer decoder) and rebuild that stage; the feature extractor and the
+        tap projections stay as they are.  What loading another ODISE head checkpoint over the same frozen towers amounts to."""
+        load_state(self.ctx, {k: v for k, v in state.items() if k.startswith("sem_seg_head.")})
+        check(self.ctx.lib.odise_hip_head_build(self.ctx.h), "head_build")
+        check(self.ctx.lib.odise_hip_clear_host_weights(self.ctx.h), "clear_host_weights")
+
     # ---- FeatureExtractorBackbone.forward -----------------------------------------------------------------------------------
     def backbone_device(self, image: DeviceArray, want_outputs: bool = True):
         B, _, H, W = image.shape

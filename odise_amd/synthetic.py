@@ -49,3 +49,78 @@ def synthetic_vocabulary(num_classes: int = 133, num_strings: int = 254, dim: in
     clp = rng.standard_normal((num_strings, dim), dtype=np.float32)
     overlap = (rng.random(num_classes) < 0.6).astype(np.int32)
     return cat, clp, sizes, overlap
+
+
+# ---------------------------------------------------------------------------------------------------------------------------------
+# Non-degenerate decisions on synthetic weights (bench.py).  Random weights as drawn collapse the 100 queries onto one mask and one
+# label - every attention sublayer of the masked decoder adds the same vector to all queries - so the panoptic / instance decision
+# kernels would run on an empty table.  The three adjustments below are the ones the full-size parity tests use (tests/fullsize.py,
+# which applies them to the fp32 oracle): (a) residual-branch gain 0.3 in the masked decoder and the learned temperature at its clamp,
+# (b) `mask_features.bias` shifted so that ~15 % of the mask logits are positive, (c) text banks - INPUTS of the path - spread over the
+# queries' own embeddings.  Here they are functions of the DEVICE's outputs on the first image (numpy only; no oracle on this side).
+# ---------------------------------------------------------------------------------------------------------------------------------
+BRANCH_GAIN = 0.3
+
+
+def apply_branch_gain(state: Dict[str, np.ndarray], gain: float = BRANCH_GAIN) -> None:
+    """In place: scale the residual branches of the masked decoder (attention out_proj and FFN linear2 weights) and set
+    `post_mask_embed.logit_scale` to ln(100), its clamp (odise.py:1013)."""
+    for name in state:
+        if name.startswith("sem_seg_head.predictor.") and (name.endswith("out_proj.weight") or name.endswith("linear2.weight")):
+            state[name] = state[name] * np.float32(gain)
+    state["sem_seg_head.predictor.post_mask_embed.logit_scale"] = np.asarray(np.log(100.0), np.float32)
+
+
+def mask_bias_shift(mask_embed: np.ndarray, pred_masks: np.ndarray, positive_fraction: float = 0.15) -> np.ndarray:
+    """delta [C] for `sem_seg_head.pixel_decoder.mask_features.bias`: me_q . delta = -s for every query, s = the (1 - positive_fraction)
+    quantile of the current mask logits.  mask_embed [Q, C] = mask embeddings of the final prediction head, pred_masks [Q, h, w]."""
+    me = np.asarray(mask_embed, np.float64)
+    s = np.quantile(np.asarray(pred_masks, np.float64).reshape(-1)[::97], 1.0 - positive_fraction)
+    return (-(s * (np.linalg.pinv(me) @ np.ones((me.shape[0], 1))))[:, 0]).astype(np.float32)
+
+
+def spread_vocabulary(mask_embed: np.ndarray, clip_embed: np.ndarray, group_sizes, text_proj_w: np.ndarray, text_proj_b: np.ndarray,
+                      seed: int = 5, null_queries: int = 6, null_bias: float = 0.07, anchored: Optional[int] = None):
+    """Text banks that make the open-vocabulary decisions non-degenerate: every (present) class gets an anchor query and its prompt
+    strings point along that query's embedding minus the mean embedding (plus seeded noise), mapped back through the pseudo-inverse of
+    `category_head.text_proj`; the null embedding points at a handful of queries.  -> (cat_text [K_tot, 768], clip_text [K_tot, 768],
+    null_embed [1, 768]).  mask_embed [Q, 256], clip_embed [Q, 768]."""
+    rng = np.random.default_rng(seed)
+    Q = mask_embed.shape[0]
+    sizes = [int(s) for s in group_sizes]
+    Kc = len(sizes)
+
+    def directions(e):
+        e = np.asarray(e, np.float64)
+        e = e / np.linalg.norm(e, axis=-1, keepdims=True)
+        mu = e.mean(0, keepdims=True)
+        d = e - mu
+        return d / np.linalg.norm(d, axis=-1, keepdims=True), mu / np.linalg.norm(mu)
+
+    def off_mean(t, mu):
+        return t - (t @ mu.T) * mu
+
+    (d1, mu1), (d2, mu2) = directions(mask_embed), directions(clip_embed)
+    perm = rng.permutation(Q)
+    usable = Q - null_queries
+    present = np.ones(Kc, bool)
+    if anchored is not None and anchored < Kc:
+        present[:] = False
+        present[rng.permutation(Kc)[:anchored]] = True
+    anchor1 = np.zeros(Kc, np.int64)
+    for j, k in enumerate(np.flatnonzero(present)):
+        anchor1[k] = perm[(j * 3) % usable]
+    anchor2 = np.where(rng.random(Kc) < 0.7, anchor1, perm[rng.integers(0, usable, Kc)])
+    t1, t2 = [], []
+    for k, n in enumerate(sizes):
+        for _ in range(n):
+            n1 = rng.standard_normal(d1.shape[1]) / d1.shape[1] ** 0.5
+            n2 = rng.standard_normal(d2.shape[1]) / d2.shape[1] ** 0.5
+            t1.append(d1[anchor1[k]] + 0.5 * n1 if present[k] else 1.1 * n1)
+            t2.append(d2[anchor2[k]] + 0.5 * n2 if present[k] else 1.1 * n2)
+    t1, t2 = off_mean(np.stack(t1), mu1), off_mean(np.stack(t2), mu2)
+    nq = d1[perm[-null_queries:]].sum(0)
+    tn = off_mean((nq / np.linalg.norm(nq))[None], mu1) + null_bias * mu1
+    W, b = np.asarray(text_proj_w, np.float64), np.asarray(text_proj_b, np.float64)
+    pinv = np.linalg.pinv(W)                                                # [768, 256]: text = pinv (target - b) solves text_proj(text) = target
+    return ((t1 - b) @ pinv.T).astype(np.float32), t2.astype(np.float32), ((tn - b) @ pinv.T).astype(np.float32)
