@@ -233,17 +233,23 @@ def calibrated_model(ctx, first_image_u8, S, K, K_TOT, things, anchored):
     hip.set_vocabulary(cat, clp, sizes, overlap, things, 0.3, 0.7)              # provisional (random) banks: the calibration pass needs one
     img01 = ctx.to_device(np.ascontiguousarray(first_image_u8.transpose(2, 0, 1)[None].astype(np.float32) / 255.0))
 
+    feats = hip.backbone_device(img01)                                          # s2..s5 fp32 NCHW: the head is rebuilt below, the features stay
+
     def head_pass():
-        hip.backbone_device(img01, want_outputs=False)
-        pm, me, _, _ = hip.head_device(None, 1, S // 4, S // 4)
-        return pm.numpy()[0], me.numpy()[0]
+        mf = hip.mask_features_device(feats, 1, S // 4, S // 4)
+        pm, me, _, _ = hip.head_device(feats, 1, S // 4, S // 4)
+        pm, me, mf_h = pm.numpy()[0], me.numpy()[0], mf.numpy()[0]
+        mf.free()
+        return pm, me, mf_h
 
     for _ in range(2):
-        pm, me = head_pass()
-        state["sem_seg_head.pixel_decoder.mask_features.bias"] = (state["sem_seg_head.pixel_decoder.mask_features.bias"]
-                                                                 + syn.mask_bias_shift(me, pm)).astype(np.float32)
+        pm, _, mf_h = head_pass()
+        shift = syn.mask_bias_shift(syn.mask_embeddings_from(pm, mf_h), pm)
+        state["sem_seg_head.pixel_decoder.mask_features.bias"] = (state["sem_seg_head.pixel_decoder.mask_features.bias"] + shift).astype(np.float32)
         hip.reload_head(state)
-    pm, me = head_pass()
+    pm, me, _ = head_pass()
+    for f in feats:
+        f.free()
     _, ce = hip.classify_device(img01, want_clip_embed=True)
     t1, t2, null = syn.spread_vocabulary(me, ce.numpy()[0], sizes, state["category_head.text_proj.weight"], state["category_head.text_proj.bias"],
                                          anchored=anchored)

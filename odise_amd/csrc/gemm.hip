@@ -49,6 +49,7 @@ struct GemmEpi {
     float alpha;
     int64_t strideC, strideR;
     int fast;  // 1: every vector access of a full 8-column chunk is aligned -> epi_fast8 (set by launch_gemm)
+    int f16path;  // 1: fp16 output whose 16-byte row chunks are all aligned and whole -> the math-first epilogue (gemm_epilogue_f16; set by launch_gemm)
     float* gn_stats;  // optional [row blocks][N][2]: per-channel (sum, sum of squares) of the block's fp16 outputs (GroupNorm statistics
                       // fused into the producing conv; set by launch_gemm only when the chosen kernel supports it)
 };
@@ -249,12 +250,16 @@ constexpr int plain_lds_bytes(int BM, int BN, int WAVES_M) {
     const int stage = (BM + BN) * 64 * 2 * 2;
     const int all_rows = BM * (BN + 4) * 4;  // the whole tile staged in one pass
     // 4-wave tiles share a CU: only stretch while the resident block count (160 KiB / LDS) is unchanged
-    return (all_rows > stage && (160 * 1024) / all_rows == (160 * 1024) / stage) ? all_rows : stage;
+    const int f32 = (all_rows > stage && (160 * 1024) / all_rows == (160 * 1024) / stage) ? all_rows : stage;
+    const int f16_all = BM * (BN + 8) * 2;   // fp16 staging of the whole tile (math-first epilogue), same residency rule
+    return (f16_all > f32 && f16_all <= 160 * 1024 && (160 * 1024) / f16_all == (160 * 1024) / f32) ? f16_all : f32;
 }
 constexpr int pp_lds_bytes(int BM, int BN, int WAVES_M) {
     const int stage = (BM + BN) * 64 * 2 * 2;
     const int half_rows = (BM / 2) * (BN + 4) * 4;  // one block per CU anyway: stage half the tile per pass when it fits
-    return (half_rows > stage && half_rows <= 160 * 1024) ? half_rows : stage;
+    const int f32 = (half_rows > stage && half_rows <= 160 * 1024) ? half_rows : stage;
+    const int f16_all = BM * (BN + 8) * 2;
+    return (f16_all > f32 && f16_all <= 160 * 1024) ? f16_all : f32;
 }
 constexpr int halo_lds_bytes(int BN) {
     const int layout = 2 * BN * 64 * 2 + 2 * (41 + 1) * 1024;  // two B stages + two halo buffers (41 groups + a dummy one)
@@ -262,6 +267,16 @@ constexpr int halo_lds_bytes(int BN) {
     const int epi = all <= 160 * 1024 ? all : all / 2;         // ... else two wave-rows per pass
     return layout > epi ? layout : epi;
 }
+// ---- fp16 staging of the math-first epilogue (gemm_epilogue_f16): (BN + 8) halves per row, EW wave-rows per pass
+constexpr int epi16_bytes(int BM, int BN, int WAVES_M, int EW) { return EW * (BM / WAVES_M) * (BN + 8) * 2; }
+constexpr int epi16_wave_rows(int BM, int BN, int WAVES_M, int lds_bytes) {
+    int ew = lds_bytes / ((BM / WAVES_M) * (BN + 8) * 2);
+    if (ew < 1) ew = 1;
+    if (ew > WAVES_M) ew = WAVES_M;
+    while (WAVES_M % ew) --ew;
+    return ew;
+}
+constexpr int max_int(int a, int b) { return a > b ? a : b; }
 constexpr int epi_wave_rows(int BM, int BN, int WAVES_M, int lds_bytes) {
     const int per_row = (BM / WAVES_M) * (BN + 4) * 4;
     int wg = lds_bytes / per_row;
@@ -272,9 +287,190 @@ constexpr int epi_wave_rows(int BM, int BN, int WAVES_M, int lds_bytes) {
 }
 constexpr int epi_lds_bytes(int BM, int BN, int WAVES_M, int WG) { return WG * (BM / WAVES_M) * (BN + 4) * 4; }
 
-template <int BM, int BN, int WAVES_M, int WAVES_N, int WG, bool HALO = false, bool STATS = false, bool PAIRS = true>
+// ---- math-first epilogue for fp16 outputs ----------------------------------------------------------------------------------------------
+// The fp32-staged epilogue below costs a 256x256 tile ~12 us, a third of a K = 1024 GEMM: the accumulators go through LDS as fp32 in up to
+// four passes in which only the waves of one or two wave-rows write while the others wait, and every thread then walks 16 dependent rounds of
+// {LDS read, bias / activation / residual arithmetic, convert, store}.  Here every wave applies the epilogue to its OWN accumulators in
+// registers (lane l of a 32x32 tile owns row l & 31 and, per register quad, four consecutive columns: bias and residual come in as 16- and
+// 8-byte loads of exactly those columns), rounds to fp16 and stages 8 bytes per quad; the tile then sits in LDS in its final form at half the
+// size - one pass for every tile but 256x320 - and the second phase is a pure copy: all of a thread's 16-byte LDS reads are issued back to
+// back, then its global stores.  Element for element the arithmetic is that of epi_fast8 in the same order: results are bit-identical
+// (tools/epi_ab.py compares the two forms; ODISE_EPI_OLD=1 in the tools build keeps the fp32-staged form).
+// Staging rows are (BN + 8) halves: 16-byte aligned for the copy's ds_read_b128; the quad writes of 16 consecutive rows land 2-way on the
+// banks (row pitch = 4 banks mod 32), which stays below the write instruction's own issue cost.
+template <int BM, int BN, int WAVES_M, int WAVES_N, int EW, bool HALO, bool STATS, bool GEGLU>
+__device__ __forceinline__ void gemm_epilogue_f16(const GemmArgs& g, f32x16 (&acc)[BM / WAVES_M / 32][BN / WAVES_N / 32], char* smem, int m0, int n0, int zb) {
+    constexpr int NT = 64 * WAVES_M * WAVES_N;
+    constexpr int WTM = BM / WAVES_M, WTN = BN / WAVES_N;
+    constexpr int TM = WTM / 32, TN = WTN / 32;
+    constexpr int ROWS = EW * WTM;                 // tile rows per pass
+    constexpr int BNO = GEGLU ? BN / 2 : BN;       // output columns of the tile
+    constexpr int PITCH = BN + 8;                  // halves per staging row
+    constexpr int CH = BNO / 8;                    // 16-byte chunks per output row
+    constexpr int TOTAL = ROWS * CH, ITERS = (TOTAL + NT - 1) / NT;
+    const GemmEpi& e = g.epi;
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+    const int wm = wave / WAVES_N, wn = wave % WAVES_N;
+    const int hi = lane >> 5, l31 = lane & 31;
+    f16* stg = reinterpret_cast<f16*>(smem);
+    const int NO = GEGLU ? (g.N >> 1) : g.N;       // output columns of the problem
+    const int no0 = GEGLU ? (n0 >> 1) : n0;
+    // tile row -> output row (the halo kernel owns a 16x16 pixel patch: m0 / BM = patch index)
+    auto row_to_m = [&](int rt) -> int {
+        if (HALO) {
+            const int patch = m0 / BM;
+            const int per_img = g.cg.halo_tx * g.cg.halo_ty;
+            const int img = patch / per_img, pr = patch - img * per_img;
+            const int oy = (pr / g.cg.halo_tx) * 16 + (rt >> 4), ox = (pr % g.cg.halo_tx) * 16 + (rt & 15);
+            return (oy < g.cg.OH && ox < g.cg.OW) ? (img * g.cg.OH + oy) * g.cg.OW + ox : g.M;
+        }
+        return m0 + rt;
+    };
+    const bool stats = STATS && (NT % CH == 0) && e.gn_stats != nullptr;
+    float s8[8], q8[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) s8[i] = q8[i] = 0.f;
+#pragma unroll
+    for (int gp = 0; gp < WAVES_M / EW; ++gp) {
+        if (gp > 0) lds_barrier();  // the copy reads of the previous pass are done
+        if (wm / EW == gp) {
+            int mr[TM];
+            float alpha_r[TM], bm_r[TM];
+            unsigned grp_r[TM];
+#pragma unroll
+            for (int p = 0; p < TM; ++p) {
+                const int m = row_to_m(wm * WTM + p * 32 + l31);
+                mr[p] = m;
+                const bool ok = m < g.M;
+                float alpha = e.alpha;
+                if (e.scale_m && ok) alpha *= e.scale_m[m];
+                alpha_r[p] = alpha;
+                bm_r[p] = (e.bias_m && ok) ? e.bias_m[m] : 0.f;
+                grp_r[p] = (e.rowgroup_add && ok) ? (unsigned)m / (unsigned)e.rows_per_group : 0u;
+            }
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int cl = wn * WTN + j * 32 + 8 * q + 4 * hi;   // tile column of this lane's four values
+                    const int n = n0 + cl;
+                    const bool nok = n < g.N;                            // N % 8 == 0 on this path: the four columns are in or out together
+                    float4 bn = make_float4(0.f, 0.f, 0.f, 0.f);
+                    if (e.bias_n && nok) bn = *reinterpret_cast<const float4*>(e.bias_n + n);
+#pragma unroll
+                    for (int p = 0; p < TM; ++p) {
+                        const bool ok = nok && mr[p] < g.M;
+                        float v[4] = {acc[p][j][4 * q], acc[p][j][4 * q + 1], acc[p][j][4 * q + 2], acc[p][j][4 * q + 3]};
+                        float b[4] = {0.f, 0.f, 0.f, 0.f};
+                        if (e.bias_n) { b[0] = bn.x; b[1] = bn.y; b[2] = bn.z; b[3] = bn.w; }
+                        if (e.rowgroup_add && ok) {
+                            const float4 r = *reinterpret_cast<const float4*>(e.rowgroup_add + (int64_t)grp_r[p] * e.ldg + n);
+                            b[0] += r.x; b[1] += r.y; b[2] += r.z; b[3] += r.w;
+                        }
+                        if (e.bias_m) {
+#pragma unroll
+                            for (int i = 0; i < 4; ++i) b[i] += bm_r[p];
+                        }
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) v[i] = v[i] * alpha_r[p] + b[i];
+                        const int rl = (wm % EW) * WTM + p * 32 + l31;   // staging row
+                        if (GEGLU) {
+                            // columns are (a, gate) pairs; the output has N/2 columns (no activation / residual on this path)
+                            typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+                            f16x2 t;
+                            t[0] = (f16)(v[0] * gelu_erf(v[1]));
+                            t[1] = (f16)(v[2] * gelu_erf(v[3]));
+                            *reinterpret_cast<f16x2*>(&stg[rl * PITCH + (cl >> 1)]) = t;
+                        } else {
+                            f16x4 rr = {0, 0, 0, 0};
+                            if (e.residual && ok) rr = *reinterpret_cast<const f16x4*>(e.residual + (int64_t)zb * e.strideR + (int64_t)mr[p] * e.ldr + n);
+                            if (e.act == ODISE_ACT_SILU) {
+#pragma unroll
+                                for (int i = 0; i < 4; ++i) v[i] = mul_sigmoid(v[i], v[i]);
+                            } else if (e.act == ODISE_ACT_RELU) {
+#pragma unroll
+                                for (int i = 0; i < 4; ++i) v[i] = v[i] > 0.f ? v[i] : 0.f;
+                            } else if (e.act == ODISE_ACT_QUICKGELU) {
+#pragma unroll
+                                for (int i = 0; i < 4; ++i) v[i] = mul_sigmoid(v[i], 1.702f * v[i]);
+                            } else if (e.act == ODISE_ACT_GELU) {
+#pragma unroll
+                                for (int i = 0; i < 4; ++i) v[i] = gelu_erf(v[i]);
+                            }
+                            f16x4 t;
+#pragma unroll
+                            for (int i = 0; i < 4; ++i) t[i] = (f16)(v[i] + (float)rr[i]);
+                            *reinterpret_cast<f16x4*>(&stg[rl * PITCH + cl]) = t;
+                        }
+                    }
+                }
+        }
+        lds_barrier();
+        // ---- copy phase: the tile is final; 16 bytes per thread and round, in batches of CB rounds: the batch's LDS reads are issued back to
+        // back, then its stores (CB is kept small while later passes' accumulators are still live in registers)
+        constexpr int CB = (EW == WAVES_M) ? (ITERS < 8 ? ITERS : 8) : (ITERS < 4 ? ITERS : 4);
+#pragma unroll
+        for (int it0 = 0; it0 < ITERS; it0 += CB) {
+            f16x8 buf[CB];
+            int mm[CB], nn[CB];
+#pragma unroll
+            for (int u = 0; u < CB; ++u) {
+                const int c = tid + (it0 + u) * NT;
+                const bool valid = (it0 + u < ITERS) && ((TOTAL % NT == 0) || c < TOTAL);
+                const int row = c / CH, c8 = c - row * CH;
+                buf[u] = f16x8{0, 0, 0, 0, 0, 0, 0, 0};
+                if (valid) buf[u] = *reinterpret_cast<const f16x8*>(&stg[row * PITCH + c8 * 8]);
+                mm[u] = valid ? row_to_m(gp * ROWS + row) : g.M;
+                nn[u] = no0 + c8 * 8;
+            }
+#pragma unroll
+            for (int u = 0; u < CB; ++u) {
+                if (mm[u] < g.M && nn[u] + 8 <= NO) {
+                    *reinterpret_cast<f16x8*>((f16*)e.C + (int64_t)zb * e.strideC + (int64_t)mm[u] * e.ldc + nn[u]) = buf[u];
+                    if (stats) {
+#pragma unroll
+                        for (int i = 0; i < 8; ++i) { const float r = (float)buf[u][i]; s8[i] += r; q8[i] += r * r; }
+                    }
+                }
+            }
+        }
+    }
+    if (stats) {
+        constexpr int RL = NT / CH;  // row lanes per column chunk
+        lds_barrier();                // the last pass is done with the staging buffer
+        float* red = reinterpret_cast<float*>(smem);  // [RL][BN][2]
+        const int c8 = tid % CH, rl = tid / CH;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            red[((rl * BN) + c8 * 8 + i) * 2 + 0] = s8[i];
+            red[((rl * BN) + c8 * 8 + i) * 2 + 1] = q8[i];
+        }
+        lds_barrier();
+        for (int c = tid; c < BN; c += NT) {
+            float a = 0.f, b = 0.f;
+            for (int r = 0; r < RL; ++r) { a += red[(r * BN + c) * 2]; b += red[(r * BN + c) * 2 + 1]; }
+            if (n0 + c < g.N) {
+                float* o = e.gn_stats + ((int64_t)(m0 / BM) * g.N + n0 + c) * 2;
+                o[0] = a;
+                o[1] = b;
+            }
+        }
+    }
+}
+
+template <int BM, int BN, int WAVES_M, int WAVES_N, int WG, bool HALO = false, bool STATS = false, bool PAIRS = true, int EW16 = 0, bool GEGLU_OK = false>
 __device__ __forceinline__ void gemm_epilogue(const GemmArgs& g, f32x16 (&acc)[BM / WAVES_M / 32][BN / WAVES_N / 32], char* smem, int m0, int n0,
                                               int z, int zb, bool split) {
+    if constexpr (EW16 > 0) {
+        if (g.epi.f16path && !split && !ODISE_ABLATE(g, 8 | 32)) {   // tools: ODISE_EPI_OLD=1 (bit 32) keeps the fp32-staged form for A/B runs
+            if constexpr (GEGLU_OK) {
+                if (g.epi.geglu) { gemm_epilogue_f16<BM, BN, WAVES_M, WAVES_N, EW16, HALO, false, true>(g, acc, smem, m0, n0, zb); return; }
+            }
+            if (!g.epi.geglu) { gemm_epilogue_f16<BM, BN, WAVES_M, WAVES_N, EW16, HALO, STATS, false>(g, acc, smem, m0, n0, zb); return; }
+        }
+    }
     constexpr int NT = 64 * WAVES_M * WAVES_N;
     constexpr int WTM = BM / WAVES_M, WTN = BN / WAVES_N;
     constexpr int TM = WTM / 32, TN = WTN / 32;
@@ -768,7 +964,8 @@ __global__ void __launch_bounds__(64 * WAVES_M * WAVES_N) gemm_kernel(GemmArgs g
     __syncthreads();  // every wave is done with the operand tiles before the staging buffer is reused
     if (ODISE_ABLATE(g, 4)) return;  // ablation: main loop only
 
-    gemm_epilogue<BM, BN, WAVES_M, WAVES_N, epi_wave_rows(BM, BN, WAVES_M, plain_lds_bytes(BM, BN, WAVES_M)), false, false, (BM * BN < 256 * 256)>(g, acc, smem, m0, n0, z, zb, split);
+    gemm_epilogue<BM, BN, WAVES_M, WAVES_N, epi_wave_rows(BM, BN, WAVES_M, plain_lds_bytes(BM, BN, WAVES_M)), false, false, (BM * BN < 256 * 256),
+                  epi16_wave_rows(BM, BN, WAVES_M, plain_lds_bytes(BM, BN, WAVES_M)), !CONV>(g, acc, smem, m0, n0, z, zb, split);
 }
 
 template <int N>
@@ -1096,7 +1293,8 @@ __global__ void __launch_bounds__(512) gemm_pp_kernel(GemmArgs g) {
     if (grp == 0) __builtin_amdgcn_s_barrier();  // re-align the two groups
     __syncthreads();
     if (ODISE_ABLATE(g, 4)) return;
-    gemm_epilogue<BM, BN, WAVES_M, WAVES_N, epi_wave_rows(BM, BN, WAVES_M, pp_lds_bytes(BM, BN, WAVES_M)), false, (CONV && BM == 512)>(g, acc, smem, m0, n0, z, zb, split);
+    gemm_epilogue<BM, BN, WAVES_M, WAVES_N, epi_wave_rows(BM, BN, WAVES_M, pp_lds_bytes(BM, BN, WAVES_M)), false, (CONV && BM == 512), true,
+                  epi16_wave_rows(BM, BN, WAVES_M, pp_lds_bytes(BM, BN, WAVES_M)), !CONV>(g, acc, smem, m0, n0, z, zb, split);
 }
 
 
@@ -1413,7 +1611,8 @@ __global__ void __launch_bounds__(512) gemm_pp2_kernel(GemmArgs g) {
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
     __syncthreads();
     if (ODISE_ABLATE(g, 4)) return;
-    gemm_epilogue<BM, BN, WAVES_M, WAVES_N, epi_wave_rows(BM, BN, WAVES_M, pp_lds_bytes(BM, BN, WAVES_M)), false, CONV>(g, acc, smem, m0, n0, z, zb, split);
+    gemm_epilogue<BM, BN, WAVES_M, WAVES_N, epi_wave_rows(BM, BN, WAVES_M, pp_lds_bytes(BM, BN, WAVES_M)), false, CONV, true,
+                  epi16_wave_rows(BM, BN, WAVES_M, pp_lds_bytes(BM, BN, WAVES_M)), !CONV>(g, acc, smem, m0, n0, z, zb, split);
 }
 
 // (A third structure - every wave free-running through the four k-steps with register double-buffered fragments and ONE barrier per
@@ -1654,7 +1853,8 @@ __global__ void __launch_bounds__(512) conv3_halo_kernel(GemmArgs g) {
     if (grp == 0) __builtin_amdgcn_s_barrier();  // re-align the two groups
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
     __syncthreads();
-    gemm_epilogue<BM, BN, WAVES_M, WAVES_N, epi_wave_rows(BM, BN, WAVES_M, halo_lds_bytes(BN)), true, true>(g, acc, smem, m0, n0, z, zb, split);
+    gemm_epilogue<BM, BN, WAVES_M, WAVES_N, epi_wave_rows(BM, BN, WAVES_M, halo_lds_bytes(BN)), true, true, true,
+                  epi16_wave_rows(BM, BN, WAVES_M, halo_lds_bytes(BN)), false>(g, acc, smem, m0, n0, z, zb, split);
 }
 
 __global__ void __launch_bounds__(256) splitk_reduce_kernel(const float* __restrict__ ws, int splitk, int M, int N, GemmEpi e) {
@@ -1779,6 +1979,7 @@ static int launch_conv3_halo(odise_hip_ctx* ctx, GemmArgs& g) {
 }
 
 static int g_gemm_debug = 0;  // see GemmArgs::dbg
+static int g_epi_old = 0;     // tools only: 1 = keep the fp32-staged epilogue (odise_hip_gemm_debug bit 1 << 24), for same-process A/B runs
 static int g_conv_flags = 0;  // tools only: 1 = tap-major K order even when Cin % 64 == 0, 2 = never use the ping-pong kernel, 4 = one N-tile per phase at BN = 256
 
 // Tile ids: 0:128x128 1:64x128 2:64x64 (4 waves)  3:256x320 4:256x256 5:256x128 (8 waves)  6:512x128 (8 waves, ping-pong only)
@@ -1916,6 +2117,10 @@ static int launch_gemm(odise_hip_ctx* ctx, GemmArgs& g, int batch, int force_til
         ok = ok && (!e.rowgroup_add || (((uintptr_t)e.rowgroup_add & 15) == 0 && e.ldg % 4 == 0));
         ok = ok && (!e.geglu || e.act == ODISE_ACT_NONE);
         g.epi.fast = ok ? 1 : 0;
+        // math-first epilogue: fp16 output in whole, 16-byte aligned 8-column chunks (GEGLU: of the N/2-wide output)
+        const int n_out = e.geglu ? g.N / 2 : g.N;
+        g.epi.f16path = (ok && e.c_dtype == ODISE_F16 && g.N % 8 == 0 && n_out % 8 == 0 && aligned(e.C, e.ldc, e.strideC, 2, 16) &&
+                         (!e.residual || aligned(e.residual, e.ldr, e.strideR, 2, 8))) ? 1 : 0;
     }
     g.stats_blocks = 0;
     if (g.epi.gn_stats) {
@@ -1933,7 +2138,7 @@ static int launch_gemm(odise_hip_ctx* ctx, GemmArgs& g, int batch, int force_til
     g.zeros = (const f16*)ctx->zeros;
 #ifdef ODISE_TOOLS
     static const int freeze_k = (getenv("ODISE_GEMM_FREEZE_K") ? 16 : 0) | (getenv("ODISE_EPI_OLD") ? 32 : 0) | (getenv("ODISE_NO_RES_PREFETCH") ? 64 : 0);
-    g.dbg = g_gemm_debug | freeze_k;
+    g.dbg = g_gemm_debug | freeze_k | (g_epi_old ? 32 : 0);
 #else
     g.dbg = 0;
 #endif
@@ -2052,7 +2257,12 @@ int group_norm_from_colpart(odise_hip_ctx* ctx, const void* x, void* y, const fl
 
 }  // namespace odise
 
-extern "C" int odise_hip_gemm_debug(int flags) { odise::g_gemm_debug = flags & 15; odise::g_conv_flags = flags >> 4; return 0; }
+extern "C" int odise_hip_gemm_debug(int flags) {
+    odise::g_gemm_debug = flags & 15;
+    odise::g_conv_flags = (flags >> 4) & 0xfffff;
+    odise::g_epi_old = (flags >> 24) & 1;
+    return 0;
+}
 extern "C" int odise_hip_gemm(odise_hip_ctx* ctx, const odise_gemm_desc* d) { return odise::gemm_forced(ctx, d, -1, 0); }
 extern "C" int odise_hip_conv2d(odise_hip_ctx* ctx, const odise_conv_desc* d) { return odise::conv_forced(ctx, d, -1, 0); }
 // test hooks: force a tile shape (0:128x128, 1:64x128, 2:64x64) and/or a split-K factor

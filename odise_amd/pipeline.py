@@ -85,6 +85,15 @@ class HipODISE:
         check(self.ctx.lib.odise_hip_head_forward(self.ctx.h, arr, B, cin, H4, W4, p(pm), p(me), p(mp), C.byref(ls)), "head_forward")
         return pm, me, mp, float(ls.value)
 
+    def mask_features_device(self, feats: list, B: int, H4: int, W4: int, cin: int = 512) -> DeviceArray:
+        """MSDeformAttnPixelDecoder.forward_features on its own (msdeformattn.py:314-358): `mask_features` [B,C,H4,W4] fp32 of the s2..s5
+        maps `feats` (fp32 NCHW DeviceArrays).  Resets the activation arena: the maps of an earlier `backbone_device` call held inside the
+        library are gone afterwards, pass `feats` to `head_device` explicitly."""
+        mf = self.ctx.empty((B, self.hidden_dim, H4, W4), np.float32)
+        arr = (C.c_void_p * 4)(*[f.ptr for f in feats])
+        check(self.ctx.lib.odise_hip_pixel_decoder_forward(self.ctx.h, arr, B, cin, H4, W4, C.c_void_p(mf.ptr), None), "pixel_decoder_forward")
+        return mf
+
     def head(self, features: Optional[Dict[str, np.ndarray]] = None, image_hw=None) -> Dict[str, np.ndarray]:
         """features: dict s2..s5 fp32 NCHW (host) or None to reuse the maps of the last `backbone` call (pass image_hw then)."""
         if features is not None:

@@ -71,9 +71,19 @@ def apply_branch_gain(state: Dict[str, np.ndarray], gain: float = BRANCH_GAIN) -
     state["sem_seg_head.predictor.post_mask_embed.logit_scale"] = np.asarray(np.log(100.0), np.float32)
 
 
+def mask_embeddings_from(pred_masks: np.ndarray, mask_features: np.ndarray) -> np.ndarray:
+    """The mask embeddings of the final prediction head - the [Q, C] matrix ME with pred_masks = ME . mask_features, an internal of the
+    decoder that no API returns (`mask_embed` of the outputs is the POOLED embedding the classifier uses) - by least squares from the
+    head's own outputs: ME = PM MF^T (MF MF^T)^-1.  pred_masks [Q, h, w], mask_features [C, h, w]."""
+    pm = np.asarray(pred_masks, np.float64).reshape(pred_masks.shape[0], -1)
+    mf = np.asarray(mask_features, np.float64).reshape(mask_features.shape[0], -1)
+    return np.linalg.solve(mf @ mf.T, mf @ pm.T).T
+
+
 def mask_bias_shift(mask_embed: np.ndarray, pred_masks: np.ndarray, positive_fraction: float = 0.15) -> np.ndarray:
     """delta [C] for `sem_seg_head.pixel_decoder.mask_features.bias`: me_q . delta = -s for every query, s = the (1 - positive_fraction)
-    quantile of the current mask logits.  mask_embed [Q, C] = mask embeddings of the final prediction head, pred_masks [Q, h, w]."""
+    quantile of the current mask logits.  mask_embed [Q, C] = mask embeddings of the final prediction head (mask_embeddings_from),
+    pred_masks [Q, h, w]."""
     me = np.asarray(mask_embed, np.float64)
     s = np.quantile(np.asarray(pred_masks, np.float64).reshape(-1)[::97], 1.0 - positive_fraction)
     return (-(s * (np.linalg.pinv(me) @ np.ones((me.shape[0], 1))))[:, 0]).astype(np.float32)
