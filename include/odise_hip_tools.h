@@ -31,8 +31,11 @@ int odise_hip_conv2d_gn_forced(odise_hip_ctx* ctx, const odise_conv_desc* d, int
 /* process-wide kernel-selection switches for A/B measurements (bits: gemm.hip launch_gemm) */
 int odise_hip_gemm_debug(int flags);
 
-/* 1: the post-processing kernels never take their exact-x4-upsampling specialisations (tests assert both forms are bit-identical) */
+/* 1: the post-processing kernels never take their exact-x4-upsampling specialisations (tests assert both forms are bit-identical);
+ * 2: the specialisations, but the per-pixel pass in its thread-per-cell-column form instead of the tiled one */
 int odise_hip_post_generic(int on);
+/* force the tile of the semantic GEMM [K, pixels] = P^T S^T (A/B of the 256-row rule in odise_hip_postprocess_batch); -1 = the rule */
+int odise_hip_sem_tile(int tile);
 
 /* 1: the feature extractor enqueues everything on one stream; 2 (default): its CLIP -> UNet branch runs on a second stream beside the VAE */
 int odise_hip_set_lanes(odise_hip_ctx* ctx, int lanes);

@@ -57,6 +57,8 @@ struct ClassifyModel {
     size_t in_cap = 0;
 };
 
+static int g_sem_tile = -1;   // tools hook (odise_hip_sem_tile): force the tile of the semantic GEMM for A/B runs; -1 = the rule in postprocess_batch
+
 static int scratch_reserve(odise_hip_ctx* ctx, void** buf, size_t* cap, size_t bytes) {
     if (*cap >= bytes) return ODISE_OK;
     ODISE_CHECK_HIP(hipStreamSynchronize(ctx->stream));
@@ -490,7 +492,11 @@ extern "C" int odise_hip_postprocess_batch(odise_hip_ctx* ctx, const odise_post_
             gd.M = K; gd.N = npix; gd.K = Qpad;
             gd.A = semT + (size_t)b * K * Qpad; gd.lda = Qpad; gd.W = S; gd.ldw = Qpad;
             gd.C = sem; gd.ldc = npix; gd.c_dtype = ODISE_F32; gd.alpha = 1.f; gd.batch = 1;
-            ODISE_TRY(ex.gemm(gd));
+            // HBM-bound (K = Qpad ~ 104): per pixel 208 B of S in, 4 B x K out.  The cost model, fitted on MFMA-bound shapes, picks 64-row tiles
+            // and every row tile re-reads the 218 MB matrix S (3x at K = 133); a 256-row tile covers up to 256 classes per pass over S - its
+            // idle MFMA rows cost nothing here (measured: tools/post_bench.py).
+            ms->macs += (double)gd.M * gd.N * gd.K;
+            ODISE_TRY(gemm_forced(ctx, &gd, g_sem_tile >= 0 ? g_sem_tile : (K <= 64 ? -1 : 5), 0));
         }
         if (amax) ODISE_TRY(launch_semantic_argmax(ctx, S, semT + (size_t)b * K * Qpad, amax, npix, Qpad, K));
         if (inst) ODISE_TRY(launch_column_stats(ctx, S, partial, stats + (size_t)b * 2 * Qpad, npix, Qpad));
@@ -550,3 +556,5 @@ extern "C" int odise_hip_infer(odise_hip_ctx* ctx, const odise_infer_desc* d) {
     p.B = B; p.pad_h = Hp; p.pad_w = Wp; p.img_hw = d->img_hw; p.mask_cls = mask_cls;
     return odise_hip_postprocess_batch(ctx, &p);
 }
+
+extern "C" int odise_hip_sem_tile(int tile) { odise::g_sem_tile = tile; return 0; }

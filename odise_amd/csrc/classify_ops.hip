@@ -192,12 +192,18 @@ __device__ __forceinline__ float sample_mask(const f16* lr, const PostGeom& g, i
     return top + ty * (bot - top);
 }
 
+// sigmoid of the per-pixel pass: v_exp_f32 + v_rcp_f32 (1 ulp each) instead of the library expf and the IEEE division (~20 VALU
+// instructions less per pixel and query, of ~70); the result is rounded to fp16 for S and compared against 0.5 for the panoptic flag, both far
+// coarser.  All three forms of the pass (generic, x4, tiled) share it, so they stay bit-identical to each other.
+__device__ __forceinline__ float post_sigmoid(float v) { return __builtin_amdgcn_rcpf(1.0f + __expf(-v)); }
+
 // fp16 sigmoid for the pixel-major matrix S.  The instance head counts a pixel as inside the mask iff its LOGIT is positive
 // (maskformer_model.py:371 `mask_pred > 0`) and averages sigmoid over exactly those pixels (:376-377); sigmoid(v) for 0 < v < ~1e-3
 // rounds to 0.5 in fp16, so such pixels get the next representable value above 0.5: `S > 0.5` then reproduces `logit > 0` exactly.
 __device__ __forceinline__ f16 sig_f16(float sg, float v) {
     const f16 h = (f16)sg;
-    return (v > 0.f && !(h > (f16)0.5f)) ? (f16)0.50048828125f : h;
+    const bool lift = (v > 0.f) & !(h > (f16)0.5f);   // bitwise: one select, no branch
+    return lift ? (f16)0.50048828125f : h;
 }
 
 // thread per output pixel.  kscore[q] = panoptic score of query q if it is kept (label != null, score > threshold) else < 0.
@@ -224,7 +230,7 @@ __global__ void __launch_bounds__(256) postprocess_pixels_kernel(const f16* __re
             const int q = q0 + j;
             if (q < Q) {  // uniform branch
                 const float v = ok ? sample_mask(logits + (int64_t)q * g.h4 * g.w4, g, oy, ox) : -1.f;
-                const float sg = 1.f / (1.f + expf(-v));
+                const float sg = post_sigmoid(v);
                 sv[j] = sig_f16(sg, v);
                 const float ks = kscore[q];
                 const bool pos = sg >= 0.5f;
@@ -297,7 +303,7 @@ __global__ void __launch_bounds__(256) postprocess_pixels_x4_kernel(const f16* _
                     const float v00 = k < 2 ? al : ac, v01 = k < 2 ? ac : ar, v10 = k < 2 ? bl : bc, v11 = k < 2 ? bc : br;
                     const float top = v00 + tx * (v01 - v00), bot = v10 + tx * (v11 - v10);
                     const float v = ok[k] ? top + ty * (bot - top) : -1.f;
-                    const float sg = 1.f / (1.f + expf(-v));
+                    const float sg = post_sigmoid(v);
                     sv[k][j] = sig_f16(sg, v);
                     const bool pos = sg >= 0.5f;
                     if (ks >= 0.f) {
@@ -326,6 +332,137 @@ __global__ void __launch_bounds__(256) postprocess_pixels_x4_kernel(const f16* _
         }
     __syncthreads();
     for (int i = threadIdx.x; i < 3 * Q; i += blockDim.x)
+        if (hist[i]) atomicAdd(&counts[i], hist[i]);
+}
+
+// ---- tiled form of postprocess_pixels_x4_kernel ------------------------------------------------------------------------------------
+// The thread-per-cell-column kernel above walks all Q queries in one thread (6 loads, 4 sigmoids per query, 100 times in a row) and
+// writes the pixel-major matrix S as 16-byte pieces of 208-byte rows, 13 separate partial-line stores per pixel: 375 us per 1024^2 image,
+// 0.58 TB/s of its 218 MB (profiles/r02_bench_full_by_shape.txt).  Here a block owns 256 consecutive pixels of one output row (64 cell
+// columns) and ALL queries: the 13 groups of 8 queries are dealt round-robin to the block's four wavefronts (4x the threads of the old
+// form), every thread evaluates its 4 pixels x 8 queries per group with the same arithmetic as before - bit-identical results - and
+// puts the fp16 sigmoids into an LDS image of the tile's S rows; the tile is then written out as ONE contiguous 53 KB run of the matrix
+// (256 pixels x 208 bytes are adjacent in memory), 16 bytes per lane, whole 128-byte lines.  The panoptic arg-max is finished across the
+// four query slices through LDS (ties to the lowest query, like the sequential walk), the area counters as before.
+constexpr int PT_PIX = 256;          // pixels of a tile
+constexpr int PT_CELLS = 64;         // cell columns of a tile (one per lane)
+__global__ void __launch_bounds__(256) postprocess_pixels_x4_tiled_kernel(const f16* __restrict__ logits, const float* __restrict__ kscore,
+                                                                         f16* __restrict__ S, int* __restrict__ ids, int* __restrict__ counts,
+                                                                         PostGeom g, int tiles_per_row) {
+    extern __shared__ __attribute__((aligned(16))) char psm[];
+    const int Q = g.Q, Qpad = g.Qpad;
+    const int pitch = Qpad * 2 + 8;                      // bytes per pixel row of the LDS image: 8-byte aligned, rows 4 pixels apart fall 2-way on the banks
+    char* tile = psm;                                    // [PT_PIX][pitch]
+    float* red_v = reinterpret_cast<float*>(psm + (size_t)PT_PIX * pitch);   // [4][PT_PIX] best score of each query slice
+    int* red_q = reinterpret_cast<int*>(red_v + 4 * PT_PIX);                // [4][PT_PIX] its query | pos << 16, -1 = none
+    int* hist = red_q + 4 * PT_PIX;                                         // [3][Q]
+    const int tid = threadIdx.x, lane = tid & 63, slice = tid >> 6;
+    for (int i = tid; i < 3 * Q; i += 256) hist[i] = 0;
+    const int oy = blockIdx.x / tiles_per_row, cx0 = (blockIdx.x - oy * tiles_per_row) * PT_CELLS;
+    const int cw = (g.ow + 3) >> 2;
+    const int cx = cx0 + lane;
+    const bool okt = cx < cw;
+    const int cxc = okt ? cx : cw - 1;
+    const int cy = oy >> 2, ky = oy & 3;
+    const int ra = max(ky < 2 ? cy - 1 : cy, 0), rb = min(ky < 2 ? cy : cy + 1, g.h4 - 1);
+    const float ty = ky == 0 ? 0.625f : ky == 1 ? 0.875f : ky == 2 ? 0.125f : 0.375f;
+    const int cl = max(cxc - 1, 0), cr = min(cxc + 1, g.w4 - 1);
+    const int oa = ra * g.w4, ob = rb * g.w4;
+    bool ok[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) ok[k] = okt && (4 * cx + k) < g.ow;
+    float best[4] = {-1.f, -1.f, -1.f, -1.f};
+    int best_q[4] = {-1, -1, -1, -1};
+    int best_pos[4] = {0, 0, 0, 0};   // int, not bool: selects instead of exec-masked moves
+    const int plane = g.h4 * g.w4;
+    __syncthreads();   // hist is zero
+    for (int q0 = slice * 8; q0 < Qpad; q0 += 32) {
+        f16x8 sv[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) sv[k] = f16x8{0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int q = q0 + j;
+            if (q < Q) {  // uniform branch
+                const f16* lr = logits + (int64_t)q * plane;
+                const float al = (float)lr[oa + cl], ac = (float)lr[oa + cxc], ar = (float)lr[oa + cr];
+                const float bl = (float)lr[ob + cl], bc = (float)lr[ob + cxc], br = (float)lr[ob + cr];
+                const float ks = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(kscore[q])));   // wave-uniform by construction: keep the test scalar
+                int npos = 0;
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const float tx = k == 0 ? 0.625f : k == 1 ? 0.875f : k == 2 ? 0.125f : 0.375f;
+                    const float v00 = k < 2 ? al : ac, v01 = k < 2 ? ac : ar, v10 = k < 2 ? bl : bc, v11 = k < 2 ? bc : br;
+                    const float top = v00 + tx * (v01 - v00), bot = v10 + tx * (v11 - v10);
+                    const float v = ok[k] ? top + ty * (bot - top) : -1.f;
+                    const float sg = post_sigmoid(v);
+                    sv[k][j] = sig_f16(sg, v);
+                    const bool pos = sg >= 0.5f;
+                    if (ks >= 0.f) {   // wave-uniform
+                        npos += __popcll(__ballot(ok[k] & pos));
+                        const float pv = ks * sg;
+                        const bool upd = ok[k] & (pv > best[k]);
+                        best[k] = upd ? pv : best[k];
+                        best_q[k] = upd ? q : best_q[k];
+                        best_pos[k] = upd ? (int)pos : best_pos[k];
+                    }
+                }
+                if (ks >= 0.f && lane == 0 && npos) atomicAdd(&hist[Q + q], npos);
+            }
+        }
+        if (S) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                typedef _Float16 f16x4v __attribute__((ext_vector_type(4)));
+                char* dst = tile + (size_t)(4 * lane + k) * pitch + q0 * 2;
+                f16x4v lo = {sv[k][0], sv[k][1], sv[k][2], sv[k][3]}, hi = {sv[k][4], sv[k][5], sv[k][6], sv[k][7]};
+                *reinterpret_cast<f16x4v*>(dst) = lo;
+                *reinterpret_cast<f16x4v*>(dst + 8) = hi;
+            }
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        red_v[slice * PT_PIX + 4 * lane + k] = best[k];
+        red_q[slice * PT_PIX + 4 * lane + k] = best_q[k] < 0 ? -1 : (best_q[k] | (best_pos[k] << 16));
+    }
+    __syncthreads();
+    // ---- panoptic arg-max across the four query slices: thread per pixel of the tile
+    {
+        const int px = 4 * cx0 + tid;                    // output column
+        if (px < g.ow) {
+            float bv = -1.f;
+            int bq = -1;
+#pragma unroll
+            for (int sl = 0; sl < 4; ++sl) {
+                const float v = red_v[sl * PT_PIX + tid];
+                const int qq = red_q[sl * PT_PIX + tid];
+                if (qq >= 0 && (v > bv || (v == bv && (qq & 0xffff) < (bq & 0xffff)))) { bv = v; bq = qq; }
+            }
+            if (ids) ids[(int64_t)oy * g.ow + px] = bq;
+            if (bq >= 0) {
+                atomicAdd(&hist[bq & 0xffff], 1);
+                if (bq & (1 << 16)) atomicAdd(&hist[2 * Q + (bq & 0xffff)], 1);
+            }
+        }
+    }
+    // ---- the tile's S rows: one contiguous run of the matrix
+    if (S) {
+        const int npx = min(PT_PIX, g.ow - 4 * cx0);
+        const int cpp = Qpad >> 3;                       // 16-byte chunks per pixel row
+        const int nchunks = npx * cpp;
+        f16* dst = S + ((int64_t)oy * g.ow + 4 * cx0) * Qpad;
+        for (int j = tid; j < nchunks; j += 256) {
+            const int pxl = j / cpp, part = j - pxl * cpp;
+            typedef _Float16 f16x4v __attribute__((ext_vector_type(4)));
+            const char* src = tile + (size_t)pxl * pitch + part * 16;
+            const f16x4v lo = *reinterpret_cast<const f16x4v*>(src), hi = *reinterpret_cast<const f16x4v*>(src + 8);
+            f16x8 o = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+            *reinterpret_cast<f16x8*>(dst + (int64_t)j * 8) = o;
+        }
+    }
+    __syncthreads();
+    for (int i = tid; i < 3 * Q; i += 256)
         if (hist[i]) atomicAdd(&counts[i], hist[i]);
 }
 
@@ -709,7 +846,7 @@ __global__ void __launch_bounds__(256) image_pad_kernel(const void* __restrict__
 }
 
 // ---- launchers -------------------------------------------------------------------------------------------------------
-static int g_post_generic = 0;  // tools hook (odise_hip_post_generic): 1 = never take the x4 specialisations (bit-equality tests)
+static int g_post_generic = 0;  // tools hook (odise_hip_post_generic): 1 = never take the x4 specialisations (bit-equality tests), 2 = x4 without the tiled form
 int launch_resize_bilinear_norm(odise_hip_ctx* ctx, const float* x, f16* y, int B, int H, int W, int S) {
     dim3 grid((unsigned)ceil_div(S * S, 256), (unsigned)B);
     hipLaunchKernelGGL(resize_bilinear_norm_kernel, grid, dim3(256), 0, ctx->stream, x, y, H, W, S);
@@ -741,7 +878,15 @@ int launch_classify_rows(odise_hip_ctx* ctx, const float* L1, const float* L2, c
 }
 int launch_postprocess_pixels(odise_hip_ctx* ctx, const f16* logits, const float* kscore, f16* S, int* ids, int* counts, const PostGeom& g) {
     const int npix = g.oh * g.ow;
-    if (g.oh == g.ih && g.ow == g.iw && g.ph == 4 * g.h4 && g.pw == 4 * g.w4 && !g_post_generic) {
+    if (g.oh == g.ih && g.ow == g.iw && g.ph == 4 * g.h4 && g.pw == 4 * g.w4 && g_post_generic != 1) {
+        const size_t lds = (size_t)PT_PIX * (g.Qpad * 2 + 8) + 8 * (size_t)PT_PIX * 4 + 3 * (size_t)g.Q * sizeof(int);
+        if (g_post_generic != 2 && lds <= 64 * 1024) {   // tiled form (two blocks per CU); odise_hip_post_generic(2) keeps the thread-per-cell-column form
+            const int tiles_per_row = (int)ceil_div((g.ow + 3) / 4, PT_CELLS);
+            hipLaunchKernelGGL(postprocess_pixels_x4_tiled_kernel, dim3((unsigned)(g.oh * tiles_per_row)), dim3(256), lds, ctx->stream, logits, kscore, S, ids,
+                               counts, g, tiles_per_row);
+            ODISE_CHECK_HIP(hipGetLastError());
+            return ODISE_OK;
+        }
         const int nthreads = g.oh * ((g.ow + 3) / 4);
         hipLaunchKernelGGL(postprocess_pixels_x4_kernel, dim3((unsigned)ceil_div(nthreads, 256)), dim3(256), 3 * (size_t)g.Q * sizeof(int),
                            ctx->stream, logits, kscore, S, ids, counts, g);
@@ -809,7 +954,7 @@ int launch_panoptic_write(odise_hip_ctx* ctx, const int* ids, const int* map, in
 int launch_instance_masks(odise_hip_ctx* ctx, const f16* logits, const int* idx, float* out, int n, const PostGeom& g, const int* n_dev) {
     if (n == 0) return ODISE_OK;
     if (g.oh == g.ih && g.ow == g.iw && g.ph == 4 * g.h4 && g.pw == 4 * g.w4 && g.ow % 4 == 0 && ((uintptr_t)out & 15) == 0 &&
-        !g_post_generic) {
+        g_post_generic != 1) {
         dim3 grid4((unsigned)ceil_div(g.oh * (g.ow / 4), 256), (unsigned)n);
         hipLaunchKernelGGL(instance_masks_x4_kernel, grid4, dim3(256), 0, ctx->stream, logits, idx, out, g, n_dev);
         ODISE_CHECK_HIP(hipGetLastError());
@@ -823,4 +968,4 @@ int launch_instance_masks(odise_hip_ctx* ctx, const f16* logits, const int* idx,
 
 }  // namespace odise
 
-extern "C" int odise_hip_post_generic(int on) { odise::g_post_generic = on ? 1 : 0; return 0; }
+extern "C" int odise_hip_post_generic(int on) { odise::g_post_generic = on; return 0; }

@@ -276,7 +276,14 @@ constexpr int epi16_wave_rows(int BM, int BN, int WAVES_M, int lds_bytes) {
     while (WAVES_M % ew) --ew;
     return ew;
 }
-constexpr int max_int(int a, int b) { return a > b ? a : b; }
+// Where the math-first form runs (0 = keep the fp32-staged epilogue).  Measured on MI355X (tools/epi16_ab.py, profiles/r03_epilogue_f16_ab.txt):
+// both forms are bound by the write burst of a round - every CU stores its tile at the same time, ~2.5 TB/s across the chip - so the
+// shorter LDS / VALU path only pays where the tile is staged in ONE pass: +4 % on the 3x3 convolutions (halo tiles), +6..15 % on the
+// GEGLU GEMMs (256x256), +15..35 % on 256x128; the two-pass 256x320 tile loses 15-30 % (half of the waves idle per pass and all stores at
+// the end, where the fp32-staged form streams them out between its four passes), and the small 4-wave tiles are within +-8 % either way.
+constexpr int epi16_rows_if_enabled(int BM, int BN, int WAVES_M, int lds_bytes) {
+    return (BN != 320 && BM * BN >= 256 * 128) ? epi16_wave_rows(BM, BN, WAVES_M, lds_bytes) : 0;
+}
 constexpr int epi_wave_rows(int BM, int BN, int WAVES_M, int lds_bytes) {
     const int per_row = (BM / WAVES_M) * (BN + 4) * 4;
     int wg = lds_bytes / per_row;
@@ -965,7 +972,7 @@ __global__ void __launch_bounds__(64 * WAVES_M * WAVES_N) gemm_kernel(GemmArgs g
     if (ODISE_ABLATE(g, 4)) return;  // ablation: main loop only
 
     gemm_epilogue<BM, BN, WAVES_M, WAVES_N, epi_wave_rows(BM, BN, WAVES_M, plain_lds_bytes(BM, BN, WAVES_M)), false, false, (BM * BN < 256 * 256),
-                  epi16_wave_rows(BM, BN, WAVES_M, plain_lds_bytes(BM, BN, WAVES_M)), !CONV>(g, acc, smem, m0, n0, z, zb, split);
+                  epi16_rows_if_enabled(BM, BN, WAVES_M, plain_lds_bytes(BM, BN, WAVES_M)), !CONV>(g, acc, smem, m0, n0, z, zb, split);
 }
 
 template <int N>
@@ -1294,7 +1301,7 @@ __global__ void __launch_bounds__(512) gemm_pp_kernel(GemmArgs g) {
     __syncthreads();
     if (ODISE_ABLATE(g, 4)) return;
     gemm_epilogue<BM, BN, WAVES_M, WAVES_N, epi_wave_rows(BM, BN, WAVES_M, pp_lds_bytes(BM, BN, WAVES_M)), false, (CONV && BM == 512), true,
-                  epi16_wave_rows(BM, BN, WAVES_M, pp_lds_bytes(BM, BN, WAVES_M)), !CONV>(g, acc, smem, m0, n0, z, zb, split);
+                  epi16_rows_if_enabled(BM, BN, WAVES_M, pp_lds_bytes(BM, BN, WAVES_M)), !CONV>(g, acc, smem, m0, n0, z, zb, split);
 }
 
 
@@ -1612,7 +1619,7 @@ __global__ void __launch_bounds__(512) gemm_pp2_kernel(GemmArgs g) {
     __syncthreads();
     if (ODISE_ABLATE(g, 4)) return;
     gemm_epilogue<BM, BN, WAVES_M, WAVES_N, epi_wave_rows(BM, BN, WAVES_M, pp_lds_bytes(BM, BN, WAVES_M)), false, CONV, true,
-                  epi16_wave_rows(BM, BN, WAVES_M, pp_lds_bytes(BM, BN, WAVES_M)), !CONV>(g, acc, smem, m0, n0, z, zb, split);
+                  epi16_rows_if_enabled(BM, BN, WAVES_M, pp_lds_bytes(BM, BN, WAVES_M)), !CONV>(g, acc, smem, m0, n0, z, zb, split);
 }
 
 // (A third structure - every wave free-running through the four k-steps with register double-buffered fragments and ONE barrier per
@@ -1854,7 +1861,7 @@ __global__ void __launch_bounds__(512) conv3_halo_kernel(GemmArgs g) {
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
     __syncthreads();
     gemm_epilogue<BM, BN, WAVES_M, WAVES_N, epi_wave_rows(BM, BN, WAVES_M, halo_lds_bytes(BN)), true, true, true,
-                  epi16_wave_rows(BM, BN, WAVES_M, halo_lds_bytes(BN)), false>(g, acc, smem, m0, n0, z, zb, split);
+                  epi16_rows_if_enabled(BM, BN, WAVES_M, halo_lds_bytes(BN)), false>(g, acc, smem, m0, n0, z, zb, split);
 }
 
 __global__ void __launch_bounds__(256) splitk_reduce_kernel(const float* __restrict__ ws, int splitk, int M, int N, GemmEpi e) {

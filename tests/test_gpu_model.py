@@ -134,23 +134,26 @@ def test_classification_stage(models, ctx):
     assert (p_got.argmax(-1) == p_ref.argmax(-1)).mean() >= 0.95
 
 
-@pytest.mark.parametrize("h,w", [(500, 502), (512, 512)])
+@pytest.mark.parametrize("h,w", [(500, 502), (512, 512), (320, 1100)])   # ragged widths: a partial last tile, a single-cell tail
 def test_postprocess_x4_kernel_matches_generic(models, h, w):
     """The x4-upsampling specialisations of the per-pixel pass and of the instance masks (output size = image size) must reproduce
     the generic kernels bit for bit, including ragged widths (ow % 4 != 0) and the clamped border taps."""
     bb, head, heads, hip = models
     img = _image_u8(h, w, seed=11)
-    fast = hip.forward([{"image": img}])[0]
-    hip.ctx.lib.odise_hip_post_generic(1)
-    try:
-        gen = hip.forward([{"image": img}])[0]
-    finally:
-        hip.ctx.lib.odise_hip_post_generic(0)
-    np.testing.assert_array_equal(fast["panoptic_seg"][0], gen["panoptic_seg"][0])
-    assert fast["panoptic_seg"][1] == gen["panoptic_seg"][1]
-    np.testing.assert_array_equal(fast["sem_seg"], gen["sem_seg"])
-    np.testing.assert_array_equal(fast["instances"]["pred_masks"], gen["instances"]["pred_masks"])
-    np.testing.assert_array_equal(fast["instances"]["scores"], gen["instances"]["scores"])
+    fast = hip.forward([{"image": img}])[0]                 # x4 specialisations, per-pixel pass in its tiled form (256-pixel row tiles through LDS)
+    other = {}
+    for mode in (1, 2):                                      # 1: generic kernels; 2: x4 specialisations with the thread-per-cell-column per-pixel pass
+        hip.ctx.lib.odise_hip_post_generic(mode)
+        try:
+            other[mode] = hip.forward([{"image": img}])[0]
+        finally:
+            hip.ctx.lib.odise_hip_post_generic(0)
+    for mode, gen in other.items():
+        np.testing.assert_array_equal(fast["panoptic_seg"][0], gen["panoptic_seg"][0])
+        assert fast["panoptic_seg"][1] == gen["panoptic_seg"][1]
+        np.testing.assert_array_equal(fast["sem_seg"], gen["sem_seg"])
+        np.testing.assert_array_equal(fast["instances"]["pred_masks"], gen["instances"]["pred_masks"])
+        np.testing.assert_array_equal(fast["instances"]["scores"], gen["instances"]["scores"])
 
 
 @pytest.mark.parametrize("h,w,oh,ow", [(512, 512, 512, 512), (500, 502, 500, 502), (512, 704, 256, 352), (300, 400, 450, 600)])

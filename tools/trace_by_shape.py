@@ -1,14 +1,24 @@
 """Per-kernel-family and per-dispatch-shape breakdown of the LAST step in a rocprofv3 kernel trace.
-usage: trace_by_shape.py <kernel_trace.csv> <steps_in_trace> [top=24]"""
+usage: trace_by_shape.py <kernel_trace.csv> [marker | <steps_in_trace>] [top=24]"""
 import collections
 import csv
 import sys
 
-path, steps = sys.argv[1], int(sys.argv[2])
+path = sys.argv[1]
+steps = sys.argv[2] if len(sys.argv) > 2 else "marker"
 top = int(sys.argv[3]) if len(sys.argv) > 3 else 24
 rows = [r for r in csv.DictReader(open(path)) if 'odise' in r['Kernel_Name']]
-n = len(rows) // steps
-last = rows[-n:]
+rows.sort(key=lambda r: int(r['Start_Timestamp']))
+if steps == "marker":
+    # a model call starts with the image_pad_kernel launches of its batch (odise_hip_infer): the trace is cut there, and the LAST BUT ONE
+    # segment is one whole timed step (the last one is followed by bench.py's own dominant-kernel timing launches)
+    starts = [i for i, r in enumerate(rows) if 'image_pad_kernel' in r['Kernel_Name'] and (i == 0 or 'image_pad_kernel' not in rows[i - 1]['Kernel_Name'])]
+    assert len(starts) >= 2, "fewer than two model calls in the trace"
+    last = rows[starts[-2]:starts[-1]]
+    n = len(last)
+else:
+    n = len(rows) // int(steps)
+    last = rows[-n:]
 agg = collections.OrderedDict()
 fam = collections.Counter()
 for r in last:
