@@ -33,7 +33,16 @@ void models_destroy(odise_hip_ctx* ctx) {
 
 int ensure_lane2(odise_hip_ctx* ctx, ModelStore* ms, size_t arena_bytes) {
     if (!ctx->stream2) {
-        ODISE_CHECK_HIP(hipStreamCreateWithFlags(&ctx->stream2, hipStreamNonBlocking));
+        int lo = 0, hi = 0;   // (least, greatest) priority: numerically, greatest <= least
+        ODISE_CHECK_HIP(hipDeviceGetStreamPriorityRange(&lo, &hi));
+        // The CLIP -> UNet lane is the step's critical path (the UNet starts when the encoder's latent exists and ~540 dependent launches
+        // follow); its workgroups go ahead of the VAE's chip-filling convolutions whenever both are ready: -1.7 ms per step, same box
+        // (profiles/r03_lane_scheduling.txt)
+        int prio = hi;
+#ifdef ODISE_TOOLS
+        if (getenv("ODISE_LANE2_NORMAL_PRIORITY")) prio = lo;   // A/B
+#endif
+        ODISE_CHECK_HIP(hipStreamCreateWithPriority(&ctx->stream2, hipStreamNonBlocking, prio));
         ODISE_CHECK_HIP(hipMalloc(&ctx->ws2, ctx->ws_bytes));
         ODISE_CHECK_HIP(hipEventCreateWithFlags(&ctx->ev_fork, hipEventDisableTiming));
         ODISE_CHECK_HIP(hipEventCreateWithFlags(&ctx->ev_mid, hipEventDisableTiming));

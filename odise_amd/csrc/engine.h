@@ -159,7 +159,8 @@ const Act* unet_taps(ModelStore* ms);
 size_t extractor_arena_bytes(int B, int H, int W);
 const Act* extractor_taps(ModelStore* ms);
 bool extractor_ready(ModelStore* ms);
-int extractor_launch(odise_hip_ctx* ctx, ModelStore* ms, const float* image, int B, int H, int W, bool standalone);
+int extractor_launch(odise_hip_ctx* ctx, ModelStore* ms, const float* image, int B, int H, int W, bool standalone, bool join = true);
+int extractor_join(odise_hip_ctx* ctx);
 
 // misc.hip
 struct LatentW {

@@ -452,7 +452,14 @@ const Act* extractor_taps(ModelStore* ms) { return ms->extractor ? ms->extractor
 bool extractor_ready(ModelStore* ms) { return ms->extractor && ms->extractor->built; }
 
 // standalone=false: called from the backbone stage, which owns the arena and the MAC counter
-int extractor_launch(odise_hip_ctx* ctx, ModelStore* ms, const float* image, int B, int H, int W, bool standalone) {
+// The UNet taps (2..5) are produced on the second lane: a caller that passed join = false consumes the VAE taps (0, 1, 6, 7) first and calls
+// this before it touches a UNet tap (stream-side wait, the host never blocks)
+int extractor_join(odise_hip_ctx* ctx) {
+    if (ctx->lanes == 2 && !standalone_graph_capture(ctx)) ODISE_CHECK_HIP(hipStreamWaitEvent(ctx->stream, ctx->ev_join, 0));
+    return ODISE_OK;
+}
+
+int extractor_launch(odise_hip_ctx* ctx, ModelStore* ms, const float* image, int B, int H, int W, bool standalone, bool join) {
     ExtractorModel* e = ms->extractor;
     Exec ex{ctx, ms};
     if (standalone) {
@@ -494,13 +501,23 @@ int extractor_launch(odise_hip_ctx* ctx, ModelStore* ms, const float* image, int
         d.C = cond_emb; d.ldc = e->ted; d.c_dtype = ODISE_F32; d.bias_n = e->cap_time.b; d.alpha = 1.f; d.batch = 1;
         return ex.gemm(d);
     };
-    if (two) {
-        Lane2 lane(ctx, ms);
+    // ENQUEUE ORDER (two lanes).  The host issues ~1600 launches per step at roughly 20 us each, so the order in which the two lanes are
+    // fed decides whether they overlap at all: with the ~450 launches of the CLIP tower enqueued first, the VAE encoder's first kernel
+    // reached the GPU 11 ms into the step, and the VAE decoder waited another 10.7 ms behind the ~540 launches of the UNet - each lane
+    // idled while the host was busy feeding the other (profiles/r03_lane_timeline.txt).  The few, chip-filling launches of the VAE go first:
+    // encoder, then the CLIP branch, then the decoder, then the UNet (which waits for the encoder's latent on the device anyway).
+#ifdef ODISE_TOOLS
+    static const bool vae_first = getenv("ODISE_LANE_ORDER_OLD") == nullptr;   // A/B of the enqueue order
+#else
+    const bool vae_first = true;
+#endif
+    auto clip_on_lane2 = [&]() -> int {
+        Lane2 lane(ctx, ms);                                                  // CLIP branch: independent of the encoder, starts at the fork
         ODISE_CHECK_HIP(hipStreamWaitEvent(ctx->stream, ctx->ev_fork, 0));
-        ODISE_TRY(conditioning());
-    } else {
-        ODISE_TRY(conditioning());
-    }
+        return conditioning();
+    };
+    if (!two) ODISE_TRY(conditioning());
+    if (two && !vae_first) ODISE_TRY(clip_on_lane2());
 
     // ---- VAE encoder ------------------------------------------------------------------------------------------------
     Act x;
@@ -546,18 +563,21 @@ int extractor_launch(odise_hip_ctx* ctx, ModelStore* ms, const float* image, int
     ODISE_TRY(ex.alloc(xt, B, lh, lw, 8));
     ODISE_TRY(ex.alloc(zdec, B, lh, lw, 8));
     ODISE_TRY(launch_latent_heads(ctx, cur.p, e->noise, xt.p, zdec.p, nullptr, B, lh * lw, e->lat));
-    // ---- UNet (t = 0) -------------------------------------------------------------------------------------------------
-    if (two) {
-        ODISE_CHECK_HIP(hipEventRecord(ctx->ev_mid, ctx->stream));            // the latent is ready
+    auto unet_on_lane2 = [&]() -> int {   // waits for the latent on the device; its ~540 launches take the host ~10 ms
         Lane2 lane(ctx, ms);
         ODISE_CHECK_HIP(hipStreamWaitEvent(ctx->stream, ctx->ev_mid, 0));
         ODISE_TRY(unet_launch(ctx, ms, ms->unet, nullptr, xt.p, cond_inputs, cond_emb, B, lh, lw, false));
         ODISE_CHECK_HIP(hipEventRecord(ctx->ev_join, ctx->stream));
+        return ODISE_OK;
+    };
+    if (two) {
+        ODISE_CHECK_HIP(hipEventRecord(ctx->ev_mid, ctx->stream));            // the latent is ready
+        if (vae_first) ODISE_TRY(clip_on_lane2());
+        else ODISE_TRY(unet_on_lane2());
     } else {
+        // ---- UNet (t = 0), single lane: before the decoder, as the reference orders its modules
         ODISE_TRY(unet_launch(ctx, ms, ms->unet, nullptr, xt.p, cond_inputs, cond_emb, B, lh, lw, false));
     }
-    const Act* ut = unet_taps(ms);
-    for (int i = 0; i < 4; ++i) e->taps[2 + i] = ut[i];
     // ---- VAE decoder up to the last tap ----------------------------------------------------------------------------------
     {
         Act h, a, b2, c;
@@ -575,7 +595,13 @@ int extractor_launch(odise_hip_ctx* ctx, ModelStore* ms, const float* image, int
         ODISE_TRY(run_vae_res(ex, e->dec_l2[1], m0, m1));
         e->taps[7] = m1;  // input of up block 5
     }
-    if (two) ODISE_CHECK_HIP(hipStreamWaitEvent(ctx->stream, ctx->ev_join, 0));   // join: the UNet taps are ready for whoever consumes them on the main stream
+    // ---- UNet (t = 0), second lane: enqueued last
+    if (two && vae_first) ODISE_TRY(unet_on_lane2());
+    {
+        const Act* ut = unet_taps(ms);
+        for (int i = 0; i < 4; ++i) e->taps[2 + i] = ut[i];
+    }
+    if (two && join) ODISE_CHECK_HIP(hipStreamWaitEvent(ctx->stream, ctx->ev_join, 0));   // join: the UNet taps are ready for whoever consumes them on the main stream
     e->last_macs = ms->macs;
     return ODISE_OK;
 }

@@ -284,6 +284,13 @@ constexpr int epi16_wave_rows(int BM, int BN, int WAVES_M, int lds_bytes) {
 constexpr int epi16_rows_if_enabled(int BM, int BN, int WAVES_M, int lds_bytes) {
     return (BN != 320 && BM * BN >= 256 * 128) ? epi16_wave_rows(BM, BN, WAVES_M, lds_bytes) : 0;
 }
+constexpr int max_int(int a, int b) { return a > b ? a : b; }
+constexpr int halo4_lds_bytes(int BN) {
+    const int layout = 2 * BN * 64 * 2 + (41 + 1) * 1024;     // two weight stages + ONE halo buffer (41 groups + a dummy one)
+    const int f16_all = 256 * (BN + 8) * 2;                   // fp16 staging of the whole tile
+    const int f32_row = 64 * (BN + 4) * 4;                    // one wave-row of the fp32-staged form
+    return max_int(max_int(layout, f16_all <= 80 * 1024 ? f16_all : 0), f32_row);
+}
 constexpr int epi_wave_rows(int BM, int BN, int WAVES_M, int lds_bytes) {
     const int per_row = (BM / WAVES_M) * (BN + 4) * 4;
     int wg = lds_bytes / per_row;
@@ -1864,6 +1871,168 @@ __global__ void __launch_bounds__(512) conv3_halo_kernel(GemmArgs g) {
                   epi16_rows_if_enabled(BM, BN, WAVES_M, halo_lds_bytes(BN)), false>(g, acc, smem, m0, n0, z, zb, split);
 }
 
+// ---- 3x3 halo convolution, 4-wave form: TWO co-resident blocks per CU --------------------------------------------------------------------
+// The 8-wave halo kernel owns a CU alone, and the rounds of a launch stay in step across the chip: every block loads its first halo and
+// weights, multiplies, then writes its tile at the same time as all the others - memory and matrix pipes take turns instead of overlapping.
+// On the 128-channel VAE level (K = 1152: 18 K-tiles per block) the two phases are nearly equal, which is why three different 8-wave
+// structures all land at 630-650 TFLOP/s (profiles/r02_vae128_level_experiments.txt): 3.5 GB of compulsory traffic at ~5 TB/s is 0.7 ms, the
+// MFMA work at the ~1.1 PFLOP/s these loops sustain is 1.1 ms, and the launch takes their SUM, 1.8 ms.
+// Here a block is four waves (one per SIMD) on the same 16x16-pixel x BN-channel tile - a wave owns 4 patch rows x all BN channels, the
+// accumulator shape of the 256-channel kernel's waves - with ONE halo buffer and two weight stages: 74 KB of LDS and <= 256 VGPRs, so two
+// blocks share a CU.  They drift apart within a few tiles (16 384 blocks per launch), and the prologue / halo reload / epilogue of one runs
+// under the K-tiles of the other: the hardware interleaves the two instruction streams per SIMD, no cross-block protocol.  Inside a
+// block the loop is the plain one (weights of K-tile t+1 in flight during K-tile t, one barrier per K-tile; the halo of the next chunk is
+// fetched at the chunk boundary, once the last tap has been read).  Same chunk-major fp32 summation order as conv3_halo_kernel: bit-identical.
+template <int BN>
+__global__ void __launch_bounds__(256, 2) conv3_halo4_kernel(GemmArgs g) {
+    constexpr int BM = 256, BK = 64, WAVES_M = 4, WAVES_N = 1;
+    constexpr int TM = 2, TN = BN / 32;
+    constexpr int JB = BN / 32;              // weight loads per thread per K-tile (BN rows x 8 slots over 256 threads)
+    constexpr int HW_ = 18, HPIX = HW_ * HW_;
+    constexpr int HGROUPS = (HPIX + 7) / 8;  // 41 real 8-pixel groups
+    constexpr int H = 11;                    // halo loads per thread per chunk (44 group slots over 4 waves; slots >= HGROUPS are dummies)
+    constexpr int B_BYTES = BN * BK * 2;
+    constexpr int HALO0 = 2 * B_BYTES;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave;
+    const int hi = lane >> 5, l31 = lane & 31;
+    int bx, by;
+    {
+        const int nbx = gridDim.x, nb = gridDim.x * gridDim.y;
+        const int bid = blockIdx.y * nbx + blockIdx.x;
+        const int q = nb >> 3, r = nb & 7;
+        const int xcd = bid & 7, idx = bid >> 3;
+        const int logical = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+        by = logical / nbx;
+        bx = logical - by * nbx;
+    }
+    const int m0 = by * BM;  // patch index * 256 (the epilogue maps tile rows to pixels)
+    const int n0 = bx * BN;
+    const int z = blockIdx.z;
+    const bool split = g.splitk > 1;
+    const int zb = 0;
+    const int nk_total = g.K / BK;
+    int kt_begin = 0, kt_end = nk_total;
+    if (split) {
+        kt_begin = z * g.ktiles_per_split;  // a multiple of 9: whole chunks
+        kt_end = kt_begin + g.ktiles_per_split;
+        if (kt_end > nk_total) kt_end = nk_total;
+    }
+    const f16* Wb = g.W;
+    const int per_img = g.cg.halo_tx * g.cg.halo_ty;
+    const int img = by / per_img, pr = by - img * per_img;
+    const int py0 = (pr / g.cg.halo_tx) * 16 - 1, px0 = (pr % g.cg.halo_tx) * 16 - 1;  // input coordinate of halo pixel (0,0)
+    const f16* Ab = g.A + (int64_t)img * g.cg.H * g.cg.W * g.cg.Cin;                    // this image's plane: 32-bit offsets below
+
+    // ---- halo DMA descriptors: load h of this wave fills group h*4 + wave; lane -> pixel 8*group + lane/8, physical slot lane & 7
+    int h_off[H];  // element offset inside the image of the lane's 16 bytes for chunk 0, or -1 (out of the image / dummy -> zero line)
+#pragma unroll
+    for (int h = 0; h < H; ++h) {
+        const int group = h * 4 + wave;
+        const int hp = group * 8 + (lane >> 3);
+        h_off[h] = -1;
+        if (group < HGROUPS && hp < HPIX) {
+            const int hy = hp / HW_, hx = hp - hy * HW_;
+            const int iy = py0 + hy, ix = px0 + hx;
+            if ((unsigned)iy < (unsigned)g.cg.H && (unsigned)ix < (unsigned)g.cg.W)
+                h_off[h] = (iy * g.cg.W + ix) * g.cg.Cin + (((lane & 7) ^ ((hx >> 1) & 7)) << 3);
+        }
+    }
+    auto issue_halo = [&](int chunk) {
+#pragma unroll
+        for (int h = 0; h < H; ++h) {
+            const int group = h * 4 + wave;
+            const f16* src = h_off[h] >= 0 ? Ab + h_off[h] + chunk * BK : g.zeros;
+            glds16(src, smem + HALO0 + (group < HGROUPS ? group : HGROUPS) * 1024);
+        }
+    };
+    // ---- weight DMA: load j fills rows [32j + 8*wave, +8) of the stage; lane -> row +lane/8, physical slot lane & 7, logical slot swizzled
+    const int rb = wave * 8 + (lane >> 3);
+    const int ls = (lane & 7) ^ ((rb >> 1) & 7);
+    const int64_t b_off0 = (int64_t)(n0 + rb) * g.ldw + ls * 8;
+    auto issue_B = [&](int stage, int kw) {
+#pragma unroll
+        for (int j = 0; j < JB; ++j) {
+            const bool ok = (n0 + rb + 32 * j) < g.N;
+            const f16* src = ok ? Wb + b_off0 + (int64_t)(32 * j) * g.ldw + kw : g.zeros;
+            glds16(src, smem + stage * B_BYTES + (32 * j + wave * 8) * 128);
+        }
+    };
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    int koff[4];
+#pragma unroll
+    for (int s = 0; s < 4; ++s) koff[s] = ((s * 2 + hi) ^ ((l31 >> 1) & 7)) << 4;
+    const int b_lane_off = l31 * 128;
+    const int a_pix0 = (wm * 4 + (l31 >> 4)) * HW_ + (l31 & 15);  // halo pixel of this lane's row of A tile 0 at tap (0,0); tile 1: +2 patch rows
+
+    // K-tile position: chunk-major (tap inner); kw = element offset inside a weight row [Cout][ky][kx][Cin]
+    int ky = 0, kx = 0, chunk = kt_begin / 9;
+    if (kt_begin < kt_end) {
+        issue_halo(chunk);
+        issue_B(0, chunk * BK);
+    }
+    for (int kt = kt_begin; kt < kt_end; ++kt) {
+        const int cur = (kt - kt_begin) & 1;
+        // K-tile kt's weights (and, at a chunk boundary, the halo) have landed - this wave's share, then everybody's; every wave is also done
+        // with the other weight stage (it finished K-tile kt-1 before arriving here)
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        int nky = ky, nkx = kx + 1, nchunk = chunk;
+        if (nkx == 3) { nkx = 0; if (++nky == 3) { nky = 0; ++nchunk; } }
+        const bool more = kt + 1 < kt_end;
+        if (more) issue_B(cur ^ 1, (nky * 3 + nkx) * g.cg.Cin + nchunk * BK);
+        const char* ha = smem + HALO0;
+        const char* fb = smem + cur * B_BYTES + b_lane_off;
+        const int pix = a_pix0 + ky * HW_ + kx;
+        const int key = (((l31 & 15) + kx) >> 1) & 7;  // swizzle key = halo COLUMN / 2 (see conv3_halo_kernel)
+        // fragments double-buffered in registers: the reads of k-step s + 1 are issued before the MFMAs of k-step s (counted lgkmcnt), so a
+        // lone wave does not sit out an LDS round trip per k-step while its SIMD partner (the other block's wave) is in a barrier or a wait
+        f16x8 af[2][TM], bf[2][TN];
+        auto read_frags = [&](int s, int b) {
+#pragma unroll
+            for (int i = 0; i < TM; ++i) af[b][i] = *reinterpret_cast<const f16x8*>(ha + (pix + i * 2 * HW_) * 128 + (((s * 2 + hi) ^ key) << 4));
+#pragma unroll
+            for (int j = 0; j < TN; ++j) bf[b][j] = *reinterpret_cast<const f16x8*>(fb + koff[s] + j * 4096);
+        };
+        read_frags(0, 0);
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            if (s + 1 < 4) read_frags(s + 1, (s + 1) & 1);
+            __builtin_amdgcn_sched_barrier(0);   // keep the prefetch ahead of the MFMAs (the scheduler otherwise sinks it to save registers)
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bf[s & 1][j], af[s & 1][i], acc[i][j], 0, 0, 0);  // transposed tile (see gemm_epilogue)
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        if (more && nchunk != chunk) {
+            // chunk boundary: the single halo buffer is refilled once every wave has read the last tap (LDS reads retired, then a barrier);
+            // the co-resident block covers the round trip
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            issue_halo(nchunk);
+        }
+        ky = nky; kx = nkx; chunk = nchunk;
+    }
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    __syncthreads();  // every wave is done with the operand buffers before the staging image reuses them
+    gemm_epilogue<BM, BN, WAVES_M, WAVES_N, epi_wave_rows(BM, BN, WAVES_M, halo4_lds_bytes(BN)), true, true, true,
+                  epi16_rows_if_enabled(BM, BN, WAVES_M, halo4_lds_bytes(BN)), false>(g, acc, smem, m0, n0, z, zb, split);
+}
+
 __global__ void __launch_bounds__(256) splitk_reduce_kernel(const float* __restrict__ ws, int splitk, int M, int N, GemmEpi e) {
     const int CH = (N + 7) / 8;
     const int64_t total = (int64_t)M * CH;
@@ -1985,15 +2154,40 @@ static int launch_conv3_halo(odise_hip_ctx* ctx, GemmArgs& g) {
     return ODISE_OK;
 }
 
+template <int BN>
+static int launch_conv3_halo4(odise_hip_ctx* ctx, GemmArgs& g) {
+    constexpr int lds = halo4_lds_bytes(BN);
+    static_assert(2 * lds <= 160 * 1024, "two blocks must fit a CU's LDS");
+    static_assert(epi_lds_bytes(256, BN, 4, epi_wave_rows(256, BN, 4, lds)) <= lds, "epilogue staging exceeds the LDS request");
+    auto kern = conv3_halo4_kernel<BN>;
+    static bool attr_set = false;  // per instantiation
+    if (!attr_set) {
+        ODISE_CHECK_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+        attr_set = true;
+    }
+    const int n_img = g.M / (g.cg.OH * g.cg.OW);
+    dim3 grid((unsigned)ceil_div(g.N, BN), (unsigned)(n_img * g.cg.halo_tx * g.cg.halo_ty), (unsigned)(g.splitk > 1 ? g.splitk : 1));
+    hipLaunchKernelGGL(kern, grid, dim3(256), lds, ctx->stream, g);
+    ODISE_CHECK_HIP(hipGetLastError());
+    if (g.splitk > 1) {
+        const int64_t total = (int64_t)g.M * ceil_div(g.N, 8);
+        const int blocks = (int)std::min<int64_t>(ceil_div(total, 256), 2048);
+        hipLaunchKernelGGL(splitk_reduce_kernel, dim3(blocks), dim3(256), 0, ctx->stream, g.ws, g.splitk, g.M, g.N, g.epi);
+        ODISE_CHECK_HIP(hipGetLastError());
+    }
+    return ODISE_OK;
+}
+
 static int g_gemm_debug = 0;  // see GemmArgs::dbg
 static int g_epi_old = 0;     // tools only: 1 = keep the fp32-staged epilogue (odise_hip_gemm_debug bit 1 << 24), for same-process A/B runs
 static int g_conv_flags = 0;  // tools only: 1 = tap-major K order even when Cin % 64 == 0, 2 = never use the ping-pong kernel, 4 = one N-tile per phase at BN = 256
 
 // Tile ids: 0:128x128 1:64x128 2:64x64 (4 waves)  3:256x320 4:256x256 5:256x128 (8 waves)  6:512x128 (8 waves, ping-pong only)
 //           7: 16x16-pixel patch x 256 channels, 8: 16x16-pixel patch x 128 channels (conv3_halo_kernel: 3x3 / stride 1 / pad 1 only)
-static const int kNumTiles = 9;
-static const int kTileBM[kNumTiles] = {128, 64, 64, 256, 256, 256, 512, 256, 256};
-static const int kTileBN[kNumTiles] = {128, 128, 64, 320, 256, 128, 128, 256, 128};
+//           9: 16x16-pixel patch x 128 channels, 4 waves, two blocks per CU (conv3_halo4_kernel)
+static const int kNumTiles = 10;
+static const int kTileBM[kNumTiles] = {128, 64, 64, 256, 256, 256, 512, 256, 256, 256};
+static const int kTileBN[kNumTiles] = {128, 128, 64, 320, 256, 128, 128, 256, 128, 128};
 
 // Tile / split-K selection by a small cost model (times in microseconds, calibrated on MI355X with tools/gemm_bench.py):
 //   t = rounds * (k_tiles_per_split * t_ktile + t_fixed) + t_reduce,   rounds = ceil(blocks * split / resident slots)
@@ -2017,6 +2211,7 @@ static const TileCost kTileCost[kNumTiles] = {
     {1.92, 12.0, 1},  // halo 256 pixels x 256 channels (measured 7 % under the im2col ping-pong tile on the 512-channel VAE layers)
     {1.12, 9.0, 1},   // halo 256 pixels x 128 channels (re-fitted in round 2: 28 us per block of 18 K-tiles on the 128-channel VAE level, where
                       // the im2col 512x128 tile takes 65 us per block of twice the size: 1.80 vs 2.07 ms per launch, tools/halo512_probe.py)
+    {2.00, 9.0, 2},   // the same tile as four waves, two blocks per CU (a block's K-tile takes about twice as long beside its partner)
 };
 // the 256-row tiles as run by the ping-pong kernel (K % 64 == 0; conv: Cin % 64 == 0, no fused upsample)
 static const TileCost kTileCostPP[2] = {
@@ -2029,7 +2224,7 @@ static const TileCost kTileCostPP[2] = {
 static const TileCost kTileCostConv512 = {2.5, 16.0, 1};
 // previous fit (before the lean epilogue / ping-pong kernel), kept selectable for A/B runs: ODISE_GEMM_FLAGS=8
 static const TileCost kTileCostOld[kNumTiles] = {{1.68, 9.5, 2}, {1.58, 4.1, 3}, {1.28, 2.4, 4}, {3.04, 29.0, 1}, {2.58, 22.0, 1},
-                                                 {1.75, 10.6, 1}, {2.25, 12.0, 1}, {1.92, 12.0, 1}, {1.32, 10.0, 1}};
+                                                 {1.75, 10.6, 1}, {2.25, 12.0, 1}, {1.92, 12.0, 1}, {1.32, 10.0, 1}, {2.64, 10.0, 2}};
 static int env_gemm_flags() {
 #ifdef ODISE_TOOLS
     static int v = -1;
@@ -2069,7 +2264,8 @@ static int launch_gemm(odise_hip_ctx* ctx, GemmArgs& g, int batch, int force_til
     for (int t = 0; t < kNumTiles; ++t) {
         if (force_tile >= 0 && force_tile < kNumTiles && t != force_tile) continue;
         if (t == 6 && (!pp_ok || (flags & 16))) continue;
-        if (t >= 7 && (!halo_ok || !pp_ok || (flags & 64))) continue;  // ODISE_GEMM_FLAGS=64: never use the halo kernel
+        if (t >= 7 && (!halo_ok || !pp_ok || (flags & 64))) continue;  // ODISE_GEMM_FLAGS=64: never use the halo kernels
+        if (t == 9 && (flags & 2048)) continue;                        // ODISE_GEMM_FLAGS=2048: never use the two-blocks-per-CU halo kernel
         const TileCost& tc = (flags & 8) ? kTileCostOld[t] : (pp_ok && (t == 3 || t == 4)) ? kTileCostPP[t - 3] : (CONV && t == 6) ? kTileCostConv512 : kTileCost[t];
         if (force_tile < 0) {
             if (kTileBM[t] > 64 && g.M <= kTileBM[t] / 2) continue;            // mostly-empty row tiles
@@ -2152,6 +2348,7 @@ static int launch_gemm(odise_hip_ctx* ctx, GemmArgs& g, int batch, int force_til
     // the 256-row tiles run the ping-pong pipelined kernel whenever its preconditions hold
     if (tile >= 7) {
         g.cg.chunk_major = 1;
+        if (tile == 9) return launch_conv3_halo4<128>(ctx, g);
         return tile == 7 ? launch_conv3_halo<256, 2>(ctx, g) : launch_conv3_halo<128, 1>(ctx, g);
     }
     g.cg.halo_tx = g.cg.halo_ty = 0;

@@ -372,14 +372,27 @@ static int backbone_forward(odise_hip_ctx* ctx, const float* image, int B, int H
     if (!crops) return ODISE_ERR_NOMEM;
     if (cs == S) ODISE_TRY(launch_crop_extract(ctx, image, crops, B, 3, H, W, S, K, g->boxes_dev));
     else ODISE_TRY(launch_crop_resize_bicubic(ctx, image, crops, B, 3, H, W, cs, S, K, g->boxes_dev));   // windows below 512: bicubic to 512 x 512
-    ODISE_TRY(extractor_launch(ctx, ms, crops, B * K, S, S, false));
+    // The extractor leaves its second lane (CLIP -> UNet) un-joined: the projections of the VAE taps - the whole s2 group (enc5, dec5: the
+    // largest maps) and enc7 - are enqueued behind the VAE decoder and run while the UNet is still busy on the other stream; the main
+    // stream waits for the UNet right before the first projection that reads one of its taps.  Summation order inside a group unchanged.
+#ifdef ODISE_TOOLS
+    static const bool defer_join = getenv("ODISE_NO_DEFER_JOIN") == nullptr;   // A/B
+#else
+    const bool defer_join = true;
+#endif
+    ODISE_TRY(extractor_launch(ctx, ms, crops, B * K, S, S, false, /*join=*/!defer_join));
     const Act* taps = extractor_taps(ms);
+    bool joined = false;
     for (int gi = 0; gi < 4; ++gi) {
         const int stride = kGroupStride[gi], fs = cs / stride;   // features are restored to window / stride (feature_extractor.py:165-168)
         Act acc;
         bool have = false;
         for (int j = 0; j < 3 && kGroups[gi][j] >= 0; ++j) {
             const int idx = kGroups[gi][j];
+            if (!joined && idx >= 2 && idx <= 5) {   // u2, u5, u8, u11
+                ODISE_TRY(extractor_join(ctx));
+                joined = true;
+            }
             Act x = taps[idx];
             if (x.h != fs || x.w != fs) {  // restore to crop/stride (nearest; only u2: 8x8 -> 16x16)
                 Act up;
@@ -395,6 +408,7 @@ static int backbone_forward(odise_hip_ctx* ctx, const float* image, int B, int H
         ODISE_TRY(launch_stitch(ctx, acc.p, g->feats[gi].p, out4 ? out4[gi] : nullptr, B, K, g->boxes_dev + (size_t)(1 + gi) * 2 * K, fs, fs,
                                 H / stride, W / stride, g->proj_dim));
     }
+    if (!joined) ODISE_TRY(extractor_join(ctx));
     ms->arena.release(mk);
     g->last_macs = ms->macs;
     (void)kFeatStride;

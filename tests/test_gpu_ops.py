@@ -189,13 +189,16 @@ def test_conv3x3_and_1x1(ctx, N, H, W, Cin, Cout, k, tile, split):
     close(out, ref.numpy(), what=f"conv{k}x{k} {N}x{H}x{W}x{Cin}->{Cout}")
 
 
-# the halo kernels (3x3 / stride 1 / pad 1, Cin % 64 == 0; tile ids 7: 16x16 pixels x 256 channels, 8: 16x16 x 128), forced: whole patches,
+# the halo kernels (3x3 / stride 1 / pad 1, Cin % 64 == 0; tile ids 7: 16x16 pixels x 256 channels, 8 / 9: 16x16 x 128), forced: whole patches,
 # ragged image sizes (partial patches in both directions), several 64-channel chunks, split-K over whole chunks, a Cout that is not a
 # multiple of the column tile
 @pytest.mark.parametrize("N,H,W,Cin,Cout,tile,split", [
     (2, 32, 32, 128, 128, 8, 0), (1, 64, 48, 128, 128, 8, 0), (2, 40, 24, 128, 128, 8, 0), (1, 33, 17, 64, 128, 8, 0), (1, 16, 16, 192, 256, 8, 0),
     (1, 32, 32, 256, 128, 8, 2), (1, 8, 8, 128, 72, 8, 0), (3, 96, 32, 128, 128, 8, 0), (1, 33, 17, 192, 128, 8, 3),
     (1, 40, 24, 128, 256, 7, 0), (1, 16, 48, 256, 512, 7, 2), (2, 32, 32, 64, 320, 7, 0),
+    # tile 9: the 128-channel tile as four waves, two co-resident blocks per CU (one halo buffer, refilled at the chunk boundaries)
+    (2, 32, 32, 128, 128, 9, 0), (2, 40, 24, 128, 128, 9, 0), (1, 33, 17, 64, 128, 9, 0), (1, 16, 16, 192, 256, 9, 0), (1, 32, 32, 256, 128, 9, 2),
+    (1, 8, 8, 128, 72, 9, 0), (3, 96, 32, 128, 128, 9, 0), (1, 33, 17, 192, 128, 9, 3), (4, 128, 128, 128, 128, 9, 0),
 ])
 def test_conv3x3_halo_tiles(ctx, N, H, W, Cin, Cout, tile, split):
     g = torch.Generator().manual_seed(N + H + W + Cin + Cout + tile)
@@ -209,12 +212,13 @@ def test_conv3x3_halo_tiles(ctx, N, H, W, Cin, Cout, tile, split):
     close(out, ref.numpy(), what=f"halo tile {tile} conv {N}x{H}x{W}x{Cin}->{Cout} split {split}")
     # same fp32 summation order (chunk-major) in both halo tiles: without split-K they are bit-identical
     one = ctx.conv2d(dx, dw, bias=db, residual=dr, force_tile=tile, force_split=1).numpy()
-    other = ctx.conv2d(dx, dw, bias=db, residual=dr, force_tile=15 - tile, force_split=1).numpy()
-    assert np.array_equal(one, other), f"tile {tile} differs bitwise from tile {15 - tile}"
+    twin = 8 if tile == 9 else 15 - tile
+    other = ctx.conv2d(dx, dw, bias=db, residual=dr, force_tile=twin, force_split=1).numpy()
+    assert np.array_equal(one, other), f"tile {tile} differs bitwise from tile {twin}"
 
 
 @pytest.mark.parametrize("N,H,W,Cin,Cout,tile", [(2, 64, 64, 128, 128, 8), (1, 40, 24, 128, 128, 8), (1, 48, 32, 128, 256, 7), (1, 33, 20, 64, 512, 7),
-                                                 (1, 64, 32, 128, 128, 6), (1, 32, 32, 128, 256, 4)])
+                                                 (1, 64, 32, 128, 128, 6), (1, 32, 32, 128, 256, 4), (2, 64, 64, 128, 128, 9), (1, 40, 24, 128, 128, 9)])
 def test_conv_fused_groupnorm_statistics(ctx, N, H, W, Cin, Cout, tile):
     """The conv -> GroupNorm pair of the ResBlocks (ldm ResnetBlock: conv1 -> norm2 -> swish): the conv epilogue reduces the statistics,
     the GroupNorm only finalises and applies.  Compared with torch conv2d -> group_norm -> silu."""

@@ -1,12 +1,15 @@
 """Per-kernel and per-dispatch-shape summary of a rocprofv3 run stored as a rocpd sqlite database (`rocprofv3 --kernel-trace --stats -d DIR -o NAME --
 <cmd>` writes DIR/NAME_results.db in ROCm 7): kernel-time totals, the per-(kernel, grid) table of the LAST step, and the busy time per
-HIP stream.  usage: db_by_shape.py <results.db> <steps_in_trace> [top=40]"""
+HIP stream.  usage: db_by_shape.py <results.db> [marker | <steps_in_trace>] [top=40]
+"marker" (default) cuts the trace at the image_pad_kernel launches that open every model call and takes the last-but-one call (the last one is
+followed by bench.py's own dominant-kernel timing launches)."""
 import collections
 import re
 import sqlite3
 import sys
 
-path, steps = sys.argv[1], int(sys.argv[2])
+path = sys.argv[1]
+steps = sys.argv[2] if len(sys.argv) > 2 else "marker"
 top = int(sys.argv[3]) if len(sys.argv) > 3 else 40
 cur = sqlite3.connect(path).cursor()
 rows = cur.execute("select name, start, end, grid_x, grid_y, grid_z, workgroup_x, workgroup_y, workgroup_z, stream_id from kernels order by start").fetchall()
@@ -29,11 +32,18 @@ print("# ---- kernel totals over the whole trace (us)")
 print("Name,Calls,TotalDurationUs,AverageUs,Percentage")
 for k, v in by_name.most_common(top):
     print(f"\"{k}\",{calls[k]},{v:.1f},{v / calls[k]:.2f},{100 * v / (total * 1e3):.2f}")
-n = len(ours) // steps
-last = ours[-n:] if steps > 0 else ours
+if steps == "marker":
+    starts = [i for i, r in enumerate(ours) if "image_pad_kernel" in r[0] and (i == 0 or "image_pad_kernel" not in ours[i - 1][0])]
+    assert len(starts) >= 2, "fewer than two model calls in the trace"
+    last = ours[starts[-2]:starts[-1]]
+    n = len(last)
+else:
+    steps = int(steps)
+    n = len(ours) // steps
+    last = ours[-n:] if steps > 0 else ours
 span = (max(r[2] for r in last) - min(r[1] for r in last)) / 1e6
 busy = sum(r[2] - r[1] for r in last) / 1e6
-print(f"# ---- last of {steps} equal slices of the trace: {n} launches, {busy:.2f} ms of kernel time inside a {span:.2f} ms span (overlap across streams shortens the span)")
+print(f"# ---- one model call ({steps}): {n} launches, {busy:.2f} ms of kernel time inside a {span:.2f} ms span (overlap across streams shortens the span)")
 streams = collections.Counter()
 for r in last:
     streams[r[9]] += (r[2] - r[1]) / 1e6
