@@ -504,8 +504,11 @@ int extractor_launch(odise_hip_ctx* ctx, ModelStore* ms, const float* image, int
     // ENQUEUE ORDER (two lanes).  The host issues ~1600 launches per step at roughly 20 us each, so the order in which the two lanes are
     // fed decides whether they overlap at all: with the ~450 launches of the CLIP tower enqueued first, the VAE encoder's first kernel
     // reached the GPU 11 ms into the step, and the VAE decoder waited another 10.7 ms behind the ~540 launches of the UNet - each lane
-    // idled while the host was busy feeding the other (profiles/r03_lane_timeline.txt).  The few, chip-filling launches of the VAE go first:
+    // idled while the host was busy feeding the other (profiles/r03_lane_scheduling.txt).  The few, chip-filling launches of the VAE go first:
     // encoder, then the CLIP branch, then the decoder, then the UNet (which waits for the encoder's latent on the device anyway).
+    // What remains: beside the VAE's convolutions (100-150 us per workgroup on every CU) each of the ~1000 dependent launches of the other
+    // lane waits for workgroups to drain, so CLIP takes 31 ms instead of 13 there.  A higher stream priority for that lane is worth -1.7 ms;
+    // reserving every 2nd .. 8th CU for it with a CU-masked VAE stream changed nothing (profiles/r03_lane_scheduling.txt).
 #ifdef ODISE_TOOLS
     static const bool vae_first = getenv("ODISE_LANE_ORDER_OLD") == nullptr;   // A/B of the enqueue order
 #else

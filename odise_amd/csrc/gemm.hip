@@ -2185,6 +2185,10 @@ static int g_conv_flags = 0;  // tools only: 1 = tap-major K order even when Cin
 // Tile ids: 0:128x128 1:64x128 2:64x64 (4 waves)  3:256x320 4:256x256 5:256x128 (8 waves)  6:512x128 (8 waves, ping-pong only)
 //           7: 16x16-pixel patch x 256 channels, 8: 16x16-pixel patch x 128 channels (conv3_halo_kernel: 3x3 / stride 1 / pad 1 only)
 //           9: 16x16-pixel patch x 128 channels, 4 waves, two blocks per CU (conv3_halo4_kernel)
+// (The dense counterpart of tile 9 - four waves on 128x256 / 256x128 with a three-slot ring of 32-deep K-tiles, two blocks per CU - was built,
+//  bit-identical, and measured 5-20 % SLOWER than the 8-wave ping-pong kernels on 19 of the step's 22 dense shapes, never more than 9 % faster
+//  (profiles/r03_gemm4_two_blocks_dense.txt): two operand streams through LDS-DMA at half the tile size cost more than the overlap of
+//  neighbouring blocks returns, where the convolution's input patch is fetched once for nine K-tiles.  Not kept.)
 static const int kNumTiles = 10;
 static const int kTileBM[kNumTiles] = {128, 64, 64, 256, 256, 256, 512, 256, 256, 256};
 static const int kTileBN[kNumTiles] = {128, 128, 64, 320, 256, 128, 128, 256, 128, 128};
@@ -2253,7 +2257,7 @@ static int launch_gemm(odise_hip_ctx* ctx, GemmArgs& g, int batch, int force_til
         halo_patches = (int64_t)(g.M / (g.cg.OH * g.cg.OW)) * g.cg.halo_tx * g.cg.halo_ty;
     }
     auto blocks = [&](int t) {
-        return (t >= 7 ? halo_patches : ceil_div(g.M, kTileBM[t])) * ceil_div(g.N, kTileBN[t]) * (int64_t)batch;
+        return ((t >= 7 && t <= 9) ? halo_patches : ceil_div(g.M, kTileBM[t])) * ceil_div(g.N, kTileBN[t]) * (int64_t)batch;
     };
     const bool no_interleave = force_tile >= 16;  // test hook: tile + 16 selects the non-interleaved issue order
     if (no_interleave) force_tile -= 16;
@@ -2264,7 +2268,7 @@ static int launch_gemm(odise_hip_ctx* ctx, GemmArgs& g, int batch, int force_til
     for (int t = 0; t < kNumTiles; ++t) {
         if (force_tile >= 0 && force_tile < kNumTiles && t != force_tile) continue;
         if (t == 6 && (!pp_ok || (flags & 16))) continue;
-        if (t >= 7 && (!halo_ok || !pp_ok || (flags & 64))) continue;  // ODISE_GEMM_FLAGS=64: never use the halo kernels
+        if (t >= 7 && t <= 9 && (!halo_ok || !pp_ok || (flags & 64))) continue;  // ODISE_GEMM_FLAGS=64: never use the halo kernels
         if (t == 9 && (flags & 2048)) continue;                        // ODISE_GEMM_FLAGS=2048: never use the two-blocks-per-CU halo kernel
         const TileCost& tc = (flags & 8) ? kTileCostOld[t] : (pp_ok && (t == 3 || t == 4)) ? kTileCostPP[t - 3] : (CONV && t == 6) ? kTileCostConv512 : kTileCost[t];
         if (force_tile < 0) {
@@ -2278,7 +2282,7 @@ static int launch_gemm(odise_hip_ctx* ctx, GemmArgs& g, int batch, int force_til
             if (force_split > 0 && sp != std::min(force_split, std::max(1, nk))) continue;
             if (sp > 1 && (size_t)sp * g.M * g.N * sizeof(float) > ctx->ws_bytes) break;
             // the halo kernel splits K in whole 64-channel chunks (9 K-tiles each)
-            const int per = t >= 7 ? (int)ceil_div(nk / 9, sp) * 9 : (int)ceil_div(nk, sp);
+            const int per = (t >= 7 && t <= 9) ? (int)ceil_div(nk / 9, sp) * 9 : (int)ceil_div(nk, sp);
             const int eff_sp = (int)ceil_div(nk, per);
             // Full residency rounds run at the calibrated K-tile time; the last (or only) partial round still costs most of a
             // block's time: an under-filled chip delivers operands only a little faster per block (measured with
@@ -2292,12 +2296,13 @@ static int launch_gemm(odise_hip_ctx* ctx, GemmArgs& g, int batch, int force_til
             if (t_us < best) { best = t_us; tile = t; best_split = eff_sp; }
         }
     }
-    if (force_tile >= 0 && force_tile < kNumTiles && !(force_tile == 6 && !pp_ok) && !(force_tile >= 7 && !(halo_ok && pp_ok))) tile = force_tile;
+    if (force_tile >= 0 && force_tile < kNumTiles && !(force_tile == 6 && !pp_ok) && !(force_tile >= 7 && force_tile <= 9 && !(halo_ok && pp_ok)))
+        tile = force_tile;
     g.splitk = 1;
     g.ktiles_per_split = nk;
     if (force_split > 0 && batch == 1) best_split = std::min(force_split, nk);
     if (best_split > 1 && batch == 1) {
-        g.ktiles_per_split = tile >= 7 ? (int)ceil_div(nk / 9, best_split) * 9 : (int)ceil_div(nk, best_split);
+        g.ktiles_per_split = (tile >= 7 && tile <= 9) ? (int)ceil_div(nk / 9, best_split) * 9 : (int)ceil_div(nk, best_split);
         g.splitk = (int)ceil_div(nk, g.ktiles_per_split);
         ODISE_REQUIRE((size_t)g.splitk * g.M * g.N * sizeof(float) <= ctx->ws_bytes, "gemm: split-K workspace too small");
     }
@@ -2332,7 +2337,7 @@ static int launch_gemm(odise_hip_ctx* ctx, GemmArgs& g, int batch, int force_til
         const int ohw = CONV ? g.cg.OH * g.cg.OW : 0;
         // kernels instantiated with the statistics epilogue: halo tiles, pp2 conv (256x256) and the 512x128 conv tile
         const bool pp2_used = (tile == 4) && pp_ok && ((flags & 512) || (!(flags & 1024) && CONV));
-        bool ok = CONV && g.splitk == 1 && g.epi.fast && g.N % 8 == 0 && (tile >= 7 || (tile == 6 && pp_ok && !(flags & 512)) || pp2_used);
+        bool ok = CONV && g.splitk == 1 && g.epi.fast && g.N % 8 == 0 && ((tile >= 7 && tile <= 9) || (tile == 6 && pp_ok && !(flags & 512)) || pp2_used);
         if (ok && tile >= 7) g.stats_blocks = g.cg.halo_tx * g.cg.halo_ty;
         else if (ok && ohw % kTileBM[tile] == 0) g.stats_blocks = ohw / kTileBM[tile];
         else ok = false;
