@@ -61,6 +61,10 @@ def parse():
     p.add_argument("--vocab", choices=sorted(VOCABS), default="coco133")
     p.add_argument("--semantic-only", action="store_true", help="semantic head only, fused argmax output (configs[4])")
     p.add_argument("--stage", choices=["full", "unet"], default="full")
+    p.add_argument("--in-flight", type=int, default=1, help="batches in flight per GPU: independent model instances (context, streams, activation arena; "
+                   "one host thread each) whose steps interleave, so the launch-bound serial tail of one batch runs under the chip-filling "
+                   "convolutions of the next.  Every step is still one synchronous model call on one batch of --images pictures")
+    p.add_argument("--clip-ln-fold", type=int, default=0, choices=[0, 1, 2], help="A/B: the CLIP towers' LayerNorm fold, 0 = the library's rule, 1 = always, 2 = never")
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--no-inclusive", action="store_true", help="skip the PCIe- / JPEG-inclusive legs")
     return p.parse_args()
@@ -277,6 +281,7 @@ def main():
 
     from odise_amd.runtime import Context
     ctx = Context(local_rank)
+    ctx.lib.odise_hip_clip_ln_fold(args.clip_ln_fold)
     B = args.images if args.images is not None else (4 if args.stage == "full" else 1)
 
     # Weights: random tensors of the real architecture's shapes (odise_amd/synthetic.py; no checkpoints, no network).  The oracle is
@@ -317,28 +322,51 @@ def main():
         hw = [(S, S)] * B
         rec = D.record_size(S, S)
         exchange = D.Exchange(ctx, rank, world, D.gloo_broadcast if world > 1 else None)
+        # further batches in flight: a model instance of their own (same weights, same calibration -> identical state), their own pictures
+        slots = [{"ctx": ctx, "hip": hip, "img": d_img}]
+        for k in range(1, max(1, args.in_flight)):
+            c2 = Context(local_rank)
+            h2, _ = calibrated_model(c2, image_u8(S, 0), S, K, K_TOT, set(range(N_THINGS)), None if K <= 200 else 188)
+            h2.panoptic_on, h2.instance_on, h2.semantic_argmax = hip.panoptic_on, hip.instance_on, hip.semantic_argmax
+            slots.append({"ctx": c2, "hip": h2, "img": [c2.to_device(image_u8(S, (k * world + rank) * B + b)) for b in range(B)]})
         import ctypes
         cw = ctypes.c_int(0)
         ctx.lib.odise_hip_comm_info(ctx.h, None, ctypes.byref(cw))
         if cw.value != args.gpus:                                        # the line must never report more GPUs than the communicator spans
             raise SystemExit(f"RCCL communicator spans {cw.value} ranks, --gpus {args.gpus}")
         rccl_ranks = cw.value
-        local = ctx.zeros((B, rec), np.int32)                            # this rank's prediction records, written by the kernels
-        allrec = ctx.zeros((world * B, rec), np.int32)
-        pan_out = [local.ptr + b * rec * 4 for b in range(B)] if hip.panoptic_on else None
-        last = {}
+        for sl in slots:
+            sl["local"] = sl["ctx"].zeros((B, rec), np.int32)            # this rank's prediction records, written by the kernels
+            sl["allrec"] = sl["ctx"].zeros((world * B, rec), np.int32)
+            sl["pan_out"] = [sl["local"].ptr + b * rec * 4 for b in range(B)] if hip.panoptic_on else None
+        import threading
+        turn = {"next": 0, "cv": threading.Condition()}
 
-        def step():
+        def step(sl=slots[0], ticket=None):
             # one model call (synchronous at its API edge: the tables are read back) + the one exchange step of the path, which then
-            # runs on the library's second stream while the next call's kernels execute
-            last["res"] = hip.infer_device(d_img, 0, hw, hw, to_host=False, pan_out=pan_out)
+            # runs on the library's exchange stream while the next call's kernels execute.  With several batches in flight the one
+            # communicator is used in global step order (`ticket`), the same order on every rank.
+            sl["res"] = sl["hip"].infer_device(sl["img"], 0, hw, hw, to_host=False, pan_out=sl["pan_out"])
             if hip.panoptic_on:
-                exchange.allgather(local, allrec)
+                if ticket is None:
+                    exchange.allgather(sl["local"], sl["allrec"])
+                else:
+                    with turn["cv"]:
+                        turn["cv"].wait_for(lambda: turn["next"] == ticket)
+                        exchange.allgather(sl["local"], sl["allrec"])
+                        turn["next"] += 1
+                        turn["cv"].notify_all()
 
         def check_exchange():
             """After the timed region: this rank's slice of the gathered buffer must hold its own records, and EVERY image's record a
             well-formed, NON-EMPTY segment table (an empty one means the timed decision kernels ran on nothing)."""
-            res = last["res"]
+            report = check_slot(slots[0])
+            for k, sl in enumerate(slots[1:], 1):
+                report[f"in_flight_{k}"] = check_slot(sl)
+            return report
+
+        def check_slot(sl):
+            res, local, allrec = sl["res"], sl["local"], sl["allrec"]
             report = {}
             if hip.instance_on:
                 report["instances_per_image"] = [int(len(r["instances"]["scores"])) for r in res]
@@ -380,20 +408,75 @@ def main():
     def barrier():
         ctx.sync()
         if args.stage == "full":
+            for sl in slots[1:]:
+                sl["ctx"].sync()
             exchange.wait(True)
         if dist is not None:
             dist.barrier()
 
-    for _ in range(args.warmup):
-        step()
-    barrier()
-    t0 = time.perf_counter()
-    ctx.timer_start()
-    for _ in range(args.steps):
-        step()
-    ev_ms = ctx.timer_stop()  # HIP events on the library's stream (synchronises)
-    barrier()
-    wall = time.perf_counter() - t0
+    n_fly = len(slots) if args.stage == "full" else 1
+    single_ms = None
+    if n_fly == 1:
+        for _ in range(args.warmup):
+            step()
+        barrier()
+        t0 = time.perf_counter()
+        ctx.timer_start()
+        for _ in range(args.steps):
+            step()
+        ev_ms = ctx.timer_stop()  # HIP events on the library's stream (synchronises)
+        barrier()
+        wall = time.perf_counter() - t0
+    else:
+        # K steps in all, dealt round-robin to the instances; each instance's steps run on its own host thread (a step is one C call that
+        # releases the interpreter lock).  The timed region opens after every instance has warmed up and drained, and closes after all K
+        # steps and their exchanges are complete on every rank.
+        gate = threading.Barrier(n_fly + 1)
+        errors = []
+        queue = {"next": 0, "lock": threading.Lock()}
+        stagger = [0.0]
+
+        def worker(k):
+            try:
+                sl = slots[k]
+                gate.wait()      # timed region open
+                time.sleep(k * stagger[0])   # instances start a fraction of a step apart (inside the timed region), so that they sit in different phases
+                while True:
+                    with queue["lock"]:
+                        i = queue["next"]
+                        queue["next"] += 1
+                    if i >= args.steps:
+                        break
+                    step(sl, i)
+                sl["ctx"].sync()
+            except BaseException as exc:   # a failed instance must not leave the others waiting at the gate
+                errors.append(exc)
+                gate.abort()
+                raise
+            gate.wait()          # done
+
+        threads = [threading.Thread(target=worker, args=(k,), daemon=True) for k in range(n_fly)]
+        for t in threads:
+            t.start()
+        for sl in slots:
+            for _ in range(max(1, args.warmup)):
+                tw = time.perf_counter()
+                step(sl)
+                sl["ctx"].sync()
+                single_ms = (time.perf_counter() - tw) * 1e3    # one batch alone on the chip (the last one: warm)
+        stagger[0] = single_ms * 1e-3 / n_fly
+        barrier()
+        try:
+            t0 = time.perf_counter()
+            gate.wait()
+            gate.wait()
+        except threading.BrokenBarrierError:
+            raise SystemExit(f"an in-flight instance failed: {errors}")
+        barrier()
+        wall = time.perf_counter() - t0
+        ev_ms = wall * 1e3   # no single stream spans the region: the host clock (which includes the final synchronisation) stands in
+        for t in threads:
+            t.join()
 
     if dist is not None:
         tt = torch.tensor([wall, ev_ms], dtype=torch.float64)
@@ -429,7 +512,7 @@ def main():
             "config": {"workload": workload, "units_per_step_per_gpu": B, "device": dev_name, "compute_units": cus,
                        "parallelism": (f"dp{world} (independent images, one RCCL all-gather of prediction records per step on the library's "
                                        f"exchange stream)") if gather else f"dp{world}",
-                       "rccl_ranks": rccl_ranks},
+                       "rccl_ranks": rccl_ranks, "batches_in_flight": n_fly, "one_batch_alone_ms": single_ms},
             "roofline": {"bound": "mfma", "achieved": achieved, "peak": MFMA_F16_PEAK / 1e12, "unit": "TFLOP/s", "frac": achieved * 1e12 / MFMA_F16_PEAK,
                          "traffic": None,
                          "kernel": "whole step (all kernels; per-kernel times in profiles/)",
@@ -456,6 +539,8 @@ def main():
         dist.barrier()
     if args.stage == "full":
         exchange.close()
+        for sl in slots[1:]:
+            sl["ctx"].close()
     if dist is not None:
         dist.destroy_process_group()
     ctx.close()

@@ -23,6 +23,15 @@ int odise_hip_sizeof_infer_desc(void);
  * (tile ids: gemm.hip kTileBM / kTileBN; -1 / 0 = automatic) */
 int odise_hip_gemm_forced(odise_hip_ctx* ctx, const odise_gemm_desc* d, int tile, int splitk);
 int odise_hip_conv2d_forced(odise_hip_ctx* ctx, const odise_conv_desc* d, int tile, int splitk);
+/* a GEMM with a LayerNorm folded into its epilogue, as the CLIP towers chain them (csrc/common.h LnEpi; any pointer may be NULL):
+ *   producer  stats_out [M][N/128][2]: partial (sum, sum of squares) of every output row, per 128 columns
+ *   consumer  part [M][parts][2] + colsum [N]: C = act(rstd_m (A W'^T - mean_m colsum) + bias_n) (+ residual), the row statistics finished from
+ *             the partials with 1/inv_c channels and eps; final_out [M][2] receives (-mean rstd, rstd)
+ *   swapped   fin [N][2] + rowsum [M]: the normalised operand is W (its rows are the tokens), statistics per output column */
+/* the CLIP towers' LayerNorm fold (extractor.cpp clip_tower): 0 = by token count (default), 1 = always, 2 = never (separate LayerNorm kernels) */
+int odise_hip_clip_ln_fold(int mode);
+int odise_hip_gemm_ln(odise_hip_ctx* ctx, const odise_gemm_desc* d, const float* part, int parts, float inv_c, float eps, const float* colsum,
+                      float* final_out, const float* fin, const float* rowsum, float* stats_out);
 /* the conv -> GroupNorm pair of the ResBlocks with the conv's tile forced: the conv epilogue reduces the GroupNorm statistics (per channel and
  * row block) into stats_scratch [N * ceil(OH*OW/64) * Cout * 2] and the GroupNorm only finalises + applies; y_norm = act(gn(conv(x))) (f16).
  * *stats_blocks = row blocks per image (0: this kernel declined the fusion, the stand-alone GroupNorm ran) */

@@ -520,6 +520,7 @@ extern "C" int odise_hip_postprocess_batch(odise_hip_ctx* ctx, const odise_post_
 
 extern "C" int odise_hip_infer(odise_hip_ctx* ctx, const odise_infer_desc* d) {
     ODISE_REQUIRE(ctx && d && d->images && d->img_hw && d->B >= 1, "infer: null argument");
+    ODISE_CHECK_HIP(hipSetDevice(ctx->device));   // the calling thread may be new (one host thread per context is the supported way to keep batches in flight)
     ModelStore* ms = store_of(ctx);
     ClassifyModel* c = ms->classify;
     if (!c || !c->has_vocab) {

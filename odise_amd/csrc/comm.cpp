@@ -152,6 +152,7 @@ static int comm_of(odise_hip_ctx* ctx, Comm** out, const char* who) {
         set_error("%s: call odise_hip_comm_init first", who);
         return ODISE_ERR_STATE;
     }
+    ODISE_CHECK_HIP(hipSetDevice(ctx->device));   // callers may be worker threads
     return ODISE_OK;
 }
 

@@ -96,6 +96,21 @@ struct odise_hip_ctx {
 };
 
 namespace odise {
+// LayerNorm folded into the GEMMs around it (gemm.hip gemm_epilogue_f16; used by the CLIP towers): statistics of the rows a GEMM writes come out
+// of its epilogue (`stats_out`), the GEMMs that would read LN(x) read x with gamma / beta folded into their weights and finish the
+// normalisation per row (`part` + `colsum`) or, with swapped operands, per column (`fin` + `rowsum`)
+struct LnEpi {
+    const float* part = nullptr;   // [M][P][2] partial (sum, sum of squares) per row of A
+    int P = 0;
+    float inv_c = 0.f, eps = 0.f;
+    const float* colsum = nullptr; // [N]
+    float* final_out = nullptr;    // [M][2] (-mean * rstd, rstd), optional
+    const float* fin = nullptr;    // [N][2] per row of W (swapped form)
+    const float* rowsum = nullptr; // [M]
+    float* stats_out = nullptr;    // [M][N / 128][2]
+};
+int gemm_forced(odise_hip_ctx* ctx, const odise_gemm_desc* d, int force_tile, int force_split, const LnEpi* ln = nullptr);   // force_tile < 0: the cost model's choice
+int gemm_ln(odise_hip_ctx* ctx, const odise_gemm_desc* d, const LnEpi& ln);   // 256x256 ping-pong tile, math-first epilogue
 void jpeg_release(odise_hip_ctx* ctx);
 void comm_release(odise_hip_ctx* ctx);
 }

@@ -237,7 +237,6 @@ void maskgen_invalidate_outputs(ModelStore* ms);   // the arena was reallocated:
 
 // gemm.hip / norm.hip internals used by Exec
 int conv_forced(odise_hip_ctx* ctx, const odise_conv_desc* d, int force_tile, int force_split, float* gn_stats, int* stats_blocks);
-int gemm_forced(odise_hip_ctx* ctx, const odise_gemm_desc* d, int force_tile, int force_split);   // force_tile < 0: the cost model's choice
 int group_norm_from_colpart(odise_hip_ctx* ctx, const void* x, void* y, const float* gamma, const float* beta, int N, int HW, int C, int groups,
                             float eps, int act, const float* colpart, int nblk);
 

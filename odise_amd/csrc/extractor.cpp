@@ -36,6 +36,9 @@ struct ClipBlock {
     NormW ln1, ln2;
     LinW qk, v, out, fc, proj;
     float* v_bias = nullptr;
+    // ln_1 / ln_2 folded into the GEMMs that read them (engine.h LnEpi): W' = fp16(W diag(gamma)), b' = b + W beta, cs = row sums of W'
+    LinW qk_f, v_f, fc_f;
+    float *qk_cs = nullptr, *v_cs = nullptr, *fc_cs = nullptr, *v_f_bias = nullptr;
 };
 
 struct ExtractorModel {
@@ -112,6 +115,32 @@ static int build_vae_attn(Packer& pk, const std::string& key, VaeAttn& a) {
     return ODISE_OK;
 }
 
+// rows [r0, r0 + O) of W [*, I] with a LayerNorm (gamma, beta) over I folded in
+static int fold_layer_norm(Packer& pk, const float* W, const float* bias, int O, int I, const float* gamma, const float* beta, LinW& lw, float** bias_dev,
+                           float** cs_dev) {
+    std::vector<f16> wf((size_t)O * I);
+    std::vector<float> bf(O), cs(O);
+    for (int o = 0; o < O; ++o) {
+        double bb = bias[o], c = 0.0;
+        for (int i = 0; i < I; ++i) {
+            const float w = W[(size_t)o * I + i];
+            const f16 h = (f16)(w * gamma[i]);
+            wf[(size_t)o * I + i] = h;
+            c += (double)(float)h;
+            bb += (double)w * beta[i];
+        }
+        bf[o] = (float)bb;
+        cs[o] = (float)c;
+    }
+    lw.in = I; lw.out = O; lw.b = nullptr;
+    ODISE_TRY(pk.upload(wf.data(), wf.size() * sizeof(f16), (void**)&lw.w));
+    ODISE_TRY(pk.upload(bf.data(), bf.size() * sizeof(float), (void**)bias_dev));
+    ODISE_TRY(pk.upload(cs.data(), cs.size() * sizeof(float), (void**)cs_dev));
+    return ODISE_OK;
+}
+
+static int g_clip_ln_fold = 0;   // odise_hip_clip_ln_fold (include/odise_hip_tools.h)
+
 static int build_clip_block(Packer& pk, const std::string& key, ClipBlock& b, int W) {
     ODISE_TRY(pk.norm(key + ".ln_1", b.ln1));
     ODISE_TRY(pk.norm(key + ".ln_2", b.ln2));
@@ -134,6 +163,17 @@ static int build_clip_block(Packer& pk, const std::string& key, ClipBlock& b, in
     ODISE_TRY(pk.linear(key + ".attn.out_proj", b.out));
     ODISE_TRY(pk.linear(key + ".mlp.c_fc", b.fc));
     ODISE_TRY(pk.linear(key + ".mlp.c_proj", b.proj));
+    const HostTensor *g1 = pk.find(key + ".ln_1.weight"), *b1 = pk.find(key + ".ln_1.bias");
+    const HostTensor *g2 = pk.find(key + ".ln_2.weight"), *b2 = pk.find(key + ".ln_2.bias");
+    const HostTensor *fw = pk.find(key + ".mlp.c_fc.weight"), *fb = pk.find(key + ".mlp.c_fc.bias");
+    if (!g1 || !b1 || !g2 || !b2 || !fw || !fb || g1->numel() != W || b1->numel() != W || g2->numel() != W || b2->numel() != W ||
+        fw->numel() != (int64_t)4 * W * W || fb->numel() != 4 * W) {
+        set_error("clip: bad or missing '%s.ln_* / mlp.c_fc'", key.c_str());
+        return ODISE_ERR_STATE;
+    }
+    ODISE_TRY(fold_layer_norm(pk, w->data.data(), bias->data.data(), 2 * W, W, g1->data.data(), b1->data.data(), b.qk_f, &b.qk_f.b, &b.qk_cs));
+    ODISE_TRY(fold_layer_norm(pk, w->data.data() + 2 * ww, bias->data.data() + 2 * W, W, W, g1->data.data(), b1->data.data(), b.v_f, &b.v_f_bias, &b.v_cs));
+    ODISE_TRY(fold_layer_norm(pk, fw->data.data(), fb->data.data(), 4 * W, W, g2->data.data(), b2->data.data(), b.fc_f, &b.fc_f.b, &b.fc_cs));
     return ODISE_OK;
 }
 
@@ -376,16 +416,57 @@ int clip_tower(Exec& ex, const Act& img, int extra, const uint8_t* mask, int64_t
     ODISE_TRY(launch_clip_assemble(ex.ctx, patches.p, e->clip_cls, e->clip_pos, n, B, T, extra, TP, Wd));
     ODISE_TRY(ex.layer_norm(n, x, M, e->clip_ln_pre, 1e-5f));
     const int heads = e->clip_heads, D = Wd / heads;
+    // ln_1 / ln_2 of the blocks never touch HBM as tensors: the GEMM that writes the residual stream (out-proj, c_proj) leaves per-row partial
+    // sums next to it, and the GEMMs that would read LN(x) read x with the affine folded into their weights (LnEpi, gemm_epilogue_f16).  8 -> 6
+    // launches per block on the chain that sits on the step's critical path.  The first block's ln_1 follows ln_pre and stays a kernel.
+    // The statistics live in the math-first epilogue, i.e. on the 256-wide tiles without split-K: the fold is taken where the cost model runs the
+    // tower's GEMMs on those tiles anyway (from ~8k tokens: 16 crops).  Below that (MaskCLIP on 4 pictures: 2.7k tokens) the small tiles + two
+    // 5 us LayerNorm launches are faster (measured: profiles/r03_lane_scheduling.txt).  g_clip_ln_fold: test hook, 1 = always, 2 = never.
+    const bool fold = Wd % 256 == 0 && (g_clip_ln_fold == 1 || (g_clip_ln_fold == 0 && M >= 8192));
+    const int P = Wd / 128;
+    float *part_a = nullptr, *part_b = nullptr, *fin = nullptr;
+    if (fold) {
+        part_a = (float*)ex.alloc_bytes((size_t)M * P * 2 * sizeof(float));
+        part_b = (float*)ex.alloc_bytes((size_t)M * P * 2 * sizeof(float));
+        fin = (float*)ex.alloc_bytes((size_t)M * 2 * sizeof(float));
+        if (!part_a || !part_b || !fin) return ODISE_ERR_NOMEM;
+    }
+    auto lin = [&](const f16* a, const LinW& w, f16* y, int act, const f16* residual, const LnEpi& ln) -> int {
+        odise_gemm_desc d;
+        memset(&d, 0, sizeof(d));
+        d.M = (int)M; d.N = w.out; d.K = w.in;
+        d.A = a; d.lda = w.in; d.W = w.w; d.ldw = w.in;
+        d.C = y; d.ldc = w.out; d.c_dtype = ODISE_F16;
+        d.bias_n = w.b; d.residual = residual; d.ldr = w.out;
+        d.act = act; d.alpha = 1.f; d.batch = 1;
+        ex.ms->macs += (double)d.M * d.N * d.K;
+        return gemm_ln(ex.ctx, &d, ln);
+    };
+    bool first = true;
     for (const ClipBlock& b : e->clip_blocks) {
-        ODISE_TRY(ex.layer_norm(x, n, M, b.ln1, 1e-5f));
-        ODISE_TRY(ex.linear(n, M, b.qk, qk));
+        const bool folded1 = fold && !first;   // statistics of x were left by the previous block's c_proj
+        first = false;
         odise_gemm_desc d;
         memset(&d, 0, sizeof(d));
         d.M = Wd; d.N = (int)M; d.K = Wd;  // V^T of every image side by side (only its first T columns are ever read: the image tokens)
-        d.A = b.v.w; d.lda = Wd; d.W = n; d.ldw = Wd;
+        d.lda = Wd; d.ldw = Wd;
         d.C = vt; d.ldc = ldvt; d.c_dtype = ODISE_F16;
-        d.bias_m = b.v_bias; d.alpha = 1.f; d.batch = 1;
-        ODISE_TRY(ex.gemm(d));
+        d.alpha = 1.f; d.batch = 1;
+        if (folded1) {
+            LnEpi l1;
+            l1.part = part_b; l1.P = P; l1.inv_c = 1.f / (float)Wd; l1.eps = 1e-5f; l1.colsum = b.qk_cs; l1.final_out = fin;
+            ODISE_TRY(lin(x, b.qk_f, qk, ODISE_ACT_NONE, nullptr, l1));
+            LnEpi lv;   // swapped operands: the normalised tokens are the rows of W, (r1, rstd) finished by the q|k GEMM above
+            lv.fin = fin; lv.rowsum = b.v_cs;
+            d.A = b.v_f.w; d.W = x; d.bias_m = b.v_f_bias;
+            ex.ms->macs += (double)d.M * d.N * d.K;
+            ODISE_TRY(gemm_ln(ex.ctx, &d, lv));
+        } else {
+            ODISE_TRY(ex.layer_norm(x, n, M, b.ln1, 1e-5f));
+            ODISE_TRY(ex.linear(n, M, b.qk, qk));
+            d.A = b.v.w; d.W = n; d.bias_m = b.v_bias;
+            ODISE_TRY(ex.gemm(d));
+        }
         odise_attn_desc a;
         memset(&a, 0, sizeof(a));
         a.B = B; a.H = heads; a.Lq = TA; a.Lk = T; a.D = D;
@@ -396,10 +477,20 @@ int clip_tower(Exec& ex, const Act& img, int extra, const uint8_t* mask, int64_t
         if (extra > 0) { a.mask = mask; a.ldmask = ldm; a.strideMask = (int64_t)TA * ldm; }
         a.scale = 1.0f / sqrtf((float)D);
         ODISE_TRY(ex.attention(a));
-        ODISE_TRY(ex.linear(att, M, b.out, x2, ODISE_ACT_NONE, x));          // x2 = x + attn
-        ODISE_TRY(ex.layer_norm(x2, n, M, b.ln2, 1e-5f));
-        ODISE_TRY(ex.linear(n, M, b.fc, hid, ODISE_ACT_QUICKGELU));
-        ODISE_TRY(ex.linear(hid, M, b.proj, x, ODISE_ACT_NONE, x2));         // x = x2 + mlp
+        if (fold) {
+            LnEpi lo, lf, lp;
+            lo.stats_out = part_a;
+            ODISE_TRY(lin(att, b.out, x2, ODISE_ACT_NONE, x, lo));               // x2 = x + attn (+ row statistics of x2)
+            lf.part = part_a; lf.P = P; lf.inv_c = 1.f / (float)Wd; lf.eps = 1e-5f; lf.colsum = b.fc_cs;
+            ODISE_TRY(lin(x2, b.fc_f, hid, ODISE_ACT_QUICKGELU, nullptr, lf));   // quick_gelu(ln_2(x2) Wfc^T + b)
+            lp.stats_out = part_b;
+            ODISE_TRY(lin(hid, b.proj, x, ODISE_ACT_NONE, x2, lp));              // x = x2 + mlp (+ row statistics of x)
+        } else {
+            ODISE_TRY(ex.linear(att, M, b.out, x2, ODISE_ACT_NONE, x));          // x2 = x + attn
+            ODISE_TRY(ex.layer_norm(x2, n, M, b.ln2, 1e-5f));
+            ODISE_TRY(ex.linear(n, M, b.fc, hid, ODISE_ACT_QUICKGELU));
+            ODISE_TRY(ex.linear(hid, M, b.proj, x, ODISE_ACT_NONE, x2));         // x = x2 + mlp
+        }
     }
     ODISE_TRY(ex.layer_norm(x, n, M, e->clip_ln_post, 1e-5f));
     odise_gemm_desc d;
@@ -625,6 +716,11 @@ static int extractor_forward(odise_hip_ctx* ctx, const float* image, int B, int 
 }  // namespace odise
 
 using namespace odise;
+
+extern "C" int odise_hip_clip_ln_fold(int mode) {
+    g_clip_ln_fold = mode;
+    return ODISE_OK;
+}
 
 extern "C" int odise_hip_extractor_build(odise_hip_ctx* ctx) {
     ODISE_REQUIRE(ctx, "extractor_build: null context");

@@ -50,6 +50,15 @@ struct GemmEpi {
     int64_t strideC, strideR;
     int fast;  // 1: every vector access of a full 8-column chunk is aligned -> epi_fast8 (set by launch_gemm)
     int f16path;  // 1: fp16 output whose 16-byte row chunks are all aligned and whole -> the math-first epilogue (gemm_epilogue_f16; set by launch_gemm)
+    // LayerNorm folded into the GEMMs around it (gemm_ln, math-first epilogue only; see gemm_epilogue_f16)
+    const float* ln_part;     // consumer, LN over the rows of A: [M][ln_P][2] partial (sum, sum of squares) of every row of the LN input
+    int ln_P;
+    float ln_inv_c, ln_eps;
+    const float* ln_colsum;   // ... [N]: sum over k of the gamma-folded fp16 weights of column n
+    float* ln_final_out;      // ... optional [M][2] = (-mean * rstd, rstd) of every row, written by the blocks of the first column tile
+    const float* ln_final;    // consumer, LN over the rows of W (swapped GEMM): [N][2] = (-mean * rstd, rstd) per output column
+    const float* ln_rowsum;   // ... [M]: sum over k of the folded weights of output row m
+    float* ln_stats_out;      // producer: [M][ceil(N / WTN)][2] partial (sum, sum of squares) of every output row (of the rounded fp16 values)
     float* gn_stats;  // optional [row blocks][N][2]: per-channel (sum, sum of squares) of the block's fp16 outputs (GroupNorm statistics
                       // fused into the producing conv; set by launch_gemm only when the chosen kernel supports it)
 };
@@ -343,6 +352,14 @@ __device__ __forceinline__ void gemm_epilogue_f16(const GemmArgs& g, f32x16 (&ac
         return m0 + rt;
     };
     const bool stats = STATS && (NT % CH == 0) && e.gn_stats != nullptr;
+    // folded-LayerNorm terms (dense GEMMs only: compiled out of the conv / GEGLU instances)
+    constexpr bool LN_OK = !HALO && !STATS && !GEGLU;
+    const float* const ln_part = LN_OK ? e.ln_part : nullptr;
+    const float* const ln_colsum = LN_OK ? e.ln_colsum : nullptr;
+    float* const ln_final_out = LN_OK ? e.ln_final_out : nullptr;
+    const float* const ln_final = LN_OK ? e.ln_final : nullptr;
+    const float* const ln_rowsum = LN_OK ? e.ln_rowsum : nullptr;
+    float* const ln_stats_out = LN_OK ? e.ln_stats_out : nullptr;
     float s8[8], q8[8];
 #pragma unroll
     for (int i = 0; i < 8; ++i) s8[i] = q8[i] = 0.f;
@@ -353,6 +370,11 @@ __device__ __forceinline__ void gemm_epilogue_f16(const GemmArgs& g, f32x16 (&ac
             int mr[TM];
             float alpha_r[TM], bm_r[TM];
             unsigned grp_r[TM];
+            // LayerNorm folded into this GEMM (gemm_ln).  With W' = W diag(gamma), b' = b + W beta and cs[n] = sum_k W'[n,k]:
+            //   LN(x) W^T + b = rstd_m (x W'^T - mean_m cs) + b'  ->  v * rstd_m + (b'[n] + r1_m cs[n]),  r1_m = -mean_m rstd_m,
+            // the row statistics coming as partial (sum, sum of squares) from the epilogue of the GEMM that produced x (ln_stats_out below).
+            // In the swapped form (rows of W are the normalised tokens) the same with rows and columns exchanged, from finished (r1, rstd).
+            float r1_r[TM], rs_r[TM], ps_r[TM], pq_r[TM];
 #pragma unroll
             for (int p = 0; p < TM; ++p) {
                 const int m = row_to_m(wm * WTM + p * 32 + l31);
@@ -360,6 +382,22 @@ __device__ __forceinline__ void gemm_epilogue_f16(const GemmArgs& g, f32x16 (&ac
                 const bool ok = m < g.M;
                 float alpha = e.alpha;
                 if (e.scale_m && ok) alpha *= e.scale_m[m];
+                r1_r[p] = rs_r[p] = ps_r[p] = pq_r[p] = 0.f;
+                if (ln_part && ok) {
+                    const float* pp = ln_part + (int64_t)m * e.ln_P * 2;
+                    float s1 = 0.f, s2 = 0.f;
+                    for (int i = 0; i < e.ln_P; ++i) { s1 += pp[2 * i]; s2 += pp[2 * i + 1]; }
+                    const float mean = s1 * e.ln_inv_c;
+                    const float var = fmaxf(s2 * e.ln_inv_c - mean * mean, 0.f);
+                    const float rstd = rsqrtf(var + e.ln_eps);
+                    alpha *= rstd;
+                    r1_r[p] = -mean * rstd;
+                    if (ln_final_out && n0 == 0 && wn == 0 && hi == 0) {
+                        ln_final_out[2 * (int64_t)m] = r1_r[p];
+                        ln_final_out[2 * (int64_t)m + 1] = rstd;
+                    }
+                }
+                if (ln_rowsum && ok) rs_r[p] = ln_rowsum[m];
                 alpha_r[p] = alpha;
                 bm_r[p] = (e.bias_m && ok) ? e.bias_m[m] : 0.f;
                 grp_r[p] = (e.rowgroup_add && ok) ? (unsigned)m / (unsigned)e.rows_per_group : 0u;
@@ -373,6 +411,14 @@ __device__ __forceinline__ void gemm_epilogue_f16(const GemmArgs& g, f32x16 (&ac
                     const bool nok = n < g.N;                            // N % 8 == 0 on this path: the four columns are in or out together
                     float4 bn = make_float4(0.f, 0.f, 0.f, 0.f);
                     if (e.bias_n && nok) bn = *reinterpret_cast<const float4*>(e.bias_n + n);
+                    float4 cs4 = make_float4(0.f, 0.f, 0.f, 0.f), fa = cs4, fb = cs4;
+                    if (ln_colsum && nok) cs4 = *reinterpret_cast<const float4*>(ln_colsum + n);
+                    if (ln_final && nok) {   // (r1, rstd) of columns n, n + 1 | n + 2, n + 3
+                        fa = *reinterpret_cast<const float4*>(ln_final + 2 * (int64_t)n);
+                        fb = *reinterpret_cast<const float4*>(ln_final + 2 * (int64_t)n + 4);
+                    }
+                    const float csv[4] = {cs4.x, cs4.y, cs4.z, cs4.w};
+                    const float r1c[4] = {fa.x, fa.z, fb.x, fb.z}, rsc[4] = {fa.y, fa.w, fb.y, fb.w};
 #pragma unroll
                     for (int p = 0; p < TM; ++p) {
                         const bool ok = nok && mr[p] < g.M;
@@ -387,8 +433,17 @@ __device__ __forceinline__ void gemm_epilogue_f16(const GemmArgs& g, f32x16 (&ac
 #pragma unroll
                             for (int i = 0; i < 4; ++i) b[i] += bm_r[p];
                         }
+                        if (ln_colsum) {
 #pragma unroll
-                        for (int i = 0; i < 4; ++i) v[i] = v[i] * alpha_r[p] + b[i];
+                            for (int i = 0; i < 4; ++i) b[i] += r1_r[p] * csv[i];
+                        }
+                        if (ln_final) {
+#pragma unroll
+                            for (int i = 0; i < 4; ++i) v[i] = v[i] * (alpha_r[p] * rsc[i]) + (b[i] + rs_r[p] * r1c[i]);
+                        } else {
+#pragma unroll
+                            for (int i = 0; i < 4; ++i) v[i] = v[i] * alpha_r[p] + b[i];
+                        }
                         const int rl = (wm % EW) * WTM + p * 32 + l31;   // staging row
                         if (GEGLU) {
                             // columns are (a, gate) pairs; the output has N/2 columns (no activation / residual on this path)
@@ -417,9 +472,25 @@ __device__ __forceinline__ void gemm_epilogue_f16(const GemmArgs& g, f32x16 (&ac
 #pragma unroll
                             for (int i = 0; i < 4; ++i) t[i] = (f16)(v[i] + (float)rr[i]);
                             *reinterpret_cast<f16x4*>(&stg[rl * PITCH + cl]) = t;
+                            if (ln_stats_out && ok) {
+#pragma unroll
+                                for (int i = 0; i < 4; ++i) { const float r = (float)t[i]; ps_r[p] += r; pq_r[p] += r * r; }
+                            }
                         }
                     }
                 }
+            if (ln_stats_out) {   // this wave's WTN columns of its rows: the two lane halves hold the two 4-column halves of every 8
+                const int part = (n0 + wn * WTN) / WTN, parts = (g.N + WTN - 1) / WTN;
+#pragma unroll
+                for (int p = 0; p < TM; ++p) {
+                    const float s1 = ps_r[p] + __shfl_xor(ps_r[p], 32), s2 = pq_r[p] + __shfl_xor(pq_r[p], 32);
+                    if (hi == 0 && mr[p] < g.M) {
+                        float* o = ln_stats_out + ((int64_t)mr[p] * parts + part) * 2;
+                        o[0] = s1;
+                        o[1] = s2;
+                    }
+                }
+            }
         }
         lds_barrier();
         // ---- copy phase: the tile is final; 16 bytes per thread and round, in batches of CB rounds: the batch's LDS reads are issued back to
@@ -2243,7 +2314,7 @@ static int env_gemm_flags() {
 }
 
 template <bool CONV>
-static int launch_gemm(odise_hip_ctx* ctx, GemmArgs& g, int batch, int force_tile, int force_split) {
+static int launch_gemm(odise_hip_ctx* ctx, GemmArgs& g, int batch, int force_tile, int force_split, unsigned tile_mask = ~0u) {
     const int64_t cus = ctx->cu_count;
     const int nk = (int)ceil_div(g.K, 64);
     // the halo kernel owns 16x16 output patches: 3x3 / stride 1 / pad 1 convs over whole 64-channel chunks
@@ -2267,6 +2338,7 @@ static int launch_gemm(odise_hip_ctx* ctx, GemmArgs& g, int batch, int force_til
     const bool pp_ok = !no_interleave && !(flags & 2) && g.K % 64 == 0 && (!CONV || (g.cg.Cin % 64 == 0 && !g.cg.ups));
     for (int t = 0; t < kNumTiles; ++t) {
         if (force_tile >= 0 && force_tile < kNumTiles && t != force_tile) continue;
+        if (!((tile_mask >> t) & 1)) continue;
         if (t == 6 && (!pp_ok || (flags & 16))) continue;
         if (t >= 7 && t <= 9 && (!halo_ok || !pp_ok || (flags & 64))) continue;  // ODISE_GEMM_FLAGS=64: never use the halo kernels
         if (t == 9 && (flags & 2048)) continue;                        // ODISE_GEMM_FLAGS=2048: never use the two-blocks-per-CU halo kernel
@@ -2330,6 +2402,13 @@ static int launch_gemm(odise_hip_ctx* ctx, GemmArgs& g, int batch, int force_til
         g.epi.f16path = (ok && e.c_dtype == ODISE_F16 && g.N % 8 == 0 && n_out % 8 == 0 && aligned(e.C, e.ldc, e.strideC, 2, 16) &&
                          (!e.residual || aligned(e.residual, e.ldr, e.strideR, 2, 8))) ? 1 : 0;
     }
+    if (g.epi.ln_part || g.epi.ln_final || g.epi.ln_stats_out) {
+        // the LayerNorm terms only exist in the math-first epilogue (256x256 / 256x128 tiles); the producer's partial sums are per 128 columns =
+        // the wave columns of the 256x256 tile
+        ODISE_REQUIRE(!CONV && (tile == 4 || tile == 5) && g.splitk == 1 && g.epi.f16path && !g.epi.geglu && batch == 1 &&
+                          (!g.epi.ln_stats_out || (tile == 4 && g.N % 128 == 0)),
+                      "gemm_ln: M=%d N=%d K=%d cannot take the folded-LayerNorm path", g.M, g.N, g.K);
+    }
     g.stats_blocks = 0;
     if (g.epi.gn_stats) {
         // fused GroupNorm statistics need: the lean epilogue on whole 8-column chunks, no split-K (the reduce kernel would own the
@@ -2387,10 +2466,9 @@ static int launch_gemm(odise_hip_ctx* ctx, GemmArgs& g, int batch, int force_til
     }
 }
 
-int gemm_forced(odise_hip_ctx* ctx, const odise_gemm_desc* d, int force_tile, int force_split);
 int conv_forced(odise_hip_ctx* ctx, const odise_conv_desc* d, int force_tile, int force_split, float* gn_stats = nullptr, int* stats_blocks = nullptr);
 
-int gemm_forced(odise_hip_ctx* ctx, const odise_gemm_desc* d, int force_tile, int force_split) {
+int gemm_forced(odise_hip_ctx* ctx, const odise_gemm_desc* d, int force_tile, int force_split, const LnEpi* ln) {
     ODISE_REQUIRE(ctx && d, "gemm: null argument");
     ODISE_REQUIRE(d->M >= 0 && d->N >= 0 && d->K > 0, "gemm: bad dims M=%d N=%d K=%d", d->M, d->N, d->K);
     if (d->M == 0 || d->N == 0) return ODISE_OK;
@@ -2415,9 +2493,20 @@ int gemm_forced(odise_hip_ctx* ctx, const odise_gemm_desc* d, int force_tile, in
     g.epi.act = d->act; g.epi.geglu = d->geglu; g.epi.alpha = d->alpha;
     g.epi.strideC = d->strideC; g.epi.strideR = d->strideR;
     g.epi.gn_stats = nullptr;
+    g.epi.ln_part = nullptr; g.epi.ln_P = 0; g.epi.ln_inv_c = 0.f; g.epi.ln_eps = 0.f; g.epi.ln_colsum = nullptr; g.epi.ln_final_out = nullptr;
+    g.epi.ln_final = nullptr; g.epi.ln_rowsum = nullptr; g.epi.ln_stats_out = nullptr;
+    if (ln) {
+        g.epi.ln_part = ln->part; g.epi.ln_P = ln->P; g.epi.ln_inv_c = ln->inv_c; g.epi.ln_eps = ln->eps; g.epi.ln_colsum = ln->colsum;
+        g.epi.ln_final_out = ln->final_out; g.epi.ln_final = ln->fin; g.epi.ln_rowsum = ln->rowsum; g.epi.ln_stats_out = ln->stats_out;
+        ODISE_REQUIRE((!ln->part || (ln->P > 0 && ln->colsum)) && (!ln->fin || ln->rowsum), "gemm_ln: incomplete LayerNorm terms");
+    }
     g.cg = ConvGeom{};
+    // folded LayerNorm: no split-K, a tile with the math-first epilogue (the producer of the statistics: the 256x256 one)
+    if (ln) return launch_gemm<false>(ctx, g, batch, force_tile, 1, ln->stats_out ? (1u << 4) : (1u << 4) | (1u << 5));
     return launch_gemm<false>(ctx, g, batch, force_tile, force_split);
 }
+
+int gemm_ln(odise_hip_ctx* ctx, const odise_gemm_desc* d, const LnEpi& ln) { return gemm_forced(ctx, d, -1, 1, &ln); }
 
 int conv_forced(odise_hip_ctx* ctx, const odise_conv_desc* d, int force_tile, int force_split, float* gn_stats, int* stats_blocks) {
     ODISE_REQUIRE(ctx && d, "conv2d: null argument");
@@ -2441,6 +2530,8 @@ int conv_forced(odise_hip_ctx* ctx, const odise_conv_desc* d, int force_tile, in
     g.epi.act = d->act; g.epi.geglu = 0; g.epi.alpha = 1.0f;
     g.epi.strideC = 0; g.epi.strideR = 0;
     g.epi.gn_stats = gn_stats;
+    g.epi.ln_part = nullptr; g.epi.ln_P = 0; g.epi.ln_inv_c = 0.f; g.epi.ln_eps = 0.f; g.epi.ln_colsum = nullptr; g.epi.ln_final_out = nullptr;
+    g.epi.ln_final = nullptr; g.epi.ln_rowsum = nullptr; g.epi.ln_stats_out = nullptr;
     if (stats_blocks) *stats_blocks = 0;
     g.cg.H = d->H; g.cg.W = d->W; g.cg.Cin = d->Cin; g.cg.KH = d->KH; g.cg.KW = d->KW;
     g.cg.stride = d->stride; g.cg.pad_t = d->pad_t; g.cg.pad_l = d->pad_l; g.cg.OH = d->OH; g.cg.OW = d->OW;
@@ -2477,6 +2568,13 @@ extern "C" int odise_hip_conv2d(odise_hip_ctx* ctx, const odise_conv_desc* d) { 
 // test hooks: force a tile shape (0:128x128, 1:64x128, 2:64x64) and/or a split-K factor
 extern "C" int odise_hip_gemm_forced(odise_hip_ctx* ctx, const odise_gemm_desc* d, int tile, int splitk) {
     return odise::gemm_forced(ctx, d, tile, splitk);
+}
+extern "C" int odise_hip_gemm_ln(odise_hip_ctx* ctx, const odise_gemm_desc* d, const float* part, int parts, float inv_c, float eps,
+                                 const float* colsum, float* final_out, const float* fin, const float* rowsum, float* stats_out) {
+    odise::LnEpi ln;
+    ln.part = part; ln.P = parts; ln.inv_c = inv_c; ln.eps = eps; ln.colsum = colsum; ln.final_out = final_out;
+    ln.fin = fin; ln.rowsum = rowsum; ln.stats_out = stats_out;
+    return odise::gemm_ln(ctx, d, ln);
 }
 extern "C" int odise_hip_conv2d_forced(odise_hip_ctx* ctx, const odise_conv_desc* d, int tile, int splitk) {
     return odise::conv_forced(ctx, d, tile, splitk);

@@ -148,9 +148,10 @@ class Context:
 
     def gemm(self, A: DeviceArray, W: DeviceArray, *, bias_n=None, bias_m=None, scale_m=None, residual=None,
              rowgroup_add=None, rows_per_group=0, act=ACT_NONE, geglu=False, alpha=1.0, out_dtype=np.float16,
-             force_tile=-1, force_split=0, out=None, lda=None) -> DeviceArray:
+             force_tile=-1, force_split=0, out=None, lda=None, ln=None) -> DeviceArray:
         """C[M,N] = epi(alpha * A[M,K] @ W[N,K]^T); 3-D inputs are batched over dim 0.  `lda` overrides the row stride of A
-        (tools: overlapping rows make A cache-resident)."""
+        (tools: overlapping rows make A cache-resident).  `ln` (test hook, odise_hip_gemm_ln): dict with any of part / parts / inv_c / eps /
+        colsum / final_out / fin / rowsum / stats_out - a LayerNorm folded into the epilogue the way the CLIP towers chain their GEMMs."""
         batched = len(A.shape) == 3 or len(W.shape) == 3
         batch = (A.shape[0] if len(A.shape) == 3 else W.shape[0]) if batched else 1
         M, K = A.shape[-2:]
@@ -178,7 +179,11 @@ class Context:
         d.strideW = N * K if len(W.shape) == 3 else 0
         d.strideC = M * No
         d.strideR = M * No
-        if force_tile >= 0 or force_split > 0:
+        if ln is not None:
+            check(self.lib.odise_hip_gemm_ln(self.h, C.byref(d), ln.get("part"), int(ln.get("parts", 0)), float(ln.get("inv_c", 0.0)),
+                                             float(ln.get("eps", 0.0)), ln.get("colsum"), ln.get("final_out"), ln.get("fin"), ln.get("rowsum"),
+                                             ln.get("stats_out")), "gemm_ln")
+        elif force_tile >= 0 or force_split > 0:
             check(self.lib.odise_hip_gemm_forced(self.h, C.byref(d), int(force_tile), int(force_split)), "gemm_forced")
         else:
             check(self.lib.odise_hip_gemm(self.h, C.byref(d)), "gemm")

@@ -110,7 +110,16 @@ def _mask_report(what, got, ref):
     return rep
 
 
-def test_backbone_full_size(full, ctx):
+@pytest.fixture(params=[0, 1], ids=["ln_kernels", "ln_folded"])
+def ln_fold(request, ctx):
+    """The CLIP towers with their LayerNorms as kernels (what 4 crops / 4 pictures run by default) and folded into the neighbouring GEMMs
+    (what the towers run from 8k tokens = the benchmarked 16 crops; extractor.cpp clip_tower): both against the same reference."""
+    ctx.lib.odise_hip_clip_ln_fold(request.param)
+    yield request.param
+    ctx.lib.odise_hip_clip_ln_fold(0)
+
+
+def test_backbone_full_size(full, ctx, ln_fold):
     """FeatureExtractorBackbone at 1024x1024: 4 crops through CLIP + VAE + UNet + truncated VAE decoder, projections, stitching."""
     hip, img = full["hip"], full["img"]
     feats_ref = full["ref"][0]
@@ -145,7 +154,7 @@ def test_head_full_size_from_reference_features(full):
     assert rep["iou_min"] > 0.93 and rep["iou_med"] > 0.985
 
 
-def test_classification_full_size(coco, ctx):
+def test_classification_full_size(coco, ctx, ln_fold):
     full = coco
     """CategoryEmbed + MaskCLIP (ViT-L/14@336, 100 mask tokens + 577 image tokens) + ensemble + null merge at K = 133 / 254 strings,
     on the ORACLE's backbone features replayed through the device head."""

@@ -147,6 +147,59 @@ def test_gemm_epilogues(ctx, tile, split):
         close(out, fn(base * sm[:, None]).numpy(), what=f"act{act}")
 
 
+@pytest.mark.parametrize("M", [584, 2336])
+def test_gemm_chain_with_folded_layer_norm(ctx, M):
+    """The CLIP tower's GEMM chain without LayerNorm kernels (extractor.cpp clip_tower, common.h LnEpi): the GEMM that writes the residual stream
+    leaves per-row partial sums, the next GEMMs read the raw stream with the affine folded into their weights - against LayerNorm + GEMM in fp32
+    on the same fp16 stream (the fold itself is exact algebra; what differs is one fp16 rounding of LN(x) that the folded form does not make)."""
+    g = torch.Generator().manual_seed(M)
+    Cw, N2 = 1024, 2048
+    att = h(torch.randn(M, Cw, generator=g))
+    Wo = h(torch.randn(Cw, Cw, generator=g) / Cw ** 0.5)
+    bo = torch.randn(Cw, generator=g) * 0.1
+    x = h(torch.randn(M, Cw, generator=g) * 2 + 0.7)
+    x[:, 5] += 40.0        # a massive-activation channel, as the CLIP residual stream has
+    x = h(x)
+    gamma = torch.rand(Cw, generator=g) + 0.5
+    beta = torch.randn(Cw, generator=g) * 0.2
+    W1 = torch.randn(N2, Cw, generator=g) / Cw ** 0.5
+    b1 = torch.randn(N2, generator=g) * 0.1
+    Wv = torch.randn(Cw, Cw, generator=g) / Cw ** 0.5
+    bv = torch.randn(Cw, generator=g) * 0.1
+    parts = Cw // 128
+    # producer: x2 = x + att Wo^T + bo, with the row statistics of the rounded x2
+    stats = ctx.empty((M, parts, 2), np.float32)
+    x2 = ctx.gemm(ctx.to_device(att.half().numpy()), ctx.to_device(Wo.half().numpy()), bias_n=ctx.to_device(bo),
+                  residual=ctx.to_device(x.half().numpy()), ln=dict(stats_out=stats))
+    x2h = torch.from_numpy(x2.numpy().astype(np.float32))
+    close(x2h.numpy(), (x + att @ Wo.t() + bo).numpy(), what="producer output")
+    st = stats.numpy().astype(np.float64)
+    blocks = x2h.double().view(M, parts, 128)
+    np.testing.assert_allclose(st[..., 0], blocks.sum(-1).numpy(), rtol=1e-5, atol=1e-3)
+    np.testing.assert_allclose(st[..., 1], (blocks ** 2).sum(-1).numpy(), rtol=1e-5, atol=1e-3)
+    # consumer: quick_gelu(LN(x2) W1^T + b1) from the raw x2
+    W1f = (W1 * gamma).half()
+    cs1 = W1f.float().sum(1)
+    b1f = b1 + W1 @ beta
+    fin = ctx.empty((M, 2), np.float32)
+    ln = dict(part=stats, parts=parts, inv_c=1.0 / Cw, eps=1e-5, colsum=ctx.to_device(cs1), final_out=fin)
+    y = ctx.gemm(x2, ctx.to_device(W1f.numpy()), bias_n=ctx.to_device(b1f), act=_lib.ACT_QUICKGELU, ln=ln).numpy()
+    nrm = F.layer_norm(x2h, (Cw,), gamma, beta, 1e-5)
+    t = nrm @ W1.t() + b1
+    close(y, (t * torch.sigmoid(1.702 * t)).numpy(), rtol=4e-3, what="folded LN consumer")
+    mean, var = x2h.double().mean(1), x2h.double().var(1, unbiased=False)
+    rstd = 1.0 / torch.sqrt(var + 1e-5)
+    f = fin.numpy().astype(np.float64)
+    np.testing.assert_allclose(f[:, 1], rstd.numpy(), rtol=2e-4)
+    np.testing.assert_allclose(f[:, 0], (-mean * rstd).numpy(), rtol=2e-4, atol=2e-4)
+    # swapped consumer: V^T = Wv LN(x2)^T + bv[:, None] (the normalised tokens are the rows of the W operand)
+    Wvf = (Wv * gamma).half()
+    csv = Wvf.float().sum(1)
+    bvf = bv + Wv @ beta
+    vt = ctx.gemm(ctx.to_device(Wvf.numpy()), x2, bias_m=ctx.to_device(bvf), ln=dict(fin=fin, rowsum=ctx.to_device(csv))).numpy()
+    close(vt, (Wv @ nrm.t() + bv[:, None]).numpy(), rtol=4e-3, what="folded LN swapped consumer")
+
+
 def test_gemm_batched_and_swapped_vt(ctx):
     # the V^T production trick: Vt[b] = Wv @ X[b]^T  ==  gemm(A=Wv, W=X[b])
     g = torch.Generator().manual_seed(9)
