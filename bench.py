@@ -175,6 +175,8 @@ def dominant_kernel(ctx):
     for _ in range(it):
         ctx.conv2d(X, Wt, out=O)
     us = ctx.timer_stop() / it * 1e3
+    tile = ctx.lib.odise_hip_last_tile() & 255            # what the library's cost model ran this shape on (gemm.hip kTileBM / kTileBN)
+    kernel = {7: "conv3_halo_kernel<256,2>", 8: "conv3_halo_kernel<128,1>", 9: "conv3_halo4_kernel<128>"}.get(tile, f"tile {tile}")
     flops = 2.0 * n * hw * hw * cout * 9 * cin
     traffic = None
     for name in ("r03_dominant_conv_traffic.json", "r02_dominant_conv_traffic.json", "r01_dominant_conv_traffic.json"):
@@ -185,7 +187,7 @@ def dominant_kernel(ctx):
             break
     for a in (X, Wt, O):
         a.free()
-    return {"kernel": "conv3_halo_kernel<256,2> (3x3 conv 512->512 @128x128, 16 crops)", "launch_us": us, "flops": flops,
+    return {"kernel": f"{kernel} (3x3 conv 512->512 @128x128, 16 crops)", "launch_us": us, "flops": flops,
             "achieved": flops / (us * 1e-6) / 1e12, "traffic": traffic, "launches_per_step": 7}
 
 

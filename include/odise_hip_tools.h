@@ -23,6 +23,8 @@ int odise_hip_sizeof_infer_desc(void);
  * (tile ids: gemm.hip kTileBM / kTileBN; -1 / 0 = automatic) */
 int odise_hip_gemm_forced(odise_hip_ctx* ctx, const odise_gemm_desc* d, int tile, int splitk);
 int odise_hip_conv2d_forced(odise_hip_ctx* ctx, const odise_conv_desc* d, int tile, int splitk);
+/* tile id | split-K factor << 8 that the calling thread's last odise_hip_gemm / odise_hip_conv2d launch ran with (-1: none yet) */
+int odise_hip_last_tile(void);
 /* a GEMM with a LayerNorm folded into its epilogue, as the CLIP towers chain them (csrc/common.h LnEpi; any pointer may be NULL):
  *   producer  stats_out [M][N/128][2]: partial (sum, sum of squares) of every output row, per 128 columns
  *   consumer  part [M][parts][2] + colsum [N]: C = act(rstd_m (A W'^T - mean_m colsum) + bias_n) (+ residual), the row statistics finished from

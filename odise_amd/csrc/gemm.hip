@@ -2288,6 +2288,9 @@ static const TileCost kTileCost[kNumTiles] = {
                       // the im2col 512x128 tile takes 65 us per block of twice the size: 1.80 vs 2.07 ms per launch, tools/halo512_probe.py)
     {2.00, 9.0, 2},   // the same tile as four waves, two blocks per CU (a block's K-tile takes about twice as long beside its partner)
 };
+// (Round 3: on launches of at least two full rounds a refit of this tile, {1.78, 12.0}, also takes the 256- / 512-channel VAE layers from the
+// 256-channel halo tile - isolated they run 2-6 % faster on it although every patch's halo is then fetched by Cout / 128 column blocks
+// (tools/conv_tiles.py) - but the two-lane step did not get faster, 87.0 / 87.4 ms against 86.9 / 86.8 ms: not adopted.)
 // the 256-row tiles as run by the ping-pong kernel (K % 64 == 0; conv: Cin % 64 == 0, no fused upsample)
 static const TileCost kTileCostPP[2] = {
     {2.55, 16.0, 1},  // 256x320
@@ -2300,6 +2303,7 @@ static const TileCost kTileCostConv512 = {2.5, 16.0, 1};
 // previous fit (before the lean epilogue / ping-pong kernel), kept selectable for A/B runs: ODISE_GEMM_FLAGS=8
 static const TileCost kTileCostOld[kNumTiles] = {{1.68, 9.5, 2}, {1.58, 4.1, 3}, {1.28, 2.4, 4}, {3.04, 29.0, 1}, {2.58, 22.0, 1},
                                                  {1.75, 10.6, 1}, {2.25, 12.0, 1}, {1.92, 12.0, 1}, {1.32, 10.0, 1}, {2.64, 10.0, 2}};
+static thread_local int g_last_tile = -1;   // odise_hip_last_tile: tile | split-K << 8 of this thread's last GEMM / conv launch
 static int env_gemm_flags() {
 #ifdef ODISE_TOOLS
     static int v = -1;
@@ -2378,6 +2382,7 @@ static int launch_gemm(odise_hip_ctx* ctx, GemmArgs& g, int batch, int force_til
         g.splitk = (int)ceil_div(nk, g.ktiles_per_split);
         ODISE_REQUIRE((size_t)g.splitk * g.M * g.N * sizeof(float) <= ctx->ws_bytes, "gemm: split-K workspace too small");
     }
+    g_last_tile = tile | (best_split << 8);
     if (flags & 32) {  // ODISE_GEMM_FLAGS=32: log every launch (tools/gemm_eff.py joins the log with a rocprofv3 kernel trace: per-shape TFLOP/s)
         fprintf(stderr, "GEMMLOG conv=%d M=%d N=%d K=%d batch=%d cin=%d kh=%d h=%d w=%d stride=%d ups=%d tile=%d split=%d pp=%d\n", (int)CONV, g.M, g.N,
                 g.K, batch, g.cg.Cin, g.cg.KH, g.cg.H, g.cg.W, g.cg.stride, g.cg.ups, tile, best_split, (int)pp_ok);
@@ -2569,6 +2574,7 @@ extern "C" int odise_hip_conv2d(odise_hip_ctx* ctx, const odise_conv_desc* d) { 
 extern "C" int odise_hip_gemm_forced(odise_hip_ctx* ctx, const odise_gemm_desc* d, int tile, int splitk) {
     return odise::gemm_forced(ctx, d, tile, splitk);
 }
+extern "C" int odise_hip_last_tile(void) { return odise::g_last_tile; }
 extern "C" int odise_hip_gemm_ln(odise_hip_ctx* ctx, const odise_gemm_desc* d, const float* part, int parts, float inv_c, float eps,
                                  const float* colsum, float* final_out, const float* fin, const float* rowsum, float* stats_out) {
     odise::LnEpi ln;

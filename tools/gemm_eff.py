@@ -16,7 +16,7 @@ import sys
 ROOT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..")
 sys.path.insert(0, ROOT)
 
-FAMILIES = ("gemm_kernel", "gemm_pp_kernel", "gemm_pp2_kernel", "conv3_halo_kernel")
+FAMILIES = ("gemm_kernel", "gemm_pp_kernel", "gemm_pp2_kernel", "conv3_halo_kernel", "conv3_halo4_kernel")
 
 
 def run(steps=3):

@@ -22,4 +22,4 @@ ctx.timer_start()
 for _ in range(iters):
     ctx.conv2d(X, Wt, force_tile=tile, out=O)
 ms = ctx.timer_stop() / iters
-print(f"conv {N}x{H}x{H} {Cin}->{Cout} tile {tile}: {ms*1e3:.1f} us {2.0*N*H*H*Cout*9*Cin/(ms*1e-3)/1e12:.1f} TF/s")
+print(f"conv {N}x{H}x{H} {Cin}->{Cout} tile {tile} (ran on tile {ctx.lib.odise_hip_last_tile() & 255}): {ms*1e3:.1f} us {2.0*N*H*H*Cout*9*Cin/(ms*1e-3)/1e12:.1f} TF/s")
