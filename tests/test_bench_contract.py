@@ -1,5 +1,5 @@
-"""The bench line the driver parses: every committed `profiles/r02_bench_*.json` (rank 0's one JSON line of a `bench.py` run on an MI355X)
-carries the keys of the measurement contract, with consistent arithmetic.  CPU only: guards the format, not the numbers."""
+"""The bench line the driver parses: every committed `profiles/r03_bench_*.json` (rank 0's one JSON line of a `bench.py` run on an MI355X, final
+round-3 binary) carries the keys of the measurement contract, with consistent arithmetic.  CPU only: guards the format, not the numbers."""
 import glob
 import json
 import os
@@ -7,7 +7,7 @@ import os
 import pytest
 
 ROOT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..")
-LINES = sorted(glob.glob(os.path.join(ROOT, "profiles", "r02_bench_*.json")))
+LINES = sorted(glob.glob(os.path.join(ROOT, "profiles", "r03_bench_*.json")))
 
 
 @pytest.mark.parametrize("path", LINES, ids=[os.path.basename(p) for p in LINES])
@@ -17,6 +17,7 @@ def test_bench_line_contract(path):
         assert k in d, k
     assert d["n_gpus"] == 1 and d["higher_is_better"] is True and d["scaling"] == "weak" and d["vs_baseline"] is None
     assert d["dtype"] == "f16" and d["data"] == "synthetic" and "workload" in d["config"] and "model" not in d["config"]
+    assert len(LINES) >= 7
     units = d["config"]["units_per_step_per_gpu"]
     assert abs(d["value"] - units * 1e3 / d["ms_per_step"]) < 1e-6 * d["value"]          # whole-job throughput = units / step time
     r = d["roofline"]
@@ -30,11 +31,23 @@ def test_bench_line_contract(path):
 
 
 def test_headline_line_has_the_cpu_baseline():
-    d = json.load(open(os.path.join(ROOT, "profiles", "r02_bench_full_b4_1024.json")))
+    d = json.load(open(os.path.join(ROOT, "profiles", "r03_bench_full_b4_1024.json")))
     assert d["metric"] == "panoptic-inference images/sec @1024x1024" and d["unit"] == "images/s"
     assert d["config"]["workload"].startswith("BASELINE configs[2]") and d["config"]["units_per_step_per_gpu"] == 4
+    assert d["config"]["rccl_ranks"] == d["n_gpus"] == 1 and d["config"]["batches_in_flight"] == 1
     c = d["cpu_baseline"]
     for k in ("value", "unit", "cores", "kind", "sample"):
         assert k in c, k
-    assert c["kind"] == "port" and c["unit"] == "images/s" and c["cores"] >= 1 and len(c["crop_seconds_live"]) >= 3
-    assert 0 < c["value"] < d["value"]
+    # whole images through the oracle (heads and post-processing included), not crops scaled up
+    assert c["kind"] == "port" and c["unit"] == "images/s" and c["cores"] >= 1 and len(c["image_seconds_live"]) >= 2
+    assert abs(c["value"] - len(c["image_seconds_live"]) / sum(c["image_seconds_live"])) < 1e-9
+    assert 0 < c["value_literal"] < c["value"] < d["value"]
+    # the decisions the timed kernels made are not degenerate: every picture has instances, the first one segments (bench.py check_exchange)
+    e = d["exchange"]
+    assert min(e["instances_per_image"]) > 0 and e["segments_image0"] > 0 and len(e["segments_per_image"]) == 4
+
+
+def test_in_flight_line_says_so():
+    d = json.load(open(os.path.join(ROOT, "profiles", "r03_bench_full_b4_1024_in_flight3.json")))
+    assert d["config"]["batches_in_flight"] == 3 and d["config"]["one_batch_alone_ms"] > d["ms_per_step"]
+    assert all(f"in_flight_{k}" in d["exchange"] for k in (1, 2))

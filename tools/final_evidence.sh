@@ -30,6 +30,6 @@ python tools/pmc_summary.py $O/pmc_FETCH_SIZE/b_counter_collection.csv $O/pmc_WR
 for d in conv_FETCH_SIZE conv_WRITE_SIZE conv_mfma conv128_mfma; do echo "== $d"; python tools/pmc_avg.py $O/$d/c_counter_collection.csv conv3_halo; done > $O/conv_pmc.txt 2>&1
 echo "pmc done" >> $O/rc.txt
 # keep the merge small: the raw traces stay on the box
-rm -rf $O/prof $O/eff $O/pmc_FETCH_SIZE $O/pmc_WRITE_SIZE $O/conv_FETCH_SIZE $O/conv_WRITE_SIZE $O/conv_mfma $O/conv128_mfma
+rm -rf $O/eff $O/pmc_FETCH_SIZE $O/pmc_WRITE_SIZE $O/conv_FETCH_SIZE $O/conv_WRITE_SIZE $O/conv_mfma $O/conv128_mfma
 cat $O/rc.txt; tail -3 $O/pytest_gpu.log; for f in $O/bench_*.json; do python -c "import json,sys; d=json.load(open('$f')); print('$f', round(d['ms_per_step'],2), round(d['value'],2), d['unit'], d.get('roofline',{}).get('frac'))"; done
 tail -5 $O/lane_timeline.txt; cat $O/hbm_bound_kernels.txt | head -20; cat $O/conv_pmc.txt
