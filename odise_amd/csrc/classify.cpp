@@ -10,6 +10,7 @@
 // round trips, maskformer_model.py:312-340) are replaced by one fused per-pixel kernel that produces integer area counters,
 // so the host decides segments from 3*Q integers per image.
 #include <math.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include <algorithm>
@@ -475,6 +476,21 @@ extern "C" int odise_hip_postprocess_batch(odise_hip_ctx* ctx, const odise_post_
         g.Q = Q; g.Qpad = Qpad;
         return g;
     };
+    // The per-image chain after the pixel pass - mask statistics for the instance scores, the sequential segment walk, the record write - is
+    // a handful of small kernels (one of them a single thread per image).  With the second lane present they run there, beside the
+    // HBM-bound semantic GEMM of the same image on the main stream; the next image's pixel pass (which overwrites S and ids) waits for them.
+#ifdef ODISE_TOOLS
+    static const bool serial_post = getenv("ODISE_POST_SERIAL") != nullptr;   // A/B: the chain on the main stream
+#else
+    const bool serial_post = false;
+#endif
+    const bool side = !serial_post && ctx->lanes == 2 && ctx->stream2 && ctx->ev_fork && ctx->ev_join;
+    bool side_pending = false;
+    auto join_side = [&]() -> int {
+        if (side_pending) ODISE_CHECK_HIP(hipStreamWaitEvent(ctx->stream, ctx->ev_join, 0));
+        side_pending = false;
+        return ODISE_OK;
+    };
     for (int b = 0; b < B; ++b) {
         const PostGeom g = geometry(b);
         const int npix = g.oh * g.ow;
@@ -485,7 +501,27 @@ extern "C" int odise_hip_postprocess_batch(odise_hip_ctx* ctx, const odise_post_
         const bool inst = want_inst;
         const bool need_S = sem || amax || inst;
         if (!need_S && !pan) continue;
+        ODISE_TRY(join_side());
         ODISE_TRY(launch_postprocess_pixels(ctx, logits, kscore + (size_t)b * Q, need_S ? S : nullptr, pan ? ids : nullptr, counts + (size_t)b * 3 * Q, g));
+        auto decisions = [&]() -> int {
+            if (inst) ODISE_TRY(launch_column_stats(ctx, S, partial, stats + (size_t)b * 2 * Qpad, npix, Qpad));
+            if (pan) {
+                ODISE_TRY(launch_panoptic_decide(ctx, counts + (size_t)b * 3 * Q, kscore + (size_t)b * Q, label + (size_t)b * Q, thing, map + (size_t)b * Q,
+                                                 pan + npix, Q, K, d->overlap_threshold, ODISE_MAX_SEGMENTS, stuff));
+                ODISE_TRY(launch_panoptic_write(ctx, ids, map + (size_t)b * Q, pan, npix));
+            }
+            return ODISE_OK;
+        };
+        if (side && (inst || pan)) {
+            ODISE_CHECK_HIP(hipEventRecord(ctx->ev_fork, ctx->stream));
+            {
+                Lane2 lane(ctx, ms);
+                ODISE_CHECK_HIP(hipStreamWaitEvent(ctx->stream, ctx->ev_fork, 0));
+                ODISE_TRY(decisions());
+                ODISE_CHECK_HIP(hipEventRecord(ctx->ev_join, ctx->stream));
+            }
+            side_pending = true;
+        }
         if (sem) {   // sem_seg[c, p] = sum_q softmax(mask_cls)[q, c] * sigmoid(mask)[q, p]  (maskformer_model.py:280-284) as an MFMA GEMM
             odise_gemm_desc gd;
             memset(&gd, 0, sizeof(gd));
@@ -499,15 +535,17 @@ extern "C" int odise_hip_postprocess_batch(odise_hip_ctx* ctx, const odise_post_
             ODISE_TRY(gemm_forced(ctx, &gd, g_sem_tile >= 0 ? g_sem_tile : (K <= 64 ? -1 : 5), 0));
         }
         if (amax) ODISE_TRY(launch_semantic_argmax(ctx, S, semT + (size_t)b * K * Qpad, amax, npix, Qpad, K));
-        if (inst) ODISE_TRY(launch_column_stats(ctx, S, partial, stats + (size_t)b * 2 * Qpad, npix, Qpad));
-        if (pan) {
-            ODISE_TRY(launch_panoptic_decide(ctx, counts + (size_t)b * 3 * Q, kscore + (size_t)b * Q, label + (size_t)b * Q, thing, map + (size_t)b * Q,
-                                             pan + npix, Q, K, d->overlap_threshold, ODISE_MAX_SEGMENTS, stuff));
-            ODISE_TRY(launch_panoptic_write(ctx, ids, map + (size_t)b * Q, pan, npix));
-        }
+        if (!side) ODISE_TRY(decisions());
     }
     if (want_inst) {   // the top-k selection of every image in one launch (one block per image), then the selected masks
-        ODISE_TRY(launch_instance_topk(ctx, probs, stats, thing, d->inst_table, d->inst_scores, B, Q, Qpad, K, topk, d->panoptic_on ? 1 : 0));
+        if (side_pending) {   // behind the last image's chain on the second lane, i.e. beside that image's semantic GEMM
+            Lane2 lane(ctx, ms);
+            ODISE_TRY(launch_instance_topk(ctx, probs, stats, thing, d->inst_table, d->inst_scores, B, Q, Qpad, K, topk, d->panoptic_on ? 1 : 0));
+            ODISE_CHECK_HIP(hipEventRecord(ctx->ev_join, ctx->stream));
+        } else {
+            ODISE_TRY(launch_instance_topk(ctx, probs, stats, thing, d->inst_table, d->inst_scores, B, Q, Qpad, K, topk, d->panoptic_on ? 1 : 0));
+        }
+        ODISE_TRY(join_side());
         for (int b = 0; b < B && d->inst_masks; ++b) {
             if (!d->inst_masks[b]) continue;
             int* tb = d->inst_table + (size_t)b * (1 + 2 * topk);
@@ -515,7 +553,7 @@ extern "C" int odise_hip_postprocess_batch(odise_hip_ctx* ctx, const odise_post_
             ODISE_TRY(launch_instance_masks(ctx, logits, tb + 1, d->inst_masks[b], std::min(topk, Q * K), geometry(b), tb));
         }
     }
-    return ODISE_OK;
+    return join_side();   // everything the call produced is ordered on the context's stream
 }
 
 extern "C" int odise_hip_infer(odise_hip_ctx* ctx, const odise_infer_desc* d) {
