@@ -65,6 +65,7 @@ def parse():
                    "one host thread each) whose steps interleave, so the launch-bound serial tail of one batch runs under the chip-filling "
                    "convolutions of the next.  Every step is still one synchronous model call on one batch of --images pictures")
     p.add_argument("--clip-ln-fold", type=int, default=0, choices=[0, 1, 2], help="A/B: the CLIP towers' LayerNorm fold, 0 = the library's rule, 1 = always, 2 = never")
+    p.add_argument("--vae-chunk-mb", type=float, default=None, help="A/B: ODISE_OPT_VAE_CHUNK_BYTES in MiB (0 = all crops per launch; default: the library's)")
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--no-inclusive", action="store_true", help="skip the PCIe- / JPEG-inclusive legs")
     return p.parse_args()
@@ -156,13 +157,23 @@ def cpu_baseline_unet():
             "sample": "UNet single-step forward (bs=1, 64x64 latent, fp32 torch CPU oracle, live path): 1 warm-up + 3 timed passes (median)"}
 
 
-def dominant_kernel(ctx):
-    """The kernel with the largest share of the step (profiles/r02_bench_full_by_shape.txt): the 3x3 convolution 512->512 at 128x128 over
-    the 16 crops of a 4-image step (VAE encoder level 2 / decoder level 2; 7 launches per step).  Timed live with HIP events on the
-    library's stream; algorithmic FLOPs per launch = 2 * pixels * Cout * 9 * Cin.  `traffic` = HBM bytes per launch from the PMC passes of
-    the same launch (tools/one_conv.py under rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, FETCH doubled as the guide's gfx950 correction
-    prescribes), recorded under profiles/; null when that file is absent."""
-    n, hw, cin, cout = 16, 128, 512, 512
+DOM = {"hw": 128, "cin": 512, "cout": 512, "launches_per_step": 7}   # the dominant kernel's shape (dominant_shape / dominant_kernel_isolated)
+
+
+def dominant_shape(crops):
+    """The kernel with the largest share of the step (profiles/r04_bench_full_by_shape.txt): the 3x3 convolution 512->512 at 128x128 over all
+    crops of a step (VAE encoder level 2 / decoder level 2; 7 launches per step).  -> (M, N, K) of its implicit GEMM, algorithmic FLOPs per
+    launch = 2 * pixels * Cout * 9 * Cin.  With ODISE_OPT_VAE_CHUNK_BYTES the library runs these levels over a few crops per launch: `crops`
+    is then the chunk, and a step has 7 * (crops of the step / chunk) launches."""
+    M = crops * DOM["hw"] * DOM["hw"]
+    return (M, DOM["cout"], 9 * DOM["cin"]), 2.0 * M * DOM["cout"] * 9 * DOM["cin"]
+
+
+def dominant_kernel_isolated(ctx, n):
+    """The same launch ALONE on an otherwise idle chip (after the timed region): the figure earlier rounds reported as `roofline`; kept as the
+    secondary `isolated` key.  The in-step figure (launch probe, HIP events on the lane the library launches the kernel on, over the timed
+    region, beside the other lane's kernels and at the clock the whole step sustains) is the `roofline` proper."""
+    hw, cin, cout = DOM["hw"], DOM["cin"], DOM["cout"]
     rng = np.random.default_rng(0)
     X = ctx.to_device(rng.standard_normal((n, hw, hw, cin), dtype=np.float32).astype(np.float16))
     Wt = ctx.to_device((rng.standard_normal((cout, 3, 3, cin), dtype=np.float32) * (9 * cin) ** -0.5).astype(np.float16))
@@ -178,17 +189,23 @@ def dominant_kernel(ctx):
     tile = ctx.lib.odise_hip_last_tile() & 255            # what the library's cost model ran this shape on (gemm.hip kTileBM / kTileBN)
     kernel = {7: "conv3_halo_kernel<256,2>", 8: "conv3_halo_kernel<128,1>", 9: "conv3_halo4_kernel<128>"}.get(tile, f"tile {tile}")
     flops = 2.0 * n * hw * hw * cout * 9 * cin
-    traffic = None
-    for name in ("r03_dominant_conv_traffic.json", "r02_dominant_conv_traffic.json", "r01_dominant_conv_traffic.json"):
+    for a in (X, Wt, O):
+        a.free()
+    return {"kernel": f"{kernel} (3x3 conv 512->512 @128x128, {n} crops per launch)", "launch_us": us, "flops": flops,
+            "achieved": flops / (us * 1e-6) / 1e12}
+
+
+def profiled_traffic():
+    """HBM bytes per launch of the dominant kernel from the separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes committed under profiles/
+    (tools/one_conv.py; FETCH doubled as the guide's gfx950 correction prescribes).  NOT measured in this run: the line carries it as a pointer
+    (`traffic_profiled`), `roofline.traffic` itself stays null."""
+    for name in ("r04_dominant_conv_traffic.json", "r03_dominant_conv_traffic.json"):
         tp = os.path.join(ROOT, "profiles", name)
         if os.path.exists(tp):
             with open(tp) as f:
-                traffic = json.load(f).get("hbm_bytes_per_launch")
-            break
-    for a in (X, Wt, O):
-        a.free()
-    return {"kernel": f"{kernel} (3x3 conv 512->512 @128x128, 16 crops)", "launch_us": us, "flops": flops,
-            "achieved": flops / (us * 1e-6) / 1e12, "traffic": traffic, "launches_per_step": 7}
+                d = json.load(f)
+            return {"file": "profiles/" + name, "hbm_bytes_per_launch": d.get("hbm_bytes_per_launch"), "crops_per_launch": d.get("crops_per_launch", 16)}
+    return None
 
 
 def inclusive_rates(ctx, hip, u8, S, B, sizes, steps):
@@ -283,7 +300,9 @@ def main():
 
     from odise_amd.runtime import Context
     ctx = Context(local_rank)
-    ctx.lib.odise_hip_clip_ln_fold(args.clip_ln_fold)
+    ctx.set_option(ctx.OPT_CLIP_LN_FOLD, args.clip_ln_fold)
+    if args.vae_chunk_mb is not None:
+        ctx.set_option(ctx.OPT_VAE_CHUNK_BYTES, int(args.vae_chunk_mb * (1 << 20)))
     B = args.images if args.images is not None else (4 if args.stage == "full" else 1)
 
     # Weights: random tensors of the real architecture's shapes (odise_amd/synthetic.py; no checkpoints, no network).  The oracle is
@@ -418,10 +437,21 @@ def main():
 
     n_fly = len(slots) if args.stage == "full" else 1
     single_ms = None
+    probe = None
+    if args.stage == "full":
+        # launch probe on the dominant kernel's shape: the library records HIP events around each of its launches in the timed region, on the
+        # lane it launches them on.  The VAE levels may run in crop chunks (ODISE_OPT_VAE_CHUNK_BYTES): the chunk follows from the option.
+        total_crops = B * ncrops
+        chunk_bytes = ctx.get_option(ctx.OPT_VAE_CHUNK_BYTES)
+        per_crop = DOM["hw"] * DOM["hw"] * DOM["cout"] * 2
+        chunk = total_crops if chunk_bytes <= 0 else max(1, min(total_crops, chunk_bytes // per_crop))
+        probe = {"crops": chunk, "shape": dominant_shape(chunk)[0], "flops": dominant_shape(chunk)[1]}
     if n_fly == 1:
         for _ in range(args.warmup):
             step()
         barrier()
+        if probe is not None:
+            ctx.probe_arm(True, *probe["shape"], max_launches=4096)
         t0 = time.perf_counter()
         ctx.timer_start()
         for _ in range(args.steps):
@@ -429,6 +459,8 @@ def main():
         ev_ms = ctx.timer_stop()  # HIP events on the library's stream (synchronises)
         barrier()
         wall = time.perf_counter() - t0
+        if probe is not None:
+            probe["us"] = ctx.probe_read()
     else:
         # K steps in all, dealt round-robin to the instances; each instance's steps run on its own host thread (a step is one C call that
         # releases the interpreter lock).  The timed region opens after every instance has warmed up and drained, and closes after all K
@@ -496,10 +528,15 @@ def main():
         except Exception as exc:  # side legs must never take the headline measurement down with them
             inclusive = {"error": f"{type(exc).__name__}: {exc}"}
 
+    # every rank: one diagnostic line on stderr (which device, how many ranks the RCCL communicator spans, this rank's own step time), so that a
+    # multi-GPU run that goes wrong leaves more than one number behind
+    print(f"[bench rank {rank}/{world}] device {local_rank} ({ctx.device_info()[0]}), rccl_ranks {rccl_ranks}, {args.steps} steps, "
+          f"{wall * 1e3 / args.steps:.2f} ms/step (max over ranks), in-step dominant-kernel launches recorded "
+          f"{0 if probe is None or 'us' not in probe else len(probe['us'])}", file=sys.stderr, flush=True)
     dom = None
-    if rank == 0 and args.stage == "full":
+    if rank == 0 and args.stage == "full" and probe is not None:
         try:
-            dom = dominant_kernel(ctx)
+            dom = dominant_kernel_isolated(ctx, probe["crops"])
         except Exception as exc:  # the whole-step roofline below still goes out
             print(f"[bench] dominant-kernel measurement failed: {type(exc).__name__}: {exc}", file=sys.stderr, flush=True)
     if rank == 0:
@@ -514,17 +551,29 @@ def main():
             "config": {"workload": workload, "units_per_step_per_gpu": B, "device": dev_name, "compute_units": cus,
                        "parallelism": (f"dp{world} (independent images, one RCCL all-gather of prediction records per step on the library's "
                                        f"exchange stream)") if gather else f"dp{world}",
-                       "rccl_ranks": rccl_ranks, "batches_in_flight": n_fly, "one_batch_alone_ms": single_ms},
+                       "rccl_ranks": rccl_ranks, "batches_in_flight": n_fly, "one_batch_alone_ms": single_ms,
+                       "vae_chunk_bytes": ctx.get_option(ctx.OPT_VAE_CHUNK_BYTES), "clip_ln_fold": ctx.get_option(ctx.OPT_CLIP_LN_FOLD)},
             "roofline": {"bound": "mfma", "achieved": achieved, "peak": MFMA_F16_PEAK / 1e12, "unit": "TFLOP/s", "frac": achieved * 1e12 / MFMA_F16_PEAK,
                          "traffic": None,
                          "kernel": "whole step (all kernels; per-kernel times in profiles/)",
                          "algorithmic_flops_per_unit": flops_per_unit, "event_ms_per_step": step_ms_ev},
         }
-        if dom is not None:
-            # the contract's roofline object describes the DOMINANT kernel; the whole-step figure moves to step_* keys
-            out["roofline"] = {"bound": "mfma", "achieved": dom["achieved"], "peak": MFMA_F16_PEAK / 1e12, "unit": "TFLOP/s",
-                               "frac": dom["achieved"] * 1e12 / MFMA_F16_PEAK, "traffic": dom["traffic"], "kernel": dom["kernel"],
-                               "launch_us": dom["launch_us"], "algorithmic_flops_per_launch": dom["flops"], "launches_per_step": dom["launches_per_step"],
+        in_step = probe.get("us") if probe is not None else None
+        if in_step is not None and len(in_step) > 0:
+            # The contract's roofline object describes the DOMINANT kernel AS IT RUNS IN THE TIMED STEP: the mean over every one of its launches
+            # in the timed region (HIP events recorded by the library on the lane that launches it), i.e. beside the other lane's kernels and at
+            # the clock the step sustains.  `isolated` = the same launch alone on the idle chip; the whole-step figure is in the step_* keys.
+            us = float(np.mean(in_step))
+            ach = probe["flops"] / (us * 1e-6) / 1e12
+            out["roofline"] = {"bound": "mfma", "achieved": ach, "peak": MFMA_F16_PEAK / 1e12, "unit": "TFLOP/s", "frac": ach * 1e12 / MFMA_F16_PEAK,
+                               "traffic": None, "traffic_profiled": profiled_traffic(),
+                               "kernel": (dom["kernel"] if dom is not None else f"3x3 conv 512->512 @128x128, {probe['crops']} crops per launch"),
+                               "where": "in the timed step (launch probe: HIP events on the launching lane, all launches of the timed region)",
+                               "launch_us": us, "launch_us_min": float(np.min(in_step)), "launch_us_max": float(np.max(in_step)),
+                               "launches_timed": int(len(in_step)), "launches_per_step": len(in_step) / args.steps,
+                               "crops_per_launch": probe["crops"], "algorithmic_flops_per_launch": probe["flops"],
+                               "isolated": None if dom is None else {"launch_us": dom["launch_us"], "achieved": dom["achieved"],
+                                                                     "frac": dom["achieved"] * 1e12 / MFMA_F16_PEAK},
                                "step_achieved": achieved, "step_frac": achieved * 1e12 / MFMA_F16_PEAK,
                                "algorithmic_flops_per_unit": flops_per_unit, "event_ms_per_step": step_ms_ev}
         if exch is not None:

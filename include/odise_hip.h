@@ -60,6 +60,22 @@ int odise_hip_sync(odise_hip_ctx* ctx);
 int odise_hip_timer_start(odise_hip_ctx* ctx);
 int odise_hip_timer_stop(odise_hip_ctx* ctx, float* elapsed_ms);
 int odise_hip_device_info(odise_hip_ctx* ctx, char* name_buf, int buf_len, int* cu_count, size_t* hbm_bytes);
+/* Per-context execution options.  They choose between arithmetic-equivalent forms of a stage, never between results and no results:
+ *   ODISE_OPT_CLIP_LN_FOLD     how the CLIP towers (clip.py:177-206, 252-323) take their LayerNorms: 0 = folded into the neighbouring GEMMs from
+ *                              8192 token rows per call (default; below that as kernels), 1 = always folded, 2 = never.  The two forms differ by
+ *                              fp16 rounding, so a caller that needs results independent of how many crops share a call pins 1 or 2.
+ *   ODISE_OPT_VAE_CHUNK_BYTES  the AutoencoderKL levels (ldm.py:493-533, 585-606) run over as many crops per launch as keep one activation
+ *                              tensor below this many bytes (default 64 MiB: the producer's output is still in the 256 MiB Infinity Cache when
+ *                              GroupNorm and the next convolution read it); 0 = all crops of a call at once.  Per-crop arithmetic is unchanged. */
+enum { ODISE_OPT_CLIP_LN_FOLD = 1, ODISE_OPT_VAE_CHUNK_BYTES = 2 };
+int odise_hip_set_option(odise_hip_ctx* ctx, int option, int64_t value);
+int odise_hip_get_option(odise_hip_ctx* ctx, int option, int64_t* value);
+/* Launch probe (measurement, bench.py's `roofline`): HIP events around every launch of ONE shape - conv != 0: the implicit GEMM of a convolution
+ * with M = N*OH*OW output pixels, N = Cout, K = KH*KW*Cin; conv = 0: odise_hip_gemm's M, N, K - recorded on whichever stream the library
+ * launches it on, for the next max_launches matching launches.  odise_hip_probe_read waits for the recorded launches, writes their durations
+ * in microseconds (at most cap) and the number recorded, and disarms the probe. */
+int odise_hip_probe_arm(odise_hip_ctx* ctx, int conv, int M, int N, int K, int max_launches);
+int odise_hip_probe_read(odise_hip_ctx* ctx, float* us_out, int cap, int* n_launches);
 
 /* ---- MSDeformAttn forward ------------------------------ */
 /* value        [B, S, M, D]      dtype value_dtype (device)

@@ -30,8 +30,6 @@ int odise_hip_last_tile(void);
  *   consumer  part [M][parts][2] + colsum [N]: C = act(rstd_m (A W'^T - mean_m colsum) + bias_n) (+ residual), the row statistics finished from
  *             the partials with 1/inv_c channels and eps; final_out [M][2] receives (-mean rstd, rstd)
  *   swapped   fin [N][2] + rowsum [M]: the normalised operand is W (its rows are the tokens), statistics per output column */
-/* the CLIP towers' LayerNorm fold (extractor.cpp clip_tower): 0 = by token count (default), 1 = always, 2 = never (separate LayerNorm kernels) */
-int odise_hip_clip_ln_fold(int mode);
 int odise_hip_gemm_ln(odise_hip_ctx* ctx, const odise_gemm_desc* d, const float* part, int parts, float inv_c, float eps, const float* colsum,
                       float* final_out, const float* fin, const float* rowsum, float* stats_out);
 /* the conv -> GroupNorm pair of the ResBlocks with the conv's tile forced: the conv epilogue reduces the GroupNorm statistics (per channel and
@@ -47,6 +45,11 @@ int odise_hip_gemm_debug(int flags);
 int odise_hip_post_generic(int on);
 /* force the tile of the semantic GEMM [K, pixels] = P^T S^T (A/B of the 256-row rule in odise_hip_postprocess_batch); -1 = the rule */
 int odise_hip_sem_tile(int tile);
+
+/* per-context log of every GEMM / convolution launch the cost model decided (tests print which choices differ between two batch sizes):
+ * odise_hip_launch_log(ctx, 1) starts / clears it, (ctx, 0) drops it; _read copies records of 6 ints (conv, M, N, K, tile id, split-K factor) */
+int odise_hip_launch_log(odise_hip_ctx* ctx, int on);
+int odise_hip_launch_log_read(odise_hip_ctx* ctx, int* out6, int cap, int* n);
 
 /* 1: the feature extractor enqueues everything on one stream; 2 (default): its CLIP -> UNet branch runs on a second stream beside the VAE */
 int odise_hip_set_lanes(odise_hip_ctx* ctx, int lanes);

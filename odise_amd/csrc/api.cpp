@@ -3,6 +3,7 @@
 #include <string.h>
 
 #include <mutex>
+#include <vector>
 
 #include "common.h"
 #include "../../include/odise_hip_tools.h"
@@ -57,6 +58,8 @@ extern "C" int odise_hip_destroy(odise_hip_ctx* ctx) {
     models_destroy(ctx);
     odise::jpeg_release(ctx);
     odise::comm_release(ctx);
+    odise::probe_release(ctx);
+    odise::launch_log_release(ctx);
     if (ctx->ws) (void)hipFree(ctx->ws);
     if (ctx->ws2) (void)hipFree(ctx->ws2);
     if (ctx->ev_fork) (void)hipEventDestroy(ctx->ev_fork);
@@ -150,6 +153,101 @@ extern "C" int odise_hip_device_info(odise_hip_ctx* ctx, char* name_buf, int buf
     if (hbm_bytes) *hbm_bytes = prop.totalGlobalMem;
     return ODISE_OK;
 }
+extern "C" int odise_hip_set_option(odise_hip_ctx* ctx, int option, int64_t value) {
+    ODISE_REQUIRE(ctx, "set_option: null context");
+    switch (option) {
+        case ODISE_OPT_CLIP_LN_FOLD:
+            ODISE_REQUIRE(value >= 0 && value <= 2, "set_option: CLIP_LN_FOLD takes 0 (by token count), 1 (always) or 2 (never)");
+            ctx->clip_ln_fold = (int)value;
+            return ODISE_OK;
+        case ODISE_OPT_VAE_CHUNK_BYTES:
+            ODISE_REQUIRE(value >= 0, "set_option: VAE_CHUNK_BYTES must be >= 0");
+            ctx->vae_chunk_bytes = value;
+            return ODISE_OK;
+        default:
+            set_error("set_option: unknown option %d", option);
+            return ODISE_ERR_ARG;
+    }
+}
+extern "C" int odise_hip_get_option(odise_hip_ctx* ctx, int option, int64_t* value) {
+    ODISE_REQUIRE(ctx && value, "get_option: null argument");
+    switch (option) {
+        case ODISE_OPT_CLIP_LN_FOLD: *value = ctx->clip_ln_fold; return ODISE_OK;
+        case ODISE_OPT_VAE_CHUNK_BYTES: *value = ctx->vae_chunk_bytes; return ODISE_OK;
+        default:
+            set_error("get_option: unknown option %d", option);
+            return ODISE_ERR_ARG;
+    }
+}
+
+namespace odise {
+void launch_log_push(odise_hip_ctx* ctx, const LaunchRec& r) { ((std::vector<LaunchRec>*)ctx->launch_log)->push_back(r); }
+void launch_log_release(odise_hip_ctx* ctx) {
+    delete (std::vector<LaunchRec>*)ctx->launch_log;
+    ctx->launch_log = nullptr;
+}
+void probe_release(odise_hip_ctx* ctx) {
+    LaunchProbe* p = (LaunchProbe*)ctx->probe;
+    if (!p) return;
+    for (int i = 0; i < 2 * p->cap; ++i) (void)hipEventDestroy(p->ev[i]);
+    delete[] p->ev;
+    delete p;
+    ctx->probe = nullptr;
+}
+}  // namespace odise
+extern "C" int odise_hip_probe_arm(odise_hip_ctx* ctx, int conv, int M, int N, int K, int max_launches) {
+    ODISE_REQUIRE(ctx && max_launches >= 1 && max_launches <= 4096, "probe_arm: 1 <= max_launches <= 4096");
+    ODISE_CHECK_HIP(hipSetDevice(ctx->device));
+    LaunchProbe* p = (LaunchProbe*)ctx->probe;
+    if (p && p->cap < max_launches) { probe_release(ctx); p = nullptr; }
+    if (!p) {
+        p = new LaunchProbe();
+        p->cap = max_launches;
+        p->ev = new hipEvent_t[2 * (size_t)max_launches]();
+        ctx->probe = p;
+        for (int i = 0; i < 2 * max_launches; ++i) ODISE_CHECK_HIP(hipEventCreate(&p->ev[i]));
+    }
+    p->conv = conv; p->M = M; p->N = N; p->K = K;
+    p->n = 0;
+    p->armed = true;
+    return ODISE_OK;
+}
+extern "C" int odise_hip_probe_read(odise_hip_ctx* ctx, float* us_out, int cap, int* n_launches) {
+    ODISE_REQUIRE(ctx && n_launches, "probe_read: null argument");
+    LaunchProbe* p = (LaunchProbe*)ctx->probe;
+    if (!p) {
+        set_error("probe_read: no probe armed on this context");
+        return ODISE_ERR_STATE;
+    }
+    p->armed = false;
+    *n_launches = p->n;
+    for (int i = 0; i < p->n && i < cap; ++i) {
+        float ms = 0.f;
+        ODISE_CHECK_HIP(hipEventSynchronize(p->ev[2 * i + 1]));
+        ODISE_CHECK_HIP(hipEventElapsedTime(&ms, p->ev[2 * i], p->ev[2 * i + 1]));
+        if (us_out) us_out[i] = ms * 1000.f;
+    }
+    return ODISE_OK;
+}
+
+extern "C" int odise_hip_launch_log(odise_hip_ctx* ctx, int on) {
+    ODISE_REQUIRE(ctx, "launch_log: null context");
+    launch_log_release(ctx);
+    if (on) ctx->launch_log = new std::vector<LaunchRec>();
+    return ODISE_OK;
+}
+extern "C" int odise_hip_launch_log_read(odise_hip_ctx* ctx, int* out6, int cap, int* n) {
+    ODISE_REQUIRE(ctx && n, "launch_log_read: null argument");
+    std::vector<LaunchRec>* v = (std::vector<LaunchRec>*)ctx->launch_log;
+    *n = v ? (int)v->size() : 0;
+    for (int i = 0; v && out6 && i < *n && i < cap; ++i) {
+        const LaunchRec& r = (*v)[i];
+        int* o = out6 + 6 * (size_t)i;
+        o[0] = r.conv; o[1] = r.M; o[2] = r.N; o[3] = r.K; o[4] = r.tile; o[5] = r.split;
+    }
+    return ODISE_OK;
+}
+
 // ABI self-description used by tests/test_lib_abi.py to validate the ctypes mirrors
 extern "C" int odise_hip_set_lanes(odise_hip_ctx* ctx, int lanes) {
     ODISE_REQUIRE(ctx && (lanes == 1 || lanes == 2), "set_lanes: 1 or 2");

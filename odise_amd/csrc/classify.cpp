@@ -21,6 +21,7 @@
 namespace odise {
 
 struct ClassifyModel {
+    std::vector<void*> owned;   // device weights of this stage (AllocScope)
     bool built = false;
     bool caption = false;  // CaptionODISE: word_head.text_proj, no null embedding, learned binary class head (odise.py:545-569)
     LinW text_proj;
@@ -87,17 +88,10 @@ void classify_destroy(ModelStore* ms) {
         }
         if (ms->classify->post_buf) (void)hipFree(ms->classify->post_buf);
         if (ms->classify->in_buf) (void)hipFree(ms->classify->in_buf);
+        free_allocs(ms->classify->owned);
     }
     delete ms->classify;
     ms->classify = nullptr;
-}
-
-static int dev_upload(odise_hip_ctx* ctx, ModelStore* ms, const void* host, size_t bytes, void** dev) {
-    ODISE_CHECK_HIP(hipStreamSynchronize(ctx->stream));
-    ODISE_CHECK_HIP(hipMalloc(dev, bytes ? bytes : 16));
-    ms->dev_allocs.push_back(*dev);
-    ODISE_CHECK_HIP(hipMemcpy(*dev, host, bytes, hipMemcpyHostToDevice));
-    return ODISE_OK;
 }
 
 static int classify_build(odise_hip_ctx* ctx) {
@@ -105,6 +99,7 @@ static int classify_build(odise_hip_ctx* ctx) {
     classify_destroy(ms);
     ClassifyModel* c = new ClassifyModel();
     ms->classify = c;
+    AllocScope scope(ms, c->owned);
     // CategoryODISE: category_head.{text_proj, null_embed} (odise.py:1236-1241); CaptionODISE: word_head.text_proj only (odise.py:1040-1060)
     Packer pcat{ctx, ms, "category_head.", ""};
     Packer pword{ctx, ms, "word_head.", ""};

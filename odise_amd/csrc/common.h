@@ -93,9 +93,30 @@ struct odise_hip_ctx {
     hipEvent_t ev_fork = nullptr, ev_mid = nullptr, ev_join = nullptr;
     int lanes = 2;  // 1 = everything on the one stream (tools A/B: odise_hip_set_lanes)
     void* comm = nullptr;  // odise::Comm* (comm.cpp): RCCL communicator + exchange stream, created by odise_hip_comm_init
+    // per-context execution options (odise_hip_set_option, include/odise_hip.h); read on the host when a stage is enqueued
+    int clip_ln_fold = 0;            // ODISE_OPT_CLIP_LN_FOLD: 0 = by token count, 1 = always, 2 = never
+    int64_t vae_chunk_bytes = 64ll << 20;   // ODISE_OPT_VAE_CHUNK_BYTES: crops per VAE launch so that one activation stays below this (0 = all crops at once)
+    void* probe = nullptr;           // odise::LaunchProbe* (api.cpp): HIP events around the launches of one kernel shape (odise_hip_probe_*)
+    void* launch_log = nullptr;      // std::vector<odise::LaunchRec>* while odise_hip_launch_log is on: (shape, tile, split-K) of every GEMM / conv launch
 };
 
 namespace odise {
+// odise_hip_probe_arm / _read: HIP events around every launch of ONE GEMM / convolution shape, recorded on the stream the launch goes to
+// (whichever lane that is), so bench.py can report the dominant kernel's duration as it runs INSIDE the timed step, beside the other lane
+struct LaunchProbe {
+    int conv = 0, M = 0, N = 0, K = 0;
+    int cap = 0, n = 0;
+    hipEvent_t* ev = nullptr;   // 2 * cap events (start, stop)
+    bool armed = false;
+};
+static inline LaunchProbe* probe_match(odise_hip_ctx* ctx, bool conv, int M, int N, int K) {
+    LaunchProbe* p = (LaunchProbe*)ctx->probe;
+    return (p && p->armed && p->n < p->cap && (p->conv != 0) == conv && p->M == M && p->N == N && p->K == K) ? p : nullptr;
+}
+void probe_release(odise_hip_ctx* ctx);
+struct LaunchRec { int conv, M, N, K, tile, split; };
+void launch_log_push(odise_hip_ctx* ctx, const LaunchRec& r);
+void launch_log_release(odise_hip_ctx* ctx);
 // LayerNorm folded into the GEMMs around it (gemm.hip gemm_epilogue_f16; used by the CLIP towers): statistics of the rows a GEMM writes come out
 // of its epilogue (`stats_out`), the GEMMs that would read LN(x) read x with gamma / beta folded into their weights and finish the
 // normalisation per row (`part` + `colsum`) or, with swapped operands, per column (`fin` + `rowsum`)

@@ -17,6 +17,13 @@ ModelStore* store_of(odise_hip_ctx* ctx) {
     return (ModelStore*)ctx->models;
 }
 
+void free_allocs(std::vector<void*>& owned) {
+    if (owned.empty()) return;
+    (void)hipDeviceSynchronize();   // a kernel of either lane may still read these weights
+    for (void* p : owned) (void)hipFree(p);
+    owned.clear();
+}
+
 void models_destroy(odise_hip_ctx* ctx) {
     if (!ctx->models) return;
     ModelStore* ms = (ModelStore*)ctx->models;
@@ -71,7 +78,7 @@ const HostTensor* Packer::find(const std::string& key) {
 
 int Packer::upload(const void* host, size_t bytes, void** dev) {
     ODISE_CHECK_HIP(hipMalloc(dev, bytes ? bytes : 16));
-    ms->dev_allocs.push_back(*dev);
+    ms->track(*dev);
     ODISE_CHECK_HIP(hipMemcpy(*dev, host, bytes, hipMemcpyHostToDevice));
     return ODISE_OK;
 }

@@ -79,7 +79,9 @@ struct UNetModel;
 
 struct ModelStore {
     std::map<std::string, HostTensor> host;
-    std::vector<void*> dev_allocs;
+    std::vector<void*> dev_allocs;              // weights that live as long as the context
+    std::vector<void*>* alloc_sink = nullptr;   // the stage being built owns what is uploaded meanwhile (AllocScope); rebuilding a stage frees it
+    void track(void* p) { (alloc_sink ? *alloc_sink : dev_allocs).push_back(p); }
     Arena arena;
     Arena arena2;   // activations of the second lane (Lane2)
     UNetModel* unet = nullptr;
@@ -90,6 +92,15 @@ struct ModelStore {
 };
 
 ModelStore* store_of(odise_hip_ctx* ctx);
+// Device weights of one stage: while an AllocScope lives, Packer::upload records its allocations in `owned`; free_allocs (device-synchronising)
+// releases them when the stage is rebuilt or destroyed, so reloading a head / swapping a model does not grow the footprint.
+struct AllocScope {
+    ModelStore* ms;
+    std::vector<void*>* prev;
+    AllocScope(ModelStore* m, std::vector<void*>& owned) : ms(m), prev(m->alloc_sink) { m->alloc_sink = &owned; }
+    ~AllocScope() { ms->alloc_sink = prev; }
+};
+void free_allocs(std::vector<void*>& owned);
 
 // ---- weight packing (host) + upload -------------------------------------------------------------------------
 struct Packer {

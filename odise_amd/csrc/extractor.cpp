@@ -42,6 +42,7 @@ struct ClipBlock {
 };
 
 struct ExtractorModel {
+    std::vector<void*> owned;   // device weights of this stage (AllocScope); the UNet owns its own
     bool built = false;
     // VAE encoder
     ConvW enc_conv_in, enc_conv_out;
@@ -77,6 +78,7 @@ struct ExtractorModel {
 };
 
 void extractor_destroy(ModelStore* ms) {
+    if (ms->extractor) free_allocs(ms->extractor->owned);
     delete ms->extractor;
     ms->extractor = nullptr;
 }
@@ -139,8 +141,6 @@ static int fold_layer_norm(Packer& pk, const float* W, const float* bias, int O,
     return ODISE_OK;
 }
 
-static int g_clip_ln_fold = 0;   // odise_hip_clip_ln_fold (include/odise_hip_tools.h)
-
 static int build_clip_block(Packer& pk, const std::string& key, ClipBlock& b, int W) {
     ODISE_TRY(pk.norm(key + ".ln_1", b.ln1));
     ODISE_TRY(pk.norm(key + ".ln_2", b.ln2));
@@ -184,6 +184,7 @@ static int extractor_build(odise_hip_ctx* ctx) {
     ms->extractor = e;
     // ---- UNet --------------------------------------------------------------------------------------------------
     ODISE_TRY(unet_build(ctx, "model.diffusion_model."));
+    AllocScope scope(ms, e->owned);
     // ---- VAE ---------------------------------------------------------------------------------------------------
     Packer pk{ctx, ms, "first_stage_model.", ""};
     ODISE_TRY(pk.conv("encoder.conv_in", e->enc_conv_in));
@@ -321,10 +322,32 @@ static int extractor_build(odise_hip_ctx* ctx) {
 }
 
 // ---------------------------------------------------------------------------------------------------------------
+// crops [n0, n0 + n) of a batched activation (the GroupNorm statistics of the whole tensor do not carry over)
+static Act crop_slice(const Act& a, int n0, int n) {
+    Act s = a;
+    s.p = a.p + (size_t)n0 * a.h * a.w * a.c;
+    s.n = n;
+    s.gn_part = nullptr;
+    s.gn_blocks = 0;
+    return s;
+}
+
+// crops per launch of a VAE level whose widest activation has `per_crop_bytes` (ODISE_OPT_VAE_CHUNK_BYTES): the tensor a kernel writes should
+// still be in the 256 MiB Infinity Cache when GroupNorm and the next convolution read it.  All 16 crops of a step make 0.27-1.07 GB tensors
+// at the 128- / 256- / 512-channel levels of 512^2 .. 128^2 - every GroupNorm pass and every convolution then streams from HBM.  The levels'
+// grids stay large in chunks (128 ch @ 512^2: 1024 tiles per crop; 512 ch @ 128^2: 128 per crop, four crops per launch).
+static int vae_chunk(const odise_hip_ctx* ctx, int B, size_t per_crop_bytes) {
+    if (ctx->vae_chunk_bytes <= 0) return B;
+    const int64_t c = ctx->vae_chunk_bytes / (int64_t)per_crop_bytes;
+    return (int)std::max<int64_t>(1, std::min<int64_t>(B, c));
+}
+
+// out.p == nullptr: allocated here; otherwise the caller's (slice of a batched) tensor is written
 static int run_vae_res(Exec& ex, const VaeRes& w, const Act& x, Act& out) {
     // both convs feed a GroupNorm (conv1 -> norm2 here, conv2 (+ skip) -> norm1 of the next block / norm_out): their epilogues
     // reduce the statistics, saving one HBM pass over tensors of up to 1 GB
-    ODISE_TRY(ex.alloc(out, x.n, x.h, x.w, w.c1.cout));
+    if (!out.p) ODISE_TRY(ex.alloc(out, x.n, x.h, x.w, w.c1.cout));
+    ODISE_REQUIRE(out.n == x.n && out.h == x.h && out.w == x.w && out.c == w.c1.cout, "vae block: output tensor does not match");
     ODISE_TRY(ex.alloc_gn_stats(out));
     const size_t mk = ex.ms->arena.mark();
     Act t1, h, t2, sk;
@@ -390,7 +413,7 @@ static int run_vae_attn(Exec& ex, const VaeAttn& w, const Act& x, Act& out) {
 // [B, clip_out] (ClipAdapter._encode_image, clip.py:177-206).  extra = Q > 0: MaskCLIP (clip.py:252-323): Q mask tokens
 // (copies of the class token) are appended AFTER the 577 image tokens; they never act as keys, so attention runs with
 // Lq = 577 + Q queries over Lk = 577 keys and `mask` [B, 577+Q, ldm] (u8, 1 = not visible) carries the per-(mask, patch)
-// visibility; the image-token stream is bit-identical to the plain tower.  out = [B, Q, clip_out] (ln_post + proj of the mask tokens).
+// visibility; with the same LayerNorm form (ODISE_OPT_CLIP_LN_FOLD) the image-token stream equals the plain tower's.  out = [B, Q, clip_out] (ln_post + proj of the mask tokens).
 // Token rows: every image owns TP = round_up(577 + Q, 8) rows of the activation matrices (the tail rows are zero at the input and never read
 // as keys, values or results), so that V^T of ALL images is ONE GEMM Wv x n^T -> [width, B*TP] whose column block b*TP.. is image b's
 // 16-byte-aligned V^T (the per-image batched form ran at 309 TFLOP/s: 3 column tiles for 577 tokens, 192 tiles on 256 CUs).
@@ -421,8 +444,10 @@ int clip_tower(Exec& ex, const Act& img, int extra, const uint8_t* mask, int64_t
     // launches per block on the chain that sits on the step's critical path.  The first block's ln_1 follows ln_pre and stays a kernel.
     // The statistics live in the math-first epilogue, i.e. on the 256-wide tiles without split-K: the fold is taken where the cost model runs the
     // tower's GEMMs on those tiles anyway (from ~8k tokens: 16 crops).  Below that (MaskCLIP on 4 pictures: 2.7k tokens) the small tiles + two
-    // 5 us LayerNorm launches are faster (measured: profiles/r03_lane_scheduling.txt).  g_clip_ln_fold: test hook, 1 = always, 2 = never.
-    const bool fold = Wd % 256 == 0 && (g_clip_ln_fold == 1 || (g_clip_ln_fold == 0 && M >= 8192));
+    // 5 us LayerNorm launches are faster (measured: profiles/r03_lane_scheduling.txt).  The rule is a per-context option (ODISE_OPT_CLIP_LN_FOLD:
+    // 0 = by token count, 1 = always, 2 = never), so a caller that needs the same arithmetic whatever the batch pins it.
+    const int fold_mode = ex.ctx->clip_ln_fold;
+    const bool fold = Wd % 256 == 0 && (fold_mode == 1 || (fold_mode == 0 && M >= 8192));
     const int P = Wd / 128;
     float *part_a = nullptr, *part_b = nullptr, *fin = nullptr;
     if (fold) {
@@ -610,6 +635,7 @@ int extractor_launch(odise_hip_ctx* ctx, ModelStore* ms, const float* image, int
         ODISE_CHECK_HIP(hipStreamWaitEvent(ctx->stream, ctx->ev_fork, 0));
         return conditioning();
     };
+    bool clip_enqueued = false;
     if (!two) ODISE_TRY(conditioning());
     if (two && !vae_first) ODISE_TRY(clip_on_lane2());
 
@@ -620,24 +646,61 @@ int extractor_launch(odise_hip_ctx* ctx, ModelStore* ms, const float* image, int
         const float sc[3] = {2.f, 2.f, 2.f}, sh[3] = {-1.f, -1.f, -1.f};  // (img - 0.5) / 0.5  (ldm.py:556)
         ODISE_TRY(launch_image_to_nhwc(ctx, image, x.p, B, 3, H * W, 8, sc, sh));
     }
-    Act cur;
-    ODISE_TRY(ex.conv(x, e->enc_conv_in, cur, 1, 1));
+    // One level = [conv_in] -> two ResBlocks -> [downsample], run over `chunk` crops at a time (vae_chunk): the level's input and output are
+    // batched tensors, everything between them lives in the chunk's scope of the arena - the same addresses for every chunk, so the working
+    // set of a level is a handful of <= 64 MiB tensors that stay in the Infinity Cache between producer and consumer.  Per-crop arithmetic is
+    // what it was (same kernels, same K order; only the row-block partition of the fused GroupNorm sums can follow a different tile choice).
+    Act cur = x;
     int flat = 0;
-    for (int l = 0; l < 4; ++l) {
-        for (int b = 0; b < 2; ++b) {
-            if (flat == 5) e->taps[0] = cur;  // input of down block 5 (ldm.py:437-438)
-            if (flat == 7) e->taps[1] = cur;
-            Act nxt;
-            ODISE_TRY(run_vae_res(ex, e->enc_blocks[l][b], cur, nxt));
-            cur = nxt;
-            ++flat;
+    auto encoder_level = [&](int l) -> int {
+        const int h = H >> l, w = W >> l;
+        const int cout = e->enc_blocks[l][1].c1.cout;
+        const int chunk = vae_chunk(ctx, B, (size_t)h * w * cout * 2);
+        const bool tap0 = flat <= 5 && 5 < flat + 2, tap1 = flat <= 7 && 7 < flat + 2;   // the input of block 5 / 7 (ldm.py:437-438) is a batched output
+        Act nxt, mid;      // mid: the tensor between the two blocks, batched only when it is a tap
+        if (l < 3) ODISE_TRY(ex.alloc(nxt, B, h / 2, w / 2, e->enc_down[l].cout));
+        else ODISE_TRY(ex.alloc(nxt, B, h, w, cout));
+        const bool scoped = chunk < B;   // all crops at once: nothing is released (the statistics of the level's output feed the next block)
+        const bool mid_is_tap = (tap0 && flat + 1 == 5) || (tap1 && flat + 1 == 7);
+        if (mid_is_tap) ODISE_TRY(ex.alloc(mid, B, h, w, e->enc_blocks[l][0].c1.cout));
+        if (mid_is_tap) e->taps[flat + 1 == 5 ? 0 : 1] = mid;
+        for (int n0 = 0; n0 < B; n0 += chunk) {
+            const int n = std::min(chunk, B - n0);
+            const size_t mk = ex.ms->arena.mark();
+            Act c0 = crop_slice(cur, n0, n);
+            if (l == 0) {
+                Act t;
+                ODISE_TRY(ex.conv(c0, e->enc_conv_in, t, 1, 1));
+                c0 = t;
+            }
+            Act b0 = mid_is_tap ? crop_slice(mid, n0, n) : Act();
+            ODISE_TRY(run_vae_res(ex, e->enc_blocks[l][0], c0, b0));
+            if (l < 3) {
+                Act b1, d = crop_slice(nxt, n0, n);
+                ODISE_TRY(run_vae_res(ex, e->enc_blocks[l][1], b0, b1));
+                // F.pad (0,1,0,1) + conv3x3 stride 2 pad 0
+                ODISE_TRY(ex.conv(b1, e->enc_down[l], d, 2, 0, false, nullptr, nullptr, 0, ODISE_ACT_NONE, 0, 0, h / 2, w / 2));
+            } else {
+                Act b1 = crop_slice(nxt, n0, n);
+                ODISE_TRY(run_vae_res(ex, e->enc_blocks[l][1], b0, b1));
+                if (!scoped) nxt = b1;    // keeps the fused GroupNorm statistics for mid.block_1
+            }
+            // the chunk's temporaries (and the statistics buffers of its slices) are released; batched outputs were allocated below the mark
+            if (scoped) ex.ms->arena.release(mk);
         }
-        if (l < 3) {
-            Act nxt;  // F.pad (0,1,0,1) + conv3x3 stride 2 pad 0
-            ODISE_TRY(ex.conv(cur, e->enc_down[l], nxt, 2, 0, false, nullptr, nullptr, 0, ODISE_ACT_NONE, 0, 0, cur.h / 2, cur.w / 2));
-            cur = nxt;
-        }
+        cur = nxt;
+        if (scoped || l < 3) { cur.gn_part = nullptr; cur.gn_blocks = 0; }
+        flat += 2;
+        return ODISE_OK;
+    };
+    ODISE_TRY(encoder_level(0));
+    // the CLIP branch is enqueued behind the first level: in chunks that level is ~200 launches (a few ms of host time, ~25 ms of device time),
+    // so the second lane's ~450 CLIP launches reach the device while the first is still busy with it
+    if (two && vae_first && vae_chunk(ctx, B, (size_t)H * W * 128 * 2) < B) {
+        ODISE_TRY(clip_on_lane2());
+        clip_enqueued = true;
     }
+    for (int l = 1; l < 4; ++l) ODISE_TRY(encoder_level(l));
     {
         Act a, b2, c, nrm, h8;
         ODISE_TRY(run_vae_res(ex, e->enc_mid1, cur, a));
@@ -666,7 +729,7 @@ int extractor_launch(odise_hip_ctx* ctx, ModelStore* ms, const float* image, int
     };
     if (two) {
         ODISE_CHECK_HIP(hipEventRecord(ctx->ev_mid, ctx->stream));            // the latent is ready
-        if (vae_first) ODISE_TRY(clip_on_lane2());
+        if (vae_first && !clip_enqueued) ODISE_TRY(clip_on_lane2());
         else ODISE_TRY(unet_on_lane2());
     } else {
         // ---- UNet (t = 0), single lane: before the decoder, as the reference orders its modules
@@ -679,14 +742,24 @@ int extractor_launch(odise_hip_ctx* ctx, ModelStore* ms, const float* image, int
         ODISE_TRY(run_vae_res(ex, e->dec_mid1, h, a));
         ODISE_TRY(run_vae_attn(ex, e->dec_attn, a, b2));
         ODISE_TRY(run_vae_res(ex, e->dec_mid2, b2, c));
-        Act l0, l1, l2, up, m0, m1;
+        Act l0, l1, l2, m1;
         ODISE_TRY(run_vae_res(ex, e->dec_l3[0], c, l0));
         ODISE_TRY(run_vae_res(ex, e->dec_l3[1], l0, l1));
         e->taps[6] = l1;  // input of up block 2 (ldm.py:515-516)
         ODISE_TRY(run_vae_res(ex, e->dec_l3[2], l1, l2));
-        ODISE_TRY(ex.conv(l2, e->dec_up3, up, 1, 1, true));
-        ODISE_TRY(run_vae_res(ex, e->dec_l2[0], up, m0));
-        ODISE_TRY(run_vae_res(ex, e->dec_l2[1], m0, m1));
+        // upsample + the two blocks at twice the resolution, in crop chunks like the encoder's levels
+        const int uh = 2 * l2.h, uw = 2 * l2.w, uc = e->dec_l2[1].c1.cout;
+        const int chunk = vae_chunk(ctx, B, (size_t)uh * uw * uc * 2);
+        ODISE_TRY(ex.alloc(m1, B, uh, uw, uc));
+        for (int n0 = 0; n0 < B; n0 += chunk) {
+            const int n = std::min(chunk, B - n0);
+            const size_t mk = ex.ms->arena.mark();
+            Act up, m0, o = crop_slice(m1, n0, n);
+            ODISE_TRY(ex.conv(crop_slice(l2, n0, n), e->dec_up3, up, 1, 1, true));
+            ODISE_TRY(run_vae_res(ex, e->dec_l2[0], up, m0));
+            ODISE_TRY(run_vae_res(ex, e->dec_l2[1], m0, o));
+            ex.ms->arena.release(mk);
+        }
         e->taps[7] = m1;  // input of up block 5
     }
     // ---- UNet (t = 0), second lane: enqueued last
@@ -716,11 +789,6 @@ static int extractor_forward(odise_hip_ctx* ctx, const float* image, int B, int 
 }  // namespace odise
 
 using namespace odise;
-
-extern "C" int odise_hip_clip_ln_fold(int mode) {
-    g_clip_ln_fold = mode;
-    return ODISE_OK;
-}
 
 extern "C" int odise_hip_extractor_build(odise_hip_ctx* ctx) {
     ODISE_REQUIRE(ctx, "extractor_build: null context");

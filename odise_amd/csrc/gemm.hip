@@ -2318,7 +2318,21 @@ static int env_gemm_flags() {
 }
 
 template <bool CONV>
+static int launch_gemm_select(odise_hip_ctx* ctx, GemmArgs& g, int batch, int force_tile, int force_split, unsigned tile_mask);
+
+template <bool CONV>
 static int launch_gemm(odise_hip_ctx* ctx, GemmArgs& g, int batch, int force_tile, int force_split, unsigned tile_mask = ~0u) {
+    LaunchProbe* pr = probe_match(ctx, CONV, g.M, g.N, g.K);
+    if (!pr) return launch_gemm_select<CONV>(ctx, g, batch, force_tile, force_split, tile_mask);
+    const int i = pr->n++;
+    ODISE_CHECK_HIP(hipEventRecord(pr->ev[2 * i], ctx->stream));
+    const int rc = launch_gemm_select<CONV>(ctx, g, batch, force_tile, force_split, tile_mask);
+    ODISE_CHECK_HIP(hipEventRecord(pr->ev[2 * i + 1], ctx->stream));
+    return rc;
+}
+
+template <bool CONV>
+static int launch_gemm_select(odise_hip_ctx* ctx, GemmArgs& g, int batch, int force_tile, int force_split, unsigned tile_mask) {
     const int64_t cus = ctx->cu_count;
     const int nk = (int)ceil_div(g.K, 64);
     // the halo kernel owns 16x16 output patches: 3x3 / stride 1 / pad 1 convs over whole 64-channel chunks
@@ -2383,6 +2397,7 @@ static int launch_gemm(odise_hip_ctx* ctx, GemmArgs& g, int batch, int force_til
         ODISE_REQUIRE((size_t)g.splitk * g.M * g.N * sizeof(float) <= ctx->ws_bytes, "gemm: split-K workspace too small");
     }
     g_last_tile = tile | (best_split << 8);
+    if (ctx->launch_log) launch_log_push(ctx, LaunchRec{(int)CONV, g.M, g.N, g.K, tile, g.splitk});
     if (flags & 32) {  // ODISE_GEMM_FLAGS=32: log every launch (tools/gemm_eff.py joins the log with a rocprofv3 kernel trace: per-shape TFLOP/s)
         fprintf(stderr, "GEMMLOG conv=%d M=%d N=%d K=%d batch=%d cin=%d kh=%d h=%d w=%d stride=%d ups=%d tile=%d split=%d pp=%d\n", (int)CONV, g.M, g.N,
                 g.K, batch, g.cg.Cin, g.cg.KH, g.cg.H, g.cg.W, g.cg.stride, g.cg.ups, tile, best_split, (int)pp_ok);

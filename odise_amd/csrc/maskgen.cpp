@@ -38,6 +38,7 @@ struct DecLayerW {
 };
 
 struct MaskGenModel {
+    std::vector<void*> owned_backbone, owned_head;   // device weights of the two separately (re)buildable halves (AllocScope)
     bool backbone_built = false, head_built = false;
     BottleneckW proj[8];
     int proj_dim = 512;
@@ -102,6 +103,10 @@ struct MaskGenModel {
 };
 
 void maskgen_destroy(ModelStore* ms) {
+    if (ms->maskgen) {
+        free_allocs(ms->maskgen->owned_backbone);
+        free_allocs(ms->maskgen->owned_head);
+    }
     delete ms->maskgen;
     ms->maskgen = nullptr;
 }
@@ -150,6 +155,9 @@ static int build_mha(Packer& pk, const std::string& key, MhaW& m, int C, bool st
 static int maskgen_build_backbone(odise_hip_ctx* ctx) {
     ModelStore* ms = store_of(ctx);
     MaskGenModel* g = maskgen_of(ms);
+    g->backbone_built = false;
+    free_allocs(g->owned_backbone);   // a rebuild (reload of the projections) replaces the previous weights
+    AllocScope scope(ms, g->owned_backbone);
     Packer pk{ctx, ms, "backbone.feature_projections.", ""};
     for (int i = 0; i < 8; ++i) {
         const std::string k = std::to_string(i) + ".0";
@@ -168,6 +176,9 @@ static int maskgen_build_backbone(odise_hip_ctx* ctx) {
 static int maskgen_build_head(odise_hip_ctx* ctx) {
     ModelStore* ms = store_of(ctx);
     MaskGenModel* g = maskgen_of(ms);
+    g->head_built = false;
+    free_allocs(g->owned_head);       // reload_head(): the previous head's ~56 MB of weights are released, not kept until the context dies
+    AllocScope scope(ms, g->owned_head);
     Packer pk{ctx, ms, "sem_seg_head.pixel_decoder.", ""};
     for (int i = 0; i < 3; ++i) {
         ODISE_TRY(pk.conv("input_proj." + std::to_string(i) + ".0", g->in_proj[i]));
@@ -792,6 +803,7 @@ extern "C" int odise_hip_head_forward(odise_hip_ctx* ctx, const float* const* fe
         size_t need = (size_t)B * H4 * W4 * 256 * 2 * 40 + ((size_t)512 << 20);
         ODISE_TRY(ensure_arena(ctx, ms, need));
         ms->arena.reset();
+        maskgen_invalidate_outputs(ms);   // backbone maps / head outputs of earlier calls lived in the arena just recycled; head_forward refills its own
         ms->macs = 0.0;
         for (int i = 0; i < 4; ++i) {
             const int h = H4 >> i, w = W4 >> i;
@@ -827,6 +839,7 @@ extern "C" int odise_hip_pixel_decoder_forward(odise_hip_ctx* ctx, const float* 
     Exec ex{ctx, ms};
     ODISE_TRY(ensure_arena(ctx, ms, (size_t)B * H4 * W4 * 256 * 2 * 40 + ((size_t)512 << 20)));
     ms->arena.reset();
+    maskgen_invalidate_outputs(ms);   // nothing of an earlier backbone / head call survives: a later classify / postprocess fails with ODISE_ERR_STATE
     ms->macs = 0.0;
     Act feats[4];
     for (int i = 0; i < 4; ++i) {
@@ -836,7 +849,6 @@ extern "C" int odise_hip_pixel_decoder_forward(odise_hip_ctx* ctx, const float* 
     }
     PixDec pd;
     ODISE_TRY(pixel_decoder_forward(ctx, feats, pd));
-    g->pred_masks = nullptr;   // the head outputs of an earlier call do not survive the arena reset
     if (mask_features) ODISE_TRY(odise_hip_cast_f16_to_f32(ctx, pd.mfT, mask_features, (size_t)B * g->C * H4 * W4));   // channel-major = NCHW
     for (int l = 0; l < 3 && multi_scale3; ++l)
         if (multi_scale3[l]) ODISE_TRY(odise_hip_nhwc_f16_to_nchw_f32(ctx, pd.ms_feat[l].p, multi_scale3[l], B, g->C, pd.ms_feat[l].h, pd.ms_feat[l].w));
@@ -858,6 +870,7 @@ extern "C" int odise_hip_predictor_forward(odise_hip_ctx* ctx, const float* cons
     Exec ex{ctx, ms};
     ODISE_TRY(ensure_arena(ctx, ms, (size_t)B * H4 * W4 * 256 * 2 * 40 + ((size_t)512 << 20)));
     ms->arena.reset();
+    maskgen_invalidate_outputs(ms);   // predictor_forward refills the head outputs; the backbone maps are gone
     ms->macs = 0.0;
     const int C = g->C;
     PixDec pd;

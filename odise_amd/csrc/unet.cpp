@@ -43,6 +43,7 @@ struct UBlock {
 };
 
 struct UNetModel {
+    std::vector<void*> owned;   // device weights of this stage (AllocScope)
     bool built = false;
     LinW te0, te2;
     LinW emb_all;  // all ResBlock emb_layers.1 stacked along N
@@ -71,6 +72,8 @@ double unet_last_macs(ModelStore* ms) { return ms->unet ? ms->unet->last_macs : 
 void unet_destroy(ModelStore* ms) {
     if (!ms->unet) return;
     if (ms->unet->graph_exec) (void)hipGraphExecDestroy(ms->unet->graph_exec);
+    free_allocs(ms->unet->owned);
+    if (ms->unet->temb_in) { (void)hipDeviceSynchronize(); (void)hipFree(ms->unet->temb_in); }
     delete ms->unet;
     ms->unet = nullptr;
 }
@@ -167,6 +170,7 @@ int unet_build(odise_hip_ctx* ctx, const char* prefix) {
     unet_destroy(ms);
     UNetModel* u = new UNetModel();
     ms->unet = u;
+    AllocScope scope(ms, u->owned);
     Packer pk{ctx, ms, prefix, ""};
     std::vector<const HostTensor*> emb_w, emb_b;
     ODISE_TRY(pk.linear("time_embed.0", u->te0));
@@ -491,9 +495,10 @@ int unet_prepare_timestep(odise_hip_ctx* ctx, ModelStore* ms, UNetModel* u, int 
                 te[(size_t)b * u->mc + half + i] = (f16)(float)sin((double)t * f);
             }
         }
-        ODISE_CHECK_HIP(hipStreamSynchronize(ctx->stream));
+        ODISE_CHECK_HIP(hipDeviceSynchronize());   // either lane may still read the previous table
+        if (u->temb_in) ODISE_CHECK_HIP(hipFree(u->temb_in));
+        u->temb_in = nullptr;
         ODISE_CHECK_HIP(hipMalloc((void**)&u->temb_in, te.size() * 2));
-        ms->dev_allocs.push_back(u->temb_in);
         ODISE_CHECK_HIP(hipMemcpy(u->temb_in, te.data(), te.size() * 2, hipMemcpyHostToDevice));
         u->cached_t = t;
         u->cached_B = B;

@@ -113,6 +113,38 @@ class Context:
     def sync(self):
         check(self.lib.odise_hip_sync(self.h), "sync")
 
+    # ---- per-context execution options (include/odise_hip.h ODISE_OPT_*) ---------------------
+    OPT_CLIP_LN_FOLD, OPT_VAE_CHUNK_BYTES = 1, 2
+
+    def set_option(self, option: int, value: int) -> None:
+        check(self.lib.odise_hip_set_option(self.h, option, value), "set_option")
+
+    def get_option(self, option: int) -> int:
+        v = C.c_int64()
+        check(self.lib.odise_hip_get_option(self.h, option, C.byref(v)), "get_option")
+        return int(v.value)
+
+    def launch_log(self, on: bool = True) -> None:
+        check(self.lib.odise_hip_launch_log(self.h, 1 if on else 0), "launch_log")
+
+    def launch_log_read(self) -> np.ndarray:
+        """[n, 6] int32 records (conv, M, N, K, tile id, split-K) of the GEMM / conv launches since launch_log(True)."""
+        n = C.c_int()
+        check(self.lib.odise_hip_launch_log_read(self.h, None, 0, C.byref(n)), "launch_log_read")
+        out = np.zeros((max(n.value, 1), 6), np.int32)
+        check(self.lib.odise_hip_launch_log_read(self.h, out.ctypes.data_as(C.c_void_p), n.value, C.byref(n)), "launch_log_read")
+        return out[: n.value]
+
+    # ---- launch probe: per-launch durations of one GEMM / conv shape as it runs inside a step ------
+    def probe_arm(self, conv: bool, M: int, N: int, K: int, max_launches: int = 256) -> None:
+        check(self.lib.odise_hip_probe_arm(self.h, 1 if conv else 0, M, N, K, max_launches), "probe_arm")
+
+    def probe_read(self, cap: int = 4096) -> np.ndarray:
+        us = np.zeros(cap, np.float32)
+        n = C.c_int()
+        check(self.lib.odise_hip_probe_read(self.h, us.ctypes.data_as(C.c_void_p), cap, C.byref(n)), "probe_read")
+        return us[: min(cap, n.value)].copy()
+
     def timer_start(self):
         check(self.lib.odise_hip_timer_start(self.h), "timer_start")
 

@@ -222,6 +222,30 @@ def head_reference(bb, head, ext, size, seed=0, use_cache=True):
     return img, r
 
 
+def classify_reference(heads, r):
+    """CategoryODISE.forward after the head (odise.py:285-323) on the oracle's head outputs `r` under the vocabulary `heads` -> mask_cls."""
+    with torch.no_grad():
+        text_embed = heads.text_proj(heads.text_embed)
+        null_embed = heads.text_proj(heads.null_embed)
+        pred_logits = om.cal_pred_logits(r["mask_embed"], text_embed, null_embed, r["logit_scale"], heads.group_sizes)
+        clip_logits = om.mask_clip_pred_logits(r["clip_embed"], heads.clip_text_embed, heads.group_sizes)
+        open_logits = om.pooling_clip_head(pred_logits[..., :-1], clip_logits, heads.category_overlapping_mask, heads.alpha, heads.beta)
+        return om.merge_with_null(pred_logits, open_logits)
+
+
+def reference_with(bb, head, ext, size, heads, seed, use_cache=True):
+    """Oracle pass over the seeded size x size image `seed` under a GIVEN vocabulary (the one spread over image 0: a batch shares one text
+    bank, like every image of an evaluation run shares the dataset's).  Returns (img_u8, dict incl. mask_cls)."""
+    key = ("ref_with", size, id(heads), seed)
+    if key in _MEMO:
+        return _MEMO[key]
+    img, r = head_reference(bb, head, ext, size, seed, use_cache)
+    r = dict(r)
+    r["mask_cls"] = classify_reference(heads, r)
+    _MEMO[key] = (img, r)
+    return img, r
+
+
 def reference(bb, head, ext, size, num_classes, num_strings, seed=0, use_cache=True):
     """Oracle pass over one size x size image (head_reference), then the spread vocabulary of `num_classes` classes / `num_strings` prompt
     strings and CategoryODISE.forward after the head (odise.py:285-323).  Returns (img_u8, heads, dict of torch tensors incl. mask_cls)."""
@@ -234,12 +258,6 @@ def reference(bb, head, ext, size, num_classes, num_strings, seed=0, use_cache=T
     heads = om.OpenVocabHeads(ext.clip, [int(s) for s in sizes], projection_dim=256, overlap=torch.from_numpy(overlap.astype(bool)))
     # at most ~2 present classes per (non-null) query: all of COCO-133 / ADE-150, a subset of the 847
     spread_vocabulary(heads, r["mask_embed"][0], r["clip_embed"][0], anchored=None if num_classes <= 200 else 188)
-    with torch.no_grad():
-        text_embed = heads.text_proj(heads.text_embed)
-        null_embed = heads.text_proj(heads.null_embed)
-        pred_logits = om.cal_pred_logits(r["mask_embed"], text_embed, null_embed, r["logit_scale"], heads.group_sizes)
-        clip_logits = om.mask_clip_pred_logits(r["clip_embed"], heads.clip_text_embed, heads.group_sizes)
-        open_logits = om.pooling_clip_head(pred_logits[..., :-1], clip_logits, heads.category_overlapping_mask, heads.alpha, heads.beta)
-        r["mask_cls"] = om.merge_with_null(pred_logits, open_logits)
+    r["mask_cls"] = classify_reference(heads, r)
     _MEMO[key] = (img, heads, r)
     return img, heads, r

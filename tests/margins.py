@@ -74,3 +74,27 @@ def instance_keys(mask_cls_ref, num_classes, thing_ids, topk, panoptic_on=True):
     keep = np.array([(int(x) in thing_ids) or not panoptic_on for x in c], bool)
     kth = float(np.sort(scores.numpy())[-k])
     return {(int(a), int(b)): i for i, (a, b) in enumerate(zip(q[keep], c[keep]))}, kth, scores.numpy()
+
+
+def segments_decided(mask_cls_ref, logits_up_ref, num_classes, thing_ids, eprob, elogit, overlap_threshold, trials=6, seed=0):
+    """Is the reference's `segments_info` FIXED by its own margins at the measured error?  The panoptic table is the end of a chain of
+    thresholds (kept queries, per-pixel arg-max, `mask_area / original_area >= overlap_threshold` per query, stuff merging;
+    maskformer_model.py:286-342) and a closed-form margin for the whole chain would have to be very conservative; instead the oracle's
+    own inputs are perturbed `trials` times inside the MEASURED per-query error bounds - class probabilities by uniform noise in
+    +-eprob_q (renormalised), mask logits by uniform noise in +-elogit_q per pixel - and the table must come out identical every time.
+    Deterministic given the measured errors.  -> (decided, number of perturbed tables that differ)."""
+    from oracle import odise_model as om
+    g = torch.Generator().manual_seed(seed)
+    lp = torch.as_tensor(mask_cls_ref).float().reshape(-1, num_classes + 1)
+    up = torch.as_tensor(logits_up_ref).float()
+    ep = torch.as_tensor(np.asarray(eprob), dtype=torch.float32).view(-1, 1)
+    el = torch.as_tensor(np.asarray(elogit), dtype=torch.float32).view(-1, 1, 1)
+    _, want = om.panoptic_inference(lp, up, num_classes, thing_ids, 0.0, overlap_threshold)
+    differ = 0
+    for _ in range(trials):
+        p = (lp.exp() + ep * (2 * torch.rand(lp.shape, generator=g) - 1)).clamp_min(1e-9)
+        p = p / p.sum(-1, keepdim=True)
+        noisy = up + el * (2 * torch.rand(up.shape, generator=g) - 1)
+        _, info = om.panoptic_inference(p.log(), noisy, num_classes, thing_ids, 0.0, overlap_threshold)
+        differ += info != want
+    return differ == 0, differ

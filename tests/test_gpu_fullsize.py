@@ -23,6 +23,7 @@ import numpy as np
 import pytest
 import torch
 
+from contracts import TAU_PROB, end_to_end_contract
 from fullsize import build_models, category_head_state, reference
 from oracle import odise_model as om
 
@@ -34,7 +35,6 @@ THINGS = set(range(80))                     # COCO panoptic: contiguous ids 0..7
 # vocabulary shapes of BASELINE configs[2] (COCO panoptic) and configs[3] (ADE20K-150: 150 classes / 403 prompt strings, 100 things)
 VOCABS = {"coco133": (133, 254, set(range(80))), "ade150": (150, 403, set(range(100)))}
 TAU_MASK = 2.5e-2    # bound on a REGULAR query's mask-logit error as a fraction of max|logit| (head alone: worst query 1.8e-2, 98 of 100 below 5.3e-3; see _mask_report)
-TAU_PROB = 3e-2      # bound on a class-probability error, absolute (measured 1.9e-2 at logit scale 100)
 
 
 def use_vocabulary(full, name):
@@ -114,9 +114,9 @@ def _mask_report(what, got, ref):
 def ln_fold(request, ctx):
     """The CLIP towers with their LayerNorms as kernels (what 4 crops / 4 pictures run by default) and folded into the neighbouring GEMMs
     (what the towers run from 8k tokens = the benchmarked 16 crops; extractor.cpp clip_tower): both against the same reference."""
-    ctx.lib.odise_hip_clip_ln_fold(request.param)
+    ctx.set_option(ctx.OPT_CLIP_LN_FOLD, 1 if request.param else 2)
     yield request.param
-    ctx.lib.odise_hip_clip_ln_fold(0)
+    ctx.set_option(ctx.OPT_CLIP_LN_FOLD, 0)
 
 
 def test_backbone_full_size(full, ctx, ln_fold):
@@ -194,49 +194,7 @@ def test_end_to_end_contract(full, vocab, overlap_threshold):
     finally:
         hip.overlap_threshold = 0.8
         use_vocabulary(full, "coco133")
-    # ---- panoptic
-    pan_ref, info_ref = ref["panoptic_seg"]
-    pan, info = got["panoptic_seg"]
-    agree = (pan == pan_ref.numpy()).mean()
-    print("vocabulary", vocab, "segments", len(info), "ref", len(info_ref), "classes", sorted({s["category_id"] for s in info_ref}), "stuff",
-          sum(not s["isthing"] for s in info_ref), "panoptic pixel agreement", agree)
-    # ---- semantic
-    sem_ref = ref["sem_seg"].numpy()
-    assert got["sem_seg"].shape == sem_ref.shape == (k, 1024, 1024)
-    serr = np.abs(got["sem_seg"] - sem_ref).max() / np.abs(sem_ref).max()
-    same = got["sem_seg"].argmax(0) == sem_ref.argmax(0)
-    sagree = same.mean()
-    # the label may only change where the reference's own top-2 margin is inside the measured error: 2 * max-err bounds how far two scores can move apart
-    top2 = np.partition(sem_ref, -2, axis=0)[-2:]
-    decided = (top2[1] - top2[0]) > 2.0 * np.abs(got["sem_seg"] - sem_ref).max()
-    print("sem_seg max-err/scale", serr, "argmax agreement", sagree, "pixels whose reference margin exceeds twice the max error", decided.mean(),
-          "agreement there", same[decided].mean() if decided.any() else 1.0)
-    # ---- instances: the same (query, class) entries wherever the k-th score is separated; matching entries have the same masks and scores
-    inst_ref, inst = ref["instances"], got["instances"]
-    s_ref = inst_ref["scores"].numpy()
-    scores_flat = torch.softmax(cls_ref[0], -1)[:, :-1].flatten()
-    top = scores_flat.topk(100, sorted=False).indices
-    q_ref, c_ref = (top // k).numpy(), (top % k).numpy()
-    keep = np.array([int(c) in things for c in c_ref])
-    key_ref = {(int(q), int(c)): i for i, (q, c) in enumerate(zip(q_ref[keep], c_ref[keep]))}
-    key_got = {(int(q), int(c)): i for i, (q, c) in enumerate(zip(inst["query_index"], inst["pred_classes"]))}
-    common = sorted(set(key_ref) & set(key_got))
-    kth = float(np.sort(scores_flat.numpy())[-100])
-    worst, worst_score = 1.0, 0.0
-    for kk in common:
-        a, b = inst["pred_masks"][key_got[kk]] > 0.5, inst_ref["pred_masks"][key_ref[kk]].numpy() > 0.5
-        worst = min(worst, (a & b).sum() / max((a | b).sum(), 1))
-        worst_score = max(worst_score, abs(float(inst["scores"][key_got[kk]]) - float(s_ref[key_ref[kk]])))
-    print("instances", len(key_got), "ref", len(key_ref), "in common", len(common), "k-th class score", kth, "worst mask IoU", worst, "worst score diff", worst_score)
-    assert info == info_ref, (info, info_ref)
-    assert agree > 0.995
-    # sem_seg = sum_q P[q,k] sigmoid(mask_q) carries the class-probability error; its per-pixel argmax is identical wherever the reference decides by
-    # more than that error, and the undecided rest (near-ties between two of the class scores) stays a small fraction
-    assert serr < TAU_PROB and same[decided].all() and sagree > 0.98
-    assert inst["pred_masks"].shape[1:] == (1024, 1024)
-    for q, c in set(key_ref) ^ set(key_got):    # entries may only differ at the selection boundary of the top-k
-        assert abs(float(scores_flat[q * k + c]) - kth) < TAU_PROB, (q, c)
-    assert len(common) >= 0.9 * len(key_ref) and worst > 0.93 and worst_score < 2 * TAU_PROB
+    end_to_end_contract(got, ref, cls_ref, k, things, tag=f"vocabulary {vocab} overlap {overlap_threshold}:")
 
 
 def test_mask_iou_contract_at_output_resolution(full, ctx):
