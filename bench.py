@@ -66,6 +66,7 @@ def parse():
                    "convolutions of the next.  Every step is still one synchronous model call on one batch of --images pictures")
     p.add_argument("--clip-ln-fold", type=int, default=0, choices=[0, 1, 2], help="A/B: the CLIP towers' LayerNorm fold, 0 = the library's rule, 1 = always, 2 = never")
     p.add_argument("--vae-chunk-mb", type=float, default=None, help="A/B: ODISE_OPT_VAE_CHUNK_BYTES in MiB (0 = all crops per launch; default: the library's)")
+    p.add_argument("--attn-kvres", type=int, default=1, choices=[0, 1], help="A/B: 0 = the CLIP towers' attention on the tiled kernel instead of the K/V-resident one")
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--no-inclusive", action="store_true", help="skip the PCIe- / JPEG-inclusive legs")
     return p.parse_args()
@@ -301,6 +302,8 @@ def main():
     from odise_amd.runtime import Context
     ctx = Context(local_rank)
     ctx.set_option(ctx.OPT_CLIP_LN_FOLD, args.clip_ln_fold)
+    if not args.attn_kvres:
+        ctx.lib.odise_hip_attn_kvres(0)
     if args.vae_chunk_mb is not None:
         ctx.set_option(ctx.OPT_VAE_CHUNK_BYTES, int(args.vae_chunk_mb * (1 << 20)))
     B = args.images if args.images is not None else (4 if args.stage == "full" else 1)

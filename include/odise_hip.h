@@ -64,9 +64,9 @@ int odise_hip_device_info(odise_hip_ctx* ctx, char* name_buf, int buf_len, int* 
  *   ODISE_OPT_CLIP_LN_FOLD     how the CLIP towers (clip.py:177-206, 252-323) take their LayerNorms: 0 = folded into the neighbouring GEMMs from
  *                              8192 token rows per call (default; below that as kernels), 1 = always folded, 2 = never.  The two forms differ by
  *                              fp16 rounding, so a caller that needs results independent of how many crops share a call pins 1 or 2.
- *   ODISE_OPT_VAE_CHUNK_BYTES  the AutoencoderKL levels (ldm.py:493-533, 585-606) run over as many crops per launch as keep one activation
- *                              tensor below this many bytes (default 64 MiB: the producer's output is still in the 256 MiB Infinity Cache when
- *                              GroupNorm and the next convolution read it); 0 = all crops of a call at once.  Per-crop arithmetic is unchanged. */
+ *   ODISE_OPT_VAE_CHUNK_BYTES  > 0: the AutoencoderKL levels (ldm.py:493-533, 585-606) run over as many crops per launch as keep one activation
+ *                              tensor below this many bytes (a smaller working set and arena); 0 (default) = all crops of a call at once, which
+ *                              measured faster on MI355X (profiles/r04_vae_chunking_experiment.txt).  Per-crop arithmetic is unchanged. */
 enum { ODISE_OPT_CLIP_LN_FOLD = 1, ODISE_OPT_VAE_CHUNK_BYTES = 2 };
 int odise_hip_set_option(odise_hip_ctx* ctx, int option, int64_t value);
 int odise_hip_get_option(odise_hip_ctx* ctx, int option, int64_t* value);
@@ -389,6 +389,11 @@ int odise_hip_comm_info(odise_hip_ctx* ctx, int* rank, int* world);   /* world =
 /* all [world * count] = concatenation over ranks of local [count] (device int32; count identical on every rank).  Record layout per
  * image (odise_amd/distributed.py): panoptic_seg [H*W] | n_segments | segments [100][3] = (id, isthing, category_id).  Asynchronous. */
 int odise_hip_allgather_predictions(odise_hip_ctx* ctx, const int32_t* local, int64_t count, int32_t* all);
+/* The same exchange for UNEVEN shards: this rank contributes n_records (0 .. max_records) records of record_len int32 each; max_records is
+ * identical on every rank (the largest shard: ceil(images / world) per batch, known to every rank without communication).  all
+ * [world * max_records * record_len]: rank r's records at row r * max_records, its missing rows filled with -1 (a valid record never starts
+ * with -1: its first element is a panoptic id >= 0).  local may alias this rank's slice of `all`.  Asynchronous. */
+int odise_hip_allgather_records(odise_hip_ctx* ctx, const int32_t* local, int n_records, int max_records, int64_t record_len, int32_t* all);
 /* data [count] int64 device, summed in place over ranks (confusion matrices of odise_hip_semantic_confusion).  Asynchronous. */
 int odise_hip_allreduce_sum_i64(odise_hip_ctx* ctx, int64_t* data, int64_t count);
 /* join the last collective: block_host != 0 waits on the host, otherwise makes the compute stream wait for it */

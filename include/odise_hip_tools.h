@@ -46,10 +46,19 @@ int odise_hip_post_generic(int on);
 /* force the tile of the semantic GEMM [K, pixels] = P^T S^T (A/B of the 256-row rule in odise_hip_postprocess_batch); -1 = the rule */
 int odise_hip_sem_tile(int tile);
 
+/* stage boundaries of the model calls made while the timeline is on: at each boundary (csrc: stage_mark) an event on the stream the stage
+ * enqueues to and the host clock.  _read synchronises the device and writes, relative to the first mark: gpu_ms[i] = when the device reached mark
+ * i, host_ms[i] = when the host had enqueued everything before it; names = '\n'-separated.  tools/stage_timeline.py prints both columns. */
+int odise_hip_stage_timeline(odise_hip_ctx* ctx, int on);
+int odise_hip_stage_timeline_read(odise_hip_ctx* ctx, char* names, int names_cap, float* gpu_ms, double* host_ms, int cap, int* n);
+
 /* per-context log of every GEMM / convolution launch the cost model decided (tests print which choices differ between two batch sizes):
  * odise_hip_launch_log(ctx, 1) starts / clears it, (ctx, 0) drops it; _read copies records of 6 ints (conv, M, N, K, tile id, split-K factor) */
 int odise_hip_launch_log(odise_hip_ctx* ctx, int on);
 int odise_hip_launch_log_read(odise_hip_ctx* ctx, int* out6, int cap, int* n);
+
+/* 0: odise_hip_attention never takes the K/V-resident kernel (d_head 64, <= 608 keys: the CLIP towers) - A/B against the tiled kernel; 1 = default */
+int odise_hip_attn_kvres(int on);
 
 /* 1: the feature extractor enqueues everything on one stream; 2 (default): its CLIP -> UNet branch runs on a second stream beside the VAE */
 int odise_hip_set_lanes(odise_hip_ctx* ctx, int lanes);

@@ -1,5 +1,6 @@
 // api.cpp — context, error reporting and memory/stream plumbing of libodise_hip.so.
 #include <stdarg.h>
+#include <time.h>
 #include <string.h>
 
 #include <mutex>
@@ -60,6 +61,7 @@ extern "C" int odise_hip_destroy(odise_hip_ctx* ctx) {
     odise::comm_release(ctx);
     odise::probe_release(ctx);
     odise::launch_log_release(ctx);
+    odise::stage_log_release(ctx);
     if (ctx->ws) (void)hipFree(ctx->ws);
     if (ctx->ws2) (void)hipFree(ctx->ws2);
     if (ctx->ev_fork) (void)hipEventDestroy(ctx->ev_fork);
@@ -181,6 +183,36 @@ extern "C" int odise_hip_get_option(odise_hip_ctx* ctx, int option, int64_t* val
 }
 
 namespace odise {
+struct StageLog {
+    std::vector<const char*> names;
+    std::vector<hipEvent_t> events;   // pooled: events[i] belongs to names[i] for i < names.size()
+    std::vector<double> host_us;
+};
+static double host_now_us() {
+    timespec ts;
+    clock_gettime(CLOCK_MONOTONIC, &ts);
+    return ts.tv_sec * 1e6 + ts.tv_nsec * 1e-3;
+}
+void stage_mark(odise_hip_ctx* ctx, const char* name) {
+    StageLog* s = (StageLog*)ctx->stages;
+    if (!s) return;
+    const size_t i = s->names.size();
+    if (i >= s->events.size()) {
+        hipEvent_t e = nullptr;
+        if (hipEventCreate(&e) != hipSuccess) return;
+        s->events.push_back(e);
+    }
+    if (hipEventRecord(s->events[i], ctx->stream) != hipSuccess) return;
+    s->names.push_back(name);
+    s->host_us.push_back(host_now_us());
+}
+void stage_log_release(odise_hip_ctx* ctx) {
+    StageLog* s = (StageLog*)ctx->stages;
+    if (!s) return;
+    for (hipEvent_t e : s->events) (void)hipEventDestroy(e);
+    delete s;
+    ctx->stages = nullptr;
+}
 void launch_log_push(odise_hip_ctx* ctx, const LaunchRec& r) { ((std::vector<LaunchRec>*)ctx->launch_log)->push_back(r); }
 void launch_log_release(odise_hip_ctx* ctx) {
     delete (std::vector<LaunchRec>*)ctx->launch_log;
@@ -230,6 +262,31 @@ extern "C" int odise_hip_probe_read(odise_hip_ctx* ctx, float* us_out, int cap, 
     return ODISE_OK;
 }
 
+extern "C" int odise_hip_stage_timeline(odise_hip_ctx* ctx, int on) {
+    ODISE_REQUIRE(ctx, "stage_timeline: null context");
+    if (!on) { stage_log_release(ctx); return ODISE_OK; }
+    StageLog* s = (StageLog*)ctx->stages;
+    if (!s) ctx->stages = s = new StageLog();
+    s->names.clear();       // start / restart: the events are reused
+    s->host_us.clear();
+    return ODISE_OK;
+}
+extern "C" int odise_hip_stage_timeline_read(odise_hip_ctx* ctx, char* names, int names_cap, float* gpu_ms, double* host_ms, int cap, int* n) {
+    ODISE_REQUIRE(ctx && n, "stage_timeline_read: null argument");
+    StageLog* s = (StageLog*)ctx->stages;
+    *n = s ? (int)s->names.size() : 0;
+    if (!s || s->names.empty()) return ODISE_OK;
+    ODISE_CHECK_HIP(hipDeviceSynchronize());
+    int off = 0;
+    for (int i = 0; i < *n && i < cap; ++i) {
+        float ms = 0.f;
+        ODISE_CHECK_HIP(hipEventElapsedTime(&ms, s->events[0], s->events[i]));
+        if (gpu_ms) gpu_ms[i] = ms;
+        if (host_ms) host_ms[i] = (s->host_us[i] - s->host_us[0]) * 1e-3;
+        if (names) off += snprintf(names + off, off < names_cap ? names_cap - off : 0, "%s\n", s->names[i]);
+    }
+    return ODISE_OK;
+}
 extern "C" int odise_hip_launch_log(odise_hip_ctx* ctx, int on) {
     ODISE_REQUIRE(ctx, "launch_log: null context");
     launch_log_release(ctx);

@@ -274,6 +274,203 @@ __global__ void __launch_bounds__(256) attn_kernel(AttnArgs a) {
     }
 }
 
+// ---- keys and values resident in LDS (CLIP ViT-L/14@336: 577 keys, d_head 64) -------------------------------------------------------------
+// The tiled kernel above restages every 64-key K / V^T tile once per 128-query block (5 times per head for 577 queries, two barriers per
+// tile) and rounds both 577s up to 640.  Here ONE block owns a (head, image): K (608 x 64, 16-byte slots XOR-swizzled) and V^T (64 x 612)
+// of that head are loaded into LDS once - 156 160 of the CU's 163 840 bytes - and after a single barrier the block's 8 waves walk their
+// 32-query tiles over 19 key tiles of 32 straight out of LDS: no further barrier, no restaging, 608 keys instead of 640.  16 crops x 16
+// heads = 256 blocks = one per CU; with fewer (head, image) pairs (MaskCLIP: 4 pictures) the query tiles of a pair are split over
+// `qsplit` blocks, each loading the pair's K / V^T (L2 hits).  Same arithmetic per score as the tiled kernel (fp32 scale + running max,
+// exp2, fp16 P into the second MFMA); the running max is updated per 32 keys instead of per 64, so results agree to fp32 rounding of the
+// rescale, not bit for bit.
+// LDS reads: K fragment = ds_read_b128 of slot (2s + hi) of row (32t + lane%32); physical slot = slot ^ ((row >> 1) & 7) makes the 16 lanes
+// of every ds_read_b128 group ({0-3,12-15,20-27}, ...: MI355X_MICROARCH.md LDS table) hit 16 distinct 16-byte positions of the 256-byte
+// LDS line.  V^T rows are 612 halves = 306 dwords apart: 306 mod 64 = 50, so the 32 lanes of a ds_read_b64 group cover all 64 banks.
+constexpr int KVR_LKP = 608;             // keys held (19 tiles of 32)
+constexpr int KVR_VROW = KVR_LKP + 4;    // halves per V^T row
+constexpr int KVR_LDS = KVR_LKP * 64 * 2 + 64 * KVR_VROW * 2;
+constexpr int KVR_WAVES = 8;
+
+__global__ void __launch_bounds__(64 * KVR_WAVES) attn_kvres_kernel(AttnArgs a, int qsplit) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    f16* Ks = reinterpret_cast<f16*>(smem);                            // [608][64], slot-swizzled
+    f16* Vs = reinterpret_cast<f16*>(smem + KVR_LKP * 64 * 2);         // [64][612]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int hi = lane >> 5, l31 = lane & 31;
+    const int b = blockIdx.z, h = blockIdx.y, part = blockIdx.x;
+    constexpr int D = 64;
+    const f16* Qb = a.Q + (int64_t)b * a.strideQ + (int64_t)h * D;
+    const f16* Kb = a.K + (int64_t)b * a.strideK + (int64_t)h * D;
+    const f16* Vb = a.Vt + (int64_t)b * a.strideVt + (int64_t)h * D * a.ldvt;
+    const f16x8 zero8 = {0, 0, 0, 0, 0, 0, 0, 0};
+    const int nkt = (a.Lk + 31) >> 5;          // key tiles of 32
+    const int lkp = nkt * 32;
+    // ---- K and V^T of this (head, image) -> LDS (rows / columns beyond Lk are zero: their scores are masked, 0 x V must stay 0) ----
+    for (int c = tid; c < lkp * 8; c += 64 * KVR_WAVES) {
+        const int key = c >> 3, sl = c & 7;
+        f16x8 v = zero8;
+        if (key < a.Lk) v = *reinterpret_cast<const f16x8*>(Kb + (int64_t)key * a.ldk + sl * 8);
+        *reinterpret_cast<f16x8*>(Ks + key * 64 + ((sl ^ ((key >> 1) & 7)) << 3)) = v;
+    }
+    const int vslots = lkp >> 3;               // 16-byte slots per V^T row
+    for (int c = tid; c < 64 * vslots; c += 64 * KVR_WAVES) {
+        const int d = c / vslots, sl = c - d * vslots;
+        const int k0 = sl * 8;
+        f16x8 v = zero8;
+        if (k0 < a.Lk) {
+            v = *reinterpret_cast<const f16x8*>(Vb + (int64_t)d * a.ldvt + k0);
+            if (k0 + 8 > a.Lk) {
+#pragma unroll
+                for (int i = 0; i < 8; ++i)
+                    if (k0 + i >= a.Lk) v[i] = (f16)0.f;
+            }
+        }
+        const f16x4 lo4 = {v[0], v[1], v[2], v[3]}, hi4 = {v[4], v[5], v[6], v[7]};
+        *reinterpret_cast<f16x4*>(Vs + d * KVR_VROW + k0) = lo4;       // rows are 8-byte aligned (1224 B apart)
+        *reinterpret_cast<f16x4*>(Vs + d * KVR_VROW + k0 + 4) = hi4;
+    }
+    __syncthreads();
+    // ---- this block's query tiles, dealt round-robin to the waves ----
+    const int nqt = (a.Lq + 31) >> 5;
+    const int per = (nqt + qsplit - 1) / qsplit;
+    const int qt_end = min(nqt, (part + 1) * per);
+    typedef float f32x2 __attribute__((ext_vector_type(2)));
+    for (int qt = part * per + wave; qt < qt_end; qt += KVR_WAVES) {
+        const int q = qt * 32 + l31;
+        const bool qok = q < a.Lq;
+        const uint8_t* Mb = a.mask ? a.mask + (int64_t)b * a.strideMask + (int64_t)(qok ? q : 0) * a.ldmask : nullptr;
+        f16x8 qf[4];
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            qf[s] = zero8;
+            if (qok) qf[s] = *reinterpret_cast<const f16x8*>(Qb + (int64_t)q * a.ldq + s * 16 + hi * 8);
+        }
+        f32x16 ot[2];
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) ot[t][r] = 0.f;
+        float m_run = -INFINITY, l_run = 0.f;
+        for (int kt = 0; kt < nkt; ++kt) {
+            const int kv0 = kt * 32;
+            // S^T tile = K[32 keys] . Q^T[32 queries]
+            f32x16 st;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) st[r] = 0.f;
+            const int krow = kv0 + l31;
+            const f16* kr = Ks + krow * 64;
+            const int ksw = (krow >> 1) & 7;
+#pragma unroll
+            for (int s = 0; s < 4; ++s) {
+                const f16x8 kf = *reinterpret_cast<const f16x8*>(kr + (((2 * s + hi) ^ ksw) << 3));
+                st = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf, qf[s], st, 0, 0, 0);
+            }
+            // scale, mask, online softmax: this lane holds 16 of the tile's 32 keys for ONE query (regs 4g..4g+3 <-> keys kv0 + 8g + 4hi ..)
+            const bool general = (Mb != nullptr) || (kv0 + 32 > a.Lk);   // wave-uniform
+            float mx;
+            if (general) {
+                mx = -INFINITY;
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const int kbase = kv0 + 8 * g + 4 * hi;
+                    uint32_t mbits = 0;
+                    if (Mb && kbase < a.Lk) mbits = *reinterpret_cast<const uint32_t*>(Mb + kbase);
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        const bool dead = (kbase + i >= a.Lk) || ((mbits >> (8 * i)) & 0xff);
+                        const float sv = dead ? -INFINITY : st[4 * g + i];
+                        st[4 * g + i] = sv;
+                        mx = fmaxf(mx, sv);
+                    }
+                }
+            } else {
+                mx = fmaxf(fmaxf(st[0], st[1]), st[2]);
+#pragma unroll
+                for (int r = 3; r < 15; r += 2) mx = fmaxf(fmaxf(mx, st[r]), st[r + 1]);   // v_max3_f32
+                mx = fmaxf(mx, st[15]);
+            }
+            mx = fmaxf(mx, __shfl_xor(mx, 32)) * a.scale_log2e;
+            const float m_new = fmaxf(m_run, mx);
+            const float m_safe = (m_new == -INFINITY) ? 0.f : m_new;
+            const float alpha = __builtin_amdgcn_exp2f(m_run - m_safe);
+            const f32x2 sc2 = {a.scale_log2e, a.scale_log2e}, nm2 = {-m_safe, -m_safe};
+            f32x2 ps2 = {0.f, 0.f};
+#pragma unroll
+            for (int r = 0; r < 16; r += 2) {
+                const f32x2 x = {st[r], st[r + 1]};
+                const f32x2 y = __builtin_elementwise_fma(x, sc2, nm2);
+                const f32x2 p = {__builtin_amdgcn_exp2f(y[0]), __builtin_amdgcn_exp2f(y[1])};
+                st[r] = p[0];
+                st[r + 1] = p[1];
+                ps2 += p;
+            }
+            l_run = l_run * alpha + (ps2[0] + ps2[1]);
+            m_run = m_new;
+            if (__builtin_amdgcn_ballot_w64(alpha != 1.0f) != 0) {
+#pragma unroll
+                for (int t = 0; t < 2; ++t)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) ot[t][r] *= alpha;
+            }
+            // O^T += V^T[64 d][32 keys] . P^T
+#pragma unroll
+            for (int s2 = 0; s2 < 2; ++s2) {
+                f16x8 pf;
+#pragma unroll
+                for (int i = 0; i < 8; ++i) pf[i] = (f16)st[8 * s2 + i];
+                const int kA = kv0 + 16 * s2 + 4 * hi, kB = kA + 8;
+#pragma unroll
+                for (int dt = 0; dt < 2; ++dt) {
+                    const f16* vr = Vs + (dt * 32 + l31) * KVR_VROW;
+                    const f16x4 va = *reinterpret_cast<const f16x4*>(vr + kA);
+                    const f16x4 vb = *reinterpret_cast<const f16x4*>(vr + kB);
+                    const f16x8 vf = {va[0], va[1], va[2], va[3], vb[0], vb[1], vb[2], vb[3]};
+                    ot[dt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf, pf, ot[dt], 0, 0, 0);
+                }
+            }
+        }
+        const float l_tot = l_run + __shfl_xor(l_run, 32);
+        const float inv = l_tot > 0.f ? 1.f / l_tot : 0.f;
+        if (qok) {
+            f16* Ob = a.O + (int64_t)b * a.strideO + (int64_t)q * a.ldo + (int64_t)h * D;
+#pragma unroll
+            for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    f16x4 o;
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) o[i] = (f16)(ot[dt][4 * g + i] * inv);
+                    *reinterpret_cast<f16x4*>(Ob + dt * 32 + 8 * g + 4 * hi) = o;
+                }
+        }
+    }
+}
+
+static int g_attn_kvres = 1;   // tools hook (odise_hip_attn_kvres): 0 = never take the K/V-resident kernel (A/B against the tiled one)
+
+static bool attn_kvres_ok(const AttnArgs& a) {
+    return g_attn_kvres && a.D == 64 && a.Lk >= 256 && a.Lk <= KVR_LKP && a.Lq >= 32 && (int64_t)a.B * a.H >= 32;
+}
+
+static int launch_attn_kvres(odise_hip_ctx* ctx, AttnArgs& a) {
+    static bool attr_set = false;
+    if (!attr_set) {
+        ODISE_CHECK_HIP(hipFuncSetAttribute((const void*)attn_kvres_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, KVR_LDS));
+        attr_set = true;
+    }
+    // one block per (head, image) when those fill the chip; otherwise the query tiles of a pair are split so that every CU gets a block
+    // (a block needs at least one query tile per wave to pay for loading K / V^T)
+    const int64_t pairs = (int64_t)a.B * a.H;
+    const int nqt = (int)ceil_div(a.Lq, 32);
+    int qsplit = (int)std::max<int64_t>(1, std::min<int64_t>(ctx->cu_count / pairs, ceil_div(nqt, KVR_WAVES)));
+    a.nsplit = 1;
+    a.part = nullptr;
+    dim3 grid((unsigned)qsplit, (unsigned)a.H, (unsigned)a.B);
+    hipLaunchKernelGGL(attn_kvres_kernel, grid, dim3(64 * KVR_WAVES), KVR_LDS, ctx->stream, a, qsplit);
+    ODISE_CHECK_HIP(hipGetLastError());
+    return ODISE_OK;
+}
+
 // O[q] = sum_s O_s 2^(m_s - M) / sum_s l_s 2^(m_s - M): one thread per (row, 4 channels)
 __global__ void __launch_bounds__(256) attn_combine_kernel(AttnArgs a) {
     const int D = a.D, D4 = D >> 2;
@@ -338,6 +535,8 @@ static int launch_attn(odise_hip_ctx* ctx, AttnArgs& a) {
 
 }  // namespace odise
 
+extern "C" int odise_hip_attn_kvres(int on) { odise::g_attn_kvres = on; return 0; }
+
 extern "C" int odise_hip_attention(odise_hip_ctx* ctx, const odise_attn_desc* d) {
     using namespace odise;
     ODISE_REQUIRE(ctx && d, "attention: null argument");
@@ -359,6 +558,7 @@ extern "C" int odise_hip_attention(odise_hip_ctx* ctx, const odise_attn_desc* d)
     a.mask = d->mask; a.ldmask = d->ldmask; a.strideMask = d->strideMask;
     a.scale_log2e = d->scale * 1.4426950408889634f;
     const int D = d->D;
+    if (attn_kvres_ok(a)) return launch_attn_kvres(ctx, a);
     if (D <= 32) return launch_attn<32>(ctx, a);
     if (D <= 48) return launch_attn<48>(ctx, a);
     if (D <= 64) return launch_attn<64>(ctx, a);

@@ -277,7 +277,9 @@ extern "C" int odise_hip_classify(odise_hip_ctx* ctx, const float* image, int B,
     ODISE_TRY(ex.alloc(img, B, S, S, 8));
     ODISE_TRY(launch_resize_bilinear_norm(ctx, image, img.p, B, H, W, S));
     ODISE_TRY(launch_maskclip_token_mask(ctx, ho.pred_masks, tmask, B, Q, ho.h4, ho.w4, S, patch, T, ldm));
+    stage_mark(ctx, "classify: text logits + MaskCLIP inputs");
     ODISE_TRY(clip_tower(ex, img, Q, tmask, ldm, ce));
+    stage_mark(ctx, "classify: MaskCLIP tower done");
     if (clip_embed_out) ODISE_TRY(odise_hip_cast_f16_to_f32(ctx, ce, clip_embed_out, (size_t)MQ * c->dim));
     ODISE_TRY(launch_l2_normalize_f16(ctx, ce, ce_n, MQ, c->dim));
     memset(&d, 0, sizeof(d));
@@ -582,13 +584,18 @@ extern "C" int odise_hip_infer(odise_hip_ctx* ctx, const odise_infer_desc* d) {
         ODISE_TRY(launch_image_pad(ctx, d->images[b], d->image_layout, h, w, padded + (size_t)b * 3 * Hp * Wp, Hp, Wp));
         if (!same) ODISE_TRY(launch_image_pad(ctx, d->images[b], d->image_layout, h, w, img01 + (size_t)b * 3 * H * W, H, W));
     }
+    stage_mark(ctx, "infer: inputs padded");
     ODISE_TRY(odise_hip_backbone_forward(ctx, padded, B, Hp, Wp, nullptr));
+    stage_mark(ctx, "backbone done (taps projected + stitched)");
     ODISE_TRY(odise_hip_head_forward(ctx, nullptr, B, 0, Hp / 4, Wp / 4, nullptr, nullptr, nullptr, nullptr));
     ODISE_TRY(odise_hip_classify(ctx, img01, B, H, W, mask_cls, nullptr));
+    stage_mark(ctx, "classification done (MaskCLIP + logits)");
     if (d->mask_cls_out) ODISE_CHECK_HIP(hipMemcpyAsync(d->mask_cls_out, mask_cls, n_cls * 4, hipMemcpyDeviceToDevice, ctx->stream));
     odise_post_desc p = d->post;
     p.B = B; p.pad_h = Hp; p.pad_w = Wp; p.img_hw = d->img_hw; p.mask_cls = mask_cls;
-    return odise_hip_postprocess_batch(ctx, &p);
+    const int rc = odise_hip_postprocess_batch(ctx, &p);
+    stage_mark(ctx, "post-processing done");
+    return rc;
 }
 
 extern "C" int odise_hip_sem_tile(int tile) { odise::g_sem_tile = tile; return 0; }

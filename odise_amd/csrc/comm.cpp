@@ -167,6 +167,28 @@ extern "C" int odise_hip_allgather_predictions(odise_hip_ctx* ctx, const int32_t
     return ODISE_OK;
 }
 
+// Uneven shards (the last batch of a dataset whose size is not a multiple of world x batch: InferenceSampler's shards differ by one image,
+// odise/data/build.py:145-151): every rank contributes n_records <= max_records records, max_records identical on every rank (each rank derives
+// it from the dataset size, distributed.shard_range - no size exchange).  This rank's slice of `all` is assembled on the exchange stream - its
+// records, then -1 rows up to max_records - and gathered in place.
+extern "C" int odise_hip_allgather_records(odise_hip_ctx* ctx, const int32_t* local, int n_records, int max_records, int64_t record_len, int32_t* all) {
+    Comm* c = nullptr;
+    if (int rc = comm_of(ctx, &c, "allgather_records")) return rc;
+    ODISE_REQUIRE(all && record_len > 0 && max_records >= 1 && n_records >= 0 && n_records <= max_records && (local || n_records == 0),
+                  "allgather_records: bad argument (n_records %d, max_records %d)", n_records, max_records);
+    const size_t slice = (size_t)max_records * record_len;
+    int32_t* mine = all + (size_t)c->rank * slice;
+    ODISE_CHECK_HIP(hipEventRecord(c->produced, ctx->stream));
+    ODISE_CHECK_HIP(hipStreamWaitEvent(c->stream, c->produced, 0));
+    if (n_records > 0 && local != mine)
+        ODISE_CHECK_HIP(hipMemcpyAsync(mine, local, (size_t)n_records * record_len * sizeof(int32_t), hipMemcpyDeviceToDevice, c->stream));
+    if (n_records < max_records)
+        ODISE_CHECK_HIP(hipMemsetAsync(mine + (size_t)n_records * record_len, 0xFF, (size_t)(max_records - n_records) * record_len * sizeof(int32_t), c->stream));
+    ODISE_CHECK_NCCL(g_rccl.AllGather(mine, all, slice, ncclInt32, c->comm, c->stream));   // in place: sendbuff = recvbuff + rank * count
+    ODISE_CHECK_HIP(hipEventRecord(c->done, c->stream));
+    return ODISE_OK;
+}
+
 extern "C" int odise_hip_allreduce_sum_i64(odise_hip_ctx* ctx, int64_t* data, int64_t count) {
     Comm* c = nullptr;
     if (int rc = comm_of(ctx, &c, "allreduce_sum_i64")) return rc;

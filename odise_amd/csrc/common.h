@@ -95,8 +95,9 @@ struct odise_hip_ctx {
     void* comm = nullptr;  // odise::Comm* (comm.cpp): RCCL communicator + exchange stream, created by odise_hip_comm_init
     // per-context execution options (odise_hip_set_option, include/odise_hip.h); read on the host when a stage is enqueued
     int clip_ln_fold = 0;            // ODISE_OPT_CLIP_LN_FOLD: 0 = by token count, 1 = always, 2 = never
-    int64_t vae_chunk_bytes = 64ll << 20;   // ODISE_OPT_VAE_CHUNK_BYTES: crops per VAE launch so that one activation stays below this (0 = all crops at once)
+    int64_t vae_chunk_bytes = 0;     // ODISE_OPT_VAE_CHUNK_BYTES: crops per VAE launch so that one activation stays below this (0 = all crops at once, the default)
     void* probe = nullptr;           // odise::LaunchProbe* (api.cpp): HIP events around the launches of one kernel shape (odise_hip_probe_*)
+    void* stages = nullptr;          // odise::StageLog* while odise_hip_stage_timeline is on: (name, HIP event on the current stream, host clock) at stage boundaries
     void* launch_log = nullptr;      // std::vector<odise::LaunchRec>* while odise_hip_launch_log is on: (shape, tile, split-K) of every GEMM / conv launch
 };
 
@@ -114,6 +115,9 @@ static inline LaunchProbe* probe_match(odise_hip_ctx* ctx, bool conv, int M, int
     return (p && p->armed && p->n < p->cap && (p->conv != 0) == conv && p->M == M && p->N == N && p->K == K) ? p : nullptr;
 }
 void probe_release(odise_hip_ctx* ctx);
+// stage boundaries of a model call for the measurement tools (tools/stage_timeline.py): no-op unless the timeline is on
+void stage_mark(odise_hip_ctx* ctx, const char* name);
+void stage_log_release(odise_hip_ctx* ctx);
 struct LaunchRec { int conv, M, N, K, tile, split; };
 void launch_log_push(odise_hip_ctx* ctx, const LaunchRec& r);
 void launch_log_release(odise_hip_ctx* ctx);

@@ -633,7 +633,10 @@ int extractor_launch(odise_hip_ctx* ctx, ModelStore* ms, const float* image, int
     auto clip_on_lane2 = [&]() -> int {
         Lane2 lane(ctx, ms);                                                  // CLIP branch: independent of the encoder, starts at the fork
         ODISE_CHECK_HIP(hipStreamWaitEvent(ctx->stream, ctx->ev_fork, 0));
-        return conditioning();
+        stage_mark(ctx, "lane 2: start (CLIP image tower of the crops)");
+        ODISE_TRY(conditioning());
+        stage_mark(ctx, "lane 2: CLIP + conditioning done");
+        return ODISE_OK;
     };
     bool clip_enqueued = false;
     if (!two) ODISE_TRY(conditioning());
@@ -723,10 +726,13 @@ int extractor_launch(odise_hip_ctx* ctx, ModelStore* ms, const float* image, int
     auto unet_on_lane2 = [&]() -> int {   // waits for the latent on the device; its ~540 launches take the host ~10 ms
         Lane2 lane(ctx, ms);
         ODISE_CHECK_HIP(hipStreamWaitEvent(ctx->stream, ctx->ev_mid, 0));
+        stage_mark(ctx, "lane 2: latent available, UNet starts");
         ODISE_TRY(unet_launch(ctx, ms, ms->unet, nullptr, xt.p, cond_inputs, cond_emb, B, lh, lw, false));
+        stage_mark(ctx, "lane 2: UNet done");
         ODISE_CHECK_HIP(hipEventRecord(ctx->ev_join, ctx->stream));
         return ODISE_OK;
     };
+    stage_mark(ctx, "extractor: VAE encoder + latent done");
     if (two) {
         ODISE_CHECK_HIP(hipEventRecord(ctx->ev_mid, ctx->stream));            // the latent is ready
         if (vae_first && !clip_enqueued) ODISE_TRY(clip_on_lane2());

@@ -391,7 +391,9 @@ static int backbone_forward(odise_hip_ctx* ctx, const float* image, int B, int H
 #else
     const bool defer_join = true;
 #endif
+    stage_mark(ctx, "backbone: crops extracted");
     ODISE_TRY(extractor_launch(ctx, ms, crops, B * K, S, S, false, /*join=*/!defer_join));
+    stage_mark(ctx, "extractor: VAE lane done (main stream; the CLIP -> UNet lane is joined later)");
     const Act* taps = extractor_taps(ms);
     bool joined = false;
     for (int gi = 0; gi < 4; ++gi) {
@@ -401,7 +403,9 @@ static int backbone_forward(odise_hip_ctx* ctx, const float* image, int B, int H
         for (int j = 0; j < 3 && kGroups[gi][j] >= 0; ++j) {
             const int idx = kGroups[gi][j];
             if (!joined && idx >= 2 && idx <= 5) {   // u2, u5, u8, u11
+                stage_mark(ctx, "backbone: VAE-tap projections done");
                 ODISE_TRY(extractor_join(ctx));
+                stage_mark(ctx, "backbone: UNet lane joined");
                 joined = true;
             }
             Act x = taps[idx];
@@ -744,7 +748,10 @@ static int predictor_forward(odise_hip_ctx* ctx, const PixDec& pd) {
 static int head_forward(odise_hip_ctx* ctx, const Act feats[4]) {
     PixDec pd;
     ODISE_TRY(pixel_decoder_forward(ctx, feats, pd));
-    return predictor_forward(ctx, pd);
+    stage_mark(ctx, "head: pixel decoder done");
+    const int rc = predictor_forward(ctx, pd);
+    stage_mark(ctx, "head: masked decoder done");
+    return rc;
 }
 
 int head_outputs(ModelStore* ms, HeadOutputs* out) {

@@ -29,6 +29,16 @@ def shard_range(n_items: int, rank: int, world: int) -> Tuple[int, int]:
     return begin, begin + base + (1 if rank < rem else 0)
 
 
+def max_shard(n_items: int, world: int) -> int:
+    """Size of the largest shard of shard_range: what every rank pads its slice of an uneven exchange to."""
+    return -(-n_items // world)
+
+
+def valid_rows(gathered: np.ndarray) -> np.ndarray:
+    """Rows of an `Exchange.allgather_records` result that hold a record (the padding rows start with -1), in rank order."""
+    return gathered[gathered[:, 0] != -1]
+
+
 def record_size(h: int, w: int) -> int:
     return h * w + 1 + MAX_SEGMENTS * 3
 
@@ -114,6 +124,16 @@ class Exchange:
         n = int(np.prod(local.shape))
         assert int(np.prod(out.shape)) == n * self.world and local.dtype == np.int32 and out.dtype == np.int32
         check(self.ctx.lib.odise_hip_allgather_predictions(self.ctx.h, local.ptr, n, out.ptr), "allgather_predictions")
+
+    def allgather_records(self, local, n_records: int, max_records: int, out) -> None:
+        """Uneven shards: this rank's first `n_records` rows of local [>= n_records, record] -> out [world * max_records, record]; the library
+        pads every rank's slice to `max_records` rows with -1 (`valid_rows` drops them).  max_records must be the same on every rank:
+        `max_shard(n_items, world)` of the batch being exchanged."""
+        from ._lib import check
+        rec = int(out.shape[-1])
+        assert 0 <= n_records <= max_records and tuple(out.shape) == (self.world * max_records, rec) and out.dtype == np.int32
+        assert n_records == 0 or (local.dtype == np.int32 and int(local.shape[-1]) == rec and int(local.shape[0]) >= n_records)
+        check(self.ctx.lib.odise_hip_allgather_records(self.ctx.h, local.ptr if n_records else None, n_records, max_records, rec, out.ptr), "allgather_records")
 
     def allreduce_sum_i64(self, data) -> None:
         from ._lib import check

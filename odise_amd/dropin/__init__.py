@@ -132,5 +132,40 @@ def new_output(shape, like=None, dtype=np.float32):
     return d.ptr, lambda: torch.from_numpy(d.numpy())
 
 
+def tensor_view(t):
+    """A torch ROCm tensor as a non-owning runtime.DeviceArray over the same memory (keeps the tensor alive)."""
+    from ..runtime import DeviceArray
+    assert t.is_cuda and t.is_contiguous()
+    v = DeviceArray.__new__(DeviceArray)
+    v.ctx = get_context()
+    v.shape = tuple(int(s) for s in t.shape)
+    v.dtype = np.dtype(str(t.dtype).replace("torch.", ""))
+    v.nbytes = int(t.numel()) * v.dtype.itemsize
+    v.ptr = t.data_ptr()
+    v._owned = False
+    v._base = t
+    return v
+
+
+class TorchOutputs:
+    """`alloc` callable for HipCategoryODISE.forward (pipeline._post_desc): the large per-image outputs are torch tensors on `device`, written
+    in place by the library - what the reference's `model(batched_inputs)` returns (odise.py:336-372) without a copy at the edge.  Allocation
+    happens on torch's current stream; that stream is drained once before the library (its own stream) writes the buffers."""
+
+    def __init__(self, device):
+        import torch
+        self.device, self.tensors = device, {}
+        self._torch = torch
+
+    def __call__(self, tag, shape, dtype):
+        torch = self._torch
+        t = torch.empty(tuple(int(s) for s in shape), dtype=getattr(torch, np.dtype(dtype).name), device=self.device)
+        self.tensors[tag] = t
+        return tensor_view(t)
+
+    def ready(self):
+        self._torch.cuda.current_stream(self.device).synchronize()
+
+
 if __name__ == "__main__":
     print(OVERLAY_DIR)

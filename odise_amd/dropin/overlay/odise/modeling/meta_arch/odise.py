@@ -403,6 +403,9 @@ class ODISE(nn.Module):
             raise RuntimeError("libodise_hip is an inference library: call model.eval() (the training branch of odise.py:246-281 is out of scope)")
         hip = self._engine()
         self._set_vocabulary(hip, text_head)
+        if self.device.type == "cuda":
+            return self._forward_eval_device(hip, batched_inputs)
+        # a model that lives on the CPU returns CPU tensors (as the reference would): the results cross PCIe once
         results = hip.forward([{**x, "image": x["image"]} for x in batched_inputs], to_host=True)
         out = []
         for r in results:
@@ -416,11 +419,60 @@ class ODISE(nn.Module):
             out.append(o)
         return out
 
+    def _forward_eval_device(self, hip, batched_inputs):
+        """The model lives on a ROCm device (`model.to("cuda")`, what tools/train_net.py does): `sem_seg`, the panoptic map and the instance
+        masks are allocated as torch tensors on that device and the library writes them in place (odise.py:336-372 returns device tensors,
+        odise/evaluation/evaluator.py:87-126 consumes them); pictures that are already device tensors are read where they are.  Nothing but
+        the few hundred bytes of segment / instance tables crosses PCIe."""
+        outs = dropin.TorchOutputs(self.device)
+        inputs, keep = [], []
+        for x in batched_inputs:
+            im = x["image"]
+            if torch.is_tensor(im) and im.is_cuda:                      # CHW uint8 / float, 0..255 (DatasetMapper's format, moved by the caller)
+                im = im.contiguous() if im.dtype == torch.uint8 else im.float().contiguous()
+                keep.append(im)
+            inputs.append({**x, "image": im})
+        if keep:
+            assert len(keep) == len(inputs) and len({t.dtype for t in keep}) == 1, "a batch mixes host and device pictures (or dtypes)"
+            torch.cuda.current_stream(self.device).synchronize()
+            sizes = [(int(x.get("height", t.shape[-2])), int(x.get("width", t.shape[-1]))) for x, t in zip(inputs, keep)]
+            results = hip.infer_device([t.data_ptr() for t in keep], 1 if keep[0].dtype == torch.uint8 else 2, [tuple(t.shape[-2:]) for t in keep], sizes,
+                                       to_host=False, alloc=_ready_alloc(outs))
+        else:
+            results = hip.forward(inputs, to_host=False, alloc=_ready_alloc(outs))
+        hip.ctx.sync()                                                  # the tensors are complete when the caller's stream touches them
+        out = []
+        for i, r in enumerate(results):
+            o = {}
+            if "sem_seg" in r:
+                o["sem_seg"] = outs.tensors[f"sem{i}"]
+            if "sem_seg_argmax" in r:
+                o["sem_seg_argmax"] = outs.tensors[f"amax{i}"]
+            if "panoptic_seg" in r:
+                seg = r["panoptic_seg"][0]
+                o["panoptic_seg"] = (outs.tensors[f"pan{i}"][: seg.shape[0] * seg.shape[1]].view(seg.shape[0], seg.shape[1]), r["panoptic_seg"][1])
+            if "instances" in r:
+                inst = r["instances"]
+                n = len(inst["scores"])
+                o["instances"] = _instances({"pred_masks": outs.tensors[f"masks{i}"][:n], "scores": inst["scores"], "pred_classes": inst["pred_classes"]},
+                                            self.device)
+            out.append(o)
+        return out
+
+
+def _ready_alloc(outs):
+    """TorchOutputs as an allocator that drains torch's stream after each allocation (a recycled block may still be in use there)."""
+    def alloc(tag, shape, dtype):
+        v = outs(tag, shape, dtype)
+        outs.ready()
+        return v
+    return alloc
+
 
 def _instances(inst, device):
     """detectron2 `Instances` (maskformer_model.py:369-379: pred_masks, pred_boxes = zeros, scores, pred_classes) when detectron2 is there,
     a namespace with the same fields otherwise."""
-    masks = torch.from_numpy(inst["pred_masks"]).to(device)
+    masks = inst["pred_masks"] if torch.is_tensor(inst["pred_masks"]) else torch.from_numpy(inst["pred_masks"]).to(device)
     fields = {"pred_masks": masks, "pred_boxes": torch.zeros(masks.shape[0], 4, device=device), "scores": torch.from_numpy(inst["scores"]).to(device),
               "pred_classes": torch.from_numpy(inst["pred_classes"]).to(device)}
     try:

@@ -245,8 +245,10 @@ class HipCategoryODISE(HipODISE):
         return cur.view(shape, dtype)
 
     # ---- outputs of one call ------------------------------------------------------------------------------------------------------
-    def _post_desc(self, n: int, out_sizes, pan_out=None) -> tuple:
-        """Pooled output buffers of `n` images + a PostDesc pointing at them (B / pad / img_hw / mask_cls are left to the caller)."""
+    def _post_desc(self, n: int, out_sizes, pan_out=None, alloc=None) -> tuple:
+        """Pooled output buffers of `n` images + a PostDesc pointing at them (B / pad / img_hw / mask_cls are left to the caller).
+        `alloc(tag, shape, dtype) -> DeviceArray` (optional) provides the LARGE per-image outputs instead of the pool - the drop-in model hands
+        out views of torch tensors on its own device, so the library writes the reference's result tensors in place (no copy at the edge)."""
         from ._lib import MAX_SEGMENTS, PostDesc
         K, topk = self.num_classes, int(self.test_topk_per_image)
         d = PostDesc()
@@ -258,19 +260,20 @@ class HipCategoryODISE(HipODISE):
         d.semantic_on, d.panoptic_on, d.instance_on = int(bool(self.semantic_on)), int(bool(self.panoptic_on)), int(bool(self.instance_on))
         d.object_mask_threshold, d.overlap_threshold, d.topk = float(self.object_mask_threshold), float(self.overlap_threshold), topk
         bufs = {"sem": [None] * n, "amax": [None] * n, "pan": [None] * n, "masks": [None] * n, "pan_ext": [False] * n}
+        big = alloc if alloc is not None else self._buf
         for i, (oh, ow) in enumerate(out_sizes):
             if self.semantic_on and not self.semantic_argmax:
-                bufs["sem"][i] = self._buf(f"sem{i}", (K, oh, ow), np.float32)
+                bufs["sem"][i] = big(f"sem{i}", (K, oh, ow), np.float32)
             if self.semantic_on and self.semantic_argmax:
-                bufs["amax"][i] = self._buf(f"amax{i}", (oh, ow), np.int32)
+                bufs["amax"][i] = big(f"amax{i}", (oh, ow), np.int32)
             if self.panoptic_on:
                 ext = pan_out[i] if pan_out is not None else None
                 if ext is not None:                                        # caller-owned record (this rank's slice of the gather buffer)
                     bufs["pan"][i], bufs["pan_ext"][i] = ext, True
                 else:
-                    bufs["pan"][i] = self._buf(f"pan{i}", (oh * ow + 1 + 3 * MAX_SEGMENTS,), np.int32)
+                    bufs["pan"][i] = big(f"pan{i}", (oh * ow + 1 + 3 * MAX_SEGMENTS,), np.int32)
             if self.instance_on:
-                bufs["masks"][i] = self._buf(f"masks{i}", (topk, oh, ow), np.float32)
+                bufs["masks"][i] = big(f"masks{i}", (topk, oh, ow), np.float32)
 
         def parr(lst):
             a = (C.c_void_p * n)(*[(b.ptr if isinstance(b, DeviceArray) else b) for b in lst])
@@ -332,13 +335,13 @@ class HipCategoryODISE(HipODISE):
         check(self.ctx.lib.odise_hip_postprocess_batch(self.ctx.h, C.byref(d)), "postprocess_batch")
         return self._collect(bufs, sizes, to_host)
 
-    def infer_device(self, images, layout: int, img_hw, out_sizes, to_host: bool = False, pan_out=None, mask_cls_out=None) -> list:
+    def infer_device(self, images, layout: int, img_hw, out_sizes, to_host: bool = False, pan_out=None, mask_cls_out=None, alloc=None) -> list:
         """One `odise_hip_infer` call: `images` = device pointers (DeviceArray or int) of uint8 HWC (layout 0) / uint8 CHW (1) / fp32 CHW
         0..255 (2) pictures with sizes img_hw [(h, w)]."""
         n = len(images)
         from ._lib import InferDesc
         d = InferDesc()
-        post, bufs, keep = self._post_desc(n, out_sizes, pan_out)
+        post, bufs, keep = self._post_desc(n, out_sizes, pan_out, alloc)
         ptrs = (C.c_void_p * n)(*[(im.ptr if isinstance(im, DeviceArray) else im) for im in images])
         iarr = (C.c_int * (2 * n))(*[int(v) for s in img_hw for v in s])
         d.B, d.images, d.image_layout, d.img_hw = n, C.cast(ptrs, C.c_void_p), layout, C.cast(iarr, C.c_void_p)
@@ -350,10 +353,11 @@ class HipCategoryODISE(HipODISE):
     def __call__(self, *args, **kwargs):                                   # nn.Module-style call: the reference's wrappers do `self.model(batched_inputs)`
         return self.forward(*args, **kwargs)
 
-    def forward(self, batched_inputs, to_host: bool = True) -> list:
+    def forward(self, batched_inputs, to_host: bool = True, alloc=None) -> list:
         """CategoryODISE.forward, eval branch (odise.py:236-246, 282-372).  "image" is a CHW uint8 / float array or CPU tensor (values
         0..255, the reference's format), or a DeviceArray uint8 [H,W,3] already in HBM (odise_amd.ingest.HipDatasetMapper).
-        `to_host=False` leaves the large outputs (sem_seg, panoptic map, instance masks) on the device, like the reference does."""
+        `to_host=False` leaves the large outputs (sem_seg, panoptic map, instance masks) on the device, like the reference does;
+        `alloc` (see _post_desc) lets the caller own them."""
         first = batched_inputs[0]["image"]
         if isinstance(first, DeviceArray):
             ims = [x["image"] for x in batched_inputs]
@@ -371,7 +375,7 @@ class HipCategoryODISE(HipODISE):
             hw = [tuple(h.shape[-2:]) for h in host]
             ims = [self.ctx.to_device(np.ascontiguousarray(h, np.uint8 if u8 else np.float32)) for h in host]
         sizes = [(int(x.get("height", s[0])), int(x.get("width", s[1]))) for x, s in zip(batched_inputs, hw)]
-        return self.infer_device(ims, layout, hw, sizes, to_host=to_host)
+        return self.infer_device(ims, layout, hw, sizes, to_host=to_host, alloc=alloc)
 
 
 class HipCaptionODISE(HipCategoryODISE):

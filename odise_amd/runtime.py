@@ -124,6 +124,20 @@ class Context:
         check(self.lib.odise_hip_get_option(self.h, option, C.byref(v)), "get_option")
         return int(v.value)
 
+    def stage_timeline(self, on: bool = True) -> None:
+        check(self.lib.odise_hip_stage_timeline(self.h, 1 if on else 0), "stage_timeline")
+
+    def stage_timeline_read(self):
+        """[(name, gpu_ms, host_ms)] of the stage boundaries since stage_timeline(True), relative to the first."""
+        cap = 512
+        names = C.create_string_buffer(1 << 16)
+        g = (C.c_float * cap)()
+        h = (C.c_double * cap)()
+        n = C.c_int()
+        check(self.lib.odise_hip_stage_timeline_read(self.h, names, len(names), g, h, cap, C.byref(n)), "stage_timeline_read")
+        nm = names.value.decode().split("\n")
+        return [(nm[i], float(g[i]), float(h[i])) for i in range(min(n.value, cap))]
+
     def launch_log(self, on: bool = True) -> None:
         check(self.lib.odise_hip_launch_log(self.h, 1 if on else 0), "launch_log")
 

@@ -132,6 +132,10 @@ class _FakeLib:
         self.log.append(("allgather", int(n)))
         return 0
 
+    def odise_hip_allgather_records(self, h, local, n_records, max_records, record_len, out):
+        self.log.append(("allgather_records", local is not None, int(n_records), int(max_records), int(record_len)))
+        return 0
+
     def odise_hip_allreduce_sum_i64(self, h, data, n):
         self.log.append(("allreduce", int(n)))
         return 0
@@ -162,6 +166,12 @@ def _exchange_worker(rank, world, port, q):
     ex = D.Exchange(Ctx, rank, world, D.gloo_broadcast)
     B, rec = 3, D.record_size(4, 5)
     ex.allgather(_FakeArray((B, rec), np.int32), _FakeArray((world * B, rec), np.int32))
+    # the last batch of 3 images over 2 ranks: shards of 2 and 1 (shard_range), both padded to max_shard = 2 by the library
+    b, e = D.shard_range(3, rank, world)
+    ex.allgather_records(_FakeArray((B, rec), np.int32), e - b, D.max_shard(3, world), _FakeArray((world * D.max_shard(3, world), rec), np.int32))
+    # ... and a batch that leaves the last rank without any image
+    b1, e1 = D.shard_range(1, rank, world)
+    ex.allgather_records(_FakeArray((B, rec), np.int32), e1 - b1, 1, _FakeArray((world, rec), np.int32))
     ex.allreduce_sum_i64(_FakeArray((5, 5), np.int64))
     ex.wait(True)
     ex.close()
@@ -185,6 +195,9 @@ def test_exchange_launcher_side_world2():
     inits = {r: [e for e in logs[r] if e[0] == "init"][0] for r in range(world)}
     assert inits[0][1] == inits[1][1] == bytes((i * 7 + 3) % 256 for i in range(128))     # the same id everywhere
     assert (inits[0][2], inits[0][3]) == (0, 2) and (inits[1][2], inits[1][3]) == (1, 2)
+    rec = D.record_size(4, 5)
+    assert ("allgather_records", True, 2, 2, rec) in logs[0] and ("allgather_records", True, 1, 2, rec) in logs[1]      # 3 images: 2 + 1, padded to 2
+    assert ("allgather_records", True, 1, 1, rec) in logs[0] and ("allgather_records", False, 0, 1, rec) in logs[1]     # 1 image: rank 1 sends padding only
     for r in range(world):
         assert ("allgather", 3 * D.record_size(4, 5)) in logs[r] and ("allreduce", 25) in logs[r] and ("wait", 1) in logs[r] and logs[r][-1] == ("destroy",)
 
@@ -195,3 +208,20 @@ def test_exchange_needs_a_broadcast_beyond_one_rank():
         h = 1
     with pytest.raises(ValueError):
         D.Exchange(Ctx, 0, 2, None)
+
+
+def test_valid_rows_drops_the_library_padding():
+    """What `odise_hip_allgather_records` leaves behind for uneven shards: rank r's records at row r * max_shard, -1 rows after them."""
+    rec = D.record_size(2, 3)
+    world, n_items = 3, 4                                    # shards of 2, 1, 1 padded to 2
+    m = D.max_shard(n_items, world)
+    assert m == 2 and [D.shard_range(n_items, r, world) for r in range(world)] == [(0, 2), (2, 3), (3, 4)]
+    out = np.full((world * m, rec), -1, np.int32)
+    item = 0
+    for r in range(world):
+        b, e = D.shard_range(n_items, r, world)
+        for i in range(e - b):
+            out[r * m + i] = item                              # a record's first element is a panoptic id >= 0
+            item += 1
+    rows = D.valid_rows(out)
+    assert rows.shape == (n_items, rec) and rows[:, 0].tolist() == [0, 1, 2, 3]

@@ -67,33 +67,10 @@ def env(ctx):
             row += 1
     enc = _BankEncoder(table)
     dropin.set_text_tools(enc.tokenize, enc)
-    # ---- the model exactly as configs/common/models/odise_with_label.py spells it
-    backbone = FeatureExtractorBackbone(
-        feature_extractor=LdmImplicitCaptionerExtractor(encoder_block_indices=(5, 7), unet_block_indices=(2, 5, 8, 11), decoder_block_indices=(2, 5), steps=(0,),
-                                                        learnable_time_embed=True, num_timesteps=1, clip_model_name="ViT-L-14-336"),
-        out_features=["s2", "s3", "s4", "s5"], use_checkpoint=True, slide_training=True)
-    shape = backbone.output_shape()
-    model = CategoryODISE(
-        backbone=backbone,
-        sem_seg_head=MaskFormerHead(
-            shape, ignore_value=255, num_classes=133,
-            pixel_decoder=MSDeformAttnPixelDecoder(shape, conv_dim=256, mask_dim=256, norm="GN", transformer_dropout=0.0, transformer_nheads=8,
-                                                   transformer_dim_feedforward=1024, transformer_enc_layers=6, transformer_in_features=["s3", "s4", "s5"],
-                                                   common_stride=4),
-            loss_weight=1.0, transformer_in_feature="multi_scale_pixel_decoder",
-            transformer_predictor=ODISEMultiScaleMaskedTransformerDecoder(
-                class_embed=PseudoClassEmbed(num_classes=133), hidden_dim=256,
-                post_mask_embed=PooledMaskEmbed(hidden_dim=256, mask_dim=256, projection_dim=256), in_channels=256, mask_classification=True,
-                num_classes=133, num_queries=100, nheads=8, dim_feedforward=2048, dec_layers=9, pre_norm=False, enforce_input_project=False, mask_dim=256)),
-        criterion=None,
-        category_head=CategoryEmbed(clip_model_name="ViT-L-14-336", labels=labels, projection_dim=256),
-        clip_head=PoolingCLIPHead(alpha=0.3, beta=0.7, train_labels=[l for l, o in zip(labels, heads.category_overlapping_mask.tolist()) if o]),
-        num_queries=100, object_mask_threshold=0.0, overlap_threshold=0.8, metadata={"thing_ids": THINGS}, size_divisibility=64,
-        sem_seg_postprocess_before_inference=True, pixel_mean=[0.0, 0.0, 0.0], pixel_std=[255.0, 255.0, 255.0], semantic_on=True, instance_on=True,
-        panoptic_on=True, test_topk_per_image=100)
-    own = {k: v for k, v in state.items() if k.startswith(("backbone.feature_projections.", "backbone.feature_extractor.clip_project", "backbone.feature_extractor.alpha",
-                                                           "backbone.feature_extractor.time_embed_project", "sem_seg_head.", "category_head."))}
-    missing, unexpected = model.load_state_dict({k: torch.as_tensor(np.asarray(v)) for k, v in own.items()}, strict=True), None
+    # ---- the model exactly as configs/common/models/odise_with_label.py spells it (odise_amd/dropin/zoo.py)
+    from odise_amd.dropin import zoo
+    model = zoo.category_odise_with_label(labels, THINGS, heads.category_overlapping_mask.tolist())
+    zoo.load_flat_state(model, state)
     model.eval()
     return dict(model=model, labels=labels, img=img, heads=heads, r=r, ext=ext, bb=bb, head=head)
 
@@ -134,6 +111,35 @@ def test_model_through_the_wrapper_protocol(env):
     assert agree > 0.995 and serr < 3e-2
     assert inst.pred_masks.shape[1:] == (1024, 1024) and inst.pred_boxes.shape == (len(inst.scores), 4) and inst.pred_classes.dtype == torch.int64
     assert abs(len(inst.scores) - len(ref["instances"]["scores"])) <= 3
+
+
+def test_model_on_the_device_writes_its_results_in_place(env):
+    """`model.to("cuda")` (what tools/train_net.py does before evaluation): the library writes `sem_seg`, the panoptic map and the instance
+    masks into torch tensors on that device (no host round trip), pictures may be device tensors too, and the values are those of the
+    host-edge path bit for bit (same kernels, other output buffers)."""
+    if not torch.cuda.is_available():
+        pytest.skip("torch sees no ROCm device")
+    model, labels, img = env["model"], env["labels"], env["img"]
+    saved = model.open_state_dict()
+    want = {k: (labels if k.endswith("test_labels") else len(labels) if k.endswith("num_classes") else v) for k, v in saved.items()}
+    model.load_open_state_dict(want)
+    try:
+        with torch.no_grad():
+            host = model([{"image": img, "height": 1024, "width": 1024}])[0]
+            model.to("cuda")
+            assert model.device.type == "cuda"
+            dev = model([{"image": img, "height": 1024, "width": 1024}])[0]                      # host picture, device results
+            dev2 = model([{"image": img.to("cuda"), "height": 1024, "width": 1024}])[0]          # device picture
+    finally:
+        model.to("cpu")
+        model.load_open_state_dict(saved)
+    for out in (dev, dev2):
+        assert out["sem_seg"].is_cuda and out["panoptic_seg"][0].is_cuda and out["instances"].pred_masks.is_cuda
+        assert out["sem_seg"].dtype == torch.float32 and out["panoptic_seg"][0].dtype == torch.int32
+        assert out["panoptic_seg"][1] == host["panoptic_seg"][1]
+        assert torch.equal(out["sem_seg"].cpu(), host["sem_seg"]) and torch.equal(out["panoptic_seg"][0].cpu(), host["panoptic_seg"][0])
+        assert torch.equal(out["instances"].pred_masks.cpu(), host["instances"].pred_masks) and torch.equal(out["instances"].scores.cpu(), host["instances"].scores)
+        assert torch.equal(out["instances"].pred_classes.cpu(), host["instances"].pred_classes)
 
 
 def test_backbone_and_extractor_stand_alone(env):

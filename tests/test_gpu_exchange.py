@@ -45,3 +45,32 @@ def test_collective_without_communicator_fails_loudly(ctx):
     a = ctx.zeros((4,), np.int32)
     rc = ctx.lib.odise_hip_allgather_predictions(ctx.h, a.ptr, 4, a.ptr)
     assert rc != 0 and b"comm_init" in ctx.lib.odise_hip_last_error()
+
+
+def test_uneven_shard_is_padded_by_the_library(ctx):
+    """odise_hip_allgather_records with a one-rank communicator: 2 of at most 3 records -> the gathered buffer holds them and one -1 row,
+    both from a separate local buffer and in place (local aliasing this rank's slice), and an empty shard gathers padding only."""
+    ex = D.Exchange(ctx, 0, 1)
+    try:
+        rec = D.record_size(5, 7)
+        host = (np.arange(3 * rec, dtype=np.int32).reshape(3, rec) % 50)
+        local = ctx.to_device(host)
+        out = ctx.zeros((3, rec), np.int32)
+        ex.allgather_records(local, 2, 3, out)
+        ex.wait(host=True)
+        got = out.numpy()
+        np.testing.assert_array_equal(got[:2], host[:2])
+        assert (got[2] == -1).all() and D.valid_rows(got).shape == (2, rec)
+        inplace = ctx.to_device(host)                       # the records already sit in this rank's slice of the gather buffer
+        ex.allgather_records(inplace, 1, 3, inplace)
+        ex.wait(host=True)
+        got = inplace.numpy()
+        np.testing.assert_array_equal(got[0], host[0])
+        assert (got[1:] == -1).all()
+        ex.allgather_records(None, 0, 2, out.view((2, rec)))
+        ex.wait(host=True)
+        assert (out.view((2, rec)).numpy() == -1).all()
+        rc = ctx.lib.odise_hip_allgather_records(ctx.h, local.ptr, 4, 3, rec, out.ptr)
+        assert rc != 0 and b"allgather_records" in ctx.lib.odise_hip_last_error()
+    finally:
+        ex.close()

@@ -399,6 +399,49 @@ def test_attention_masked_and_spiked(ctx, Lk):
     close(out, ref.numpy(), rtol=5e-3, atol=3e-3, what="masked attention")
 
 
+@pytest.mark.parametrize("B,H,Lq,Lk,masked", [(16, 16, 577, 577, False),     # the crops' CLIP tower of a 4-picture step: one block per (head, image)
+                                              (2, 16, 577, 577, False),      # 32 pairs: query tiles split over three blocks per pair
+                                              (4, 16, 677, 577, True),       # MaskCLIP: 100 mask tokens after the 577 image tokens, u8 visibility
+                                              (4, 8, 100, 300, True), (3, 16, 33, 608, False), (2, 16, 1200, 257, False)])
+def test_attention_kv_resident(ctx, B, H, Lq, Lk, masked):
+    """d_head 64 with <= 608 keys runs the K/V-resident kernel (attn.hip attn_kvres_kernel): against fp32 torch, and against the tiled kernel
+    on the same inputs (tools hook odise_hip_attn_kvres)."""
+    g = torch.Generator().manual_seed(B * 1000 + Lq + Lk)
+    D = 64
+    HD = H * D
+    Q, K, V = (h(torch.randn(B, L, HD, generator=g)) for L in (Lq, Lk, Lk))
+    K[:, min(200, Lk - 1)] = Q[:, 5] * 3        # a spike in a late key tile: the online-softmax rescale path
+    scale = D ** -0.5
+    q = Q.view(B, Lq, H, D).transpose(1, 2)
+    k = K.view(B, Lk, H, D).transpose(1, 2)
+    v = V.view(B, Lk, H, D).transpose(1, 2)
+    s = q @ k.transpose(-1, -2) * scale
+    dm = None
+    if masked:
+        mask = torch.rand(B, Lq, Lk, generator=g) < 0.4
+        mask[:, 3, :] = True                       # fully masked row -> 0
+        mask[:, 7, :] = False
+        mask[:, 7, 32:] = True                     # only the first key tile visible
+        s = s.masked_fill(mask[:, None], float("-inf"))
+        ldm = (Lk + 3) // 4 * 4
+        m8 = np.zeros((B, Lq, ldm), dtype=np.uint8)
+        m8[:, :, :Lk] = mask.numpy()
+        dm = ctx.to_device(m8)
+    ref = (torch.nan_to_num(torch.softmax(s, -1), nan=0.0) @ v).transpose(1, 2).reshape(B, Lq, HD)
+    ldvt = (Lk + 7) // 8 * 8
+    dq, dk, dv = ctx.to_device(Q.half().numpy()), ctx.to_device(K.half().numpy()), ctx.to_device(_vt(V.half().numpy(), ldvt))
+    out = ctx.attention(dq, dk, dv, H, scale, mask=dm, Lk=Lk).numpy()
+    close(out, ref.numpy(), rtol=5e-3, atol=3e-3, what=f"kv-resident attention B{B} H{H} Lq{Lq} Lk{Lk} masked={masked}")
+    ctx.lib.odise_hip_attn_kvres(0)
+    try:
+        tiled = ctx.attention(dq, dk, dv, H, scale, mask=dm, Lk=Lk).numpy()
+    finally:
+        ctx.lib.odise_hip_attn_kvres(1)
+    diff = float(np.abs(out.astype(np.float32) - tiled.astype(np.float32)).max())
+    print(f"kv-resident vs tiled attention B{B} H{H} Lq{Lq} Lk{Lk}: max abs diff {diff:.2e}")
+    assert diff < 2e-3, diff                       # same products, same fp32 softmax; the running max steps per 32 keys instead of 64
+
+
 # ---------------------------------------------------------------------------------------------------------------
 # Layout helpers and MaskPooling
 # ---------------------------------------------------------------------------------------------------------------

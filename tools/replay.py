@@ -7,8 +7,13 @@
   eval   `inference_on_dataset` (odise/evaluation/evaluator.py:60-142): batches from a loader, `min(5, total - 1)` warm-up iterations
          excluded, device synchronised after every batch, wall clock by `time.perf_counter`; prints s/iter and images/s.
 
+  overlay  the same evaluator loop through the DROP-IN model: the overlay's `CategoryODISE` (odise_amd/dropin/zoo.py, the released label model)
+         moved to the device, wrapped in the reference-protocol `OpenPanopticInference` stand-in, batches of CPU uint8 CHW tensors as
+         detectron2's DatasetMapper yields them; the results are device tensors the library wrote in place.  Compared with `eval` (the
+         ctypes-level model on resident uint8 pictures) this prices the boundary: picture upload + torch allocation of the outputs.
+
 Weights: random tensors of the real shapes (odise_amd/synthetic.py); text banks: seeded random rows of the real count.
-usage: replay.py demo | eval [--iters N] [--batch B]"""
+usage: replay.py demo | eval | overlay [--iters N] [--batch B]"""
 import argparse
 import os
 import sys
@@ -61,9 +66,62 @@ def inference_on_dataset(hip, ctx, loader, total):
     return total_compute_time / iters, (time.perf_counter() - start_time) / iters, images / (time.perf_counter() - start_time)
 
 
+class _Banks:
+    """Stands in for tokenizer + CLIP text tower (no BPE merges file here): prompt strings -> rows of seeded banks."""
+
+    def __init__(self, table):
+        self.table = table
+
+    def tokenize(self, strings):
+        return list(strings)
+
+    def build_text_embed(self, strings):
+        return np.stack([self.table[s] for s in strings]).astype(np.float32)
+
+
+def overlay_eval(ctx, args):
+    import torch
+    from odise_amd import dropin
+    from odise_amd.dropin import zoo
+    from odise_amd.synthetic import synthetic_state, synthetic_vocabulary
+    K, K_TOT = 133, 254
+    cat, clp, sizes, overlap = synthetic_vocabulary(K, K_TOT, 768)
+    labels, table, row = [], {}, 0
+    for k, n in enumerate(sizes):
+        names = [f"class{k}_{j}" for j in range(int(n))]
+        labels.append(names)
+        for s in names:
+            table[s], table[f"a photo of a {s}."] = cat[row], clp[row]
+            row += 1
+    dropin.set_context(ctx)
+    dropin.set_text_tools(_Banks(table).tokenize, _Banks(table))
+    model = zoo.category_odise_with_label(labels, range(80), [bool(o) for o in overlap])
+    zoo.load_flat_state(model, synthetic_state())
+    model.eval().to("cuda")
+    model.load_open_state_dict({k: (labels if k.endswith("test_labels") else v) for k, v in model.open_state_dict().items()})
+    batches = [[{"image": torch.from_numpy(np.ascontiguousarray(bench.image_u8(1024, (i * args.batch + b) % 8).transpose(2, 0, 1))), "height": 1024, "width": 1024}
+                for b in range(args.batch)] for i in range(args.iters)]
+    total, num_warmup = len(batches), min(5, len(batches) - 1)
+    t_comp, images = 0.0, 0
+    with torch.no_grad():
+        for idx, inputs in enumerate(batches):
+            if idx == num_warmup:
+                start, t_comp, images = time.perf_counter(), 0.0, 0
+            t0 = time.perf_counter()
+            out = model(inputs)
+            torch.cuda.synchronize()
+            t_comp += time.perf_counter() - t0
+            images += len(inputs)
+    assert out[0]["sem_seg"].is_cuda and out[0]["panoptic_seg"][0].is_cuda and out[0]["instances"].pred_masks.is_cuda
+    iters = total - num_warmup
+    wall = time.perf_counter() - start
+    print(f"eval-loop replay THROUGH THE DROP-IN MODEL (overlay CategoryODISE on cuda, CPU uint8 CHW pictures in, device tensors out; evaluator.py "
+          f"convention): {t_comp / iters:.4f} s/iter inference, {wall / iters:.4f} s/iter total, {images / wall:.2f} images/s at batch {args.batch} x 1024x1024")
+
+
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("mode", choices=["demo", "eval"])
+    ap.add_argument("mode", choices=["demo", "eval", "overlay"])
     ap.add_argument("--iters", type=int, default=15)
     ap.add_argument("--batch", type=int, default=4)
     args = ap.parse_args()
@@ -71,6 +129,8 @@ def main():
     from odise_amd.runtime import Context
     from odise_amd.synthetic import synthetic_state, synthetic_vocabulary
     ctx = Context(0)
+    if args.mode == "overlay":
+        return overlay_eval(ctx, args)
     if args.mode == "demo":
         K, K_TOT, things = 1486, 2482, 80 + 100 + 1203                                             # COCO things + ADE things + all of LVIS
         hip = HipCategoryODISE(ctx, synthetic_state(), overlap_threshold=0.0)

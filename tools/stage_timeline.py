@@ -1,0 +1,49 @@
+"""Stage boundaries of the benchmarked step on both clocks (csrc stage_mark, include/odise_hip_tools.h odise_hip_stage_timeline): when the DEVICE
+reached each boundary (HIP event on the lane that enqueues the stage) and when the HOST had enqueued everything before it.  A host column that
+runs ahead of the device column means the lanes are fed in time; where the device waits for the host the step is launch-bound.
+usage: stage_timeline.py [--images 4] [--reps 3]"""
+import argparse
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..")
+sys.path.insert(0, ROOT)
+import bench  # noqa: E402
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--images", type=int, default=4)
+    ap.add_argument("--reps", type=int, default=3)
+    ap.add_argument("--lanes", type=int, default=2)
+    args = ap.parse_args()
+    from odise_amd.runtime import Context
+    ctx = Context(0)
+    if args.lanes == 1:
+        ctx.lib.odise_hip_set_lanes(ctx.h, 1)
+    S, B = 1024, args.images
+    u8 = [bench.image_u8(S, b) for b in range(B)]
+    hip, _ = bench.calibrated_model(ctx, u8[0], S, 133, 254, set(range(80)), None)
+    d_img = [ctx.to_device(u) for u in u8]
+    hw = [(S, S)] * B
+    for _ in range(2):
+        hip.infer_device(d_img, 0, hw, hw, to_host=False)
+    ctx.sync()
+    rows = None
+    for _ in range(args.reps):
+        ctx.stage_timeline(True)
+        hip.infer_device(d_img, 0, hw, hw, to_host=False)
+        ctx.sync()
+        t = ctx.stage_timeline_read()
+        rows = t if rows is None else [(a[0], a[1] + b[1], a[2] + b[2]) for a, b in zip(rows, t)]
+    ctx.stage_timeline(False)
+    print(f"# one odise_hip_infer over {B} x {S}x{S} pictures, {args.lanes} lane(s), mean of {args.reps} calls; ms since the first mark")
+    print(f"{'device reached':>15} {'host enqueued':>14}  stage boundary")
+    for name, g, h in sorted(rows, key=lambda r: r[1]):
+        print(f"{g / args.reps:15.2f} {h / args.reps:14.2f}  {name}")
+
+
+if __name__ == "__main__":
+    main()
