@@ -305,29 +305,53 @@ __global__ void __launch_bounds__(64 * KVR_WAVES) attn_kvres_kernel(AttnArgs a, 
     const f16x8 zero8 = {0, 0, 0, 0, 0, 0, 0, 0};
     const int nkt = (a.Lk + 31) >> 5;          // key tiles of 32
     const int lkp = nkt * 32;
-    // ---- K and V^T of this (head, image) -> LDS (rows / columns beyond Lk are zero: their scores are masked, 0 x V must stay 0) ----
-    for (int c = tid; c < lkp * 8; c += 64 * KVR_WAVES) {
-        const int key = c >> 3, sl = c & 7;
-        f16x8 v = zero8;
-        if (key < a.Lk) v = *reinterpret_cast<const f16x8*>(Kb + (int64_t)key * a.ldk + sl * 8);
-        *reinterpret_cast<f16x8*>(Ks + key * 64 + ((sl ^ ((key >> 1) & 7)) << 3)) = v;
-    }
-    const int vslots = lkp >> 3;               // 16-byte slots per V^T row
-    for (int c = tid; c < 64 * vslots; c += 64 * KVR_WAVES) {
-        const int d = c / vslots, sl = c - d * vslots;
-        const int k0 = sl * 8;
-        f16x8 v = zero8;
-        if (k0 < a.Lk) {
-            v = *reinterpret_cast<const f16x8*>(Vb + (int64_t)d * a.ldvt + k0);
-            if (k0 + 8 > a.Lk) {
+    // ---- K and V^T of this (head, image) -> LDS (rows / columns beyond Lk are zero: their scores are masked, 0 x V must stay 0).
+    // All of a thread's 16-byte loads are in flight before its first LDS write (two batches of up to 10): the prologue costs two memory
+    // round trips, not twenty (a load -> write loop waits for vmcnt(0) every iteration: measured 15-20 of the kernel's 54 us).
+    constexpr int NT = 64 * KVR_WAVES;
+    constexpr int PER = (KVR_LKP * 8 + NT - 1) / NT;      // 16-byte slots per thread and operand (10)
+    const int vslots = lkp >> 3;                           // 16-byte slots per V^T row
+    {
+        f16x8 buf[PER];
 #pragma unroll
-                for (int i = 0; i < 8; ++i)
-                    if (k0 + i >= a.Lk) v[i] = (f16)0.f;
+        for (int u = 0; u < PER; ++u) {
+            const int c = tid + u * NT;
+            const int key = c >> 3, sl = c & 7;
+            // unconditional load from a clamped (always valid) address, zeroed by a select afterwards: a branch per load would make the
+            // compiler wait for each load before issuing the next
+            const f16x8 t = *reinterpret_cast<const f16x8*>(Kb + (int64_t)min(key, a.Lk - 1) * a.ldk + sl * 8);
+            buf[u] = key < a.Lk ? t : zero8;
+        }
+#pragma unroll
+        for (int u = 0; u < PER; ++u) {
+            const int c = tid + u * NT;
+            const int key = c >> 3, sl = c & 7;
+            if (c < lkp * 8) *reinterpret_cast<f16x8*>(Ks + key * 64 + ((sl ^ ((key >> 1) & 7)) << 3)) = buf[u];
+        }
+#pragma unroll
+        for (int u = 0; u < PER; ++u) {
+            const int c = tid + u * NT;
+            const int d = c / vslots, sl = c - d * vslots;
+            const int k0 = sl * 8;
+            // (ldvt >= round_up(Lk, 8): the slot that straddles Lk is readable; slots beyond it are clamped to it and zeroed)
+            const int dc = min(d, 63), kc = min(k0, (a.Lk - 1) & ~7);
+            f16x8 v = *reinterpret_cast<const f16x8*>(Vb + (int64_t)dc * a.ldvt + kc);
+#pragma unroll
+            for (int i = 0; i < 8; ++i) v[i] = (k0 + i < a.Lk) ? v[i] : (f16)0.f;
+            buf[u] = v;
+        }
+#pragma unroll
+        for (int u = 0; u < PER; ++u) {
+            const int c = tid + u * NT;
+            const int d = c / vslots, sl = c - d * vslots;
+            const int k0 = sl * 8;
+            if (c < 64 * vslots) {
+                const f16x8 v = buf[u];
+                const f16x4 lo4 = {v[0], v[1], v[2], v[3]}, hi4 = {v[4], v[5], v[6], v[7]};
+                *reinterpret_cast<f16x4*>(Vs + d * KVR_VROW + k0) = lo4;       // rows are 8-byte aligned (1224 B apart)
+                *reinterpret_cast<f16x4*>(Vs + d * KVR_VROW + k0 + 4) = hi4;
             }
         }
-        const f16x4 lo4 = {v[0], v[1], v[2], v[3]}, hi4 = {v[4], v[5], v[6], v[7]};
-        *reinterpret_cast<f16x4*>(Vs + d * KVR_VROW + k0) = lo4;       // rows are 8-byte aligned (1224 B apart)
-        *reinterpret_cast<f16x4*>(Vs + d * KVR_VROW + k0 + 4) = hi4;
     }
     __syncthreads();
     // ---- this block's query tiles, dealt round-robin to the waves ----
@@ -448,8 +472,15 @@ __global__ void __launch_bounds__(64 * KVR_WAVES) attn_kvres_kernel(AttnArgs a, 
 
 static int g_attn_kvres = 1;   // tools hook (odise_hip_attn_kvres): 0 = never take the K/V-resident kernel (A/B against the tiled one)
 
-static bool attn_kvres_ok(const AttnArgs& a) {
-    return g_attn_kvres && a.D == 64 && a.Lk >= 256 && a.Lk <= KVR_LKP && a.Lq >= 32 && (int64_t)a.B * a.H >= 32;
+// Taken where one block per (head, image) - or a whole number of query splits of it - fills the chip in (nearly) whole rounds: 16 crops x 16
+// heads = 256 pairs = one round.  288 pairs (18 crops) would run two rounds for 1.125 of work, and a pair split over few blocks pays the
+// 148 KB prologue per block for too few query tiles (MaskCLIP on 4 pictures): the tiled kernel keeps those (tools/attn_bench.py).
+static bool attn_kvres_ok(const AttnArgs& a, int cus) {
+    if (!(g_attn_kvres && a.D == 64 && a.Lk >= 256 && a.Lk <= KVR_LKP && a.Lq >= 256)) return false;
+    const int64_t pairs = (int64_t)a.B * a.H;
+    if (pairs < cus) return false;
+    const double rounds = (double)pairs / cus;
+    return ceil(rounds) / rounds <= 1.07;
 }
 
 static int launch_attn_kvres(odise_hip_ctx* ctx, AttnArgs& a) {
@@ -558,7 +589,7 @@ extern "C" int odise_hip_attention(odise_hip_ctx* ctx, const odise_attn_desc* d)
     a.mask = d->mask; a.ldmask = d->ldmask; a.strideMask = d->strideMask;
     a.scale_log2e = d->scale * 1.4426950408889634f;
     const int D = d->D;
-    if (attn_kvres_ok(a)) return launch_attn_kvres(ctx, a);
+    if (attn_kvres_ok(a, ctx->cu_count)) return launch_attn_kvres(ctx, a);
     if (D <= 32) return launch_attn<32>(ctx, a);
     if (D <= 48) return launch_attn<48>(ctx, a);
     if (D <= 64) return launch_attn<64>(ctx, a);

@@ -80,6 +80,7 @@ struct GemmArgs {
     int splitk;
     int ktiles_per_split;
     float* ws;
+    int* tile_counters;  // split-K: one arrival counter per output tile (zero between launches); null = the partials are folded by splitk_reduce_kernel
     const f16* zeros;  // >= 16 zero bytes (source of padded / out-of-range operand slots)
     int dbg;           // ablation switches (tools only): 1 = no operand DMA after the first tile, 2 = no fragment reads after the first
     int stats_blocks;  // out: row blocks per image of the fused GroupNorm statistics (0 = not produced, epi.gn_stats was cleared)
@@ -810,6 +811,61 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& g, f32x16 (&acc)[B
                 }
             }
         }
+    }
+    if (split && g.tile_counters) {
+        // ---- split-K fold without a second launch.  Every split of a tile has just written its fp32 partial; the block that arrives LAST at the
+        // tile's counter folds the `splitk` partials - in split order 0, 1, 2 ..., the order of splitk_reduce_kernel: the same bits - and runs
+        // the epilogue.  At one crop the UNet issues ~190 split-K GEMMs whose reduce kernels were a dependent launch each (~9 us of dispatch
+        // latency for a few microseconds of work).  Visibility across XCDs (private L2s): device-scope release fence after the partial stores,
+        // device-scope atomic on the counter, acquire fence before the partials are read.
+        __threadfence();
+        __syncthreads();
+        int* flag = reinterpret_cast<int*>(smem);
+        if (tid == 0) {
+            int* cnt = g.tile_counters + (int64_t)blockIdx.y * gridDim.x + blockIdx.x;
+            const int prev = atomicAdd(cnt, 1);
+            const int last = prev == g.splitk - 1;
+            if (last) *cnt = 0;            // ready for the next launch (stream order: no other block touches this counter any more)
+            *flag = last;
+        }
+        __syncthreads();
+        if (*flag == 0) return;
+        __threadfence();
+        const float* ws = g.ws;
+        const bool vec = (g.N & 3) == 0;
+        for (int c = tid; c < BM * CH; c += NT) {
+            const int rt = c / CH, c8 = c - rt * CH;
+            int m = m0 + rt;
+            if (HALO) {
+                const int patch = m0 / BM;
+                const int per_img = g.cg.halo_tx * g.cg.halo_ty;
+                const int img = patch / per_img, pr = patch - img * per_img;
+                const int oy = (pr / g.cg.halo_tx) * 16 + (rt >> 4), ox = (pr % g.cg.halo_tx) * 16 + (rt & 15);
+                m = (oy < g.cg.OH && ox < g.cg.OW) ? (img * g.cg.OH + oy) * g.cg.OW + ox : g.M;
+            }
+            const int n = n0 + c8 * 8;
+            if (m >= g.M || n >= g.N) continue;
+            const int nv = (g.N - n) < 8 ? (g.N - n) : 8;
+            float v[8];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) v[i] = 0.f;
+            if (vec && nv == 8) {
+                for (int s = 0; s < g.splitk; ++s) {
+                    const float4* w = reinterpret_cast<const float4*>(ws + ((int64_t)s * g.M + m) * g.N + n);
+                    const float4 a = w[0], b = w[1];
+                    v[0] += a.x; v[1] += a.y; v[2] += a.z; v[3] += a.w;
+                    v[4] += b.x; v[5] += b.y; v[6] += b.z; v[7] += b.w;
+                }
+            } else {
+                for (int s = 0; s < g.splitk; ++s) {
+                    const float* w = ws + ((int64_t)s * g.M + m) * g.N + n;
+                    for (int i = 0; i < nv; ++i) v[i] += w[i];
+                }
+            }
+            if (g.epi.fast && n + 8 <= g.N) epi_fast8(g.epi, v, m, n, 0);
+            else epi_store8(g.epi, v, m, n, g.N, 0);
+        }
+        return;
     }
     if (stats) {
         constexpr int RL = NT / CH;  // row lanes per column chunk
@@ -2149,7 +2205,7 @@ static int launch_gemm_t(odise_hip_ctx* ctx, GemmArgs& g, int batch) {
     dim3 grid((unsigned)ceil_div(g.N, BN), (unsigned)ceil_div(g.M, BM), (unsigned)(g.splitk > 1 ? g.splitk : batch));
     hipLaunchKernelGGL(kern, grid, dim3(NT), lds, ctx->stream, g);
     ODISE_CHECK_HIP(hipGetLastError());
-    if (g.splitk > 1) {
+    if (g.splitk > 1 && !g.tile_counters) {
         const int64_t total = (int64_t)g.M * ceil_div(g.N, 8);
         const int blocks = (int)std::min<int64_t>(ceil_div(total, 256), 2048);
         hipLaunchKernelGGL(splitk_reduce_kernel, dim3(blocks), dim3(256), 0, ctx->stream, g.ws, g.splitk, g.M, g.N, g.epi);
@@ -2171,7 +2227,7 @@ static int launch_gemm_pp(odise_hip_ctx* ctx, GemmArgs& g, int batch) {
     dim3 grid((unsigned)ceil_div(g.N, BN), (unsigned)ceil_div(g.M, BM), (unsigned)(g.splitk > 1 ? g.splitk : batch));
     hipLaunchKernelGGL(kern, grid, dim3(512), lds, ctx->stream, g);
     ODISE_CHECK_HIP(hipGetLastError());
-    if (g.splitk > 1) {
+    if (g.splitk > 1 && !g.tile_counters) {
         const int64_t total = (int64_t)g.M * ceil_div(g.N, 8);
         const int blocks = (int)std::min<int64_t>(ceil_div(total, 256), 2048);
         hipLaunchKernelGGL(splitk_reduce_kernel, dim3(blocks), dim3(256), 0, ctx->stream, g.ws, g.splitk, g.M, g.N, g.epi);
@@ -2193,7 +2249,7 @@ static int launch_gemm_pp2(odise_hip_ctx* ctx, GemmArgs& g, int batch) {
     dim3 grid((unsigned)ceil_div(g.N, BN), (unsigned)ceil_div(g.M, BM), (unsigned)(g.splitk > 1 ? g.splitk : batch));
     hipLaunchKernelGGL(kern, grid, dim3(512), lds, ctx->stream, g);
     ODISE_CHECK_HIP(hipGetLastError());
-    if (g.splitk > 1) {
+    if (g.splitk > 1 && !g.tile_counters) {
         const int64_t total = (int64_t)g.M * ceil_div(g.N, 8);
         const int blocks = (int)std::min<int64_t>(ceil_div(total, 256), 2048);
         hipLaunchKernelGGL(splitk_reduce_kernel, dim3(blocks), dim3(256), 0, ctx->stream, g.ws, g.splitk, g.M, g.N, g.epi);
@@ -2216,7 +2272,7 @@ static int launch_conv3_halo(odise_hip_ctx* ctx, GemmArgs& g) {
     dim3 grid((unsigned)ceil_div(g.N, BN), (unsigned)(n_img * g.cg.halo_tx * g.cg.halo_ty), (unsigned)(g.splitk > 1 ? g.splitk : 1));
     hipLaunchKernelGGL(kern, grid, dim3(512), lds, ctx->stream, g);
     ODISE_CHECK_HIP(hipGetLastError());
-    if (g.splitk > 1) {
+    if (g.splitk > 1 && !g.tile_counters) {
         const int64_t total = (int64_t)g.M * ceil_div(g.N, 8);
         const int blocks = (int)std::min<int64_t>(ceil_div(total, 256), 2048);
         hipLaunchKernelGGL(splitk_reduce_kernel, dim3(blocks), dim3(256), 0, ctx->stream, g.ws, g.splitk, g.M, g.N, g.epi);
@@ -2240,7 +2296,7 @@ static int launch_conv3_halo4(odise_hip_ctx* ctx, GemmArgs& g) {
     dim3 grid((unsigned)ceil_div(g.N, BN), (unsigned)(n_img * g.cg.halo_tx * g.cg.halo_ty), (unsigned)(g.splitk > 1 ? g.splitk : 1));
     hipLaunchKernelGGL(kern, grid, dim3(256), lds, ctx->stream, g);
     ODISE_CHECK_HIP(hipGetLastError());
-    if (g.splitk > 1) {
+    if (g.splitk > 1 && !g.tile_counters) {
         const int64_t total = (int64_t)g.M * ceil_div(g.N, 8);
         const int blocks = (int)std::min<int64_t>(ceil_div(total, 256), 2048);
         hipLaunchKernelGGL(splitk_reduce_kernel, dim3(blocks), dim3(256), 0, ctx->stream, g.ws, g.splitk, g.M, g.N, g.epi);
@@ -2261,6 +2317,7 @@ static int g_conv_flags = 0;  // tools only: 1 = tap-major K order even when Cin
 //  (profiles/r03_gemm4_two_blocks_dense.txt): two operand streams through LDS-DMA at half the tile size cost more than the overlap of
 //  neighbouring blocks returns, where the convolution's input patch is fetched once for nine K-tiles.  Not kept.)
 static const int kNumTiles = 10;
+static const int kTileCounters = ODISE_WS_TILE_COUNTERS;   // arrival counters behind each split-K workspace (common.h)
 static const int kTileBM[kNumTiles] = {128, 64, 64, 256, 256, 256, 512, 256, 256, 256};
 static const int kTileBN[kNumTiles] = {128, 128, 64, 320, 256, 128, 128, 256, 128, 128};
 
@@ -2403,6 +2460,13 @@ static int launch_gemm_select(odise_hip_ctx* ctx, GemmArgs& g, int batch, int fo
                 g.K, batch, g.cg.Cin, g.cg.KH, g.cg.H, g.cg.W, g.cg.stride, g.cg.ups, tile, best_split, (int)pp_ok);
     }
     g.ws = (float*)ctx->ws;
+    // split-K partials are folded by the last block of every tile (gemm_epilogue) unless the launch has more tiles than arrival counters
+    // (kTileCounters ints behind the workspace) or the tools build asks for the separate reduce kernel (ODISE_GEMM_FLAGS=4096, A/B)
+    g.tile_counters = nullptr;
+    if (g.splitk > 1 && !(flags & 4096)) {
+        const int64_t tiles = ((tile >= 7 && tile <= 9) ? halo_patches : ceil_div(g.M, kTileBM[tile])) * ceil_div(g.N, kTileBN[tile]);
+        if (tiles <= kTileCounters) g.tile_counters = (int*)((char*)ctx->ws + ctx->ws_bytes);
+    }
     {
         // epi_fast8 preconditions: every vector access of a full 8-column chunk is naturally aligned
         const GemmEpi& e = g.epi;

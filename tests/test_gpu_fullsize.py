@@ -23,7 +23,7 @@ import numpy as np
 import pytest
 import torch
 
-from contracts import TAU_PROB, end_to_end_contract
+from contracts import TAU_PROB, class_probability_contract, end_to_end_contract
 from fullsize import build_models, category_head_state, reference
 from oracle import odise_model as om
 
@@ -166,23 +166,12 @@ def test_classification_full_size(coco, ctx, ln_fold):
     got, ce = got.numpy(), ce.numpy()
     err, cos, scale = _rel(ce, out_ref["clip_embed"].numpy())
     print(f"MaskCLIP embed {ce.shape} max|ref| {scale:.3f} max-err/scale {err:.3e} cos {cos:.6f}")
-    p_ref, p_got = np.exp(cls_ref.numpy()), np.exp(got)
-    perr = np.abs(p_got - p_ref).max()
-    top2 = np.sort(p_ref[0], axis=-1)[:, -2:]
-    margin = top2[:, 1] - top2[:, 0]
-    decided = margin > 2 * TAU_PROB
-    same = p_got[0].argmax(-1) == p_ref[0].argmax(-1)
-    print(f"class prob max abs err {perr:.3e} (bound {TAU_PROB}); labels: {len(set(p_ref[0].argmax(-1).tolist()))} distinct, "
-          f"{int((p_ref[0].argmax(-1) == K).sum())} null; queries with top-2 margin > {2 * TAU_PROB}: {int(decided.sum())}/100; label agreement "
-          f"{int(same.sum())}/100; inside the margin {int((~decided).sum())}, of which differing {int((~same & ~decided).sum())}")
     assert err < 1e-2 and cos > 0.9999
-    assert perr < TAU_PROB
-    assert same[decided].all(), "argmax label differs on a query whose reference margin exceeds the fp16 bound"
-    assert decided.sum() >= 60 and same.sum() >= 95
+    class_probability_contract(got[0], cls_ref[0].numpy(), K, tag="one picture, 4 crops:", min_decided=60, min_same=95)
 
 
 @pytest.mark.parametrize("vocab,overlap_threshold", [("coco133", 0.8), ("coco133", 0.0), ("ade150", 0.8)])   # evaluation config / demo config (demo.py:316-318) / configs[3] vocabulary
-def test_end_to_end_contract(full, vocab, overlap_threshold):
+def test_end_to_end_contract(full, ctx, vocab, overlap_threshold):
     """One `model(batched_inputs)` call at 1024x1024 against the oracle's: identical segments_info, labels / masks as in the module docstring."""
     hip, img = full["hip"], full["img"]
     _, out_ref, _, _ = full["ref"]
@@ -194,7 +183,17 @@ def test_end_to_end_contract(full, vocab, overlap_threshold):
     finally:
         hip.overlap_threshold = 0.8
         use_vocabulary(full, "coco133")
-    end_to_end_contract(got, ref, cls_ref, k, things, tag=f"vocabulary {vocab} overlap {overlap_threshold}:")
+    cls_got = ctx.empty((1, hip.num_queries, k + 1), np.float32)
+    hip.overlap_threshold = overlap_threshold
+    try:
+        use_vocabulary(full, vocab)
+        dev = ctx.to_device(np.ascontiguousarray(img.numpy()))
+        hip.infer_device([dev], 1, [(1024, 1024)], [(1024, 1024)], to_host=False, mask_cls_out=cls_got)     # the same call again for its class probabilities
+    finally:
+        hip.overlap_threshold = 0.8
+        use_vocabulary(full, "coco133")
+    perr = class_probability_contract(cls_got.numpy()[0], cls_ref[0].numpy(), k, tag=f"vocabulary {vocab} overlap {overlap_threshold}:")
+    end_to_end_contract(got, ref, cls_ref, k, things, tag=f"vocabulary {vocab} overlap {overlap_threshold}:", perr=perr)
 
 
 def test_mask_iou_contract_at_output_resolution(full, ctx):

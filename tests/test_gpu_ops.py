@@ -399,10 +399,10 @@ def test_attention_masked_and_spiked(ctx, Lk):
     close(out, ref.numpy(), rtol=5e-3, atol=3e-3, what="masked attention")
 
 
-@pytest.mark.parametrize("B,H,Lq,Lk,masked", [(16, 16, 577, 577, False),     # the crops' CLIP tower of a 4-picture step: one block per (head, image)
-                                              (2, 16, 577, 577, False),      # 32 pairs: query tiles split over three blocks per pair
-                                              (4, 16, 677, 577, True),       # MaskCLIP: 100 mask tokens after the 577 image tokens, u8 visibility
-                                              (4, 8, 100, 300, True), (3, 16, 33, 608, False), (2, 16, 1200, 257, False)])
+@pytest.mark.parametrize("B,H,Lq,Lk,masked", [(16, 16, 577, 577, False),     # the crops' CLIP tower of a 4-picture step: one block per (head, image) = 256 blocks
+                                              (16, 16, 677, 577, True),      # MaskCLIP's shape on 16 pictures: 100 mask tokens after the image tokens, u8 visibility
+                                              (32, 8, 300, 608, True), (16, 16, 1200, 257, False),   # the key-count limits of the resident form
+                                              (2, 16, 577, 577, False), (4, 16, 677, 577, True)])    # too few (head, image) pairs: these stay on the tiled kernel
 def test_attention_kv_resident(ctx, B, H, Lq, Lk, masked):
     """d_head 64 with <= 608 keys runs the K/V-resident kernel (attn.hip attn_kvres_kernel): against fp32 torch, and against the tiled kernel
     on the same inputs (tools hook odise_hip_attn_kvres)."""

@@ -125,6 +125,9 @@ def main():
     ap.add_argument("--iters", type=int, default=15)
     ap.add_argument("--batch", type=int, default=4)
     args = ap.parse_args()
+    if args.mode == "overlay":
+        import torch   # before the library: the process then runs ONE HIP runtime (torch's), which both torch and libodise_hip.so bind to
+        torch.cuda.init()
     from odise_amd.pipeline import HipCategoryODISE
     from odise_amd.runtime import Context
     from odise_amd.synthetic import synthetic_state, synthetic_vocabulary
