@@ -100,6 +100,20 @@ __device__ __forceinline__ void glds16(const void* gsrc, void* lds_base) {
                                      (__attribute__((address_space(3))) void*)lds_base, 16, 0, 0);
 }
 
+// Split-K partials that another block of the same launch will read (fused fold, gemm_epilogue): device-scope relaxed atomics, i.e. stores that
+// write through and loads that are served at the device's coherence point (sc1) - the XCDs' private L2s are not coherent for plain accesses
+// within a kernel, and a release / acquire fence pair instead costs an L2 write-back + invalidate PER BLOCK (measured: +54 us per split-K GEMM
+// at one crop, 16.5 instead of 6.2 ms for the UNet).
+__device__ __forceinline__ void ws_store2(float* p, float a, float b) {
+    const unsigned long long v = (unsigned long long)__float_as_uint(a) | ((unsigned long long)__float_as_uint(b) << 32);
+    __hip_atomic_store(reinterpret_cast<unsigned long long*>(p), v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ void ws_load2(const float* p, float& a, float& b) {
+    const unsigned long long v = __hip_atomic_load(reinterpret_cast<const unsigned long long*>(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    a = __uint_as_float((unsigned)v);
+    b = __uint_as_float((unsigned)(v >> 32));
+}
+
 // Applies the epilogue to 8 consecutive columns (n..n+7) of row m and stores them.
 __device__ __forceinline__ void epi_store8(const GemmEpi& e, float (&v)[8], int m, int n, int N, int z) {
     const int nvalid = (N - n) < 8 ? (N - n) : 8;
@@ -789,7 +803,9 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& g, f32x16 (&acc)[B
                 if (split) {
                     float* w = g.ws + ((int64_t)z * g.M + m) * g.N + n;
                     const int nv = (g.N - n) < 8 ? (g.N - n) : 8;
-                    if (nv == 8 && (g.N & 3) == 0) {
+                    if (g.tile_counters && (g.N & 1) == 0) {        // fused fold: coherent stores (ws_store2); N even keeps the pairs 8-byte aligned
+                        for (int i = 0; i + 1 < nv; i += 2) ws_store2(w + i, v[i], v[i + 1]);
+                    } else if (nv == 8 && (g.N & 3) == 0) {
                         *reinterpret_cast<float4*>(w) = t0;
                         *reinterpret_cast<float4*>(w + 4) = t1;
                     } else {
@@ -816,9 +832,8 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& g, f32x16 (&acc)[B
         // ---- split-K fold without a second launch.  Every split of a tile has just written its fp32 partial; the block that arrives LAST at the
         // tile's counter folds the `splitk` partials - in split order 0, 1, 2 ..., the order of splitk_reduce_kernel: the same bits - and runs
         // the epilogue.  At one crop the UNet issues ~190 split-K GEMMs whose reduce kernels were a dependent launch each (~9 us of dispatch
-        // latency for a few microseconds of work).  Visibility across XCDs (private L2s): device-scope release fence after the partial stores,
-        // device-scope atomic on the counter, acquire fence before the partials are read.
-        __threadfence();
+        // latency for a few microseconds of work).  Visibility across XCDs (private L2s): the partials are written and read with device-scope
+        // atomics (ws_store2 / ws_load2), the block barrier below drains every wave's stores (vmcnt) before thread 0 bumps the counter.
         __syncthreads();
         int* flag = reinterpret_cast<int*>(smem);
         if (tid == 0) {
@@ -830,9 +845,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& g, f32x16 (&acc)[B
         }
         __syncthreads();
         if (*flag == 0) return;
-        __threadfence();
         const float* ws = g.ws;
-        const bool vec = (g.N & 3) == 0;
         for (int c = tid; c < BM * CH; c += NT) {
             const int rt = c / CH, c8 = c - rt * CH;
             int m = m0 + rt;
@@ -849,17 +862,24 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& g, f32x16 (&acc)[B
             float v[8];
 #pragma unroll
             for (int i = 0; i < 8; ++i) v[i] = 0.f;
-            if (vec && nv == 8) {
+            if (nv == 8) {
                 for (int s = 0; s < g.splitk; ++s) {
-                    const float4* w = reinterpret_cast<const float4*>(ws + ((int64_t)s * g.M + m) * g.N + n);
-                    const float4 a = w[0], b = w[1];
-                    v[0] += a.x; v[1] += a.y; v[2] += a.z; v[3] += a.w;
-                    v[4] += b.x; v[5] += b.y; v[6] += b.z; v[7] += b.w;
+                    const float* w = ws + ((int64_t)s * g.M + m) * g.N + n;
+                    float t[8];
+#pragma unroll
+                    for (int i = 0; i < 8; i += 2) ws_load2(w + i, t[i], t[i + 1]);
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) v[i] += t[i];
                 }
             } else {
                 for (int s = 0; s < g.splitk; ++s) {
                     const float* w = ws + ((int64_t)s * g.M + m) * g.N + n;
-                    for (int i = 0; i < nv; ++i) v[i] += w[i];
+                    for (int i = 0; i + 1 < nv; i += 2) {
+                        float a, b;
+                        ws_load2(w + i, a, b);
+                        v[i] += a;
+                        v[i + 1] += b;
+                    }
                 }
             }
             if (g.epi.fast && n + 8 <= g.N) epi_fast8(g.epi, v, m, n, 0);
@@ -2305,6 +2325,7 @@ static int launch_conv3_halo4(odise_hip_ctx* ctx, GemmArgs& g) {
     return ODISE_OK;
 }
 
+static int g_splitk_fused = 1;  // tools hook (odise_hip_splitk_fused): 0 = split-K partials are folded by splitk_reduce_kernel (a second launch), for A/B runs
 static int g_gemm_debug = 0;  // see GemmArgs::dbg
 static int g_epi_old = 0;     // tools only: 1 = keep the fp32-staged epilogue (odise_hip_gemm_debug bit 1 << 24), for same-process A/B runs
 static int g_conv_flags = 0;  // tools only: 1 = tap-major K order even when Cin % 64 == 0, 2 = never use the ping-pong kernel, 4 = one N-tile per phase at BN = 256
@@ -2463,9 +2484,9 @@ static int launch_gemm_select(odise_hip_ctx* ctx, GemmArgs& g, int batch, int fo
     // split-K partials are folded by the last block of every tile (gemm_epilogue) unless the launch has more tiles than arrival counters
     // (kTileCounters ints behind the workspace) or the tools build asks for the separate reduce kernel (ODISE_GEMM_FLAGS=4096, A/B)
     g.tile_counters = nullptr;
-    if (g.splitk > 1 && !(flags & 4096)) {
+    if (g.splitk > 1 && !(flags & 4096) && g_splitk_fused) {
         const int64_t tiles = ((tile >= 7 && tile <= 9) ? halo_patches : ceil_div(g.M, kTileBM[tile])) * ceil_div(g.N, kTileBN[tile]);
-        if (tiles <= kTileCounters) g.tile_counters = (int*)((char*)ctx->ws + ctx->ws_bytes);
+        if (tiles <= kTileCounters && g.N % 2 == 0) g.tile_counters = (int*)((char*)ctx->ws + ctx->ws_bytes);
     }
     {
         // epi_fast8 preconditions: every vector access of a full 8-column chunk is naturally aligned
@@ -2641,6 +2662,7 @@ int group_norm_from_colpart(odise_hip_ctx* ctx, const void* x, void* y, const fl
 
 }  // namespace odise
 
+extern "C" int odise_hip_splitk_fused(int on) { odise::g_splitk_fused = on; return 0; }
 extern "C" int odise_hip_gemm_debug(int flags) {
     odise::g_gemm_debug = flags & 15;
     odise::g_conv_flags = (flags >> 4) & 0xfffff;

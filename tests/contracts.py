@@ -8,15 +8,17 @@ import torch
 TAU_PROB = 3e-2      # bound on a class-probability error, absolute (measured 1.9e-2 at logit scale 100)
 
 
-def end_to_end_contract(got, ref, cls_ref, k, things, tag="", size=1024, segments_strict=True, perr=0.0):
+def end_to_end_contract(got, ref, cls_ref, k, things, tag="", size=1024, segments_strict=True, perr=None):
     """`got`: one dict of HipCategoryODISE.forward (host arrays); `ref`: om.postprocess(...)[i] of the oracle; cls_ref [1 or Q.., K+1] the oracle's
     class log-probabilities of this image.  Asserts: identical segments_info, panoptic map > 99.5 % equal, semantic scores within TAU_PROB and
     identical arg-max wherever the reference's top-2 margin exceeds twice the measured error, instance sets identical away from the top-k
     boundary with mask IoU > 0.93.  `segments_strict=False` (the caller found the reference's own table not fixed by its margins at the measured
     error, margins.segments_decided): the table is reported and the panoptic map held to 97 % instead.  `perr` = the measured class-probability error
     of this picture (class_probability_contract): semantic scores are sums of probabilities x sigmoids and instance scores are probabilities, so a
-    re-decided query (perr > TAU_PROB) raises their bounds to its error.  Returns the printed figures."""
-    tau = max(TAU_PROB, 1.1 * perr)
+    re-decided query (error above TAU_PROB) raises their bounds to its error, and its own instance mask is held to IoU > 0.8 instead of 0.93 (the
+    floors of tests/test_gpu_fullsize.py::test_mask_iou_contract_at_output_resolution).  `perr`: float or the per-query array.  Returns the printed figures."""
+    eq = np.zeros(cls_ref.reshape(-1, k + 1).shape[0]) if perr is None else np.broadcast_to(np.asarray(perr, np.float64), (cls_ref.reshape(-1, k + 1).shape[0],))
+    tau = max(TAU_PROB, 1.1 * float(eq.max()))
     cls_ref = torch.as_tensor(cls_ref).reshape(-1, k + 1)
     pan_ref, info_ref = ref["panoptic_seg"]
     pan, info = got["panoptic_seg"]
@@ -45,12 +47,17 @@ def end_to_end_contract(got, ref, cls_ref, k, things, tag="", size=1024, segment
     key_got = {(int(q), int(c)): i for i, (q, c) in enumerate(zip(inst["query_index"], inst["pred_classes"]))}
     common = sorted(set(key_ref) & set(key_got))
     kth = float(np.sort(scores_flat.numpy())[-100])
-    worst, worst_score = 1.0, 0.0
+    worst, worst_redecided, worst_score = 1.0, 1.0, 0.0
     for kk in common:
         a, b = inst["pred_masks"][key_got[kk]] > 0.5, inst_ref["pred_masks"][key_ref[kk]].numpy() > 0.5
-        worst = min(worst, (a & b).sum() / max((a | b).sum(), 1))
+        iou = (a & b).sum() / max((a | b).sum(), 1)
+        if eq[kk[0]] < TAU_PROB:
+            worst = min(worst, iou)
+        else:
+            worst_redecided = min(worst_redecided, iou)
         worst_score = max(worst_score, abs(float(inst["scores"][key_got[kk]]) - float(s_ref[key_ref[kk]])))
-    print(tag, "instances", len(key_got), "ref", len(key_ref), "in common", len(common), "k-th class score", kth, "worst mask IoU", worst, "worst score diff", worst_score)
+    print(tag, "instances", len(key_got), "ref", len(key_ref), "in common", len(common), "k-th class score", kth, "worst mask IoU", worst,
+          "(of re-decided queries:", worst_redecided, ") worst score diff", worst_score)
     if segments_strict:
         assert info == info_ref, (tag, info, info_ref)
         assert agree > 0.995, (tag, agree)
@@ -63,7 +70,7 @@ def end_to_end_contract(got, ref, cls_ref, k, things, tag="", size=1024, segment
     assert inst["pred_masks"].shape[1:] == (size, size)
     for q, c in set(key_ref) ^ set(key_got):    # entries may only differ at the selection boundary of the top-k
         assert abs(float(scores_flat[q * k + c]) - kth) < tau, (tag, q, c)
-    assert len(common) >= 0.9 * len(key_ref) and worst > 0.93 and worst_score < 2 * tau, (tag, len(common), worst, worst_score)
+    assert len(common) >= 0.9 * len(key_ref) and worst > 0.93 and worst_redecided > 0.8 and worst_score < 2 * tau, (tag, len(common), worst, worst_redecided, worst_score)
     return dict(segments=len(info), panoptic_agreement=agree, sem_err=serr, sem_agreement=sagree, instances=len(key_got), worst_iou=float(worst))
 
 
@@ -80,7 +87,7 @@ def class_probability_contract(got_logp, ref_logp, k, tag="", min_decided=50, mi
         that changes with any change of summation order).  They are counted, bounded in number and size, and - like every query - held to
         their own margin:
       * the arg-max label is identical on EVERY query whose reference top-2 margin exceeds twice that query's own measured error.
-    Returns the largest error."""
+    Returns the per-query errors e_q."""
     p_ref, p_got = np.exp(np.asarray(ref_logp, np.float64).reshape(-1, k + 1)), np.exp(np.asarray(got_logp, np.float64).reshape(-1, k + 1))
     eprob = np.abs(p_got - p_ref).max(-1)
     perr = float(eprob.max())
@@ -96,7 +103,7 @@ def class_probability_contract(got_logp, ref_logp, k, tag="", min_decided=50, mi
     assert (~regular).sum() <= MAX_REDECIDED and perr < TAU_REDECIDED, (tag, int((~regular).sum()), perr)
     assert same[decided].all(), f"{tag}: argmax label differs on a query whose reference margin exceeds twice its measured error"
     assert decided.sum() >= min_decided and same.sum() >= min_same, (tag, int(decided.sum()), int(same.sum()))
-    return perr
+    return eprob
 
 
 def device_pair_report(a, b, logp_a, logp_b, k, tag=""):

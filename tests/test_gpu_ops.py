@@ -322,15 +322,39 @@ def test_conv_fused_upsample_residual_timeemb(ctx):
 # Norms
 # ---------------------------------------------------------------------------------------------------------------
 @pytest.mark.parametrize("N,HW,C,act", [(2, 64, 320, 1), (1, 4096, 320, 0), (3, 256, 128, 1), (1, 64, 2560, 1), (2, 1024, 960, 2),
-                                        (1, 100, 512, 0)])
-def test_group_norm(ctx, N, HW, C, act):
+                                        (1, 100, 512, 0), (2, 32768, 128, 1), (1, 16384, 512, 0), (16, 1024, 640, 1)])
+@pytest.mark.parametrize("form", ["default", "three launches"])
+def test_group_norm(ctx, N, HW, C, act, form):
+    """Groups of at most 128 KiB take the one-launch kernel (norm.hip gn_group_kernel), larger ones partial / finalize / apply; both forms on
+    every shape (tools hook odise_hip_gn_group)."""
     g = torch.Generator().manual_seed(C + HW)
     x = h(torch.randn(N, HW, C, generator=g) * 2 + 0.5)
     gamma, beta = torch.randn(C, generator=g), torch.randn(C, generator=g)
     ref = F.group_norm(x.permute(0, 2, 1), 32, gamma, beta, eps=1e-5).permute(0, 2, 1)
     ref = {0: lambda t: t, 1: F.silu, 2: F.relu}[act](ref)
-    out = ctx.group_norm(ctx.to_device(x.half().numpy()), ctx.to_device(gamma), ctx.to_device(beta), 32, 1e-5, act).numpy()
-    close(out, ref.numpy(), rtol=3e-3, what=f"group_norm C={C}")
+    ctx.lib.odise_hip_gn_group(0 if form == "three launches" else 1)
+    try:
+        out = ctx.group_norm(ctx.to_device(x.half().numpy()), ctx.to_device(gamma), ctx.to_device(beta), 32, 1e-5, act).numpy()
+    finally:
+        ctx.lib.odise_hip_gn_group(1)
+    close(out, ref.numpy(), rtol=3e-3, what=f"group_norm C={C} ({form})")
+
+
+@pytest.mark.parametrize("HW,C", [(256, 256), (40000, 256)])      # the one-launch kernel / the three-launch form
+def test_group_norm_residual_and_accumulate(ctx, HW, C):
+    """odise_hip_group_norm_ex: y = relu(GroupNorm(x) + residual) + accum (the BottleneckBlock tails of the tap projections)."""
+    import ctypes as C_
+    g = torch.Generator().manual_seed(HW)
+    N = 2
+    x, r, a = (h(torch.randn(N, HW, C, generator=g)) for _ in range(3))
+    gamma, beta = torch.randn(C, generator=g), torch.randn(C, generator=g)
+    ref = F.relu(F.group_norm(x.permute(0, 2, 1), 32, gamma, beta, eps=1e-5).permute(0, 2, 1) + r) + a
+    dx, dr, da = (ctx.to_device(t.half().numpy()) for t in (x, r, a))
+    dg, db = ctx.to_device(gamma), ctx.to_device(beta)
+    y = ctx.empty((N, HW, C), np.float16)
+    rc = ctx.lib.odise_hip_group_norm_ex(ctx.h, dx.ptr, y.ptr, dg.ptr, db.ptr, N, HW, C, 32, C_.c_float(1e-5), 2, dr.ptr, da.ptr)
+    assert rc == 0, ctx.lib.odise_hip_last_error()
+    close(y.numpy(), ref.numpy(), rtol=3e-3, atol=3e-3, what=f"group_norm_ex HW={HW}")
 
 
 @pytest.mark.parametrize("rows,C", [(77, 768), (4096, 320), (5, 1280), (577, 1024), (100, 256)])
