@@ -67,8 +67,6 @@ def parse():
     p.add_argument("--clip-ln-fold", type=int, default=0, choices=[0, 1, 2], help="A/B: the CLIP towers' LayerNorm fold, 0 = the library's rule, 1 = always, 2 = never")
     p.add_argument("--vae-chunk-mb", type=float, default=None, help="A/B: ODISE_OPT_VAE_CHUNK_BYTES in MiB (0 = all crops per launch; default: the library's)")
     p.add_argument("--attn-kvres", type=int, default=1, choices=[0, 1], help="A/B: 0 = the CLIP towers' attention on the tiled kernel instead of the K/V-resident one")
-    p.add_argument("--splitk-fused", type=int, default=1, choices=[0, 1], help="A/B: 0 = split-K partials folded by a second launch")
-    p.add_argument("--gn-group", type=int, default=1, choices=[0, 1], help="A/B: 0 = GroupNorm always as three launches")
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--no-inclusive", action="store_true", help="skip the PCIe- / JPEG-inclusive legs")
     return p.parse_args()
@@ -306,8 +304,6 @@ def main():
     ctx.set_option(ctx.OPT_CLIP_LN_FOLD, args.clip_ln_fold)
     if not args.attn_kvres:
         ctx.lib.odise_hip_attn_kvres(0)
-    ctx.lib.odise_hip_splitk_fused(args.splitk_fused)
-    ctx.lib.odise_hip_gn_group(args.gn_group)
     if args.vae_chunk_mb is not None:
         ctx.set_option(ctx.OPT_VAE_CHUNK_BYTES, int(args.vae_chunk_mb * (1 << 20)))
     B = args.images if args.images is not None else (4 if args.stage == "full" else 1)

@@ -43,8 +43,7 @@ extern "C" int odise_hip_create(int device, odise_hip_ctx** out) {
     ODISE_CHECK_HIP(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
     c->own_stream = true;
     c->ws_bytes = (size_t)256 << 20;
-    ODISE_CHECK_HIP(hipMalloc(&c->ws, c->ws_bytes + ODISE_WS_TILE_COUNTERS * sizeof(int)));
-    ODISE_CHECK_HIP(hipMemset((char*)c->ws + c->ws_bytes, 0, ODISE_WS_TILE_COUNTERS * sizeof(int)));
+    ODISE_CHECK_HIP(hipMalloc(&c->ws, c->ws_bytes));
     ODISE_CHECK_HIP(hipMalloc(&c->zeros, 256));
     ODISE_CHECK_HIP(hipMemset(c->zeros, 0, 256));
     ODISE_CHECK_HIP(hipEventCreate(&c->ev0));

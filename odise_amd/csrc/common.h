@@ -36,10 +36,6 @@ void set_error(const char* fmt, ...);
         }                                                                                  \
     } while (0)
 
-// every split-K workspace (ctx->ws, ctx->ws2) is followed by this many zero-initialised int arrival counters (gemm.hip: the last block of a
-// tile folds the partials)
-#define ODISE_WS_TILE_COUNTERS 16384
-
 static inline int64_t ceil_div(int64_t a, int64_t b) { return (a + b - 1) / b; }
 static inline int64_t round_up(int64_t a, int64_t b) { return ceil_div(a, b) * b; }
 

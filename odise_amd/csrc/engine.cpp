@@ -50,8 +50,7 @@ int ensure_lane2(odise_hip_ctx* ctx, ModelStore* ms, size_t arena_bytes) {
         if (getenv("ODISE_LANE2_NORMAL_PRIORITY")) prio = lo;   // A/B
 #endif
         ODISE_CHECK_HIP(hipStreamCreateWithPriority(&ctx->stream2, hipStreamNonBlocking, prio));
-        ODISE_CHECK_HIP(hipMalloc(&ctx->ws2, ctx->ws_bytes + ODISE_WS_TILE_COUNTERS * sizeof(int)));
-        ODISE_CHECK_HIP(hipMemset((char*)ctx->ws2 + ctx->ws_bytes, 0, ODISE_WS_TILE_COUNTERS * sizeof(int)));
+        ODISE_CHECK_HIP(hipMalloc(&ctx->ws2, ctx->ws_bytes));
         ODISE_CHECK_HIP(hipEventCreateWithFlags(&ctx->ev_fork, hipEventDisableTiming));
         ODISE_CHECK_HIP(hipEventCreateWithFlags(&ctx->ev_mid, hipEventDisableTiming));
         ODISE_CHECK_HIP(hipEventCreateWithFlags(&ctx->ev_join, hipEventDisableTiming));

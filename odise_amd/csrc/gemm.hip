@@ -80,7 +80,6 @@ struct GemmArgs {
     int splitk;
     int ktiles_per_split;
     float* ws;
-    int* tile_counters;  // split-K: one arrival counter per output tile (zero between launches); null = the partials are folded by splitk_reduce_kernel
     const f16* zeros;  // >= 16 zero bytes (source of padded / out-of-range operand slots)
     int dbg;           // ablation switches (tools only): 1 = no operand DMA after the first tile, 2 = no fragment reads after the first
     int stats_blocks;  // out: row blocks per image of the fused GroupNorm statistics (0 = not produced, epi.gn_stats was cleared)
@@ -98,20 +97,6 @@ __device__ __forceinline__ void lds_barrier() {
 __device__ __forceinline__ void glds16(const void* gsrc, void* lds_base) {
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gsrc,
                                      (__attribute__((address_space(3))) void*)lds_base, 16, 0, 0);
-}
-
-// Split-K partials that another block of the same launch will read (fused fold, gemm_epilogue): device-scope relaxed atomics, i.e. stores that
-// write through and loads that are served at the device's coherence point (sc1) - the XCDs' private L2s are not coherent for plain accesses
-// within a kernel, and a release / acquire fence pair instead costs an L2 write-back + invalidate PER BLOCK (measured: +54 us per split-K GEMM
-// at one crop, 16.5 instead of 6.2 ms for the UNet).
-__device__ __forceinline__ void ws_store2(float* p, float a, float b) {
-    const unsigned long long v = (unsigned long long)__float_as_uint(a) | ((unsigned long long)__float_as_uint(b) << 32);
-    __hip_atomic_store(reinterpret_cast<unsigned long long*>(p), v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-__device__ __forceinline__ void ws_load2(const float* p, float& a, float& b) {
-    const unsigned long long v = __hip_atomic_load(reinterpret_cast<const unsigned long long*>(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    a = __uint_as_float((unsigned)v);
-    b = __uint_as_float((unsigned)(v >> 32));
 }
 
 // Applies the epilogue to 8 consecutive columns (n..n+7) of row m and stores them.
@@ -803,9 +788,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& g, f32x16 (&acc)[B
                 if (split) {
                     float* w = g.ws + ((int64_t)z * g.M + m) * g.N + n;
                     const int nv = (g.N - n) < 8 ? (g.N - n) : 8;
-                    if (g.tile_counters && (g.N & 1) == 0) {        // fused fold: coherent stores (ws_store2); N even keeps the pairs 8-byte aligned
-                        for (int i = 0; i + 1 < nv; i += 2) ws_store2(w + i, v[i], v[i + 1]);
-                    } else if (nv == 8 && (g.N & 3) == 0) {
+                    if (nv == 8 && (g.N & 3) == 0) {
                         *reinterpret_cast<float4*>(w) = t0;
                         *reinterpret_cast<float4*>(w + 4) = t1;
                     } else {
@@ -827,65 +810,6 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& g, f32x16 (&acc)[B
                 }
             }
         }
-    }
-    if (split && g.tile_counters) {
-        // ---- split-K fold without a second launch.  Every split of a tile has just written its fp32 partial; the block that arrives LAST at the
-        // tile's counter folds the `splitk` partials - in split order 0, 1, 2 ..., the order of splitk_reduce_kernel: the same bits - and runs
-        // the epilogue.  At one crop the UNet issues ~190 split-K GEMMs whose reduce kernels were a dependent launch each (~9 us of dispatch
-        // latency for a few microseconds of work).  Visibility across XCDs (private L2s): the partials are written and read with device-scope
-        // atomics (ws_store2 / ws_load2), the block barrier below drains every wave's stores (vmcnt) before thread 0 bumps the counter.
-        __syncthreads();
-        int* flag = reinterpret_cast<int*>(smem);
-        if (tid == 0) {
-            int* cnt = g.tile_counters + (int64_t)blockIdx.y * gridDim.x + blockIdx.x;
-            const int prev = atomicAdd(cnt, 1);
-            const int last = prev == g.splitk - 1;
-            if (last) *cnt = 0;            // ready for the next launch (stream order: no other block touches this counter any more)
-            *flag = last;
-        }
-        __syncthreads();
-        if (*flag == 0) return;
-        const float* ws = g.ws;
-        for (int c = tid; c < BM * CH; c += NT) {
-            const int rt = c / CH, c8 = c - rt * CH;
-            int m = m0 + rt;
-            if (HALO) {
-                const int patch = m0 / BM;
-                const int per_img = g.cg.halo_tx * g.cg.halo_ty;
-                const int img = patch / per_img, pr = patch - img * per_img;
-                const int oy = (pr / g.cg.halo_tx) * 16 + (rt >> 4), ox = (pr % g.cg.halo_tx) * 16 + (rt & 15);
-                m = (oy < g.cg.OH && ox < g.cg.OW) ? (img * g.cg.OH + oy) * g.cg.OW + ox : g.M;
-            }
-            const int n = n0 + c8 * 8;
-            if (m >= g.M || n >= g.N) continue;
-            const int nv = (g.N - n) < 8 ? (g.N - n) : 8;
-            float v[8];
-#pragma unroll
-            for (int i = 0; i < 8; ++i) v[i] = 0.f;
-            if (nv == 8) {
-                for (int s = 0; s < g.splitk; ++s) {
-                    const float* w = ws + ((int64_t)s * g.M + m) * g.N + n;
-                    float t[8];
-#pragma unroll
-                    for (int i = 0; i < 8; i += 2) ws_load2(w + i, t[i], t[i + 1]);
-#pragma unroll
-                    for (int i = 0; i < 8; ++i) v[i] += t[i];
-                }
-            } else {
-                for (int s = 0; s < g.splitk; ++s) {
-                    const float* w = ws + ((int64_t)s * g.M + m) * g.N + n;
-                    for (int i = 0; i + 1 < nv; i += 2) {
-                        float a, b;
-                        ws_load2(w + i, a, b);
-                        v[i] += a;
-                        v[i + 1] += b;
-                    }
-                }
-            }
-            if (g.epi.fast && n + 8 <= g.N) epi_fast8(g.epi, v, m, n, 0);
-            else epi_store8(g.epi, v, m, n, g.N, 0);
-        }
-        return;
     }
     if (stats) {
         constexpr int RL = NT / CH;  // row lanes per column chunk
@@ -2225,7 +2149,7 @@ static int launch_gemm_t(odise_hip_ctx* ctx, GemmArgs& g, int batch) {
     dim3 grid((unsigned)ceil_div(g.N, BN), (unsigned)ceil_div(g.M, BM), (unsigned)(g.splitk > 1 ? g.splitk : batch));
     hipLaunchKernelGGL(kern, grid, dim3(NT), lds, ctx->stream, g);
     ODISE_CHECK_HIP(hipGetLastError());
-    if (g.splitk > 1 && !g.tile_counters) {
+    if (g.splitk > 1) {
         const int64_t total = (int64_t)g.M * ceil_div(g.N, 8);
         const int blocks = (int)std::min<int64_t>(ceil_div(total, 256), 2048);
         hipLaunchKernelGGL(splitk_reduce_kernel, dim3(blocks), dim3(256), 0, ctx->stream, g.ws, g.splitk, g.M, g.N, g.epi);
@@ -2247,7 +2171,7 @@ static int launch_gemm_pp(odise_hip_ctx* ctx, GemmArgs& g, int batch) {
     dim3 grid((unsigned)ceil_div(g.N, BN), (unsigned)ceil_div(g.M, BM), (unsigned)(g.splitk > 1 ? g.splitk : batch));
     hipLaunchKernelGGL(kern, grid, dim3(512), lds, ctx->stream, g);
     ODISE_CHECK_HIP(hipGetLastError());
-    if (g.splitk > 1 && !g.tile_counters) {
+    if (g.splitk > 1) {
         const int64_t total = (int64_t)g.M * ceil_div(g.N, 8);
         const int blocks = (int)std::min<int64_t>(ceil_div(total, 256), 2048);
         hipLaunchKernelGGL(splitk_reduce_kernel, dim3(blocks), dim3(256), 0, ctx->stream, g.ws, g.splitk, g.M, g.N, g.epi);
@@ -2269,7 +2193,7 @@ static int launch_gemm_pp2(odise_hip_ctx* ctx, GemmArgs& g, int batch) {
     dim3 grid((unsigned)ceil_div(g.N, BN), (unsigned)ceil_div(g.M, BM), (unsigned)(g.splitk > 1 ? g.splitk : batch));
     hipLaunchKernelGGL(kern, grid, dim3(512), lds, ctx->stream, g);
     ODISE_CHECK_HIP(hipGetLastError());
-    if (g.splitk > 1 && !g.tile_counters) {
+    if (g.splitk > 1) {
         const int64_t total = (int64_t)g.M * ceil_div(g.N, 8);
         const int blocks = (int)std::min<int64_t>(ceil_div(total, 256), 2048);
         hipLaunchKernelGGL(splitk_reduce_kernel, dim3(blocks), dim3(256), 0, ctx->stream, g.ws, g.splitk, g.M, g.N, g.epi);
@@ -2292,7 +2216,7 @@ static int launch_conv3_halo(odise_hip_ctx* ctx, GemmArgs& g) {
     dim3 grid((unsigned)ceil_div(g.N, BN), (unsigned)(n_img * g.cg.halo_tx * g.cg.halo_ty), (unsigned)(g.splitk > 1 ? g.splitk : 1));
     hipLaunchKernelGGL(kern, grid, dim3(512), lds, ctx->stream, g);
     ODISE_CHECK_HIP(hipGetLastError());
-    if (g.splitk > 1 && !g.tile_counters) {
+    if (g.splitk > 1) {
         const int64_t total = (int64_t)g.M * ceil_div(g.N, 8);
         const int blocks = (int)std::min<int64_t>(ceil_div(total, 256), 2048);
         hipLaunchKernelGGL(splitk_reduce_kernel, dim3(blocks), dim3(256), 0, ctx->stream, g.ws, g.splitk, g.M, g.N, g.epi);
@@ -2316,7 +2240,7 @@ static int launch_conv3_halo4(odise_hip_ctx* ctx, GemmArgs& g) {
     dim3 grid((unsigned)ceil_div(g.N, BN), (unsigned)(n_img * g.cg.halo_tx * g.cg.halo_ty), (unsigned)(g.splitk > 1 ? g.splitk : 1));
     hipLaunchKernelGGL(kern, grid, dim3(256), lds, ctx->stream, g);
     ODISE_CHECK_HIP(hipGetLastError());
-    if (g.splitk > 1 && !g.tile_counters) {
+    if (g.splitk > 1) {
         const int64_t total = (int64_t)g.M * ceil_div(g.N, 8);
         const int blocks = (int)std::min<int64_t>(ceil_div(total, 256), 2048);
         hipLaunchKernelGGL(splitk_reduce_kernel, dim3(blocks), dim3(256), 0, ctx->stream, g.ws, g.splitk, g.M, g.N, g.epi);
@@ -2325,7 +2249,6 @@ static int launch_conv3_halo4(odise_hip_ctx* ctx, GemmArgs& g) {
     return ODISE_OK;
 }
 
-static int g_splitk_fused = 1;  // tools hook (odise_hip_splitk_fused): 0 = split-K partials are folded by splitk_reduce_kernel (a second launch), for A/B runs
 static int g_gemm_debug = 0;  // see GemmArgs::dbg
 static int g_epi_old = 0;     // tools only: 1 = keep the fp32-staged epilogue (odise_hip_gemm_debug bit 1 << 24), for same-process A/B runs
 static int g_conv_flags = 0;  // tools only: 1 = tap-major K order even when Cin % 64 == 0, 2 = never use the ping-pong kernel, 4 = one N-tile per phase at BN = 256
@@ -2338,7 +2261,6 @@ static int g_conv_flags = 0;  // tools only: 1 = tap-major K order even when Cin
 //  (profiles/r03_gemm4_two_blocks_dense.txt): two operand streams through LDS-DMA at half the tile size cost more than the overlap of
 //  neighbouring blocks returns, where the convolution's input patch is fetched once for nine K-tiles.  Not kept.)
 static const int kNumTiles = 10;
-static const int kTileCounters = ODISE_WS_TILE_COUNTERS;   // arrival counters behind each split-K workspace (common.h)
 static const int kTileBM[kNumTiles] = {128, 64, 64, 256, 256, 256, 512, 256, 256, 256};
 static const int kTileBN[kNumTiles] = {128, 128, 64, 320, 256, 128, 128, 256, 128, 128};
 
@@ -2481,13 +2403,6 @@ static int launch_gemm_select(odise_hip_ctx* ctx, GemmArgs& g, int batch, int fo
                 g.K, batch, g.cg.Cin, g.cg.KH, g.cg.H, g.cg.W, g.cg.stride, g.cg.ups, tile, best_split, (int)pp_ok);
     }
     g.ws = (float*)ctx->ws;
-    // split-K partials are folded by the last block of every tile (gemm_epilogue) unless the launch has more tiles than arrival counters
-    // (kTileCounters ints behind the workspace) or the tools build asks for the separate reduce kernel (ODISE_GEMM_FLAGS=4096, A/B)
-    g.tile_counters = nullptr;
-    if (g.splitk > 1 && !(flags & 4096) && g_splitk_fused) {
-        const int64_t tiles = ((tile >= 7 && tile <= 9) ? halo_patches : ceil_div(g.M, kTileBM[tile])) * ceil_div(g.N, kTileBN[tile]);
-        if (tiles <= kTileCounters && g.N % 2 == 0) g.tile_counters = (int*)((char*)ctx->ws + ctx->ws_bytes);
-    }
     {
         // epi_fast8 preconditions: every vector access of a full 8-column chunk is naturally aligned
         const GemmEpi& e = g.epi;
@@ -2662,7 +2577,6 @@ int group_norm_from_colpart(odise_hip_ctx* ctx, const void* x, void* y, const fl
 
 }  // namespace odise
 
-extern "C" int odise_hip_splitk_fused(int on) { odise::g_splitk_fused = on; return 0; }
 extern "C" int odise_hip_gemm_debug(int flags) {
     odise::g_gemm_debug = flags & 15;
     odise::g_conv_flags = (flags >> 4) & 0xfffff;

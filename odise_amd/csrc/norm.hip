@@ -228,117 +228,6 @@ __global__ void __launch_bounds__(256) gn_apply_kernel(const f16* __restrict__ x
     }
 }
 
-// ---- GroupNorm in ONE launch for small groups: grid (G, N), a block owns one (group, image) ---------------------------------------------------
-// The three-launch form above is built for tensors that fill the chip per pass; on the UNet's 61 GroupNorms at one crop (and the smaller
-// levels at any batch, the projection blocks, the VAE's 64^2 level) each launch is a few microseconds of work behind ~8 us of dependent
-// dispatch latency.  Here a block reads its group's HW x cpg elements (cpg = C / G channels, contiguous per pixel: cpg / 2 dwords) twice - the
-// second pass hits the L2 - folds (sum, sum of squares) in fp32 per thread, in fp64 across the block in a fixed order, and streams
-// act(x * scale + shift (+ residual)) (+ accum) out.  Deterministic (no atomics).  Statistics differ from the three-launch form by fp32
-// summation order only.
-__global__ void __launch_bounds__(256) gn_group_kernel(const f16* __restrict__ x, f16* __restrict__ y, const float* __restrict__ gamma,
-                                                      const float* __restrict__ beta, int HW, int C, int G, float eps, int act,
-                                                      const f16* __restrict__ residual, const f16* __restrict__ accum) {
-    __shared__ double red[2 * 256];
-    __shared__ float tab[2 * 128];           // per channel of the group: scale, shift (cpg <= 128)
-    const int gI = blockIdx.x, n = blockIdx.y, tid = threadIdx.x;
-    const int cpg = C / G, D = cpg >> 1;     // dwords (channel pairs) per pixel
-    const int total = HW * D;
-    const int64_t base = (int64_t)n * HW * C + (int64_t)gI * cpg;
-    const f16* xb = x + base;
-    typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
-    float s = 0.f, q = 0.f;
-    // eight independent 4-byte loads in flight per thread and sweep (idx -> pixel idx / D, channel pair idx % D); a one-load loop would pay an
-    // L2 round trip per element
-    constexpr int U = 8;
-    for (int i0 = tid; i0 < total; i0 += 256 * U) {
-        f16x2 v[U];
-#pragma unroll
-        for (int u = 0; u < U; ++u) {
-            const int idx = i0 + u * 256;
-            const int pp = idx / D, dd = idx - pp * D;
-            const f16x2 z = {(f16)0.f, (f16)0.f};
-            v[u] = z;
-            if (idx < total) v[u] = *reinterpret_cast<const f16x2*>(xb + (int64_t)pp * C + 2 * dd);
-        }
-#pragma unroll
-        for (int u = 0; u < U; ++u) {
-            const float a = (float)v[u][0], b = (float)v[u][1];
-            s += a + b;
-            q += a * a + b * b;
-        }
-    }
-    red[2 * tid] = (double)s;
-    red[2 * tid + 1] = (double)q;
-    __syncthreads();
-    for (int w = 128; w > 0; w >>= 1) {
-        if (tid < w) {
-            red[2 * tid] += red[2 * (tid + w)];
-            red[2 * tid + 1] += red[2 * (tid + w) + 1];
-        }
-        __syncthreads();
-    }
-    const double cnt = (double)HW * cpg;
-    const double mu = red[0] / cnt;
-    double var = red[1] / cnt - mu * mu;
-    if (var < 0.0) var = 0.0;
-    const float rs = (float)(1.0 / sqrt(var + (double)eps)), muf = (float)mu;
-    if (tid < cpg) {
-        const int c = gI * cpg + tid;
-        const float sc = rs * (gamma ? gamma[c] : 1.f);
-        tab[2 * tid] = sc;
-        tab[2 * tid + 1] = (beta ? beta[c] : 0.f) - muf * sc;
-    }
-    __syncthreads();
-    f16* yb = y + base;
-    const f16* rb = residual ? residual + base : nullptr;
-    const f16* ab = accum ? accum + base : nullptr;
-    for (int i0 = tid; i0 < total; i0 += 256 * U) {
-        f16x2 v[U], r[U], a2[U];
-        int64_t off[U];
-        int dd[U];
-#pragma unroll
-        for (int u = 0; u < U; ++u) {
-            const int idx = i0 + u * 256;
-            const int pp = idx / D;
-            dd[u] = idx - pp * D;
-            off[u] = (int64_t)pp * C + 2 * dd[u];
-            const f16x2 z = {(f16)0.f, (f16)0.f};
-            v[u] = r[u] = a2[u] = z;
-            if (idx < total) {
-                v[u] = *reinterpret_cast<const f16x2*>(xb + off[u]);
-                if (rb) r[u] = *reinterpret_cast<const f16x2*>(rb + off[u]);
-                if (ab) a2[u] = *reinterpret_cast<const f16x2*>(ab + off[u]);
-            }
-        }
-#pragma unroll
-        for (int u = 0; u < U; ++u) {
-            if (i0 + u * 256 >= total) break;
-            float t0 = (float)v[u][0] * tab[4 * dd[u]] + tab[4 * dd[u] + 1] + (float)r[u][0];
-            float t1 = (float)v[u][1] * tab[4 * dd[u] + 2] + tab[4 * dd[u] + 3] + (float)r[u][1];
-            if (act == ODISE_ACT_SILU) {
-                t0 = mul_sigmoid(t0, t0);
-                t1 = mul_sigmoid(t1, t1);
-            } else if (act != ODISE_ACT_NONE) {
-                t0 = act_apply(t0, act);
-                t1 = act_apply(t1, act);
-            }
-            const f16x2 o = {(f16)(t0 + (float)a2[u][0]), (f16)(t1 + (float)a2[u][1])};
-            *reinterpret_cast<f16x2*>(yb + off[u]) = o;
-        }
-    }
-}
-
-static int g_gn_group = 1;   // tools hook (odise_hip_gn_group): 0 = always the three-launch form (A/B)
-
-// the one-launch form pays where the passes are latency-bound: a group of at most 128 KiB, and enough (group, image) blocks to spread over the chip
-// or a tensor too small to matter
-static bool gn_group_ok(int N, int HW, int C, int groups) {
-    const int cpg = C / groups;
-    if (!g_gn_group || (cpg & 1) || cpg > 128 || cpg < 2) return false;
-    const int64_t group_bytes = (int64_t)HW * cpg * 2;
-    return group_bytes <= (128 << 10) && (int64_t)HW * (cpg / 2) < (1ll << 30);
-}
-
 // One wavefront handles R rows at a time (all R row loads are issued before the first reduction, for memory-level
 // parallelism); NV = 16-byte vectors per lane kept in registers (C <= 512*NV); x is read exactly once.
 template <int NV, int R>
@@ -441,12 +330,6 @@ extern "C" int odise_hip_group_norm_ex(odise_hip_ctx* ctx, const void* x, void* 
     ODISE_REQUIRE(C % groups == 0 && C % 8 == 0 && C <= GN_MAX_C, "group_norm: C=%d must be a multiple of 8 and of groups=%d, <= %d", C, groups, GN_MAX_C);
     ODISE_REQUIRE(groups <= 256, "group_norm: groups=%d > 256", groups);
     if (N == 0) return ODISE_OK;
-    if (gn_group_ok(N, HW, C, groups)) {
-        hipLaunchKernelGGL(gn_group_kernel, dim3(groups, N), dim3(256), 0, ctx->stream, (const f16*)x, (f16*)y, gamma, beta, HW, C, groups, eps, act,
-                           (const f16*)residual, (const f16*)accum);
-        ODISE_CHECK_HIP(hipGetLastError());
-        return ODISE_OK;
-    }
     const int V = C / 8;
     const int VW = V < 256 ? V : 256;
     const int PL = 256 / VW;
@@ -482,12 +365,6 @@ int group_norm_from_colpart(odise_hip_ctx* ctx, const void* x, void* y, const fl
     ODISE_REQUIRE(C % groups == 0 && C % 8 == 0 && C <= GN_MAX_C && groups <= 256, "group_norm: bad channel / group count");
     ODISE_REQUIRE((int64_t)HW * (C / 8) < (1ll << 31) - (1 << 24), "group_norm: image too large");
     ODISE_REQUIRE((size_t)N * groups * 2 * sizeof(float) <= ctx->ws_bytes, "group_norm: workspace too small");
-    if (gn_group_ok(N, HW, C, groups)) {   // small groups: one launch that re-derives the statistics beats finalize + apply (the conv's partial sums go unused)
-        hipLaunchKernelGGL(gn_group_kernel, dim3(groups, N), dim3(256), 0, ctx->stream, (const f16*)x, (f16*)y, gamma, beta, HW, C, groups, eps, act,
-                           (const f16*)nullptr, (const f16*)nullptr);
-        ODISE_CHECK_HIP(hipGetLastError());
-        return ODISE_OK;
-    }
     float* stats = (float*)ctx->ws;
     hipLaunchKernelGGL(gn_finalize_cols_kernel, dim3(groups, N), dim3(256), 0, ctx->stream, colpart, stats, HW, C, groups, nblk, eps);
     ODISE_CHECK_HIP(hipGetLastError());
@@ -499,8 +376,6 @@ int group_norm_from_colpart(odise_hip_ctx* ctx, const void* x, void* y, const fl
     return ODISE_OK;
 }
 }  // namespace odise
-
-extern "C" int odise_hip_gn_group(int on) { odise::g_gn_group = on; return 0; }
 
 extern "C" int odise_hip_layer_norm(odise_hip_ctx* ctx, const void* x, void* y, const float* gamma, const float* beta,
                                     int rows, int C, float eps) {

@@ -323,24 +323,17 @@ def test_conv_fused_upsample_residual_timeemb(ctx):
 # ---------------------------------------------------------------------------------------------------------------
 @pytest.mark.parametrize("N,HW,C,act", [(2, 64, 320, 1), (1, 4096, 320, 0), (3, 256, 128, 1), (1, 64, 2560, 1), (2, 1024, 960, 2),
                                         (1, 100, 512, 0), (2, 32768, 128, 1), (1, 16384, 512, 0), (16, 1024, 640, 1)])
-@pytest.mark.parametrize("form", ["default", "three launches"])
-def test_group_norm(ctx, N, HW, C, act, form):
-    """Groups of at most 128 KiB take the one-launch kernel (norm.hip gn_group_kernel), larger ones partial / finalize / apply; both forms on
-    every shape (tools hook odise_hip_gn_group)."""
+def test_group_norm(ctx, N, HW, C, act):
     g = torch.Generator().manual_seed(C + HW)
     x = h(torch.randn(N, HW, C, generator=g) * 2 + 0.5)
     gamma, beta = torch.randn(C, generator=g), torch.randn(C, generator=g)
     ref = F.group_norm(x.permute(0, 2, 1), 32, gamma, beta, eps=1e-5).permute(0, 2, 1)
     ref = {0: lambda t: t, 1: F.silu, 2: F.relu}[act](ref)
-    ctx.lib.odise_hip_gn_group(0 if form == "three launches" else 1)
-    try:
-        out = ctx.group_norm(ctx.to_device(x.half().numpy()), ctx.to_device(gamma), ctx.to_device(beta), 32, 1e-5, act).numpy()
-    finally:
-        ctx.lib.odise_hip_gn_group(1)
-    close(out, ref.numpy(), rtol=3e-3, what=f"group_norm C={C} ({form})")
+    out = ctx.group_norm(ctx.to_device(x.half().numpy()), ctx.to_device(gamma), ctx.to_device(beta), 32, 1e-5, act).numpy()
+    close(out, ref.numpy(), rtol=3e-3, what=f"group_norm C={C}")
 
 
-@pytest.mark.parametrize("HW,C", [(256, 256), (40000, 256)])      # the one-launch kernel / the three-launch form
+@pytest.mark.parametrize("HW,C", [(256, 256), (40000, 256)])
 def test_group_norm_residual_and_accumulate(ctx, HW, C):
     """odise_hip_group_norm_ex: y = relu(GroupNorm(x) + residual) + accum (the BottleneckBlock tails of the tap projections)."""
     import ctypes as C_
