@@ -289,8 +289,8 @@ __global__ void __launch_bounds__(256) attn_kernel(AttnArgs a) {
 constexpr int KVR_LKP = 608;             // keys held (19 tiles of 32)
 constexpr int KVR_VROW = KVR_LKP + 4;    // halves per V^T row
 constexpr int KVR_LDS = KVR_LKP * 64 * 2 + 64 * KVR_VROW * 2;
-constexpr int KVR_WAVES = 8;
 
+template <int KVR_WAVES>
 __global__ void __launch_bounds__(64 * KVR_WAVES) attn_kvres_kernel(AttnArgs a, int qsplit) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     f16* Ks = reinterpret_cast<f16*>(smem);                            // [608][64], slot-swizzled
@@ -470,7 +470,7 @@ __global__ void __launch_bounds__(64 * KVR_WAVES) attn_kvres_kernel(AttnArgs a, 
     }
 }
 
-static int g_attn_kvres = 1;   // tools hook (odise_hip_attn_kvres): 0 = never take the K/V-resident kernel (A/B against the tiled one)
+static int g_attn_kvres = 1;   // tools hook (odise_hip_attn_kvres): 0 = never take the K/V-resident kernel (A/B against the tiled one); 8 / 12 / 16 = waves per block (1 = default)
 
 // Taken where one block per (head, image) - or a whole number of query splits of it - fills the chip in (nearly) whole rounds: 16 crops x 16
 // heads = 256 pairs = one round.  288 pairs (18 crops) would run two rounds for 1.125 of work, and a pair split over few blocks pays the
@@ -483,10 +483,11 @@ static bool attn_kvres_ok(const AttnArgs& a, int cus) {
     return ceil(rounds) / rounds <= 1.07;
 }
 
+template <int KVR_WAVES>
 static int launch_attn_kvres(odise_hip_ctx* ctx, AttnArgs& a) {
     static bool attr_set = false;
     if (!attr_set) {
-        ODISE_CHECK_HIP(hipFuncSetAttribute((const void*)attn_kvres_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, KVR_LDS));
+        ODISE_CHECK_HIP(hipFuncSetAttribute((const void*)attn_kvres_kernel<KVR_WAVES>, hipFuncAttributeMaxDynamicSharedMemorySize, KVR_LDS));
         attr_set = true;
     }
     // one block per (head, image) when those fill the chip; otherwise the query tiles of a pair are split so that every CU gets a block
@@ -497,7 +498,7 @@ static int launch_attn_kvres(odise_hip_ctx* ctx, AttnArgs& a) {
     a.nsplit = 1;
     a.part = nullptr;
     dim3 grid((unsigned)qsplit, (unsigned)a.H, (unsigned)a.B);
-    hipLaunchKernelGGL(attn_kvres_kernel, grid, dim3(64 * KVR_WAVES), KVR_LDS, ctx->stream, a, qsplit);
+    hipLaunchKernelGGL(attn_kvres_kernel<KVR_WAVES>, grid, dim3(64 * KVR_WAVES), KVR_LDS, ctx->stream, a, qsplit);
     ODISE_CHECK_HIP(hipGetLastError());
     return ODISE_OK;
 }
@@ -589,7 +590,11 @@ extern "C" int odise_hip_attention(odise_hip_ctx* ctx, const odise_attn_desc* d)
     a.mask = d->mask; a.ldmask = d->ldmask; a.strideMask = d->strideMask;
     a.scale_log2e = d->scale * 1.4426950408889634f;
     const int D = d->D;
-    if (attn_kvres_ok(a, ctx->cu_count)) return launch_attn_kvres(ctx, a);
+    if (attn_kvres_ok(a, ctx->cu_count)) {
+        if (g_attn_kvres == 12) return launch_attn_kvres<12>(ctx, a);
+        if (g_attn_kvres == 16) return launch_attn_kvres<16>(ctx, a);
+        return launch_attn_kvres<8>(ctx, a);
+    }
     if (D <= 32) return launch_attn<32>(ctx, a);
     if (D <= 48) return launch_attn<48>(ctx, a);
     if (D <= 64) return launch_attn<64>(ctx, a);

@@ -420,9 +420,10 @@ def test_attention_masked_and_spiked(ctx, Lk):
                                               (16, 16, 677, 577, True),      # MaskCLIP's shape on 16 pictures: 100 mask tokens after the image tokens, u8 visibility
                                               (32, 8, 300, 608, True), (16, 16, 1200, 257, False),   # the key-count limits of the resident form
                                               (2, 16, 577, 577, False), (4, 16, 677, 577, True)])    # too few (head, image) pairs: these stay on the tiled kernel
-def test_attention_kv_resident(ctx, B, H, Lq, Lk, masked):
-    """d_head 64 with <= 608 keys runs the K/V-resident kernel (attn.hip attn_kvres_kernel): against fp32 torch, and against the tiled kernel
-    on the same inputs (tools hook odise_hip_attn_kvres)."""
+@pytest.mark.parametrize("waves", [8, 12, 16])
+def test_attention_kv_resident(ctx, B, H, Lq, Lk, masked, waves):
+    """d_head 64 with <= 608 keys and enough (head, image) pairs runs the K/V-resident kernel (attn.hip attn_kvres_kernel; 8 / 12 / 16 waves per
+    block are instantiated): against fp32 torch, and against the tiled kernel on the same inputs (tools hook odise_hip_attn_kvres)."""
     g = torch.Generator().manual_seed(B * 1000 + Lq + Lk)
     D = 64
     HD = H * D
@@ -447,6 +448,7 @@ def test_attention_kv_resident(ctx, B, H, Lq, Lk, masked):
     ref = (torch.nan_to_num(torch.softmax(s, -1), nan=0.0) @ v).transpose(1, 2).reshape(B, Lq, HD)
     ldvt = (Lk + 7) // 8 * 8
     dq, dk, dv = ctx.to_device(Q.half().numpy()), ctx.to_device(K.half().numpy()), ctx.to_device(_vt(V.half().numpy(), ldvt))
+    ctx.lib.odise_hip_attn_kvres(waves)
     out = ctx.attention(dq, dk, dv, H, scale, mask=dm, Lk=Lk).numpy()
     close(out, ref.numpy(), rtol=5e-3, atol=3e-3, what=f"kv-resident attention B{B} H{H} Lq{Lq} Lk{Lk} masked={masked}")
     ctx.lib.odise_hip_attn_kvres(0)

@@ -29,7 +29,7 @@ def main():
         o = ctx.empty((B, Lq, HD), np.float16)
         flops = 4.0 * B * H * Lq * Lk * D
         line = f"{name:38s} B={B:2d} Lq={Lq} Lk={Lk}:"
-        for on in (1, 0):
+        for on in (8, 12, 16, 0):
             ctx.lib.odise_hip_attn_kvres(on)
             for _ in range(5):
                 ctx.attention(q, k, vt, H, D ** -0.5, mask=m, Lk=Lk, out=o)
@@ -38,7 +38,7 @@ def main():
             for _ in range(reps):
                 ctx.attention(q, k, vt, H, D ** -0.5, mask=m, Lk=Lk, out=o)
             us = ctx.timer_stop() / reps * 1e3
-            line += f"  {'kv-resident' if on else 'tiled'} {us:7.1f} us = {flops / us / 1e6:6.1f} TFLOP/s"
+            line += f"  {('kv-resident/' + str(on) + ' waves') if on else 'tiled'} {us:7.1f} us = {flops / us / 1e6:6.1f} TFLOP/s"
         ctx.lib.odise_hip_attn_kvres(1)
         print(line, flush=True)
 
