@@ -277,7 +277,7 @@ __global__ void __launch_bounds__(256) attn_kernel(AttnArgs a) {
 // ---- keys and values resident in LDS (CLIP ViT-L/14@336: 577 keys, d_head 64) -------------------------------------------------------------
 // The tiled kernel above restages every 64-key K / V^T tile once per 128-query block (5 times per head for 577 queries, two barriers per
 // tile) and rounds both 577s up to 640.  Here ONE block owns a (head, image): K (608 x 64, 16-byte slots XOR-swizzled) and V^T (64 x 612)
-// of that head are loaded into LDS once - 156 160 of the CU's 163 840 bytes - and after a single barrier the block's 8 waves walk their
+// of that head are loaded into LDS once - 156 160 of the CU's 163 840 bytes - and after a single barrier the block's 16 waves walk their
 // 32-query tiles over 19 key tiles of 32 straight out of LDS: no further barrier, no restaging, 608 keys instead of 640.  16 crops x 16
 // heads = 256 blocks = one per CU; with fewer (head, image) pairs (MaskCLIP: 4 pictures) the query tiles of a pair are split over
 // `qsplit` blocks, each loading the pair's K / V^T (L2 hits).  Same arithmetic per score as the tiled kernel (fp32 scale + running max,
@@ -470,7 +470,7 @@ __global__ void __launch_bounds__(64 * KVR_WAVES) attn_kvres_kernel(AttnArgs a, 
     }
 }
 
-static int g_attn_kvres = 1;   // tools hook (odise_hip_attn_kvres): 0 = never take the K/V-resident kernel (A/B against the tiled one); 8 / 12 / 16 = waves per block (1 = default)
+static int g_attn_kvres = 1;   // tools hook (odise_hip_attn_kvres): 0 = never take the K/V-resident kernel (A/B against the tiled one); 8 / 12 / 16 = waves per block (1 = the default, 16)
 
 // Taken where one block per (head, image) - or a whole number of query splits of it - fills the chip in (nearly) whole rounds: 16 crops x 16
 // heads = 256 pairs = one round.  288 pairs (18 crops) would run two rounds for 1.125 of work, and a pair split over few blocks pays the
@@ -591,9 +591,11 @@ extern "C" int odise_hip_attention(odise_hip_ctx* ctx, const odise_attn_desc* d)
     a.scale_log2e = d->scale * 1.4426950408889634f;
     const int D = d->D;
     if (attn_kvres_ok(a, ctx->cu_count)) {
+        // 16 waves (four per SIMD) measured best: 48.1 us against 52.2 (8 waves), 51.4 (12) and 54.4 (tiled kernel) on the 16-crop tower, 91.1 against
+        // 96.6 (tiled) on 32 crops (tools/attn_bench.py, profiles/r04_attention_kv_resident.txt)
         if (g_attn_kvres == 12) return launch_attn_kvres<12>(ctx, a);
-        if (g_attn_kvres == 16) return launch_attn_kvres<16>(ctx, a);
-        return launch_attn_kvres<8>(ctx, a);
+        if (g_attn_kvres == 8) return launch_attn_kvres<8>(ctx, a);
+        return launch_attn_kvres<16>(ctx, a);
     }
     if (D <= 32) return launch_attn<32>(ctx, a);
     if (D <= 48) return launch_attn<48>(ctx, a);

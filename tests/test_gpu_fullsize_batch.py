@@ -35,10 +35,23 @@ PAIR_PROB = 0.2             # a query re-decided in one of the two runs moves by
 PAIR_PROB_SAME_FORM = 0.2
 PAIR_SEM = 0.2
 PAIR_LABELS = 96            # ... so the pair is held to: at least this many of the 100 labels identical, panoptic map > 99.5 % equal
-ELOGIT = 5e-3               # mask-logit error as a fraction of max|logit| assumed by segments_decided (measured: 99.9 % of the pixels below 6.6e-3, tests/test_gpu_fullsize.py)
+ELOGIT = 5e-3               # mask-logit error as a fraction of max|logit| assumed by segments_decided where the device logits are not at hand
+TAU_MASK = 2.5e-2           # a query whose worst mask-logit error exceeds this was re-decided (tests/test_gpu_fullsize.py)
+MAX_MASK_REDECIDED = 5      # per picture, as in test_mask_iou_contract_at_output_resolution
 
 
-def _segments_strict(i, cls_got, r, k, things, size, overlap_threshold=0.8):
+def _mask_errors(hip, refs, size):
+    """Mask logits of the LAST call (the head is re-run on the backbone maps still in the arena: same kernels, same inputs, same bits) against
+    the oracle's, per picture and query: worst-pixel error as a fraction of the picture's max |logit|.  -> [B, Q]"""
+    pm = hip.head_device(None, len(refs), size // 4, size // 4)[0].numpy()
+    out = []
+    for i, (_, r) in enumerate(refs):
+        ref = r["pred_masks"][0].numpy()
+        out.append(np.abs(pm[i] - ref).reshape(ref.shape[0], -1).max(-1) / np.abs(ref).max())
+    return np.stack(out)
+
+
+def _segments_strict(i, cls_got, r, k, things, size, overlap_threshold=0.8, elogit_rel=None):
     """Picture 0 carries the vocabulary (its decisions are spread by construction) and is always held to `segments_info == reference`; the
     other pictures where the reference's own table is fixed by its margins at the error measured on that picture (margins.segments_decided)."""
     if i == 0:
@@ -46,7 +59,8 @@ def _segments_strict(i, cls_got, r, k, things, size, overlap_threshold=0.8):
     ref_lp = r["mask_cls"][0].numpy()
     eprob = np.abs(np.exp(np.asarray(cls_got, np.float64)) - np.exp(ref_lp.astype(np.float64))).max(-1)
     up = upsampled_reference_logits(r["pred_masks"][0], (size, size), (size, size), (size, size))
-    elogit = np.full(len(eprob), ELOGIT * float(r["pred_masks"].abs().max()))
+    scale = float(r["pred_masks"].abs().max())
+    elogit = np.full(len(eprob), ELOGIT * scale) if elogit_rel is None else np.asarray(elogit_rel, np.float64) * scale
     decided, differ = segments_decided(ref_lp, up, k, things, eprob, elogit, overlap_threshold)
     print(f"picture {i}: the oracle's segments_info under 6 perturbations inside the measured error: {differ} differ -> {'strict' if decided else 'reported only'}")
     return decided
@@ -92,13 +106,17 @@ def test_batch_of_four_1024_matches_oracle_and_single_runs(ctx, fullsize_model):
     imgs = [r[0] for r in refs]
     assert ctx.get_option(ctx.OPT_CLIP_LN_FOLD) == 0, "the library's own rule must decide the LayerNorm form"
     batch, cls_b, log_b = _run(ctx, hip, imgs, 1024, log=True)
+    merr = _mask_errors(hip, refs, 1024)
     # ---- every picture of the batch against ITS oracle pass
     strict = []
     for i, (img, r) in enumerate(refs):
+        regular = merr[i] < TAU_MASK
+        print(f"batch of 4, picture {i}: mask logits within {TAU_MASK} of max|logit| on {int(regular.sum())}/100 queries (worst {merr[i].max():.3e}, median {np.median(merr[i]):.2e})")
+        assert regular.sum() >= 100 - MAX_MASK_REDECIDED and merr[i].max() < 8e-2, (i, int(regular.sum()), float(merr[i].max()))
         perr = class_probability_contract(cls_b[i], r["mask_cls"][0].numpy(), k, tag=f"batch of 4, picture {i}:")
         ref = om.postprocess(r["mask_cls"], r["pred_masks"], (1024, 1024), [(1024, 1024)], [(1024, 1024)], k, things, 0.8)[0]
-        strict.append(_segments_strict(i, cls_b[i], r, k, things, 1024))
-        end_to_end_contract(batch[i], ref, r["mask_cls"], k, things, tag=f"batch of 4, picture {i}:", segments_strict=strict[i], perr=perr)
+        strict.append(_segments_strict(i, cls_b[i], r, k, things, 1024, elogit_rel=merr[i]))
+        end_to_end_contract(batch[i], ref, r["mask_cls"], k, things, tag=f"batch of 4, picture {i}:", segments_strict=strict[i], perr=perr, mask_regular=regular)
     # two device runs of a picture whose segment table the reference's margins do not fix may disagree on a whole segment
     pan_floor = [0.995 if st else 0.95 for st in strict]
     # ---- batched against alone, default forms (picture by picture: the host copies are ~1 GB each)

@@ -147,7 +147,7 @@ def test_gemm_epilogues(ctx, tile, split):
         close(out, fn(base * sm[:, None]).numpy(), what=f"act{act}")
 
 
-@pytest.mark.parametrize("M", [584, 2336])
+@pytest.mark.parametrize("M", [584, 2336, 33280])   # 33280 rows = 520 tiles > 2 x 256 CUs: the first-generation ping-pong kernel carries the fold there (MaskCLIP from 13 pictures, 57 crops)
 def test_gemm_chain_with_folded_layer_norm(ctx, M):
     """The CLIP tower's GEMM chain without LayerNorm kernels (extractor.cpp clip_tower, common.h LnEpi): the GEMM that writes the residual stream
     leaves per-row partial sums, the next GEMMs read the raw stream with the affine folded into their weights - against LayerNorm + GEMM in fp32

@@ -1,19 +1,30 @@
 #!/bin/bash
 # Round evidence from the tree's built libraries, one GPU box, one pass (run through gpurun): GPU test suite, smoke, the bench lines of the five
-# configurations, kernel trace by shape + lane timeline, GEMM efficiency by shape, HBM counters.  Output under gpurun_out/final/ (copied into profiles/).
+# configurations, stage timelines, kernel trace by shape + lane timeline, GEMM efficiency by shape, HBM counters, the reference's calling conventions.
+# Output under gpurun_out/final/ (copied into profiles/ as rNN_*).
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 O=gpurun_out/final; rm -rf $O; mkdir -p $O
 T=$PWD/odise_amd/lib/libodise_hip_tools.so
 python -m pytest tests -m gpu -q -x > $O/pytest_gpu.log 2>&1; echo "pytest rc=$?" > $O/rc.txt
 python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" > $O/smoke.log 2>&1; echo "smoke rc=$?" >> $O/rc.txt
+rocm-smi --showclocks --showpower --showtemp --showperflevel > $O/smi_before.txt 2>&1
 python bench.py > $O/bench_full_b4_1024.json 2> $O/bench_full.err; echo "bench rc=$?" >> $O/rc.txt
+python bench.py --steps 20 --warmup 3 --no-cpu-baseline --no-inclusive > $O/bench_full_b4_1024_steps20.json 2> $O/bench_full20.err
 python bench.py --stage unet --images 1 > $O/bench_unet_b1.json 2> $O/bench_unet_b1.err
 python bench.py --stage unet --images 4 --no-cpu-baseline > $O/bench_unet_b4.json 2> $O/bench_unet_b4.err
 python bench.py --stage unet --images 16 --no-cpu-baseline > $O/bench_unet_b16.json 2> $O/bench_unet_b16.err
 python bench.py --vocab ade150 --images 8 --no-cpu-baseline --no-inclusive > $O/bench_ade150_b8_1024.json 2> $O/bench_ade150.err
 python bench.py --vocab ade847 --size 1280 --images 2 --semantic-only --no-cpu-baseline --no-inclusive > $O/bench_ade847_b2_1280_semantic.json 2> $O/bench_ade847.err
-python bench.py --in-flight 3 --steps 12 --no-cpu-baseline --no-inclusive > $O/bench_full_b4_1024_in_flight3.json 2> $O/bench_inflight.err
+python bench.py --in-flight 2 --steps 12 --no-cpu-baseline --no-inclusive > $O/bench_full_b4_1024_in_flight2.json 2> $O/bench_inflight.err
+python bench.py --steps 10 --warmup 2 --no-cpu-baseline --no-inclusive --attn-kvres 0 > $O/bench_full_b4_1024_tiled_attention.json 2> $O/bench_tiled_attn.err
 echo "bench lines done" >> $O/rc.txt
+python tools/stage_timeline.py --lanes 2 > $O/stage_timeline_2lanes.txt 2>&1
+python tools/stage_timeline.py --lanes 1 > $O/stage_timeline_1lane.txt 2>&1
+python tools/attn_bench.py 50 > $O/attn_bench.txt 2>&1
+python tools/replay.py eval --iters 12 > $O/replay_eval.txt 2>&1
+python tools/replay.py overlay --iters 12 > $O/replay_overlay.txt 2>&1
+python tools/replay.py demo > $O/replay_demo.txt 2>&1
+echo "timelines + replay done" >> $O/rc.txt
 rocprofv3 --kernel-trace -d $O/prof -o bench -- python bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-inclusive > $O/prof_bench.json 2> $O/prof.err
 python tools/db_by_shape.py $O/prof/bench_results.db marker 60 > $O/bench_full_by_shape.txt 2>&1
 python tools/lane_timeline.py $O/prof/bench_results.db > $O/lane_timeline.txt 2>&1
@@ -26,10 +37,11 @@ for c in FETCH_SIZE WRITE_SIZE; do
 done
 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d $O/conv_mfma -o c -- python tools/one_conv.py -1 5 16 128 512 512 > $O/conv_mfma.log 2>&1
 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d $O/conv128_mfma -o c -- python tools/one_conv.py -1 5 16 512 128 128 > $O/conv128_mfma.log 2>&1
-python tools/pmc_summary.py $O/pmc_FETCH_SIZE/b_counter_collection.csv $O/pmc_WRITE_SIZE/b_counter_collection.csv $O/hbm_bound_kernels.json msda_forward gn_apply postprocess_pixels instance_masks layer_norm semantic > $O/hbm_bound_kernels.txt 2>&1
+python tools/pmc_summary.py $O/pmc_FETCH_SIZE/b_counter_collection.csv $O/pmc_WRITE_SIZE/b_counter_collection.csv $O/hbm_bound_kernels.json msda_forward gn_apply postprocess_pixels instance_masks layer_norm semantic attn_kvres > $O/hbm_bound_kernels.txt 2>&1
 for d in conv_FETCH_SIZE conv_WRITE_SIZE conv_mfma conv128_mfma; do echo "== $d"; python tools/pmc_avg.py $O/$d/c_counter_collection.csv conv3_halo; done > $O/conv_pmc.txt 2>&1
+python tools/conv_traffic_json.py $O/conv_pmc.txt $O/dominant_conv_traffic.json 16 > /dev/null 2> $O/conv_traffic.err
 echo "pmc done" >> $O/rc.txt
 # keep the merge small: the raw traces stay on the box
-rm -rf $O/eff $O/pmc_FETCH_SIZE $O/pmc_WRITE_SIZE $O/conv_FETCH_SIZE $O/conv_WRITE_SIZE $O/conv_mfma $O/conv128_mfma
+rm -rf $O/eff $O/prof $O/pmc_FETCH_SIZE $O/pmc_WRITE_SIZE $O/conv_FETCH_SIZE $O/conv_WRITE_SIZE $O/conv_mfma $O/conv128_mfma
 cat $O/rc.txt; tail -3 $O/pytest_gpu.log; for f in $O/bench_*.json; do python -c "import json,sys; d=json.load(open('$f')); print('$f', round(d['ms_per_step'],2), round(d['value'],2), d['unit'], d.get('roofline',{}).get('frac'))"; done
-tail -5 $O/lane_timeline.txt; cat $O/hbm_bound_kernels.txt | head -20; cat $O/conv_pmc.txt
+head -3 $O/lane_timeline.txt; tail -2 $O/replay_eval.txt $O/replay_overlay.txt; cat $O/conv_pmc.txt
