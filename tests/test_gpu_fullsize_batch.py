@@ -35,6 +35,17 @@ PAIR_PROB = 0.2             # a query re-decided in one of the two runs moves by
 PAIR_PROB_SAME_FORM = 0.2
 PAIR_SEM = 0.2
 PAIR_LABELS = 96            # ... so the pair is held to: at least this many of the 100 labels identical, panoptic map > 99.5 % equal
+
+
+def _pair_panoptic_ok(rep, strict):
+    """Two device runs of one picture: where the reference's margins fix the segment table (strict) the tables must be identical and the maps
+    > 99.5 % equal; elsewhere the two runs may settle on different tables (a segment next to the 0.8 overlap threshold appears in one of
+    them) - then the maps differ by that segment's area, which is reported and only sanity-bounded."""
+    if rep["segments_same"]:
+        return rep["panoptic_same"] > 0.995
+    return (not strict) and rep["panoptic_same"] > 0.8
+
+
 ELOGIT = 5e-3               # mask-logit error as a fraction of max|logit| assumed by segments_decided where the device logits are not at hand
 TAU_MASK = 2.5e-2           # a query whose worst mask-logit error exceeds this was re-decided (tests/test_gpu_fullsize.py)
 MAX_MASK_REDECIDED = 5      # per picture, as in test_mask_iou_contract_at_output_resolution
@@ -117,15 +128,14 @@ def test_batch_of_four_1024_matches_oracle_and_single_runs(ctx, fullsize_model):
         ref = om.postprocess(r["mask_cls"], r["pred_masks"], (1024, 1024), [(1024, 1024)], [(1024, 1024)], k, things, 0.8)[0]
         strict.append(_segments_strict(i, cls_b[i], r, k, things, 1024, elogit_rel=merr[i]))
         end_to_end_contract(batch[i], ref, r["mask_cls"], k, things, tag=f"batch of 4, picture {i}:", segments_strict=strict[i], perr=perr, mask_regular=regular)
-    # two device runs of a picture whose segment table the reference's margins do not fix may disagree on a whole segment
-    pan_floor = [0.995 if st else 0.95 for st in strict]
+
     # ---- batched against alone, default forms (picture by picture: the host copies are ~1 GB each)
     log_1 = None
     for i, img in enumerate(imgs):
         alone, cls_1, rec = _run(ctx, hip, [img], 1024, log=(i == 0))
         log_1 = rec if rec is not None else log_1
         rep = device_pair_report(batch[i], alone[0], cls_b[i], cls_1[0], k, tag=f"picture {i} in the batch of 4 vs alone (library defaults):")
-        assert rep["prob"] < PAIR_PROB and rep["sem"] < PAIR_SEM and rep["labels_same"] >= PAIR_LABELS and rep["panoptic_same"] > pan_floor[i] and rep["sem_argmax_same"] > 0.99, rep
+        assert rep["prob"] < PAIR_PROB and rep["sem"] < PAIR_SEM and rep["labels_same"] >= PAIR_LABELS and _pair_panoptic_ok(rep, strict[i]) and rep["sem_argmax_same"] > 0.99, rep
         assert rep["instances"][2] >= 0.9 * max(rep["instances"][0], 1), rep
         del alone
     launch_choice_diff(log_b, 16, log_1, 4)
@@ -146,7 +156,7 @@ def test_batch_of_four_1024_matches_oracle_and_single_runs(ctx, fullsize_model):
         ctx.set_option(ctx.OPT_VAE_CHUNK_BYTES, 0)
     for i in range(len(imgs)):
         rep = device_pair_report(batch[i], batch_c[i], cls_b[i], cls_c[i], k, tag=f"picture {i}: batch of 4 with the VAE in 64 MiB crop chunks vs all crops per launch:")
-        assert rep["prob"] < PAIR_PROB and rep["labels_same"] >= PAIR_LABELS and rep["panoptic_same"] > pan_floor[i], rep
+        assert rep["prob"] < PAIR_PROB and rep["labels_same"] >= PAIR_LABELS and _pair_panoptic_ok(rep, strict[i]), rep
     # (pinning the fold also folds MaskCLIP's 2.7k-token tower, which the default rule leaves on LayerNorm kernels: the pinned batch is not the default batch)
     print("batch of 4, default forms vs fold pinned: class probability difference", float(np.abs(np.exp(cls_bf) - np.exp(cls_b)).max()))
 
@@ -176,9 +186,8 @@ def test_batch_of_eight_1024_ade150(ctx, fullsize_model):
         for i, img in enumerate(imgs):
             alone, cls_1, _ = _run(ctx, hip, [img], 1024)
             rep = device_pair_report(batch[i], alone[0], cls_b[i], cls_1[0], k, tag=f"picture {i} in the batch of 8 vs alone (library defaults):")
-            # pictures 4-7 have no oracle pass: their segment tables are held to the looser floor, like the pictures the margins leave undecided
-            floor = 0.995 if (i < 4 and i not in undecided) else 0.95
-            assert rep["prob"] < PAIR_PROB and rep["labels_same"] >= PAIR_LABELS and rep["panoptic_same"] > floor, rep
+            # pictures 4-7 have no oracle pass: treated like the pictures whose table the margins leave undecided
+            assert rep["prob"] < PAIR_PROB and rep["labels_same"] >= PAIR_LABELS and _pair_panoptic_ok(rep, i < 4 and i not in undecided), rep
             assert rep["instances"][2] >= 0.9 * max(rep["instances"][0], 1), rep
     finally:
         hip.semantic_on = True
