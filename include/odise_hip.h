@@ -71,7 +71,7 @@ enum { ODISE_OPT_CLIP_LN_FOLD = 1, ODISE_OPT_VAE_CHUNK_BYTES = 2 };
 int odise_hip_set_option(odise_hip_ctx* ctx, int option, int64_t value);
 int odise_hip_get_option(odise_hip_ctx* ctx, int option, int64_t* value);
 /* Launch probe (measurement, bench.py's `roofline`): HIP events around every launch of ONE shape - conv != 0: the implicit GEMM of a convolution
- * with M = N*OH*OW output pixels, N = Cout, K = KH*KW*Cin; conv = 0: odise_hip_gemm's M, N, K - recorded on whichever stream the library
+ * with M = N*OH*OW output pixels, N = Cout, K = KH*KW*Cin (convolutions with the fused 2x upsample are not matched); conv = 0: odise_hip_gemm's M, N, K - recorded on whichever stream the library
  * launches it on, for the next max_launches matching launches.  odise_hip_probe_read waits for the recorded launches, writes their durations
  * in microseconds (at most cap) and the number recorded, and disarms the probe. */
 int odise_hip_probe_arm(odise_hip_ctx* ctx, int conv, int M, int N, int K, int max_launches);

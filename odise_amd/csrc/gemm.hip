@@ -2323,6 +2323,7 @@ static int launch_gemm_select(odise_hip_ctx* ctx, GemmArgs& g, int batch, int fo
 template <bool CONV>
 static int launch_gemm(odise_hip_ctx* ctx, GemmArgs& g, int batch, int force_tile, int force_split, unsigned tile_mask = ~0u) {
     LaunchProbe* pr = probe_match(ctx, CONV, g.M, g.N, g.K);
+    if (pr && CONV && g.cg.ups) pr = nullptr;   // a convolution with the fused nearest-2x upsample has the same (M, N, K) and runs another kernel: not the probed shape
     if (!pr) return launch_gemm_select<CONV>(ctx, g, batch, force_tile, force_split, tile_mask);
     const int i = pr->n++;
     ODISE_CHECK_HIP(hipEventRecord(pr->ev[2 * i], ctx->stream));
