@@ -14,7 +14,7 @@ The classes are `torch.nn.Module`s that only HOLD state: parameters with the ref
 wrappers swap (`test_labels`, `metadata`, `num_classes`, ...).  `forward` hands device pointers to the C ABI; on the fused path
 (`CategoryODISE.forward` -> `odise_hip_infer`) nothing is computed by PyTorch.  Two classes, when called STAND-ALONE, finish small host-side
 arithmetic in torch on CPU tensors: `PoolingCLIPHead.forward` (cosine logits of 100 x K embeddings and the geometric ensemble, after the
-library's MaskCLIP tower) and `PooledMaskEmbed.forward` (re-uploads its few weights per call); the fused model does the same arithmetic in
+library's MaskCLIP tower) and `PooledMaskEmbed.forward` (its few weights are uploaded once per parameter version); the fused model does the same arithmetic in
 `odise_hip_classify` / `odise_hip_head_forward`.  Frozen Stable-Diffusion / CLIP weights never enter a state dict (as in the reference, helper.py:35-46): they come from the
 checkpoint files named by `init_checkpoint` / `clip_model_name` through odise_amd.checkpoint, or from `set_frozen_state` (tests,
 synthetic benchmarks).  One process drives one GPU through one library context (`get_context`).

@@ -82,13 +82,27 @@ class PooledMaskEmbed(nn.Module):
         self.logit_scale = nn.Parameter(torch.ones([]) * np.log(1 / temperature))
         self.mask_pooling = MaskPooling()
 
-    def _linear(self, ctx, x, lin, act=0, residual=None):
-        w = ctx.to_device(_np(lin.weight).astype(np.float16))
-        b = ctx.to_device(_np(lin.bias).astype(np.float32)) if lin.bias is not None else None
-        return ctx.gemm(x, w, bias_n=b, act=act, residual=residual)
+    def _device_weights(self, ctx):
+        """The module's few weights on the device, uploaded once per parameter version (`load_state_dict` bumps it), not per call."""
+        version = tuple(p._version for p in self.parameters())
+        if getattr(self, "_dev", None) is None or self._dev[0] != version or self._dev[1] is not ctx:
+            w = {}
+            for name, mod in (("pool_ln", self.pool_proj[0]), ("pool_lin", self.pool_proj[1]), ("embed_ln", self.mask_embed[0]),
+                              *[(f"mlp{i}", lin) for i, lin in enumerate(self.mask_embed[1].layers)]):
+                if isinstance(mod, nn.LayerNorm):
+                    w[name] = (ctx.to_device(_np(mod.weight).astype(np.float32)), ctx.to_device(_np(mod.bias).astype(np.float32)), mod.eps)
+                else:
+                    w[name] = (ctx.to_device(_np(mod.weight).astype(np.float16)), ctx.to_device(_np(mod.bias).astype(np.float32)) if mod.bias is not None else None)
+            self._dev = (version, ctx, w)
+        return self._dev[2]
 
-    def _layer_norm(self, ctx, x, ln):
-        return ctx.layer_norm(x, ctx.to_device(_np(ln.weight).astype(np.float32)), ctx.to_device(_np(ln.bias).astype(np.float32)), eps=ln.eps)
+    @staticmethod
+    def _linear(ctx, x, wb, act=0, residual=None):
+        return ctx.gemm(x, wb[0], bias_n=wb[1], act=act, residual=residual)
+
+    @staticmethod
+    def _layer_norm(ctx, x, gbe):
+        return ctx.layer_norm(x, gbe[0], gbe[1], eps=gbe[2])
 
     def forward(self, decoder_output, input_mask_embed, mask_features, pred_logits, pred_masks):
         from odise_amd._lib import ACT_RELU
@@ -97,11 +111,12 @@ class PooledMaskEmbed(nn.Module):
         B, Q, Cd = pooled.shape
         x = ctx.to_device(_np(pooled).reshape(B * Q, Cd).astype(np.float16))
         dec = ctx.to_device(_np(decoder_output).reshape(B * Q, Cd).astype(np.float16))
-        x = self._linear(ctx, self._layer_norm(ctx, x, self.pool_proj[0]), self.pool_proj[1], residual=dec)   # pool_proj(x) += decoder_output (:1000)
-        h = self._layer_norm(ctx, x, self.mask_embed[0])
+        w = self._device_weights(ctx)
+        x = self._linear(ctx, self._layer_norm(ctx, x, w["pool_ln"]), w["pool_lin"], residual=dec)   # pool_proj(x) += decoder_output (:1000)
+        h = self._layer_norm(ctx, x, w["embed_ln"])
         mlp = self.mask_embed[1]
-        for i, lin in enumerate(mlp.layers):
-            h = self._linear(ctx, h, lin, act=ACT_RELU if i < mlp.num_layers - 1 else 0)
+        for i in range(mlp.num_layers):
+            h = self._linear(ctx, h, w[f"mlp{i}"], act=ACT_RELU if i < mlp.num_layers - 1 else 0)
         dev = decoder_output.device
         to_t = lambda a: torch.from_numpy(a.numpy().astype(np.float32).reshape(B, Q, -1)).to(dev)
         return {"mask_embed": to_t(h), "mask_pooled_features": to_t(x), "logit_scale": torch.clamp(self.logit_scale.detach().exp(), max=100)}
