@@ -303,7 +303,7 @@ def main():
     ctx = Context(local_rank)
     ctx.set_option(ctx.OPT_CLIP_LN_FOLD, args.clip_ln_fold)
     if not args.attn_kvres:
-        ctx.lib.odise_hip_attn_kvres(0)
+        ctx.set_option(ctx.OPT_ATTN_KV_RESIDENT, 2)
     if args.vae_chunk_mb is not None:
         ctx.set_option(ctx.OPT_VAE_CHUNK_BYTES, int(args.vae_chunk_mb * (1 << 20)))
     B = args.images if args.images is not None else (4 if args.stage == "full" else 1)

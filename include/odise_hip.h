@@ -66,8 +66,11 @@ int odise_hip_device_info(odise_hip_ctx* ctx, char* name_buf, int buf_len, int* 
  *                              fp16 rounding, so a caller that needs results independent of how many crops share a call pins 1 or 2.
  *   ODISE_OPT_VAE_CHUNK_BYTES  > 0: the AutoencoderKL levels (ldm.py:493-533, 585-606) run over as many crops per launch as keep one activation
  *                              tensor below this many bytes (a smaller working set and arena); 0 (default) = all crops of a call at once, which
- *                              measured faster on MI355X (profiles/r04_vae_chunking_experiment.txt).  Per-crop arithmetic is unchanged. */
-enum { ODISE_OPT_CLIP_LN_FOLD = 1, ODISE_OPT_VAE_CHUNK_BYTES = 2 };
+ *                              measured faster on MI355X (profiles/r04_vae_chunking_experiment.txt).  Per-crop arithmetic is unchanged.
+ *   ODISE_OPT_ATTN_KV_RESIDENT 0 (default) = attention with d_head 64 and at most 608 keys runs the K / V^T-resident kernel where (head, image)
+ *                              pairs fill the chip in whole rounds (the CLIP tower of 16 / 32 crops), the tiled kernel elsewhere; 2 = always the
+ *                              tiled kernel.  The two forms step the running softmax maximum per 32 / per 64 keys: results agree to fp32 rounding. */
+enum { ODISE_OPT_CLIP_LN_FOLD = 1, ODISE_OPT_VAE_CHUNK_BYTES = 2, ODISE_OPT_ATTN_KV_RESIDENT = 3 };
 int odise_hip_set_option(odise_hip_ctx* ctx, int option, int64_t value);
 int odise_hip_get_option(odise_hip_ctx* ctx, int option, int64_t* value);
 /* Launch probe (measurement, bench.py's `roofline`): HIP events around every launch of ONE shape - conv != 0: the implicit GEMM of a convolution

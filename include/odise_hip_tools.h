@@ -57,9 +57,6 @@ int odise_hip_stage_timeline_read(odise_hip_ctx* ctx, char* names, int names_cap
 int odise_hip_launch_log(odise_hip_ctx* ctx, int on);
 int odise_hip_launch_log_read(odise_hip_ctx* ctx, int* out6, int cap, int* n);
 
-/* 0: odise_hip_attention never takes the K/V-resident kernel (d_head 64, <= 608 keys: the CLIP towers) - A/B against the tiled kernel; 1 = default */
-int odise_hip_attn_kvres(int on);
-
 /* 1: the feature extractor enqueues everything on one stream; 2 (default): its CLIP -> UNet branch runs on a second stream beside the VAE */
 int odise_hip_set_lanes(odise_hip_ctx* ctx, int lanes);
 

@@ -162,6 +162,10 @@ extern "C" int odise_hip_set_option(odise_hip_ctx* ctx, int option, int64_t valu
             ODISE_REQUIRE(value >= 0 && value <= 2, "set_option: CLIP_LN_FOLD takes 0 (by token count), 1 (always) or 2 (never)");
             ctx->clip_ln_fold = (int)value;
             return ODISE_OK;
+        case ODISE_OPT_ATTN_KV_RESIDENT:
+            ODISE_REQUIRE(value == 0 || value == 2, "set_option: ATTN_KV_RESIDENT takes 0 (the library's rule) or 2 (never)");
+            ctx->attn_kv_resident = (int)value;
+            return ODISE_OK;
         case ODISE_OPT_VAE_CHUNK_BYTES:
             ODISE_REQUIRE(value >= 0, "set_option: VAE_CHUNK_BYTES must be >= 0");
             ctx->vae_chunk_bytes = value;
@@ -176,6 +180,7 @@ extern "C" int odise_hip_get_option(odise_hip_ctx* ctx, int option, int64_t* val
     switch (option) {
         case ODISE_OPT_CLIP_LN_FOLD: *value = ctx->clip_ln_fold; return ODISE_OK;
         case ODISE_OPT_VAE_CHUNK_BYTES: *value = ctx->vae_chunk_bytes; return ODISE_OK;
+        case ODISE_OPT_ATTN_KV_RESIDENT: *value = ctx->attn_kv_resident; return ODISE_OK;
         default:
             set_error("get_option: unknown option %d", option);
             return ODISE_ERR_ARG;

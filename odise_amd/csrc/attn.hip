@@ -470,13 +470,13 @@ __global__ void __launch_bounds__(64 * KVR_WAVES) attn_kvres_kernel(AttnArgs a, 
     }
 }
 
-static int g_attn_kvres = 1;   // tools hook (odise_hip_attn_kvres): 0 = never take the K/V-resident kernel (A/B against the tiled one); 8 / 12 / 16 = waves per block (1 = the default, 16)
-
 // Taken where one block per (head, image) - or a whole number of query splits of it - fills the chip in (nearly) whole rounds: 16 crops x 16
 // heads = 256 pairs = one round.  288 pairs (18 crops) would run two rounds for 1.125 of work, and a pair split over few blocks pays the
 // 148 KB prologue per block for too few query tiles (MaskCLIP on 4 pictures): the tiled kernel keeps those (tools/attn_bench.py).
-static bool attn_kvres_ok(const AttnArgs& a, int cus) {
-    if (!(g_attn_kvres && a.D == 64 && a.Lk >= 256 && a.Lk <= KVR_LKP && a.Lq >= 256)) return false;
+static bool attn_kvres_ok(const odise_hip_ctx* ctx, const AttnArgs& a) {
+    const int cus = ctx->cu_count;
+    if (ctx->attn_kv_resident == 2) return false;   // ODISE_OPT_ATTN_KV_RESIDENT: never
+    if (!(a.D == 64 && a.Lk >= 256 && a.Lk <= KVR_LKP && a.Lq >= 256)) return false;
     const int64_t pairs = (int64_t)a.B * a.H;
     if (pairs < cus) return false;
     const double rounds = (double)pairs / cus;
@@ -567,8 +567,6 @@ static int launch_attn(odise_hip_ctx* ctx, AttnArgs& a) {
 
 }  // namespace odise
 
-extern "C" int odise_hip_attn_kvres(int on) { odise::g_attn_kvres = on; return 0; }
-
 extern "C" int odise_hip_attention(odise_hip_ctx* ctx, const odise_attn_desc* d) {
     using namespace odise;
     ODISE_REQUIRE(ctx && d, "attention: null argument");
@@ -590,13 +588,9 @@ extern "C" int odise_hip_attention(odise_hip_ctx* ctx, const odise_attn_desc* d)
     a.mask = d->mask; a.ldmask = d->ldmask; a.strideMask = d->strideMask;
     a.scale_log2e = d->scale * 1.4426950408889634f;
     const int D = d->D;
-    if (attn_kvres_ok(a, ctx->cu_count)) {
-        // 16 waves (four per SIMD) measured best: 48.1 us against 52.2 (8 waves), 51.4 (12) and 54.4 (tiled kernel) on the 16-crop tower, 91.1 against
-        // 96.6 (tiled) on 32 crops (tools/attn_bench.py, profiles/r04_attention_kv_resident.txt)
-        if (g_attn_kvres == 12) return launch_attn_kvres<12>(ctx, a);
-        if (g_attn_kvres == 8) return launch_attn_kvres<8>(ctx, a);
-        return launch_attn_kvres<16>(ctx, a);
-    }
+    // 16 waves per block (four per SIMD) measured best: 48.1 us against 52.2 (8 waves), 51.4 (12) and 54.4 (tiled kernel) on the 16-crop tower, 91.1
+    // against 96.6 (tiled) on 32 crops (tools/attn_bench.py, profiles/r04_attention_kv_resident.txt); only that form is instantiated
+    if (attn_kvres_ok(ctx, a)) return launch_attn_kvres<16>(ctx, a);
     if (D <= 32) return launch_attn<32>(ctx, a);
     if (D <= 48) return launch_attn<48>(ctx, a);
     if (D <= 64) return launch_attn<64>(ctx, a);

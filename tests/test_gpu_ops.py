@@ -420,10 +420,9 @@ def test_attention_masked_and_spiked(ctx, Lk):
                                               (16, 16, 677, 577, True),      # MaskCLIP's shape on 16 pictures: 100 mask tokens after the image tokens, u8 visibility
                                               (32, 8, 300, 608, True), (16, 16, 1200, 257, False),   # the key-count limits of the resident form
                                               (2, 16, 577, 577, False), (4, 16, 677, 577, True)])    # too few (head, image) pairs: these stay on the tiled kernel
-@pytest.mark.parametrize("waves", [8, 12, 16])
-def test_attention_kv_resident(ctx, B, H, Lq, Lk, masked, waves):
-    """d_head 64 with <= 608 keys and enough (head, image) pairs runs the K/V-resident kernel (attn.hip attn_kvres_kernel; 8 / 12 / 16 waves per
-    block are instantiated): against fp32 torch, and against the tiled kernel on the same inputs (tools hook odise_hip_attn_kvres)."""
+def test_attention_kv_resident(ctx, B, H, Lq, Lk, masked):
+    """d_head 64 with <= 608 keys and enough (head, image) pairs runs the K/V-resident kernel (attn.hip attn_kvres_kernel): against fp32 torch,
+    and against the tiled kernel on the same inputs (per-context option ODISE_OPT_ATTN_KV_RESIDENT = 2)."""
     g = torch.Generator().manual_seed(B * 1000 + Lq + Lk)
     D = 64
     HD = H * D
@@ -448,14 +447,14 @@ def test_attention_kv_resident(ctx, B, H, Lq, Lk, masked, waves):
     ref = (torch.nan_to_num(torch.softmax(s, -1), nan=0.0) @ v).transpose(1, 2).reshape(B, Lq, HD)
     ldvt = (Lk + 7) // 8 * 8
     dq, dk, dv = ctx.to_device(Q.half().numpy()), ctx.to_device(K.half().numpy()), ctx.to_device(_vt(V.half().numpy(), ldvt))
-    ctx.lib.odise_hip_attn_kvres(waves)
+    assert ctx.get_option(ctx.OPT_ATTN_KV_RESIDENT) == 0
     out = ctx.attention(dq, dk, dv, H, scale, mask=dm, Lk=Lk).numpy()
     close(out, ref.numpy(), rtol=5e-3, atol=3e-3, what=f"kv-resident attention B{B} H{H} Lq{Lq} Lk{Lk} masked={masked}")
-    ctx.lib.odise_hip_attn_kvres(0)
+    ctx.set_option(ctx.OPT_ATTN_KV_RESIDENT, 2)
     try:
         tiled = ctx.attention(dq, dk, dv, H, scale, mask=dm, Lk=Lk).numpy()
     finally:
-        ctx.lib.odise_hip_attn_kvres(1)
+        ctx.set_option(ctx.OPT_ATTN_KV_RESIDENT, 0)
     diff = float(np.abs(out.astype(np.float32) - tiled.astype(np.float32)).max())
     print(f"kv-resident vs tiled attention B{B} H{H} Lq{Lq} Lk{Lk}: max abs diff {diff:.2e}")
     assert diff < 2e-3, diff                       # same products, same fp32 softmax; the running max steps per 32 keys instead of 64

@@ -29,8 +29,8 @@ def main():
         o = ctx.empty((B, Lq, HD), np.float16)
         flops = 4.0 * B * H * Lq * Lk * D
         line = f"{name:38s} B={B:2d} Lq={Lq} Lk={Lk}:"
-        for on in (8, 12, 16, 0):
-            ctx.lib.odise_hip_attn_kvres(on)
+        for on in (1, 0):
+            ctx.set_option(ctx.OPT_ATTN_KV_RESIDENT, 0 if on else 2)
             for _ in range(5):
                 ctx.attention(q, k, vt, H, D ** -0.5, mask=m, Lk=Lk, out=o)
             ctx.sync()
@@ -38,8 +38,8 @@ def main():
             for _ in range(reps):
                 ctx.attention(q, k, vt, H, D ** -0.5, mask=m, Lk=Lk, out=o)
             us = ctx.timer_stop() / reps * 1e3
-            line += f"  {('kv-resident/' + str(on) + ' waves') if on else 'tiled'} {us:7.1f} us = {flops / us / 1e6:6.1f} TFLOP/s"
-        ctx.lib.odise_hip_attn_kvres(1)
+            line += f"  {'library rule (K/V-resident where it applies)' if on else 'tiled'} {us:7.1f} us = {flops / us / 1e6:6.1f} TFLOP/s"
+        ctx.set_option(ctx.OPT_ATTN_KV_RESIDENT, 0)
         print(line, flush=True)
 
 
