@@ -44,8 +44,12 @@ import numpy as np  # noqa: E402
 # re-derives the extractor / UNet part on the meta device): per 512^2 crop CLIP 0.382 + VAE encoder 1.117 + UNet 0.740 + truncated VAE decoder
 # 0.623 = 2.8625 TFLOP; per 1024^2 image 4 crops = 11.450, tap projections 0.125, mask generator 0.391, classification (MaskCLIP with 100
 # mask tokens, text logits) 0.410, post-processing einsum 0.028 (K = 133).
-CROP_FLOPS = 2.8625e12
-FLOPS_PER_IMAGE_1024 = 12.40e12
+# Not counted since round 4: the last CLIP block's out-proj / MLP / attention rows of the 576 patch tokens - the reference computes them and reads
+# only ln_post(x[:, 0]) (clip.py:196-206); the device path runs that block on the class-token rows only.  Per crop 576 rows x (1024x1024 +
+# 2 x 1024x4096) MACs + 576 x 577 x 64 x 16 heads x 2 attention MACs = 6.12 GMAC.
+CLIP_LAST_BLOCK_DEAD_FLOPS = 0.01224e12
+CROP_FLOPS = 2.8625e12 - CLIP_LAST_BLOCK_DEAD_FLOPS
+FLOPS_PER_IMAGE_1024 = 12.40e12 - 4 * CLIP_LAST_BLOCK_DEAD_FLOPS
 UNET_FLOPS_LIVE = 0.7401e12
 MFMA_F16_PEAK = 2.5e15            # dense fp16 MFMA, /opt/skills/guides/MI355X_MICROARCH.md
 VOCABS = {"coco133": (133, 254, 80), "ade150": (150, 403, 100), "ade847": (847, 1342, 0)}   # classes, prompt strings, "thing" classes
