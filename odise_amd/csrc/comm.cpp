@@ -35,12 +35,21 @@ static Rccl g_rccl;
 
 static int rccl_load() {
     if (g_rccl.handle) return ODISE_OK;
+    // An RCCL that is ALREADY in the process wins: with torch imported first the process runs torch's bundled HIP runtime (same SONAME as
+    // /opt/rocm's) and torch's own librccl.so is loaded with it - the communicator must come from the RCCL that was
+    // built against the runtime it runs on, not from a second copy out of the system directory.
     const char* names[] = {getenv("ODISE_RCCL_LIB"), "librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
     void* h = nullptr;
+    if (!(names[0] && *names[0])) {
+        for (const char* n : {"librccl.so", "librccl.so.1"}) {
+            h = dlopen(n, RTLD_NOW | RTLD_LOCAL | RTLD_NOLOAD);
+            if (h) break;
+        }
+    }
     for (const char* n : names) {
+        if (h) break;
         if (!n || !*n) continue;
         h = dlopen(n, RTLD_NOW | RTLD_LOCAL);
-        if (h) break;
     }
     if (!h) {
         set_error("comm: cannot load librccl.so.1 (%s); set ODISE_RCCL_LIB or add the ROCm lib directory to LD_LIBRARY_PATH", dlerror());
