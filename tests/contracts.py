@@ -8,7 +8,7 @@ import torch
 TAU_PROB = 3e-2      # bound on a class-probability error, absolute (measured 1.9e-2 at logit scale 100)
 
 
-def end_to_end_contract(got, ref, cls_ref, k, things, tag="", size=1024, segments_strict=True, perr=None, mask_regular=None):
+def end_to_end_contract(got, ref, cls_ref, k, things, tag="", size=1024, segments_strict=True, perr=None, mask_regular=None, mask_margin=None):
     """`got`: one dict of HipCategoryODISE.forward (host arrays); `ref`: om.postprocess(...)[i] of the oracle; cls_ref [1 or Q.., K+1] the oracle's
     class log-probabilities of this image.  Asserts: identical segments_info, panoptic map > 99.5 % equal, semantic scores within TAU_PROB and
     identical arg-max wherever the reference's top-2 margin exceeds twice the measured error, instance sets identical away from the top-k
@@ -18,7 +18,11 @@ def end_to_end_contract(got, ref, cls_ref, k, things, tag="", size=1024, segment
     re-decided query (error above TAU_PROB) raises their bounds to its error, and its own instance mask is held to IoU > 0.8 instead of 0.93 (the
     floors of tests/test_gpu_fullsize.py::test_mask_iou_contract_at_output_resolution).  `perr`: float or the per-query array; `mask_regular` [Q] bool (optional): queries whose MASK LOGITS stayed within
     TAU_MASK of the reference's (the others went the other way at one of the decoder's hard decisions, test_gpu_fullsize._mask_report) - only the
-    regular ones are held to the 0.93 floor.  Returns the printed figures."""
+    regular ones are held to the 0.93 floor.  `mask_margin` = (reference logits upsampled to the output size [Q, H, W], measured mask-logit error per
+    query [Q], absolute): replaces the raw floor by the exact statement - an instance-mask pixel may differ from the reference's only where the
+    reference logit lies within that query's own measured error (bilinear upsampling is a convex combination, so the bound measured at the head's
+    resolution carries over); the raw IoU is then only reported and sanity-bounded (smooth synthetic logit fields put 3-7 % of a mask's pixels
+    next to zero).  Returns the printed figures."""
     eq = np.zeros(cls_ref.reshape(-1, k + 1).shape[0]) if perr is None else np.broadcast_to(np.asarray(perr, np.float64), (cls_ref.reshape(-1, k + 1).shape[0],))
     tau = max(TAU_PROB, 1.1 * float(eq.max()))
     cls_ref = torch.as_tensor(cls_ref).reshape(-1, k + 1)
@@ -49,10 +53,14 @@ def end_to_end_contract(got, ref, cls_ref, k, things, tag="", size=1024, segment
     key_got = {(int(q), int(c)): i for i, (q, c) in enumerate(zip(inst["query_index"], inst["pred_classes"]))}
     common = sorted(set(key_ref) & set(key_got))
     kth = float(np.sort(scores_flat.numpy())[-100])
-    worst, worst_redecided, worst_score = 1.0, 1.0, 0.0
+    worst, worst_redecided, worst_score, outside = 1.0, 1.0, 0.0, 0
     for kk in common:
         a, b = inst["pred_masks"][key_got[kk]] > 0.5, inst_ref["pred_masks"][key_ref[kk]].numpy() > 0.5
         iou = (a & b).sum() / max((a | b).sum(), 1)
+        if mask_margin is not None:
+            up, el = mask_margin
+            decided_px = np.abs(np.asarray(up[kk[0]])) > 1.01 * float(el[kk[0]]) + 1e-4     # (slack for the device's own bilinear arithmetic)
+            outside += int(((a != b) & decided_px).sum())
         if eq[kk[0]] < TAU_PROB and (mask_regular is None or bool(mask_regular[kk[0]])):
             worst = min(worst, iou)
         else:
@@ -72,7 +80,11 @@ def end_to_end_contract(got, ref, cls_ref, k, things, tag="", size=1024, segment
     assert inst["pred_masks"].shape[1:] == (size, size)
     for q, c in set(key_ref) ^ set(key_got):    # entries may only differ at the selection boundary of the top-k
         assert abs(float(scores_flat[q * k + c]) - kth) < tau, (tag, q, c)
-    assert len(common) >= 0.9 * len(key_ref) and worst > 0.93 and worst_redecided > 0.8 and worst_score < 2 * tau, (tag, len(common), worst, worst_redecided, worst_score)
+    if mask_margin is not None:
+        print(tag, "instance-mask pixels that differ although the reference logit exceeds the query's measured error:", outside)
+        assert outside == 0, (tag, outside)
+    floor = 0.93 if mask_margin is None else 0.88
+    assert len(common) >= 0.9 * len(key_ref) and worst > floor and worst_redecided > 0.8 and worst_score < 2 * tau, (tag, len(common), worst, worst_redecided, worst_score)
     return dict(segments=len(info), panoptic_agreement=agree, sem_err=serr, sem_agreement=sagree, instances=len(key_got), worst_iou=float(worst))
 
 

@@ -62,14 +62,15 @@ def _mask_errors(hip, refs, size):
     return np.stack(out)
 
 
-def _segments_strict(i, cls_got, r, k, things, size, overlap_threshold=0.8, elogit_rel=None):
+def _segments_strict(i, cls_got, r, k, things, size, overlap_threshold=0.8, elogit_rel=None, up=None):
     """Picture 0 carries the vocabulary (its decisions are spread by construction) and is always held to `segments_info == reference`; the
     other pictures where the reference's own table is fixed by its margins at the error measured on that picture (margins.segments_decided)."""
     if i == 0:
         return True
     ref_lp = r["mask_cls"][0].numpy()
     eprob = np.abs(np.exp(np.asarray(cls_got, np.float64)) - np.exp(ref_lp.astype(np.float64))).max(-1)
-    up = upsampled_reference_logits(r["pred_masks"][0], (size, size), (size, size), (size, size))
+    if up is None:
+        up = upsampled_reference_logits(r["pred_masks"][0], (size, size), (size, size), (size, size))
     scale = float(r["pred_masks"].abs().max())
     elogit = np.full(len(eprob), ELOGIT * scale) if elogit_rel is None else np.asarray(elogit_rel, np.float64) * scale
     decided, differ = segments_decided(ref_lp, up, k, things, eprob, elogit, overlap_threshold)
@@ -126,8 +127,11 @@ def test_batch_of_four_1024_matches_oracle_and_single_runs(ctx, fullsize_model):
         assert regular.sum() >= 100 - MAX_MASK_REDECIDED and merr[i].max() < 8e-2, (i, int(regular.sum()), float(merr[i].max()))
         perr = class_probability_contract(cls_b[i], r["mask_cls"][0].numpy(), k, tag=f"batch of 4, picture {i}:")
         ref = om.postprocess(r["mask_cls"], r["pred_masks"], (1024, 1024), [(1024, 1024)], [(1024, 1024)], k, things, 0.8)[0]
-        strict.append(_segments_strict(i, cls_b[i], r, k, things, 1024, elogit_rel=merr[i]))
-        end_to_end_contract(batch[i], ref, r["mask_cls"], k, things, tag=f"batch of 4, picture {i}:", segments_strict=strict[i], perr=perr, mask_regular=regular)
+        up = upsampled_reference_logits(r["pred_masks"][0], (1024, 1024), (1024, 1024), (1024, 1024))
+        strict.append(_segments_strict(i, cls_b[i], r, k, things, 1024, elogit_rel=merr[i], up=up))
+        end_to_end_contract(batch[i], ref, r["mask_cls"], k, things, tag=f"batch of 4, picture {i}:", segments_strict=strict[i], perr=perr, mask_regular=regular,
+                            mask_margin=(up.numpy(), merr[i] * float(r["pred_masks"].abs().max())))
+        del up
 
     # ---- batched against alone, default forms (picture by picture: the host copies are ~1 GB each)
     log_1 = None
