@@ -76,7 +76,7 @@ def instance_keys(mask_cls_ref, num_classes, thing_ids, topk, panoptic_on=True):
     return {(int(a), int(b)): i for i, (a, b) in enumerate(zip(q[keep], c[keep]))}, kth, scores.numpy()
 
 
-def segments_decided(mask_cls_ref, logits_up_ref, num_classes, thing_ids, eprob, elogit, overlap_threshold, trials=6, seed=0):
+def segments_decided(mask_cls_ref, logits_up_ref, num_classes, thing_ids, eprob, elogit, overlap_threshold, trials=10, seed=0):
     """Is the reference's `segments_info` FIXED by its own margins at the measured error?  The panoptic table is the end of a chain of
     thresholds (kept queries, per-pixel arg-max, `mask_area / original_area >= overlap_threshold` per query, stuff merging;
     maskformer_model.py:286-342) and a closed-form margin for the whole chain would have to be very conservative; instead the oracle's
@@ -87,8 +87,9 @@ def segments_decided(mask_cls_ref, logits_up_ref, num_classes, thing_ids, eprob,
     g = torch.Generator().manual_seed(seed)
     lp = torch.as_tensor(mask_cls_ref).float().reshape(-1, num_classes + 1)
     up = torch.as_tensor(logits_up_ref).float()
-    ep = torch.as_tensor(np.asarray(eprob), dtype=torch.float32).view(-1, 1)
-    el = torch.as_tensor(np.asarray(elogit), dtype=torch.float32).view(-1, 1, 1)
+    # amplitude 1.5 x the measured errors: random draws inside a bound find its worst case less often than a structured error does
+    ep = 1.5 * torch.as_tensor(np.asarray(eprob), dtype=torch.float32).view(-1, 1)
+    el = 1.5 * torch.as_tensor(np.asarray(elogit), dtype=torch.float32).view(-1, 1, 1)
     _, want = om.panoptic_inference(lp, up, num_classes, thing_ids, 0.0, overlap_threshold)
     differ = 0
     for _ in range(trials):
