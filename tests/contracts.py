@@ -5,7 +5,9 @@ Reference lines: odise/modeling/meta_arch/odise.py:282-372, third_party/Mask2For
 import numpy as np
 import torch
 
-TAU_PROB = 3e-2      # bound on a class-probability error, absolute (measured 1.9e-2 at logit scale 100)
+TAU_PROB = 3e-2      # bound on a class-probability error, absolute (measured 0.5-2.6e-2 at logit scale 100)
+TAU_SEM = 4e-2       # bound on a semantic score's error relative to the largest score: sum_q P[q,k] sigmoid(mask_q) carries the probability error AND the
+                     # mask-logit error of every query that covers the pixel (measured 0.8-2.8e-2 over ten boxes / draws of round 4; 2.3-2.8e-2 on picture 0)
 
 
 def end_to_end_contract(got, ref, cls_ref, k, things, tag="", size=1024, segments_strict=True, perr=None, mask_regular=None, mask_margin=None):
@@ -76,7 +78,7 @@ def end_to_end_contract(got, ref, cls_ref, k, things, tag="", size=1024, segment
         assert agree > 0.97 or info != info_ref, (tag, agree)
     # sem_seg = sum_q P[q,k] sigmoid(mask_q) carries the class-probability error; its per-pixel argmax is identical wherever the reference decides by
     # more than that error, and the undecided rest (near-ties between two of the class scores) stays a small fraction
-    assert serr < tau and same[decided].all() and sagree > 0.98, (tag, serr, sagree)
+    assert serr < max(TAU_SEM, tau) and same[decided].all() and sagree > 0.98, (tag, serr, sagree)
     assert inst["pred_masks"].shape[1:] == (size, size)
     for q, c in set(key_ref) ^ set(key_got):    # entries may only differ at the selection boundary of the top-k
         assert abs(float(scores_flat[q * k + c]) - kth) < tau, (tag, q, c)
