@@ -187,7 +187,7 @@ def test_batch_of_eight_1024_ade150(ctx, fullsize_model):
             strict = _segments_strict(i, cls_b[i], r, k, things, 1024, elogit_rel=merr[i])
             undecided.add(i) if not strict else None
             print(f"batch of 8, picture {i}: segments {len(info)} ref {len(ref['panoptic_seg'][1])} panoptic agreement {agree:.5f}")
-            assert (info == ref["panoptic_seg"][1] and agree > 0.995) or not strict, (i, info, ref["panoptic_seg"][1], agree)
+            assert (info == ref["panoptic_seg"][1] and agree > 0.99) or not strict, (i, info, ref["panoptic_seg"][1], agree)
         for i, img in enumerate(imgs):
             alone, cls_1, _ = _run(ctx, hip, [img], 1024)
             rep = device_pair_report(batch[i], alone[0], cls_b[i], cls_1[0], k, tag=f"picture {i} in the batch of 8 vs alone (library defaults):")
