@@ -350,7 +350,7 @@ def test_group_norm_residual_and_accumulate(ctx, HW, C):
     close(y.numpy(), ref.numpy(), rtol=3e-3, atol=3e-3, what=f"group_norm_ex HW={HW}")
 
 
-@pytest.mark.parametrize("rows,C", [(77, 768), (4096, 320), (5, 1280), (577, 1024), (100, 256)])
+@pytest.mark.parametrize("rows,C", [(77, 768), (4096, 320), (5, 1280), (577, 1024), (100, 256), (20003, 256), (301, 128), (9, 64)])   # C <= 256: two rows per wavefront
 def test_layer_norm(ctx, rows, C):
     g = torch.Generator().manual_seed(rows + C)
     x = h(torch.randn(rows, C, generator=g) * 3 + 1)
