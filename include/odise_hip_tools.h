@@ -26,7 +26,7 @@ int odise_hip_conv2d_forced(odise_hip_ctx* ctx, const odise_conv_desc* d, int ti
 /* tile id | split-K factor << 8 that the calling thread's last odise_hip_gemm / odise_hip_conv2d launch ran with (-1: none yet) */
 int odise_hip_last_tile(void);
 /* a GEMM with a LayerNorm folded into its epilogue, as the CLIP towers chain them (csrc/common.h LnEpi; any pointer may be NULL):
- *   producer  stats_out [M][N/128][2]: partial (sum, sum of squares) of every output row, per 128 columns
+ *   producer  stats_out [M][N/64][2]: partial (sum, sum of squares) of every output row, per 64 columns
  *   consumer  part [M][parts][2] + colsum [N]: C = act(rstd_m (A W'^T - mean_m colsum) + bias_n) (+ residual), the row statistics finished from
  *             the partials with 1/inv_c channels and eps; final_out [M][2] receives (-mean rstd, rstd)
  *   swapped   fin [N][2] + rowsum [M]: the normalised operand is W (its rows are the tokens), statistics per output column */
@@ -60,10 +60,9 @@ int odise_hip_launch_log_read(odise_hip_ctx* ctx, int* out6, int cap, int* n);
 /* 1: the feature extractor enqueues everything on one stream; 2 (default): its CLIP -> UNet branch runs on a second stream beside the VAE */
 int odise_hip_set_lanes(odise_hip_ctx* ctx, int lanes);
 
-/* probes (probe.hip): MFMA output layout, sustained MFMA rate on register-resident operands, LDS port rates */
+/* probe (probe.hip): MFMA output layout (tests/test_gpu_probe.py).  The rate probes and yardstick kernels live in odise_hip_lab.h and only
+ * in the measurement build of the library. */
 int odise_hip_mfma_probe(odise_hip_ctx* ctx, float* host_out);
-int odise_hip_mfma_rate(odise_hip_ctx* ctx, int variant, int iters, int blocks, int reps, float* ms_out, double* flops_out, double* mhz_out);
-int odise_hip_lds_rate(odise_hip_ctx* ctx, int variant, int rounds, int blocks, double* clocks_per_round, float* ms_out);
 
 #ifdef __cplusplus
 }

@@ -14,6 +14,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("ODISE_HIP_LIB") or os.path.join(HERE, "lib", "libodise_hip.so")  # env: developer A/B builds
 HEADER_PATH = os.path.join(HERE, "..", "include", "odise_hip.h")
 TOOLS_HEADER_PATH = os.path.join(HERE, "..", "include", "odise_hip_tools.h")   # developer hooks: not part of the boundary
+LAB_HEADER_PATH = os.path.join(HERE, "..", "include", "odise_hip_lab.h")       # measurement build only (libodise_hip_tools.so)
 
 F16, F32 = 0, 1
 ACT_NONE, ACT_SILU, ACT_RELU, ACT_GELU, ACT_QUICKGELU = 0, 1, 2, 3, 4
@@ -167,7 +168,11 @@ def load() -> C.CDLL:
     if missing:
         raise RuntimeError(f"libodise_hip.so does not export: {missing}")
     lib.odise_hip_last_error.restype = C.c_char_p
-    for name, args in {**header_prototypes(), **header_prototypes(TOOLS_HEADER_PATH)}.items():
+    protos = {**header_prototypes(), **header_prototypes(TOOLS_HEADER_PATH)}
+    lab = header_prototypes(LAB_HEADER_PATH)
+    if all(hasattr(lib, n) for n in lab):   # the measurement build (ODISE_HIP_LIB=.../libodise_hip_tools.so) also carries the lab hooks
+        protos.update(lab)
+    for name, args in protos.items():
         fn = getattr(lib, name)
         if name != "odise_hip_last_error":
             fn.restype = c_int

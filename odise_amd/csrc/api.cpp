@@ -6,6 +6,7 @@
 #include <mutex>
 #include <vector>
 
+#include <algorithm>
 #include "common.h"
 #include "../../include/odise_hip_tools.h"
 
@@ -40,6 +41,12 @@ extern "C" int odise_hip_create(int device, odise_hip_ctx** out) {
     hipDeviceProp_t prop;
     ODISE_CHECK_HIP(hipGetDeviceProperties(&prop, device));
     c->cu_count = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    {
+        int optin = 0;
+        if (hipDeviceGetAttribute(&optin, hipDeviceAttributeMaxSharedMemoryPerBlock, device) != hipSuccess) optin = 0;
+        const size_t m = std::max<size_t>({(size_t)optin, prop.sharedMemPerBlock, prop.maxSharedMemoryPerMultiProcessor, (size_t)65536});
+        c->max_lds_optin = (int)std::min<size_t>(m, (size_t)1 << 30);
+    }
     ODISE_CHECK_HIP(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
     c->own_stream = true;
     c->ws_bytes = (size_t)256 << 20;

@@ -306,10 +306,10 @@ __global__ void __launch_bounds__(64 * KVR_WAVES) attn_kvres_kernel(AttnArgs a, 
     const int nkt = (a.Lk + 31) >> 5;          // key tiles of 32
     const int lkp = nkt * 32;
     // ---- K and V^T of this (head, image) -> LDS (rows / columns beyond Lk are zero: their scores are masked, 0 x V must stay 0).
-    // All of a thread's 16-byte loads are in flight before its first LDS write (two batches of up to 10): the prologue costs two memory
+    // All of a thread's 16-byte loads are in flight before its first LDS write (two batches - K, then V^T - of PER loads each: 5 with the 16 waves instantiated): the prologue costs two memory
     // round trips, not twenty (a load -> write loop waits for vmcnt(0) every iteration: measured 15-20 of the kernel's 54 us).
     constexpr int NT = 64 * KVR_WAVES;
-    constexpr int PER = (KVR_LKP * 8 + NT - 1) / NT;      // 16-byte slots per thread and operand (10)
+    constexpr int PER = (KVR_LKP * 8 + NT - 1) / NT;      // 16-byte slots per thread and operand (608 * 8 / 1024 -> 5 at 16 waves)
     const int vslots = lkp >> 3;                           // 16-byte slots per V^T row
     {
         f16x8 buf[PER];
@@ -476,6 +476,7 @@ __global__ void __launch_bounds__(64 * KVR_WAVES) attn_kvres_kernel(AttnArgs a, 
 static bool attn_kvres_ok(const odise_hip_ctx* ctx, const AttnArgs& a) {
     const int cus = ctx->cu_count;
     if (ctx->attn_kv_resident == 2) return false;   // ODISE_OPT_ATTN_KV_RESIDENT: never
+    if (ctx->max_lds_optin < KVR_LDS) return false; // a device (or partition) that cannot give one block 152.5 KiB of LDS keeps the tiled kernel
     if (!(a.D == 64 && a.Lk >= 256 && a.Lk <= KVR_LKP && a.Lq >= 256)) return false;
     const int64_t pairs = (int64_t)a.B * a.H;
     if (pairs < cus) return false;
@@ -485,11 +486,8 @@ static bool attn_kvres_ok(const odise_hip_ctx* ctx, const AttnArgs& a) {
 
 template <int KVR_WAVES>
 static int launch_attn_kvres(odise_hip_ctx* ctx, AttnArgs& a) {
-    static bool attr_set = false;
-    if (!attr_set) {
-        ODISE_CHECK_HIP(hipFuncSetAttribute((const void*)attn_kvres_kernel<KVR_WAVES>, hipFuncAttributeMaxDynamicSharedMemorySize, KVR_LDS));
-        attr_set = true;
-    }
+    static LdsAttrOnce once;  // tracked per device inside
+    ODISE_TRY(ensure_dyn_lds(ctx, once, (const void*)attn_kvres_kernel<KVR_WAVES>, KVR_LDS));
     // one block per (head, image) when those fill the chip; otherwise the query tiles of a pair are split so that every CU gets a block
     // (a block needs at least one query tile per wave to pay for loading K / V^T)
     const int64_t pairs = (int64_t)a.B * a.H;

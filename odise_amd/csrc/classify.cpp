@@ -236,6 +236,7 @@ extern "C" int odise_hip_set_vocabulary(odise_hip_ctx* ctx, const float* cat_tex
 // odise_hip_head_forward; mask_cls [B,Q,K+1] f32 device (log-probabilities, odise.py:323); clip_embed (optional) [B,Q,dim] f32.
 extern "C" int odise_hip_classify(odise_hip_ctx* ctx, const float* image, int B, int H, int W, float* mask_cls, float* clip_embed_out) {
     ODISE_REQUIRE(ctx && image && mask_cls, "classify: null argument");
+    ODISE_CHECK_HIP(hipSetDevice(ctx->device));   // the caller may be a new host thread, or hold another device current
     ModelStore* ms = store_of(ctx);
     ClassifyModel* c = ms->classify;
     if (!c || !c->has_vocab) {
@@ -305,6 +306,7 @@ extern "C" int odise_hip_postprocess_pixels(odise_hip_ctx* ctx, int b, const flo
                                             int img_h, int img_w, int out_h, int out_w, float* sem_seg, int* ids, int* counts,
                                             float* inst_stats) {
     ODISE_REQUIRE(ctx && kscore, "postprocess_pixels: null argument");
+    ODISE_CHECK_HIP(hipSetDevice(ctx->device));   // the caller may be a new host thread, or hold another device current
     ModelStore* ms = store_of(ctx);
     HeadOutputs ho;
     ODISE_TRY(head_outputs(ms, &ho));
@@ -360,12 +362,14 @@ extern "C" int odise_hip_postprocess_pixels(odise_hip_ctx* ctx, int b, const flo
 
 extern "C" int odise_hip_panoptic_write(odise_hip_ctx* ctx, const int* ids, const int* map, int* seg, int npix) {
     ODISE_REQUIRE(ctx && ids && map && seg, "panoptic_write: null argument");
+    ODISE_CHECK_HIP(hipSetDevice(ctx->device));   // the caller may be a new host thread, or hold another device current
     return launch_panoptic_write(ctx, ids, map, seg, npix);
 }
 
 extern "C" int odise_hip_instance_masks(odise_hip_ctx* ctx, int b, const int* idx, int n, int pad_h, int pad_w, int img_h, int img_w, int out_h,
                                         int out_w, float* out) {
     ODISE_REQUIRE(ctx && (n == 0 || (idx && out)), "instance_masks: null argument");
+    ODISE_CHECK_HIP(hipSetDevice(ctx->device));   // the caller may be a new host thread, or hold another device current
     ModelStore* ms = store_of(ctx);
     HeadOutputs ho;
     ODISE_TRY(head_outputs(ms, &ho));
@@ -379,6 +383,7 @@ extern "C" int odise_hip_instance_masks(odise_hip_ctx* ctx, int b, const int* id
 extern "C" int odise_hip_maskclip_embed(odise_hip_ctx* ctx, const float* image, int B, int H, int W, const float* pred_masks, int Q, int h, int w,
                                         float* clip_embed) {
     ODISE_REQUIRE(ctx && image && pred_masks && clip_embed && B >= 1 && Q >= 1 && h >= 1 && w >= 1, "maskclip_embed: bad argument");
+    ODISE_CHECK_HIP(hipSetDevice(ctx->device));   // the caller may be a new host thread, or hold another device current
     ModelStore* ms = store_of(ctx);
     int S = 0, patch = 0, T = 0, cdim = 0;
     if (clip_dims(ms, &S, &patch, &T, &cdim) != ODISE_OK) {
@@ -412,6 +417,7 @@ extern "C" int odise_hip_maskclip_embed(odise_hip_ctx* ctx, const float* image, 
 // ---- the three heads for a batch, decisions on the device -------------------------------------------------------------------------------
 extern "C" int odise_hip_postprocess_batch(odise_hip_ctx* ctx, const odise_post_desc* d) {
     ODISE_REQUIRE(ctx && d, "postprocess_batch: null argument");
+    ODISE_CHECK_HIP(hipSetDevice(ctx->device));   // the caller may be a new host thread, or hold another device current
     ModelStore* ms = store_of(ctx);
     ClassifyModel* c = ms->classify;
     if (!c || !c->has_vocab) {

@@ -4,6 +4,7 @@
 #include <hip/hip_fp16.h>
 #include <stdint.h>
 #include <stdio.h>
+#include <atomic>
 #include <string>
 
 #include "../../include/odise_hip.h"
@@ -34,6 +35,12 @@ void set_error(const char* fmt, ...);
             ::odise::set_error(__VA_ARGS__);                                               \
             return ODISE_ERR_ARG;                                                          \
         }                                                                                  \
+    } while (0)
+
+#define ODISE_TRY(expr)                \
+    do {                               \
+        int _rc = (expr);              \
+        if (_rc != ODISE_OK) return _rc; \
     } while (0)
 
 static inline int64_t ceil_div(int64_t a, int64_t b) { return (a + b - 1) / b; }
@@ -74,6 +81,7 @@ struct odise_hip_ctx {
     hipStream_t stream = nullptr;
     bool own_stream = false;
     int cu_count = 256;
+    int max_lds_optin = 65536;   // the most LDS a block may opt into on this device (160 KiB on gfx950; the largest of what the runtime reports, api.cpp)
     // split-K / scratch workspace
     void* ws = nullptr;
     size_t ws_bytes = 0;
@@ -103,6 +111,21 @@ struct odise_hip_ctx {
 };
 
 namespace odise {
+// hipFuncSetAttribute(MaxDynamicSharedMemorySize) is a PER-DEVICE property of a kernel: remember it per (kernel instantiation, device), not per
+// process, and let any number of host threads race to set it (the call is idempotent; the bit is published after it succeeded).
+struct LdsAttrOnce {
+    std::atomic<uint64_t> done{0};   // bit d: set on device d (devices >= 64 set it on every launch)
+};
+static inline int ensure_dyn_lds(odise_hip_ctx* ctx, LdsAttrOnce& once, const void* kernel, int bytes) {
+    const int d = ctx->device;
+    if (d >= 0 && d < 64 && ((once.done.load(std::memory_order_acquire) >> d) & 1)) return ODISE_OK;
+    ODISE_CHECK_HIP(hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
+    if (d >= 0 && d < 64) once.done.fetch_or(1ull << d, std::memory_order_release);
+    return ODISE_OK;
+}
+}  // namespace odise
+
+namespace odise {
 // odise_hip_probe_arm / _read: HIP events around every launch of ONE GEMM / convolution shape, recorded on the stream the launch goes to
 // (whichever lane that is), so bench.py can report the dominant kernel's duration as it runs INSIDE the timed step, beside the other lane
 struct LaunchProbe {
@@ -125,6 +148,7 @@ void launch_log_release(odise_hip_ctx* ctx);
 // LayerNorm folded into the GEMMs around it (gemm.hip gemm_epilogue_f16; used by the CLIP towers): statistics of the rows a GEMM writes come out
 // of its epilogue (`stats_out`), the GEMMs that would read LN(x) read x with gamma / beta folded into their weights and finish the
 // normalisation per row (`part` + `colsum`) or, with swapped operands, per column (`fin` + `rowsum`)
+constexpr int kLnPartCols = 64;   // columns per partial (sum, sum of squares) of a row: the wave column of the 8-phase 256x256 tile, half of the ping-pong tiles'
 struct LnEpi {
     const float* part = nullptr;   // [M][P][2] partial (sum, sum of squares) per row of A
     int P = 0;
@@ -133,7 +157,7 @@ struct LnEpi {
     float* final_out = nullptr;    // [M][2] (-mean * rstd, rstd), optional
     const float* fin = nullptr;    // [N][2] per row of W (swapped form)
     const float* rowsum = nullptr; // [M]
-    float* stats_out = nullptr;    // [M][N / 128][2]
+    float* stats_out = nullptr;    // [M][N / kLnPartCols][2]
 };
 int gemm_forced(odise_hip_ctx* ctx, const odise_gemm_desc* d, int force_tile, int force_split, const LnEpi* ln = nullptr);   // force_tile < 0: the cost model's choice
 int gemm_ln(odise_hip_ctx* ctx, const odise_gemm_desc* d, const LnEpi& ln);   // 256x256 ping-pong tile, math-first epilogue

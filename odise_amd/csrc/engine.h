@@ -12,12 +12,6 @@
 
 namespace odise {
 
-#define ODISE_TRY(expr)                \
-    do {                               \
-        int _rc = (expr);              \
-        if (_rc != ODISE_OK) return _rc; \
-    } while (0)
-
 struct HostTensor {
     std::vector<float> data;
     std::vector<int64_t> shape;

@@ -448,7 +448,7 @@ int clip_tower(Exec& ex, const Act& img, int extra, const uint8_t* mask, int64_t
     // 0 = by token count, 1 = always, 2 = never), so a caller that needs the same arithmetic whatever the batch pins it.
     const int fold_mode = ex.ctx->clip_ln_fold;
     const bool fold = Wd % 256 == 0 && (fold_mode == 1 || (fold_mode == 0 && M >= 8192));
-    const int P = Wd / 128;
+    const int P = Wd / kLnPartCols;
     float *part_a = nullptr, *part_b = nullptr, *fin = nullptr;
     if (fold) {
         part_a = (float*)ex.alloc_bytes((size_t)M * P * 2 * sizeof(float));
@@ -831,6 +831,7 @@ extern "C" int odise_hip_extractor_build(odise_hip_ctx* ctx) {
 
 extern "C" int odise_hip_extractor_forward_nhwc(odise_hip_ctx* ctx, const float* image, int B, int H, int W, void** taps8, int* shapes8x4) {
     ODISE_REQUIRE(ctx, "extractor_forward: null context");
+    ODISE_CHECK_HIP(hipSetDevice(ctx->device));   // the caller may be a new host thread, or hold another device current
     ODISE_TRY(extractor_forward(ctx, image, B, H, W));
     ExtractorModel* e = store_of(ctx)->extractor;
     for (int i = 0; i < 8; ++i) {
@@ -845,6 +846,7 @@ extern "C" int odise_hip_extractor_forward_nhwc(odise_hip_ctx* ctx, const float*
 
 extern "C" int odise_hip_extractor_forward(odise_hip_ctx* ctx, const float* image, int B, int H, int W, float** taps8) {
     ODISE_REQUIRE(ctx && taps8, "extractor_forward: null argument");
+    ODISE_CHECK_HIP(hipSetDevice(ctx->device));   // the caller may be a new host thread, or hold another device current
     ODISE_TRY(extractor_forward(ctx, image, B, H, W));
     ExtractorModel* e = store_of(ctx)->extractor;
     for (int i = 0; i < 8; ++i) {

@@ -20,6 +20,7 @@
 //   cost model.  Every variant keeps the same fp32 summation order: results are bit-identical across kernels for a given K order.
 #include "common.h"
 #include <stdlib.h>
+#include <type_traits>
 
 // Timing-only ablation switches (GemmArgs::dbg: drop the operand DMA / fragment reads / epilogue, freeze the K walk) and the
 // ODISE_GEMM_FLAGS / ODISE_GEMM_FREEZE_K environment switches exist only in the measurement build of the library
@@ -58,7 +59,7 @@ struct GemmEpi {
     float* ln_final_out;      // ... optional [M][2] = (-mean * rstd, rstd) of every row, written by the blocks of the first column tile
     const float* ln_final;    // consumer, LN over the rows of W (swapped GEMM): [N][2] = (-mean * rstd, rstd) per output column
     const float* ln_rowsum;   // ... [M]: sum over k of the folded weights of output row m
-    float* ln_stats_out;      // producer: [M][ceil(N / WTN)][2] partial (sum, sum of squares) of every output row (of the rounded fp16 values)
+    float* ln_stats_out;      // producer: [M][ceil(N / kLnPartCols)][2] partial (sum, sum of squares) of every output row (of the rounded fp16 values)
     float* gn_stats;  // optional [row blocks][N][2]: per-channel (sum, sum of squares) of the block's fp16 outputs (GroupNorm statistics
                       // fused into the producing conv; set by launch_gemm only when the chosen kernel supports it)
 };
@@ -374,7 +375,8 @@ __device__ __forceinline__ void gemm_epilogue_f16(const GemmArgs& g, f32x16 (&ac
             //   LN(x) W^T + b = rstd_m (x W'^T - mean_m cs) + b'  ->  v * rstd_m + (b'[n] + r1_m cs[n]),  r1_m = -mean_m rstd_m,
             // the row statistics coming as partial (sum, sum of squares) from the epilogue of the GEMM that produced x (ln_stats_out below).
             // In the swapped form (rows of W are the normalised tokens) the same with rows and columns exchanged, from finished (r1, rstd).
-            float r1_r[TM], rs_r[TM], ps_r[TM], pq_r[TM];
+            constexpr int NPW = (WTN % kLnPartCols == 0) ? WTN / kLnPartCols : 1;   // statistics parts (kLnPartCols columns each) per wave column
+            float r1_r[TM], rs_r[TM], ps_r[TM][NPW], pq_r[TM][NPW];
 #pragma unroll
             for (int p = 0; p < TM; ++p) {
                 const int m = row_to_m(wm * WTM + p * 32 + l31);
@@ -382,7 +384,9 @@ __device__ __forceinline__ void gemm_epilogue_f16(const GemmArgs& g, f32x16 (&ac
                 const bool ok = m < g.M;
                 float alpha = e.alpha;
                 if (e.scale_m && ok) alpha *= e.scale_m[m];
-                r1_r[p] = rs_r[p] = ps_r[p] = pq_r[p] = 0.f;
+                r1_r[p] = rs_r[p] = 0.f;
+#pragma unroll
+                for (int u = 0; u < NPW; ++u) ps_r[p][u] = pq_r[p][u] = 0.f;
                 if (ln_part && ok) {
                     const float* pp = ln_part + (int64_t)m * e.ln_P * 2;
                     float s1 = 0.f, s2 = 0.f;
@@ -473,23 +477,27 @@ __device__ __forceinline__ void gemm_epilogue_f16(const GemmArgs& g, f32x16 (&ac
                             for (int i = 0; i < 4; ++i) t[i] = (f16)(v[i] + (float)rr[i]);
                             *reinterpret_cast<f16x4*>(&stg[rl * PITCH + cl]) = t;
                             if (ln_stats_out && ok) {
+                                constexpr int TPP = kLnPartCols / 32;   // 32-column tiles per part
 #pragma unroll
-                                for (int i = 0; i < 4; ++i) { const float r = (float)t[i]; ps_r[p] += r; pq_r[p] += r * r; }
+                                for (int i = 0; i < 4; ++i) { const float r = (float)t[i]; ps_r[p][(j / TPP) % NPW] += r; pq_r[p][(j / TPP) % NPW] += r * r; }
                             }
                         }
                     }
                 }
-            if (ln_stats_out) {   // this wave's WTN columns of its rows: the two lane halves hold the two 4-column halves of every 8
-                const int part = (n0 + wn * WTN) / WTN, parts = (g.N + WTN - 1) / WTN;
+            if (ln_stats_out) {   // this wave's WTN columns of its rows, in parts of kLnPartCols (the same partition whatever the kernel's wave layout):
+                                  // the two lane halves hold the two 4-column halves of every 8
+                const int part0 = (n0 + wn * WTN) / kLnPartCols, parts = (g.N + kLnPartCols - 1) / kLnPartCols;
 #pragma unroll
-                for (int p = 0; p < TM; ++p) {
-                    const float s1 = ps_r[p] + __shfl_xor(ps_r[p], 32), s2 = pq_r[p] + __shfl_xor(pq_r[p], 32);
-                    if (hi == 0 && mr[p] < g.M) {
-                        float* o = ln_stats_out + ((int64_t)mr[p] * parts + part) * 2;
-                        o[0] = s1;
-                        o[1] = s2;
+                for (int p = 0; p < TM; ++p)
+#pragma unroll
+                    for (int u = 0; u < NPW; ++u) {
+                        const float s1 = ps_r[p][u] + __shfl_xor(ps_r[p][u], 32), s2 = pq_r[p][u] + __shfl_xor(pq_r[p][u], 32);
+                        if (hi == 0 && mr[p] < g.M && part0 + u < parts) {
+                            float* o = ln_stats_out + ((int64_t)mr[p] * parts + part0 + u) * 2;
+                            o[0] = s1;
+                            o[1] = s2;
+                        }
                     }
-                }
             }
         }
         lds_barrier();
@@ -1700,6 +1708,293 @@ __global__ void __launch_bounds__(512) gemm_pp2_kernel(GemmArgs g) {
                   epi16_rows_if_enabled(BM, BN, WAVES_M, pp_lds_bytes(BM, BN, WAVES_M)), !CONV>(g, acc, smem, m0, n0, z, zb, split);
 }
 
+// ---- 8-phase pipelined 256x256 tile (round 5) ---------------------------------------------------------------------------------------
+// The schedule of /opt/skills/guides/cdna_hip_programming.md section 5 ("The 256^2 8-phase template"), first built as a yardstick
+// (csrc/gemm8p.hip, tools/gemm8p_bench.py: 1320-1360 TFLOP/s on uniform random operands at 4096^3 / 8192^3 / 65536x1024x4096 against
+// 1030-1110 for the two ping-pong kernels above on the same box, same process, same data: profiles/r05_8phase_vs_pp2.txt) and then moved
+// onto the product's operands, MFMA shape and epilogue:
+//   * 8 waves as 2(M) x 4(N), 128x64 per wave = 4 x 2 tiles of v_mfma_f32_32x32x16_f16 (the shape every kernel of this file uses: with the
+//     k-steps of a K-tile taken in the same order the fp32 sums are the same bits as the other kernels');
+//   * LDS: 2 K-tile buffers x {A0, A1, B0, B1} half-tiles (128 rows x 128 B each; half X0 / X1 = the first / second 64 rows (32 columns) of
+//     every wave row (wave column)), each two global_load_lds_dwordx4 per thread;
+//   * a K-tile is four phases, each one 64x32 quadrant of the wave tile over the whole K-tile (8 MFMAs = 512 matrix-pipe cycles):
+//       phase 1: read B0, A0; stage A1(t+1) -> C[0][0]     phase 3: read A1; stage A0(t+2)  -> C[1][1]
+//       phase 2: read B1;     stage B0(t+2) -> C[0][1]     phase 4: stage B1(t+2); vmcnt(6) -> C[1][0]
+//     {reads, 2 DMA, [wait]} s_barrier lgkmcnt(0) {MFMA} s_barrier; wave row 1 runs one barrier behind wave row 0 (one wave of each per
+//     SIMD), so one group multiplies while the other reads and stages;
+//   * three half-tiles of DMA stay in flight across every barrier; the one vector-memory wait per K-tile (phase 4) retires K-tile t+1,
+//     which is read from the next phase on; a buffer is restaged two phases after its last read (B0: one phase, its reads are retired by
+//     lgkmcnt(8) before phase 1's first barrier).
+// Rows beyond M / N and padded convolution taps read a zero line (no predication of the DMA, uniform vmcnt accounting).
+template <bool CONV>
+__global__ void __launch_bounds__(512) gemm8_kernel(GemmArgs g) {
+    constexpr int BM = 256, BN = 256, BK = 64, WAVES_M = 2, WAVES_N = 4;
+    constexpr int HALF = 128 * BK * 2, STAGE = 4 * HALF;
+    constexpr int OFF_A0 = 0, OFF_A1 = HALF, OFF_B0 = 2 * HALF, OFF_B1 = 3 * HALF;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wr = wave >> 2, wc = wave & 3;
+    const int hi = lane >> 5, l31 = lane & 31;
+    int bx, by;
+    {
+        const int nbx = gridDim.x, nb = gridDim.x * gridDim.y;
+        const int bid = blockIdx.y * nbx + blockIdx.x;
+        const int q = nb >> 3, r = nb & 7;
+        const int xcd = bid & 7, idx = bid >> 3;
+        const int logical = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+        by = logical / nbx;
+        bx = logical - by * nbx;
+    }
+    const int m0 = by * BM;
+    const int n0 = bx * BN;
+    const int z = blockIdx.z;
+    const bool split = g.splitk > 1;
+    const int zb = split ? 0 : z;
+    const int nk_total = g.K / BK;
+    int kt_begin = 0, kt_end = nk_total;
+    if (split) {
+        kt_begin = z * g.ktiles_per_split;
+        kt_end = kt_begin + g.ktiles_per_split;
+        if (kt_end > nk_total) kt_end = nk_total;
+    }
+    const int nk = kt_end - kt_begin;
+    const f16* Ab = g.A + (int64_t)zb * g.strideA;
+    const f16* Wb = g.W + (int64_t)zb * g.strideW;
+
+    // ---- staging descriptors: the thread fills physical 16-byte slot (lane & 7) of half-tile row i*64 + srow (piece i = 0, 1) and fetches
+    // logical slot ls (XOR swizzle on the source: the LDS image of a DMA instruction is lane-linear)
+    const int srow = wave * 8 + (lane >> 3);
+    const int ls = (lane & 7) ^ ((srow >> 1) & 7);
+    // A half h, piece i: tile row i*128 + h*64 + srow.  Dense: one base pointer, row validity by compare.  Conv: per row the window's
+    // top-left input coordinate (packed y << 16 | x & 0xffff; rows >= M get y far out of range) and a 32-bit element offset.
+    int a_yx[2][2], a_eoff[2][2];
+    bool a_ok[2][2];
+#pragma unroll
+    for (int h = 0; h < 2; ++h)
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int m = m0 + i * 128 + h * 64 + srow;
+            const bool ok = m < g.M;
+            a_ok[h][i] = ok;
+            a_yx[h][i] = 0;
+            a_eoff[h][i] = 0;
+            if (CONV) {
+                const int ohw = g.cg.OH * g.cg.OW;
+                const int mm = ok ? m : 0;
+                const int img = mm / ohw;
+                const int rem = mm - img * ohw;
+                const int oy = rem / g.cg.OW;
+                const int ox = rem - oy * g.cg.OW;
+                const int iy0 = ok ? oy * g.cg.stride - g.cg.pad_t : -30000;
+                const int ix0 = ox * g.cg.stride - g.cg.pad_l;
+                a_yx[h][i] = (int)(((unsigned)iy0 << 16) | ((unsigned)ix0 & 0xffffu));
+                a_eoff[h][i] = ok ? (int)((((int64_t)img * g.cg.H + iy0) * g.cg.W + ix0) * g.cg.Cin) + ls * 8 : 0;
+            }
+        }
+    const f16* const a_src = Ab + (int64_t)(m0 + srow) * g.lda + ls * 8;   // dense only
+    // B half h, piece i: tile row (i*2 + wave/4)*64 + h*32 + (wave%4)*8 + lane/8
+    const int b_row = (wave >> 2) * 64 + (wave & 3) * 8 + (lane >> 3);
+    const f16* const b_src = Wb + (int64_t)(n0 + b_row) * g.ldw + ls * 8;
+    bool b_ok[2][2];
+#pragma unroll
+    for (int h = 0; h < 2; ++h)
+#pragma unroll
+        for (int i = 0; i < 2; ++i) b_ok[h][i] = (n0 + b_row + i * 128 + h * 32) < g.N;
+    char* const lds_w = smem + wave * 1024;   // this wave's 8 rows inside a 64-row piece
+
+    // K-tile position (wave-uniform, advanced incrementally; conv taps are whole 64-channel chunks walked chunk-major or tap-major: see gemm_kernel::prep_tile)
+    struct TileK {
+        int ky, kx, c0;
+        int64_t a_delta;  // element offset added to the A row offset
+        int kw;           // element offset inside a weight row
+    };
+    auto finish = [&](TileK& t) {
+        if (CONV) {
+            t.a_delta = ((int64_t)t.ky * g.cg.W + t.kx) * g.cg.Cin + t.c0;
+            t.kw = (t.ky * g.cg.KW + t.kx) * g.cg.Cin + t.c0;
+        } else {
+            t.a_delta = t.c0;
+            t.kw = t.c0;
+        }
+    };
+    auto decode = [&](int kt) {
+        TileK t;
+        t.ky = t.kx = 0;
+        t.c0 = kt * BK;
+        if (CONV) {
+            int tap;
+            if (g.cg.chunk_major) {
+                const int taps = g.cg.KH * g.cg.KW;
+                const int chunk = kt / taps;
+                tap = kt - chunk * taps;
+                t.c0 = chunk * BK;
+            } else {
+                tap = (kt * BK) / g.cg.Cin;
+                t.c0 = kt * BK - tap * g.cg.Cin;
+            }
+            t.ky = tap / g.cg.KW;
+            t.kx = tap - t.ky * g.cg.KW;
+        }
+        finish(t);
+        return t;
+    };
+    auto advance = [&](TileK& t) {
+        if (CONV) {
+            if (g.cg.chunk_major) {
+                if (++t.kx == g.cg.KW) {
+                    t.kx = 0;
+                    if (++t.ky == g.cg.KH) { t.ky = 0; t.c0 += BK; }
+                }
+            } else {
+                t.c0 += BK;
+                if (t.c0 == g.cg.Cin) {
+                    t.c0 = 0;
+                    if (++t.kx == g.cg.KW) { t.kx = 0; ++t.ky; }
+                }
+            }
+        } else {
+            t.c0 += BK;
+        }
+        finish(t);
+    };
+    auto stage_A = [&](int h, int buf, const TileK& t) {
+        char* d = lds_w + buf * STAGE + (h ? OFF_A1 : OFF_A0);
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const f16* src;
+            if (CONV) {
+                const int iy = (a_yx[h][i] >> 16) + t.ky, ix = (int)(short)(a_yx[h][i] & 0xffff) + t.kx;
+                const bool ok = (unsigned)iy < (unsigned)g.cg.H && (unsigned)ix < (unsigned)g.cg.W;
+                src = ok ? Ab + ((int64_t)a_eoff[h][i] + t.a_delta) : g.zeros;
+            } else {
+                src = a_ok[h][i] ? a_src + (int64_t)(i * 128 + h * 64) * g.lda + t.a_delta : g.zeros;
+            }
+            glds16(src, d + i * 8192);
+        }
+    };
+    auto stage_B = [&](int h, int buf, const TileK& t) {
+        char* d = lds_w + buf * STAGE + (h ? OFF_B1 : OFF_B0);
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const f16* src = b_ok[h][i] ? b_src + (int64_t)(i * 128 + h * 32) * g.ldw + t.kw : g.zeros;
+            glds16(src, d + i * 8192);
+        }
+    };
+
+    f32x16 acc[4][2];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    // ---- fragment addresses: lane reads row (l & 31) of a 32-row tile, logical slot 2s + (l >> 5) of k-step s -> physical ^ ((row >> 1) & 7)
+    int koff[4];
+#pragma unroll
+    for (int s = 0; s < 4; ++s) koff[s] = ((s * 2 + hi) ^ ((l31 >> 1) & 7)) << 4;
+    const int a_lane = (wr * 64 + l31) * 128;   // + i * 4096 per 32-row tile of the sub-tile
+    const int b_lane = (wc * 32 + l31) * 128;
+    f16x8 af[2][4], b0f[4], b1f[4];
+    auto read_A = [&](int h, int buf) {
+        const char* p = smem + buf * STAGE + (h ? OFF_A1 : OFF_A0) + a_lane;
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int s = 0; s < 4; ++s) af[i][s] = *reinterpret_cast<const f16x8*>(p + i * 4096 + koff[s]);
+    };
+    auto read_B = [&](f16x8 (&bf)[4], int h, int buf) {
+        const char* p = smem + buf * STAGE + (h ? OFF_B1 : OFF_B0) + b_lane;
+#pragma unroll
+        for (int s = 0; s < 4; ++s) bf[s] = *reinterpret_cast<const f16x8*>(p + koff[s]);
+    };
+#define G8_BAR()                               \
+    do {                                       \
+        __builtin_amdgcn_sched_barrier(0);     \
+        __builtin_amdgcn_s_barrier();          \
+        __builtin_amdgcn_sched_barrier(0);     \
+    } while (0)
+    // the 8 MFMAs of quadrant (ih, jh); operands swapped (transposed tile in the registers, see gemm_epilogue)
+#define G8_MMA(ih, bfr, jh)                                                                                                         \
+    do {                                                                                                                            \
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                                                          \
+        __builtin_amdgcn_sched_barrier(0);                                                                                          \
+        __builtin_amdgcn_s_setprio(1);                                                                                              \
+        _Pragma("unroll") for (int s = 0; s < 4; ++s)                                                                               \
+            _Pragma("unroll") for (int i = 0; i < 2; ++i)                                                                           \
+                acc[(ih) * 2 + i][jh] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bfr[s], af[i][s], acc[(ih) * 2 + i][jh], 0, 0, 0);   \
+        __builtin_amdgcn_s_setprio(0);                                                                                              \
+        G8_BAR();                                                                                                                   \
+    } while (0)
+
+    TileK t1 = decode(kt_begin), t2;   // t1 / t2: K-tiles t+1 / t+2 of the tile being multiplied
+    // one K-tile (4 phases) on buffer `buf`; has1 / has2: K-tiles t+1 / t+2 exist (compile-time constants in the steady loop, block-uniform
+    // run-time flags in the tail of at most three K-tiles)
+    auto ktile = [&](const int buf, const bool has1, const bool has2) __attribute__((always_inline)) {
+        // phase 1
+        read_B(b0f, 0, buf);
+        __builtin_amdgcn_sched_barrier(0);
+        read_A(0, buf);
+        if (has1) stage_A(1, buf ^ 1, t1);
+        __builtin_amdgcn_sched_barrier(0);
+        asm volatile("s_waitcnt lgkmcnt(8)" ::: "memory");
+        G8_BAR();
+        G8_MMA(0, b0f, 0);
+        // phase 2
+        read_B(b1f, 1, buf);
+        if (has2) stage_B(0, buf, t2);
+        G8_BAR();
+        G8_MMA(0, b1f, 1);
+        // phase 3
+        read_A(1, buf);
+        if (has2) stage_A(0, buf, t2);
+        G8_BAR();
+        G8_MMA(1, b1f, 1);
+        // phase 4
+        if (has2) { stage_B(1, buf, t2); wait_vmcnt<6>(); }
+        else if (has1) wait_vmcnt<0>();
+        G8_BAR();
+        G8_MMA(1, b0f, 0);
+        t1 = t2;
+        advance(t2);
+    };
+
+    // ---- prologue: K-tile 0 (B0, A0, B1, A1) and B0, A0, B1 of K-tile 1
+    if (nk > 0) {
+        const TileK t0 = t1;
+        advance(t1);
+        stage_B(0, 0, t0); stage_A(0, 0, t0); stage_B(1, 0, t0); stage_A(1, 0, t0);
+        if (nk > 1) {
+            stage_B(0, 1, t1); stage_A(0, 1, t1); stage_B(1, 1, t1);
+            wait_vmcnt<6>();
+        } else {
+            wait_vmcnt<0>();
+        }
+    }
+    t2 = t1;
+    advance(t2);
+    G8_BAR();
+    if (wr == 1) G8_BAR();   // stagger: wave row 1 runs one barrier behind wave row 0
+
+    int kt = 0;
+    for (; kt + 3 < nk; kt += 2) {   // steady state: two K-tiles per iteration, buffers and flags compile-time constants
+        ktile(0, true, true);
+        ktile(1, true, true);
+    }
+    for (; kt < nk; ++kt) ktile(kt & 1, kt + 1 < nk, kt + 2 < nk);   // the last one to three K-tiles (kt is even here)
+    if (wr == 0) G8_BAR();   // re-align the two groups
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    __syncthreads();
+#undef G8_MMA
+#undef G8_BAR
+    constexpr int LDS = pp_lds_bytes(BM, BN, WAVES_M);
+    gemm_epilogue<BM, BN, WAVES_M, WAVES_N, epi_wave_rows(BM, BN, WAVES_M, LDS), false, CONV, true, epi16_rows_if_enabled(BM, BN, WAVES_M, LDS), !CONV>(
+        g, acc, smem, m0, n0, z, zb, split);
+}
+
 // (A third structure - every wave free-running through the four k-steps with register double-buffered fragments and ONE barrier per
 // K-tile, i.e. the classic software-pipelined GEMM - was built and measured too: bit-identical results, 5-12 % SLOWER than the
 // ping-pong kernels on the large shapes (898 vs 1012 TFLOP/s at 65536x512x4096), so the barrier count is not what bounds them.)
@@ -2140,11 +2435,8 @@ static int launch_gemm_t(odise_hip_ctx* ctx, GemmArgs& g, int batch) {
     static_assert(epi_lds_bytes(BM, BN, WAVES_M, epi_wave_rows(BM, BN, WAVES_M, lds)) <= lds, "epilogue staging exceeds the LDS request");
     auto kern = gemm_kernel<BM, BN, WAVES_M, WAVES_N, CONV, INTERLEAVE>;
     if (lds > 65536) {
-        static bool attr_set = false;  // per instantiation
-        if (!attr_set) {
-            ODISE_CHECK_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
-            attr_set = true;
-        }
+        static LdsAttrOnce once;  // per instantiation; tracked per device inside
+        ODISE_TRY(ensure_dyn_lds(ctx, once, (const void*)kern, lds));
     }
     dim3 grid((unsigned)ceil_div(g.N, BN), (unsigned)ceil_div(g.M, BM), (unsigned)(g.splitk > 1 ? g.splitk : batch));
     hipLaunchKernelGGL(kern, grid, dim3(NT), lds, ctx->stream, g);
@@ -2163,11 +2455,8 @@ static int launch_gemm_pp(odise_hip_ctx* ctx, GemmArgs& g, int batch) {
     constexpr int lds = pp_lds_bytes(BM, BN, 8 / WAVES_N);
     static_assert(epi_lds_bytes(BM, BN, 8 / WAVES_N, epi_wave_rows(BM, BN, 8 / WAVES_N, lds)) <= lds, "epilogue staging exceeds the LDS request");
     auto kern = gemm_pp_kernel<BM, BN, WAVES_N, PT, CONV>;
-    static bool attr_set = false;  // per instantiation
-    if (!attr_set) {
-        ODISE_CHECK_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
-        attr_set = true;
-    }
+    static LdsAttrOnce once;  // per instantiation; tracked per device inside
+    ODISE_TRY(ensure_dyn_lds(ctx, once, (const void*)kern, lds));
     dim3 grid((unsigned)ceil_div(g.N, BN), (unsigned)ceil_div(g.M, BM), (unsigned)(g.splitk > 1 ? g.splitk : batch));
     hipLaunchKernelGGL(kern, grid, dim3(512), lds, ctx->stream, g);
     ODISE_CHECK_HIP(hipGetLastError());
@@ -2185,12 +2474,29 @@ static int launch_gemm_pp2(odise_hip_ctx* ctx, GemmArgs& g, int batch) {
     static_assert((BN / WAVES_N / 32) % PT == 0, "whole phases");
     constexpr int lds = pp_lds_bytes(BM, BN, 8 / WAVES_N);
     auto kern = gemm_pp2_kernel<BM, BN, WAVES_N, PT, CONV>;
-    static bool attr_set = false;  // per instantiation
-    if (!attr_set) {
-        ODISE_CHECK_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
-        attr_set = true;
-    }
+    static LdsAttrOnce once;  // per instantiation; tracked per device inside
+    ODISE_TRY(ensure_dyn_lds(ctx, once, (const void*)kern, lds));
     dim3 grid((unsigned)ceil_div(g.N, BN), (unsigned)ceil_div(g.M, BM), (unsigned)(g.splitk > 1 ? g.splitk : batch));
+    hipLaunchKernelGGL(kern, grid, dim3(512), lds, ctx->stream, g);
+    ODISE_CHECK_HIP(hipGetLastError());
+    if (g.splitk > 1) {
+        const int64_t total = (int64_t)g.M * ceil_div(g.N, 8);
+        const int blocks = (int)std::min<int64_t>(ceil_div(total, 256), 2048);
+        hipLaunchKernelGGL(splitk_reduce_kernel, dim3(blocks), dim3(256), 0, ctx->stream, g.ws, g.splitk, g.M, g.N, g.epi);
+        ODISE_CHECK_HIP(hipGetLastError());
+    }
+    return ODISE_OK;
+}
+
+template <bool CONV>
+static int launch_gemm8(odise_hip_ctx* ctx, GemmArgs& g, int batch) {
+    constexpr int lds = pp_lds_bytes(256, 256, 2);
+    static_assert(lds >= 2 * 4 * 128 * 64 * 2, "operand stages exceed the LDS request");
+    static_assert(epi_lds_bytes(256, 256, 2, epi_wave_rows(256, 256, 2, lds)) <= lds, "epilogue staging exceeds the LDS request");
+    auto kern = gemm8_kernel<CONV>;
+    static LdsAttrOnce once;  // per instantiation; tracked per device inside
+    ODISE_TRY(ensure_dyn_lds(ctx, once, (const void*)kern, lds));
+    dim3 grid((unsigned)ceil_div(g.N, 256), (unsigned)ceil_div(g.M, 256), (unsigned)(g.splitk > 1 ? g.splitk : batch));
     hipLaunchKernelGGL(kern, grid, dim3(512), lds, ctx->stream, g);
     ODISE_CHECK_HIP(hipGetLastError());
     if (g.splitk > 1) {
@@ -2207,11 +2513,8 @@ static int launch_conv3_halo(odise_hip_ctx* ctx, GemmArgs& g) {
     constexpr int lds = halo_lds_bytes(BN);
     static_assert(epi_lds_bytes(256, BN, 4, epi_wave_rows(256, BN, 4, lds)) <= lds, "epilogue staging exceeds the LDS request");
     auto kern = conv3_halo_kernel<BN, PT>;
-    static bool attr_set = false;  // per instantiation
-    if (!attr_set) {
-        ODISE_CHECK_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
-        attr_set = true;
-    }
+    static LdsAttrOnce once;  // per instantiation; tracked per device inside
+    ODISE_TRY(ensure_dyn_lds(ctx, once, (const void*)kern, lds));
     const int n_img = g.M / (g.cg.OH * g.cg.OW);
     dim3 grid((unsigned)ceil_div(g.N, BN), (unsigned)(n_img * g.cg.halo_tx * g.cg.halo_ty), (unsigned)(g.splitk > 1 ? g.splitk : 1));
     hipLaunchKernelGGL(kern, grid, dim3(512), lds, ctx->stream, g);
@@ -2231,11 +2534,8 @@ static int launch_conv3_halo4(odise_hip_ctx* ctx, GemmArgs& g) {
     static_assert(2 * lds <= 160 * 1024, "two blocks must fit a CU's LDS");
     static_assert(epi_lds_bytes(256, BN, 4, epi_wave_rows(256, BN, 4, lds)) <= lds, "epilogue staging exceeds the LDS request");
     auto kern = conv3_halo4_kernel<BN>;
-    static bool attr_set = false;  // per instantiation
-    if (!attr_set) {
-        ODISE_CHECK_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
-        attr_set = true;
-    }
+    static LdsAttrOnce once;  // per instantiation; tracked per device inside
+    ODISE_TRY(ensure_dyn_lds(ctx, once, (const void*)kern, lds));
     const int n_img = g.M / (g.cg.OH * g.cg.OW);
     dim3 grid((unsigned)ceil_div(g.N, BN), (unsigned)(n_img * g.cg.halo_tx * g.cg.halo_ty), (unsigned)(g.splitk > 1 ? g.splitk : 1));
     hipLaunchKernelGGL(kern, grid, dim3(256), lds, ctx->stream, g);
@@ -2300,6 +2600,8 @@ static const TileCost kTileCostPP[2] = {
 // 18 K-tiles on the 128-channel VAE level; the dense fit above says 52 us).  Still ahead of the plain 256x128 tile on the stride-2 conv
 // of that level (622 vs 651 us), behind the halo tile on the stride-1 ones.
 static const TileCost kTileCostConv512 = {2.5, 16.0, 1};
+// the 256x256 tile as run by the 8-phase kernel (round 5; fitted on tools/gemm8p_bench.py: 4096^3 101 us = 64 K-tiles, 65536x512x4608 244 us = 2 rounds of 72)
+static const TileCost kTileCost8 = {1.50, 9.0, 1};
 // previous fit (before the lean epilogue / ping-pong kernel), kept selectable for A/B runs: ODISE_GEMM_FLAGS=8
 static const TileCost kTileCostOld[kNumTiles] = {{1.68, 9.5, 2}, {1.58, 4.1, 3}, {1.28, 2.4, 4}, {3.04, 29.0, 1}, {2.58, 22.0, 1},
                                                  {1.75, 10.6, 1}, {2.25, 12.0, 1}, {1.92, 12.0, 1}, {1.32, 10.0, 1}, {2.64, 10.0, 2}};
@@ -2324,11 +2626,16 @@ template <bool CONV>
 static int launch_gemm(odise_hip_ctx* ctx, GemmArgs& g, int batch, int force_tile, int force_split, unsigned tile_mask = ~0u) {
     LaunchProbe* pr = probe_match(ctx, CONV, g.M, g.N, g.K);
     if (pr && CONV && g.cg.ups) pr = nullptr;   // a convolution with the fused nearest-2x upsample has the same (M, N, K) and runs another kernel: not the probed shape
+    if (pr) {   // a measurement hook must never fail a model call: not inside a stream capture (event timing of captured nodes is invalid) ...
+        hipStreamCaptureStatus st = hipStreamCaptureStatusNone;
+        if (hipStreamIsCapturing(ctx->stream, &st) != hipSuccess || st != hipStreamCaptureStatusNone) pr = nullptr;
+    }
     if (!pr) return launch_gemm_select<CONV>(ctx, g, batch, force_tile, force_split, tile_mask);
-    const int i = pr->n++;
-    ODISE_CHECK_HIP(hipEventRecord(pr->ev[2 * i], ctx->stream));
+    const int i = pr->n;
+    const bool started = hipEventRecord(pr->ev[2 * i], ctx->stream) == hipSuccess;
     const int rc = launch_gemm_select<CONV>(ctx, g, batch, force_tile, force_split, tile_mask);
-    ODISE_CHECK_HIP(hipEventRecord(pr->ev[2 * i + 1], ctx->stream));
+    if (started && hipEventRecord(pr->ev[2 * i + 1], ctx->stream) == hipSuccess) pr->n = i + 1;   // ... counted only when both records succeeded
+    else { (void)hipGetLastError(); pr->armed = false; }                                           // ... and disarmed, not fatal, when one did not
     return rc;
 }
 
@@ -2355,13 +2662,18 @@ static int launch_gemm_select(odise_hip_ctx* ctx, GemmArgs& g, int batch, int fo
     double best = 1e30;
     const int flags = g_conv_flags | env_gemm_flags();
     const bool pp_ok = !no_interleave && !(flags & 2) && g.K % 64 == 0 && (!CONV || (g.cg.Cin % 64 == 0 && !g.cg.ups));
+    // the 8-phase kernel runs the 256x256 tile wherever the ping-pong kernels could (its convolution form keeps 32-bit element offsets);
+    // ODISE_GEMM_FLAGS 4096 = never, and the switches that name a ping-pong generation (512 / 1024) keep their meaning
+    const bool g8_ok = pp_ok && !(flags & (4096 | 512 | 1024)) &&
+                       (!CONV || (int64_t)(g.M / (g.cg.OH * g.cg.OW)) * g.cg.H * g.cg.W * g.cg.Cin < ((int64_t)1 << 31));
     for (int t = 0; t < kNumTiles; ++t) {
         if (force_tile >= 0 && force_tile < kNumTiles && t != force_tile) continue;
         if (!((tile_mask >> t) & 1)) continue;
         if (t == 6 && (!pp_ok || (flags & 16))) continue;
         if (t >= 7 && t <= 9 && (!halo_ok || !pp_ok || (flags & 64))) continue;  // ODISE_GEMM_FLAGS=64: never use the halo kernels
         if (t == 9 && (flags & 2048)) continue;                        // ODISE_GEMM_FLAGS=2048: never use the two-blocks-per-CU halo kernel
-        const TileCost& tc = (flags & 8) ? kTileCostOld[t] : (pp_ok && (t == 3 || t == 4)) ? kTileCostPP[t - 3] : (CONV && t == 6) ? kTileCostConv512 : kTileCost[t];
+        const TileCost& tc = (flags & 8) ? kTileCostOld[t] : (g8_ok && t == 4) ? kTileCost8 : (pp_ok && (t == 3 || t == 4)) ? kTileCostPP[t - 3] :
+                             (CONV && t == 6) ? kTileCostConv512 : kTileCost[t];
         if (force_tile < 0) {
             if (kTileBM[t] > 64 && g.M <= kTileBM[t] / 2) continue;            // mostly-empty row tiles
             if (kTileBN[t] > 64 && g.N <= kTileBN[t] / 2 && t != 2) continue;  // mostly-empty column tiles
@@ -2427,7 +2739,7 @@ static int launch_gemm_select(odise_hip_ctx* ctx, GemmArgs& g, int batch, int fo
         // the LayerNorm terms only exist in the math-first epilogue (256x256 / 256x128 tiles); the producer's partial sums are per 128 columns =
         // the wave columns of the 256x256 tile
         ODISE_REQUIRE(!CONV && (tile == 4 || tile == 5) && g.splitk == 1 && g.epi.f16path && !g.epi.geglu && batch == 1 &&
-                          (!g.epi.ln_stats_out || (tile == 4 && g.N % 128 == 0)),
+                          (!g.epi.ln_stats_out || (tile == 4 && g.N % kLnPartCols == 0)),
                       "gemm_ln: M=%d N=%d K=%d cannot take the folded-LayerNorm path", g.M, g.N, g.K);
     }
     g.stats_blocks = 0;
@@ -2436,7 +2748,7 @@ static int launch_gemm_select(odise_hip_ctx* ctx, GemmArgs& g, int batch, int fo
         // epilogue), a column-chunk count that divides the thread count, and row blocks that never straddle two images
         const int ohw = CONV ? g.cg.OH * g.cg.OW : 0;
         // kernels instantiated with the statistics epilogue: halo tiles, pp2 conv (256x256) and the 512x128 conv tile
-        const bool pp2_used = (tile == 4) && pp_ok && ((flags & 512) || (!(flags & 1024) && CONV));
+        const bool pp2_used = (tile == 4) && pp_ok && (g8_ok || (flags & 512) || (!(flags & 1024) && CONV));   // gemm8_kernel<true> carries the statistics epilogue too
         bool ok = CONV && g.splitk == 1 && g.epi.fast && g.N % 8 == 0 && ((tile >= 7 && tile <= 9) || (tile == 6 && pp_ok && !(flags & 512)) || pp2_used);
         if (ok && tile >= 7) g.stats_blocks = g.cg.halo_tx * g.cg.halo_ty;
         else if (ok && ohw % kTileBM[tile] == 0) g.stats_blocks = ohw / kTileBM[tile];
@@ -2460,6 +2772,7 @@ static int launch_gemm_select(odise_hip_ctx* ctx, GemmArgs& g, int batch, int fo
     // second-generation ping-pong kernel (fragment reads under the MFMAs): measured +3..18 % on the implicit-GEMM convs and on
     // dense problems that do not fill the chip twice; the large dense GEMMs keep the first generation (-5..12 % there).
     // ODISE_GEMM_FLAGS: 512 forces it, 1024 forbids it.
+    if (tile == 4 && g8_ok) return launch_gemm8<CONV>(ctx, g, batch);
     const bool pp2_auto = !(flags & 1024) && ((CONV && tile != 6) || (!CONV && blocks(tile) * (g.splitk > 1 ? g.splitk : 1) <= 2 * cus));
     if ((tile == 3 || tile == 4 || tile == 6) && pp_ok && ((flags & 512) || pp2_auto)) {
         if (tile == 6) return launch_gemm_pp2<512, 128, 1, 2, CONV>(ctx, g, batch);

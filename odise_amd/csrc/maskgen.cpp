@@ -780,15 +780,18 @@ using namespace odise;
 
 extern "C" int odise_hip_backbone_build(odise_hip_ctx* ctx) {
     ODISE_REQUIRE(ctx, "backbone_build: null context");
+    ODISE_CHECK_HIP(hipSetDevice(ctx->device));   // the caller may be a new host thread, or hold another device current
     return maskgen_build_backbone(ctx);
 }
 extern "C" int odise_hip_head_build(odise_hip_ctx* ctx) {
     ODISE_REQUIRE(ctx, "head_build: null context");
+    ODISE_CHECK_HIP(hipSetDevice(ctx->device));   // the caller may be a new host thread, or hold another device current
     return maskgen_build_head(ctx);
 }
 
 extern "C" int odise_hip_backbone_forward(odise_hip_ctx* ctx, const float* image, int B, int H, int W, float** out4) {
     ODISE_REQUIRE(ctx, "backbone_forward: null context");
+    ODISE_CHECK_HIP(hipSetDevice(ctx->device));   // the caller may be a new host thread, or hold another device current
     return backbone_forward(ctx, image, B, H, W, out4);
 }
 
@@ -797,6 +800,7 @@ extern "C" int odise_hip_backbone_forward(odise_hip_ctx* ctx, const float* image
 extern "C" int odise_hip_head_forward(odise_hip_ctx* ctx, const float* const* feats4, int B, int Cin, int H4, int W4, float* pred_masks,
                                       float* mask_embed, float* mask_pooled, float* logit_scale) {
     ODISE_REQUIRE(ctx, "head_forward: null context");
+    ODISE_CHECK_HIP(hipSetDevice(ctx->device));   // the caller may be a new host thread, or hold another device current
     ModelStore* ms = store_of(ctx);
     MaskGenModel* g = ms->maskgen;
     if (!g || !g->head_built) {
@@ -836,6 +840,7 @@ extern "C" int odise_hip_head_forward(odise_hip_ctx* ctx, const float* const* fe
 extern "C" int odise_hip_pixel_decoder_forward(odise_hip_ctx* ctx, const float* const* feats4, int B, int Cin, int H4, int W4, float* mask_features,
                                                float* const* multi_scale3) {
     ODISE_REQUIRE(ctx && feats4, "pixel_decoder_forward: null argument");
+    ODISE_CHECK_HIP(hipSetDevice(ctx->device));   // the caller may be a new host thread, or hold another device current
     ModelStore* ms = store_of(ctx);
     MaskGenModel* g = ms->maskgen;
     if (!g || !g->head_built) {
@@ -867,6 +872,7 @@ extern "C" int odise_hip_pixel_decoder_forward(odise_hip_ctx* ctx, const float* 
 extern "C" int odise_hip_predictor_forward(odise_hip_ctx* ctx, const float* const* multi_scale3, const int* hw3, const float* mask_features, int B, int H4,
                                            int W4, float* pred_masks, float* mask_embed, float* mask_pooled, float* logit_scale) {
     ODISE_REQUIRE(ctx && multi_scale3 && hw3 && mask_features, "predictor_forward: null argument");
+    ODISE_CHECK_HIP(hipSetDevice(ctx->device));   // the caller may be a new host thread, or hold another device current
     ModelStore* ms = store_of(ctx);
     MaskGenModel* g = ms->maskgen;
     if (!g || !g->head_built) {

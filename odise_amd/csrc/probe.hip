@@ -43,6 +43,7 @@ extern "C" int odise_hip_mfma_probe(odise_hip_ctx* ctx, float* host_out /* [3][6
     return ODISE_OK;
 }
 
+#ifdef ODISE_TOOLS   // the rate probes below exist only in the measurement build (libodise_hip_tools.so; include/odise_hip_lab.h)
 // ---- MFMA issue-rate probe (tools/mfma_rate.py): what the matrix pipes sustain on this part without any operand traffic -----------
 // Every wave runs `iters` rounds of 16 v_mfma_f32_32x32x16_f16 over CHAINS independent accumulator tiles.  MODE selects the
 // synchronisation skeleton around each round: 0 none (free running), 1 one workgroup barrier per round, 2 the ping-pong skeleton of
@@ -107,9 +108,58 @@ __global__ void __launch_bounds__(THREADS) mfma_rate_kernel(float* out, int iter
 }
 }  // namespace odise
 
+// The same probe on v_mfma_f32_16x16x32_f16 (round 5: the MFMA shape of the guide's 8-phase GEMM template): 32 instructions per round over
+// 4 * CHAINS independent 16x16 accumulators = the same FLOPs per round as the 16 32x32x16 instructions above.
+namespace odise {
+template <int CHAINS, int MODE, int THREADS>
+__global__ void __launch_bounds__(THREADS) mfma_rate16_kernel(float* out, int iters, float seed, unsigned long long* clocks) {
+    const int wave = threadIdx.x >> 6;
+    const int grp = wave >> 2;
+    unsigned long long c0 = 0, r0 = 0;
+    if (blockIdx.x == 0 && threadIdx.x == 0) { c0 = __builtin_readcyclecounter(); r0 = wall_clock64(); }
+    f16x8 af[4], bf[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            unsigned h = (unsigned)(threadIdx.x * 8 + e) * 2654435761u + (unsigned)q * 40503u + blockIdx.x * 97u;
+            h ^= h >> 15; h *= 2246822519u; h ^= h >> 13;
+            af[q][e] = (f16)(seed * ((float)(h & 0xffff) / 32768.f - 1.f));
+            bf[q][e] = (f16)(seed * ((float)(h >> 16) / 32768.f - 1.f));
+        }
+    constexpr int NA = 4 * CHAINS;
+    f32x4 acc[NA];
+#pragma unroll
+    for (int c = 0; c < NA; ++c) acc[c] = f32x4{0.f, 0.f, 0.f, 0.f};
+    if (MODE == 2 && grp == 1) __builtin_amdgcn_s_barrier();
+    for (int it = 0; it < iters; ++it) {
+        if (MODE == 2) { __builtin_amdgcn_sched_barrier(0); __builtin_amdgcn_s_barrier(); __builtin_amdgcn_sched_barrier(0); }
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int s = 0; s < 32 / NA; ++s)
+#pragma unroll
+            for (int c = 0; c < NA; ++c)
+                acc[c] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[(c & 1) * 2 + (s & 1)], bf[(c >> 1 & 1) * 2 + (s >> 1 & 1)], acc[c], 0, 0, 0);
+        __builtin_amdgcn_s_setprio(0);
+        if (MODE == 2) { __builtin_amdgcn_sched_barrier(0); __builtin_amdgcn_s_barrier(); __builtin_amdgcn_sched_barrier(0); }
+    }
+    if (MODE == 2 && grp == 0) __builtin_amdgcn_s_barrier();
+    float s = 0.f;
+#pragma unroll
+    for (int c = 0; c < NA; ++c)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) s += acc[c][r];
+    if (s == 12345.678f) out[threadIdx.x] = s;
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        clocks[0] = __builtin_readcyclecounter() - c0;
+        clocks[1] = wall_clock64() - r0;
+    }
+}
+}  // namespace odise
+
 // variant: 0 free/2 waves per SIMD/4 chains, 1 free/1 wave per SIMD/4 chains, 2 ping-pong skeleton, 3 barrier per round,
 // 4 barrier per two rounds, 5 free/2 waves/8 chains, 6 free/1 wave/8 chains, 7 = 0 with random operands, 8 = 2 with random operands,
-// 9 = 6 with random operands.  Returns the average launch time of `reps` launches and the shader clock (MHz) of the last one.
+// 9 = 6 with random operands; 10 / 11 / 12 = 7 / 8 / 9 on v_mfma_f32_16x16x32_f16 (mfma_rate16_kernel).  Returns the average launch time of `reps` launches and the shader clock (MHz) of the last one.
 extern "C" int odise_hip_mfma_rate(odise_hip_ctx* ctx, int variant, int iters, int blocks, int reps, float* ms_out, double* flops_out, double* mhz_out) {
     using namespace odise;
     ODISE_REQUIRE(ctx && ms_out && flops_out && iters > 0 && blocks > 0 && reps > 0, "mfma_rate: bad argument");
@@ -127,6 +177,9 @@ extern "C" int odise_hip_mfma_rate(odise_hip_ctx* ctx, int variant, int iters, i
             case 6: threads = 256; hipLaunchKernelGGL((mfma_rate_kernel<8, 0, 256, false>), dim3(blocks), dim3(256), 0, ctx->stream, d, iters, 0.5f, clk); break;
             case 7: hipLaunchKernelGGL((mfma_rate_kernel<4, 0, 512, true>), dim3(blocks), dim3(512), 0, ctx->stream, d, iters, 0.5f, clk); break;
             case 8: hipLaunchKernelGGL((mfma_rate_kernel<4, 2, 512, true>), dim3(blocks), dim3(512), 0, ctx->stream, d, iters, 0.5f, clk); break;
+            case 10: hipLaunchKernelGGL((mfma_rate16_kernel<4, 0, 512>), dim3(blocks), dim3(512), 0, ctx->stream, d, iters, 0.5f, clk); break;
+            case 11: hipLaunchKernelGGL((mfma_rate16_kernel<4, 2, 512>), dim3(blocks), dim3(512), 0, ctx->stream, d, iters, 0.5f, clk); break;
+            case 12: threads = 256; hipLaunchKernelGGL((mfma_rate16_kernel<8, 0, 256>), dim3(blocks), dim3(256), 0, ctx->stream, d, iters, 0.5f, clk); break;
             default: threads = 256; hipLaunchKernelGGL((mfma_rate_kernel<8, 0, 256, true>), dim3(blocks), dim3(256), 0, ctx->stream, d, iters, 0.5f, clk); break;
         }
     };
@@ -206,3 +259,4 @@ extern "C" int odise_hip_lds_rate(odise_hip_ctx* ctx, int variant, int rounds, i
     *clocks_per_round = (double)hc / rounds;
     return ODISE_OK;
 }
+#endif  // ODISE_TOOLS

@@ -570,6 +570,7 @@ extern "C" int odise_hip_unet_use_graph(odise_hip_ctx* ctx, int enable) {
 extern "C" int odise_hip_unet_features_nhwc(odise_hip_ctx* ctx, const float* x_t, const float* context, const float* cond_emb, int B,
                                             int h, int w, int t, void** taps4) {
     ODISE_REQUIRE(ctx, "unet_features: null context");
+    ODISE_CHECK_HIP(hipSetDevice(ctx->device));   // the caller may be a new host thread, or hold another device current
     ODISE_TRY(unet_forward(ctx, x_t, context, cond_emb, B, h, w, t));
     if (taps4) {
         ModelStore* ms = store_of(ctx);
@@ -581,6 +582,7 @@ extern "C" int odise_hip_unet_features_nhwc(odise_hip_ctx* ctx, const float* x_t
 extern "C" int odise_hip_unet_features(odise_hip_ctx* ctx, const float* x_t, const float* context, const float* cond_emb, int B, int h,
                                        int w, int t, float* tap_u2, float* tap_u5, float* tap_u8, float* tap_u11) {
     ODISE_REQUIRE(ctx, "unet_features: null context");
+    ODISE_CHECK_HIP(hipSetDevice(ctx->device));   // the caller may be a new host thread, or hold another device current
     ODISE_TRY(unet_forward(ctx, x_t, context, cond_emb, B, h, w, t));
     ModelStore* ms = store_of(ctx);
     float* outs[4] = {tap_u2, tap_u5, tap_u8, tap_u11};

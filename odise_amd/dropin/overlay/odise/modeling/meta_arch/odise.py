@@ -83,8 +83,10 @@ class PooledMaskEmbed(nn.Module):
         self.mask_pooling = MaskPooling()
 
     def _device_weights(self, ctx):
-        """The module's few weights on the device, uploaded once per parameter version (`load_state_dict` bumps it), not per call."""
-        version = tuple(p._version for p in self.parameters())
+        """The module's few weights on the device, uploaded once per parameter state, not per call.  The key holds `_version` (in-place
+        updates: `load_state_dict`, optimiser steps) AND the storage identity / dtype / device of every parameter: `param.data = ...`
+        (`Module.to(dtype)`, manual weight swaps, some checkpoint loaders) replaces the storage without bumping the version."""
+        version = tuple((p._version, p.data_ptr(), p.dtype, str(p.device)) for p in self.parameters())
         if getattr(self, "_dev", None) is None or self._dev[0] != version or self._dev[1] is not ctx:
             w = {}
             for name, mod in (("pool_ln", self.pool_proj[0]), ("pool_lin", self.pool_proj[1]), ("embed_ln", self.mask_embed[0]),
@@ -95,6 +97,12 @@ class PooledMaskEmbed(nn.Module):
                     w[name] = (ctx.to_device(_np(mod.weight).astype(np.float16)), ctx.to_device(_np(mod.bias).astype(np.float32)) if mod.bias is not None else None)
             self._dev = (version, ctx, w)
         return self._dev[2]
+
+    # the cache holds ctypes-backed device buffers: never part of a pickle or a copy.deepcopy of the model (both go through __getstate__)
+    def __getstate__(self):
+        state = self.__dict__.copy()
+        state.pop("_dev", None)
+        return state
 
     @staticmethod
     def _linear(ctx, x, wb, act=0, residual=None):

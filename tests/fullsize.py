@@ -261,3 +261,26 @@ def reference(bb, head, ext, size, num_classes, num_strings, seed=0, use_cache=T
     r["mask_cls"] = classify_reference(heads, r)
     _MEMO[key] = (img, heads, r)
     return img, heads, r
+
+
+def ideal_on_device_features(ext, head, heads, feats_dev, img, tag=None):
+    """The fp32 ORACLE head + classification (CPU) on the DEVICE's backbone features of one picture: what an ideal, infinitely precise head
+    would make of the features the device computed (tools/parity_attribution.py cell B, profiles/r05_parity_attribution.txt).  A device
+    result that differs from the pure oracle by more than rounding noise on some query must differ from THIS by rounding noise only - then
+    the re-decision is the reference's own decision chain reacting to the ~3e-3 feature error, not an error of the device's head.
+    feats_dev: dict s2..s5 of fp32 NCHW arrays [1, 512, h, w] (HipODISE.backbone of that picture); img: uint8 CHW tensor.
+    -> dict with pred_masks [1,Q,h,w], mask_embed, clip_embed, logit_scale, mask_cls [1,Q,K+1] (torch, fp32).  Memoised per (features, vocabulary)."""
+    h = hashlib.sha256()
+    for k in ("s2", "s3", "s4", "s5"):
+        a = np.ascontiguousarray(feats_dev[k], np.float32)
+        h.update(a[..., ::7].tobytes())
+    key = ("ideal", h.hexdigest())
+    if key not in _MEMO:
+        img01 = img.float()[None] / 255.0
+        with torch.no_grad():
+            out = head({k: torch.from_numpy(np.ascontiguousarray(feats_dev[k], np.float32)) for k in ("s2", "s3", "s4", "s5")})
+            ce = om.mask_clip_embed(ext.clip, img01, out["pred_masks"])
+        _MEMO[key] = {"pred_masks": out["pred_masks"], "mask_embed": out["mask_embed"], "clip_embed": ce, "logit_scale": float(out["logit_scale"])}
+    r = dict(_MEMO[key])
+    r["mask_cls"] = classify_reference(heads, r)
+    return r

@@ -123,3 +123,23 @@ def test_default_train_labels_and_overlap_mask_match_the_reference(env, monkeypa
     monkeypatch.setattr(sys, "path", [p for p in sys.path if not p.startswith(REFERENCE)])
     with pytest.raises(FileNotFoundError):
         ck.default_train_labels()
+
+
+def test_pooled_mask_embed_cache_is_not_copied_and_sees_data_swaps(env):
+    """the device-weight cache of the overlay PooledMaskEmbed must not travel with copy.deepcopy / pickle, and its key must change
+    when a parameter's storage is replaced without a version bump (`param.data = ...`)."""
+    import copy
+    import pickle
+    from odise.modeling.meta_arch.odise import PooledMaskEmbed
+    m = PooledMaskEmbed(hidden_dim=32, mask_dim=32, projection_dim=16)
+    key = lambda mod: tuple((p._version, p.data_ptr(), p.dtype, str(p.device)) for p in mod.parameters())
+    k0 = key(m)
+    m._dev = (k0, object(), {"sentinel": 1})
+    c = copy.deepcopy(m)
+    assert getattr(c, "_dev", None) is None and m._dev[2] == {"sentinel": 1}
+    m2 = pickle.loads(pickle.dumps(m))
+    assert getattr(m2, "_dev", None) is None
+    p = m.pool_proj[1].weight
+    v = p._version
+    p.data = p.data.clone()                       # storage swapped, version unchanged
+    assert p._version == v and key(m) != k0

@@ -106,6 +106,56 @@ def test_gemm_plain(ctx, M, N, K, tile, split):
     close(out32, ref.numpy(), rtol=1e-4, atol=1e-4 * float(ref.abs().max()), what="gemm f32 out")
 
 
+# ---- the 8-phase 256x256 kernel (gemm8_kernel, round 5: tile 4 wherever K % 64 == 0) against the ping-pong kernel it replaces on that tile
+# (odise_hip_gemm_debug 1024 << 4 names it): same MFMA shape, same k order -> the same bits.  Ragged M / N (zero-line rows), one to many
+# K-tiles with odd and even counts (the tail of one to three K-tiles), split-K, batched, every epilogue family.
+@pytest.mark.parametrize("M,N,K,split,batch", [(256, 256, 64, 1, 1), (256, 256, 128, 1, 1), (512, 512, 192, 1, 1), (300, 330, 256, 1, 1), (1000, 264, 320, 1, 1),
+                                               (2720, 1024, 1024, 1, 1), (512, 256, 1536, 3, 1), (700, 300, 448, 2, 1), (256, 512, 512, 1, 3), (9344, 1024, 1024, 1, 1)])
+def test_gemm8_bit_identical_to_pingpong(ctx, M, N, K, split, batch):
+    g = torch.Generator().manual_seed(M + 3 * N + 7 * K + split)
+    shp = (lambda r, c: (batch, r, c)) if batch > 1 else (lambda r, c: (r, c))
+    A = h(torch.randn(*shp(M, K), generator=g))
+    W = h(torch.randn(*shp(N, K), generator=g) / K ** 0.5)
+    bias = torch.randn(N, generator=g)
+    res = h(torch.randn(M, N, generator=g))
+    dA, dW, db = ctx.to_device(A.half().numpy()), ctx.to_device(W.half().numpy()), ctx.to_device(bias)
+    dr = ctx.to_device(res.half().numpy()) if batch == 1 else None
+    outs = {}
+    try:
+        for name, flags in (("g8", 0), ("pp", 1024 << 4)):
+            ctx.lib.odise_hip_gemm_debug(flags)
+            outs[name] = [ctx.gemm(dA, dW, bias_n=db, act=_lib.ACT_SILU, residual=dr, force_tile=4, force_split=split).numpy(),
+                          ctx.gemm(dA, dW, out_dtype=np.float32, force_tile=4, force_split=split).numpy()]
+            if batch == 1 and N % 16 == 0:
+                outs[name].append(ctx.gemm(dA, dW, bias_n=db, geglu=True, force_tile=4, force_split=split).numpy())
+    finally:
+        ctx.lib.odise_hip_gemm_debug(0)
+    ref = (A @ W.transpose(-1, -2)).numpy()
+    close(outs["g8"][1], ref, rtol=1e-4, atol=1e-4 * float(np.abs(ref).max()), what=f"gemm8 {M}x{N}x{K} f32 out")
+    for a, b in zip(outs["g8"], outs["pp"]):
+        assert np.array_equal(a, b), f"gemm8 differs bitwise from the ping-pong kernel at {M}x{N}x{K} split {split} batch {batch}"
+
+
+@pytest.mark.parametrize("N,H,W,Cin,Cout,k,stride,split", [(2, 16, 16, 128, 256, 3, 1, 1), (1, 33, 17, 64, 300, 3, 1, 1), (2, 32, 32, 192, 256, 3, 1, 2),
+                                                           (1, 32, 32, 128, 256, 1, 1, 1), (2, 32, 32, 64, 512, 3, 2, 1), (1, 24, 40, 320, 320, 3, 1, 1)])
+def test_conv_gemm8_bit_identical_to_pingpong(ctx, N, H, W, Cin, Cout, k, stride, split):
+    g = torch.Generator().manual_seed(N + H + Cin + Cout + k)
+    x = h(torch.randn(N, H, W, Cin, generator=g))
+    w = h(torch.randn(Cout, k, k, Cin, generator=g) / (k * k * Cin) ** 0.5)
+    b = torch.randn(Cout, generator=g)
+    dx, dw, db = ctx.to_device(x.half().numpy()), ctx.to_device(w.half().numpy()), ctx.to_device(b)
+    outs = {}
+    try:
+        for name, flags in (("g8", 0), ("pp", 1024 << 4)):
+            ctx.lib.odise_hip_gemm_debug(flags)
+            outs[name] = ctx.conv2d(dx, dw, bias=db, stride=stride, act=_lib.ACT_SILU, force_tile=4, force_split=split).numpy()
+    finally:
+        ctx.lib.odise_hip_gemm_debug(0)
+    ref = F.silu(_conv_ref(x, w, stride, k // 2, b)).numpy()
+    close(outs["g8"], ref, what=f"conv gemm8 {N}x{H}x{W}x{Cin}->{Cout} k{k} s{stride}")
+    assert np.array_equal(outs["g8"], outs["pp"]), "gemm8 conv differs bitwise from the ping-pong kernel"
+
+
 def test_gemm_asymmetric_identity(ctx):
     # transpose-detecting check (guide rule 16): A = I, W asymmetric -> C = W^T
     n = 128
@@ -166,7 +216,7 @@ def test_gemm_chain_with_folded_layer_norm(ctx, M):
     b1 = torch.randn(N2, generator=g) * 0.1
     Wv = torch.randn(Cw, Cw, generator=g) / Cw ** 0.5
     bv = torch.randn(Cw, generator=g) * 0.1
-    parts = Cw // 128
+    parts = Cw // 64    # csrc/common.h kLnPartCols
     # producer: x2 = x + att Wo^T + bo, with the row statistics of the rounded x2
     stats = ctx.empty((M, parts, 2), np.float32)
     x2 = ctx.gemm(ctx.to_device(att.half().numpy()), ctx.to_device(Wo.half().numpy()), bias_n=ctx.to_device(bo),
@@ -174,7 +224,7 @@ def test_gemm_chain_with_folded_layer_norm(ctx, M):
     x2h = torch.from_numpy(x2.numpy().astype(np.float32))
     close(x2h.numpy(), (x + att @ Wo.t() + bo).numpy(), what="producer output")
     st = stats.numpy().astype(np.float64)
-    blocks = x2h.double().view(M, parts, 128)
+    blocks = x2h.double().view(M, parts, 64)
     np.testing.assert_allclose(st[..., 0], blocks.sum(-1).numpy(), rtol=1e-5, atol=1e-3)
     np.testing.assert_allclose(st[..., 1], (blocks ** 2).sum(-1).numpy(), rtol=1e-5, atol=1e-3)
     # consumer: quick_gelu(LN(x2) W1^T + b1) from the raw x2

@@ -56,6 +56,9 @@ def test_every_export_is_declared_and_every_prototype_has_argtypes(lib):
     exported = {l.split()[-1] for l in out.splitlines() if l.split() and l.split()[-1].startswith("odise_hip_")}
     declared = set(_lib.header_symbols()) | set(_lib.header_symbols(_lib.TOOLS_HEADER_PATH))
     assert exported == declared, (sorted(exported - declared), sorted(declared - exported))
+    # the measurement-only hooks (rate probes, yardstick kernels: include/odise_hip_lab.h) are NOT in the product library
+    lab = set(_lib.header_symbols(_lib.LAB_HEADER_PATH))
+    assert lab and not (lab & exported), sorted(lab & exported)
     protos = {**_lib.header_prototypes(), **_lib.header_prototypes(_lib.TOOLS_HEADER_PATH)}
     assert set(protos) == declared
     for name, args in protos.items():

@@ -12,10 +12,12 @@ lib = ctx.lib
 NAMES = {0: "free running, 2 waves/SIMD, 4 chains", 1: "free running, 1 wave/SIMD, 4 chains", 2: "ping-pong skeleton (2 barriers / 16 MFMAs, staggered)",
          3: "workgroup barrier every 16 MFMAs", 4: "workgroup barrier every 32 MFMAs", 5: "free running, 2 waves/SIMD, 8 chains",
          6: "free running, 1 wave/SIMD, 8 chains", 7: "RANDOM operands, free running, 2 waves/SIMD, 4 chains",
-         8: "RANDOM operands, ping-pong skeleton", 9: "RANDOM operands, free running, 1 wave/SIMD, 8 chains"}
+         8: "RANDOM operands, ping-pong skeleton", 9: "RANDOM operands, free running, 1 wave/SIMD, 8 chains",
+         10: "16x16x32 MFMA, RANDOM operands, free running, 2 waves/SIMD", 11: "16x16x32 MFMA, RANDOM operands, ping-pong skeleton",
+         12: "16x16x32 MFMA, RANDOM operands, free running, 1 wave/SIMD"}
 cus = ctx.device_info()[1]
 for rnd in range(2):
-    for v in (0, 2, 6, 7, 8, 9):
+    for v in (0, 2, 6, 7, 8, 9, 10, 11, 12):
         ms, fl, mhz = C.c_float(0), C.c_double(0), C.c_double(0)
         rc = lib.odise_hip_mfma_rate(ctx.h, v, 2000, cus * 4, 10, C.byref(ms), C.byref(fl), C.byref(mhz))
         assert rc == 0, rc
