@@ -71,6 +71,8 @@ def parse():
     p.add_argument("--clip-ln-fold", type=int, default=0, choices=[0, 1, 2], help="A/B: the CLIP towers' LayerNorm fold, 0 = the library's rule, 1 = always, 2 = never")
     p.add_argument("--vae-chunk-mb", type=float, default=None, help="A/B: ODISE_OPT_VAE_CHUNK_BYTES in MiB (0 = all crops per launch; default: the library's)")
     p.add_argument("--attn-kvres", type=int, default=1, choices=[0, 1], help="A/B: 0 = the CLIP towers' attention on the tiled kernel instead of the K/V-resident one")
+    p.add_argument("--gemm-flags", type=int, default=0, help="A/B: kernel-selection switches of the GEMM / convolution library (csrc/gemm.hip launch_gemm_select; "
+                   "4096 = never the 8-phase kernels, 8192 = the 8-phase kernels on 32x32x16 MFMAs), process-wide")
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--no-inclusive", action="store_true", help="skip the PCIe- / JPEG-inclusive legs")
     return p.parse_args()
@@ -192,7 +194,7 @@ def dominant_kernel_isolated(ctx, n):
         ctx.conv2d(X, Wt, out=O)
     us = ctx.timer_stop() / it * 1e3
     tile = ctx.lib.odise_hip_last_tile() & 255            # what the library's cost model ran this shape on (gemm.hip kTileBM / kTileBN)
-    kernel = {7: "conv3_halo_kernel<256,2>", 8: "conv3_halo_kernel<128,1>", 9: "conv3_halo4_kernel<128>"}.get(tile, f"tile {tile}")
+    kernel = {4: "gemm8_kernel<256,256,conv,16x16x32>", 7: "conv3_halo_kernel<256,2>", 8: "conv3_halo_kernel<128,1>", 9: "conv3_halo4_kernel<128>"}.get(tile, f"tile {tile}")
     flops = 2.0 * n * hw * hw * cout * 9 * cin
     for a in (X, Wt, O):
         a.free()
@@ -306,6 +308,8 @@ def main():
     from odise_amd.runtime import Context
     ctx = Context(local_rank)
     ctx.set_option(ctx.OPT_CLIP_LN_FOLD, args.clip_ln_fold)
+    if args.gemm_flags:
+        ctx.lib.odise_hip_gemm_debug(args.gemm_flags << 4)
     if not args.attn_kvres:
         ctx.set_option(ctx.OPT_ATTN_KV_RESIDENT, 2)
     if args.vae_chunk_mb is not None:
@@ -559,7 +563,8 @@ def main():
                        "parallelism": (f"dp{world} (independent images, one RCCL all-gather of prediction records per step on the library's "
                                        f"exchange stream)") if gather else f"dp{world}",
                        "rccl_ranks": rccl_ranks, "batches_in_flight": n_fly, "one_batch_alone_ms": single_ms,
-                       "vae_chunk_bytes": ctx.get_option(ctx.OPT_VAE_CHUNK_BYTES), "clip_ln_fold": ctx.get_option(ctx.OPT_CLIP_LN_FOLD)},
+                       "vae_chunk_bytes": ctx.get_option(ctx.OPT_VAE_CHUNK_BYTES), "clip_ln_fold": ctx.get_option(ctx.OPT_CLIP_LN_FOLD),
+                       "gemm_flags": args.gemm_flags},
             "roofline": {"bound": "mfma", "achieved": achieved, "peak": MFMA_F16_PEAK / 1e12, "unit": "TFLOP/s", "frac": achieved * 1e12 / MFMA_F16_PEAK,
                          "traffic": None,
                          "kernel": "whole step (all kernels; per-kernel times in profiles/)",

@@ -60,6 +60,11 @@ int odise_hip_launch_log_read(odise_hip_ctx* ctx, int* out6, int cap, int* n);
 /* 1: the feature extractor enqueues everything on one stream; 2 (default): its CLIP -> UNet branch runs on a second stream beside the VAE */
 int odise_hip_set_lanes(odise_hip_ctx* ctx, int lanes);
 
+/* the s2..s5 backbone maps still resident in the context's arena after odise_hip_backbone_forward / odise_hip_infer, converted to fp32 NCHW
+ * [B,C,h,w] device arrays out4[i] (NULL entries are skipped); shape_bchw4x4 (optional, host) receives the four (B, C, h, w).  What the
+ * parity tests feed to the fp32 oracle head to attribute a re-decided query (tests/fullsize.py ideal_on_device_features) */
+int odise_hip_backbone_maps(odise_hip_ctx* ctx, float** out4, int* shape_bchw4x4);
+
 /* probe (probe.hip): MFMA output layout (tests/test_gpu_probe.py).  The rate probes and yardstick kernels live in odise_hip_lab.h and only
  * in the measurement build of the library. */
 int odise_hip_mfma_probe(odise_hip_ctx* ctx, float* host_out);

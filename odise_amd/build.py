@@ -41,16 +41,18 @@ def _headers_mtime() -> float:
     return m
 
 
-def build(verbose: bool = True, force: bool = False, tools: bool = False) -> str:
+def build(verbose: bool = True, force: bool = False, tools: bool = False, m32: bool = False) -> str:
     """tools=True builds the measurement variant (libodise_hip_tools.so, -DODISE_TOOLS: timing ablations and the ODISE_GEMM_FLAGS /
-    ODISE_NO_GN_FUSION environment switches compiled in); tools/ scripts select it with ODISE_HIP_LIB.  The product library has none."""
-    objdir = OBJDIR + ("_tools" if tools else "")
-    lib_path = os.path.join(LIBDIR, "libodise_hip_tools.so") if tools else LIB
+    ODISE_NO_GN_FUSION environment switches compiled in); tools/ scripts select it with ODISE_HIP_LIB.  The product library has none.
+    m32=True builds the A/B variant libodise_hip_m32.so (-DODISE_MFMA32: every main loop of csrc/gemm.hip on v_mfma_f32_32x32x16_f16, the
+    MFMA shape of rounds 1-4, instead of 16x16x32) for same-box comparisons of whole steps (tools/final_evidence.sh); never loaded by default."""
+    objdir = OBJDIR + ("_tools" if tools else "_m32" if m32 else "")
+    lib_path = os.path.join(LIBDIR, "libodise_hip_tools.so") if tools else os.path.join(LIBDIR, "libodise_hip_m32.so") if m32 else LIB
     os.makedirs(objdir, exist_ok=True)
     hipcc = _hipcc()
     hm = _headers_mtime()
     flags = ["-O3", "-std=c++17", "-fPIC", f"--offload-arch={ARCH}",
-             "-Wno-unused-result", "-x", "hip"] + (["-DODISE_TOOLS=1"] if tools else [])
+             "-Wno-unused-result", "-x", "hip"] + (["-DODISE_TOOLS=1"] if tools else []) + (["-DODISE_MFMA32=1"] if m32 else [])
     # per-source extras.  attn.hip: MFMA results are consumed by VALU code every tile (softmax, rescale), so keep them in VGPRs -
     # the default AGPR form costs a v_accvgpr_read/write per element (128 VALU slots per tile) and a wave of occupancy.
     extra = {"attn.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form"]}
@@ -88,4 +90,4 @@ def build(verbose: bool = True, force: bool = False, tools: bool = False) -> str
 
 
 if __name__ == "__main__":
-    print(build(force="--force" in sys.argv, tools="--tools" in sys.argv))
+    print(build(force="--force" in sys.argv, tools="--tools" in sys.argv, m32="--m32" in sys.argv))

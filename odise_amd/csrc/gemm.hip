@@ -311,6 +311,43 @@ constexpr int epi_wave_rows(int BM, int BN, int WAVES_M, int lds_bytes) {
 }
 constexpr int epi_lds_bytes(int BM, int BN, int WAVES_M, int WG) { return WG * (BM / WAVES_M) * (BN + 4) * 4; }
 
+// ---- how a wave's sub-tile sits in its accumulator registers -------------------------------------------------------------------------
+// Per 32x32 block (p, j) of the sub-tile a lane owns NR rows x NC column quads; quad (rr, cc) = registers 4 (rr NC + cc) .. + 3 of the
+// block's 16 = four consecutive columns of one row (the kernels multiply with the MFMA operands swapped, see gemm_epilogue).
+//   L16 = false: one v_mfma_f32_32x32x16_f16 tile - row l & 31, quads 8 cc + 4 (l >> 5)                     (f32x16 acc[TM][TN])
+//   L16 = true : 2 x 2 v_mfma_f32_16x16x32_f16 tiles - rows 16 rr + (l & 15), quads 16 cc + 4 (l >> 4)      (f32x4 acc[TM][TN][4], [2 rr + cc])
+// Round 5: on operands that toggle like real data the matrix pipes are power-bound, and the 16x16x32 instruction sustains 1.95 PFLOP/s
+// (1.84 GHz) where 32x32x16 sustains 1.62 (1.52 GHz) - tools/mfma_rate.py, profiles/r05_mfma_rate_by_shape.txt; same FLOPs, fragment
+// bytes and LDS reads per 32x32 block either way.
+template <bool L16>
+struct FragLayout;
+template <>
+struct FragLayout<false> {
+    static constexpr int NR = 1, NC = 4;
+    static __device__ __forceinline__ int row(int lane, int) { return lane & 31; }
+    static __device__ __forceinline__ int col(int lane, int cc) { return 8 * cc + 4 * (lane >> 5); }
+    static __device__ __forceinline__ bool leader(int lane) { return lane < 32; }                    // one lane per row
+    static __device__ __forceinline__ float row_sum(float v) { return v + __shfl_xor(v, 32); }       // over the lanes that share a row
+};
+template <>
+struct FragLayout<true> {
+    static constexpr int NR = 2, NC = 2;
+    static __device__ __forceinline__ int row(int lane, int rr) { return 16 * rr + (lane & 15); }
+    static __device__ __forceinline__ int col(int lane, int cc) { return 16 * cc + 4 * (lane >> 4); }
+    static __device__ __forceinline__ bool leader(int lane) { return lane < 16; }
+    static __device__ __forceinline__ float row_sum(float v) { v += __shfl_xor(v, 16); return v + __shfl_xor(v, 32); }
+};
+template <class ACC>
+struct AccTraits;
+template <int TM_, int TN_>
+struct AccTraits<f32x16[TM_][TN_]> { static constexpr bool L16 = false; static constexpr int TM = TM_, TN = TN_; };
+template <int TM_, int TN_>
+struct AccTraits<f32x4[TM_][TN_][4]> { static constexpr bool L16 = true; static constexpr int TM = TM_, TN = TN_; };
+template <int TM, int TN>
+__device__ __forceinline__ float acc_get(const f32x16 (&a)[TM][TN], int p, int j, int r) { return a[p][j][r]; }
+template <int TM, int TN>
+__device__ __forceinline__ float acc_get(const f32x4 (&a)[TM][TN][4], int p, int j, int r) { return a[p][j][r >> 2][r & 3]; }
+
 // ---- math-first epilogue for fp16 outputs ----------------------------------------------------------------------------------------------
 // The fp32-staged epilogue below costs a 256x256 tile ~12 us, a third of a K = 1024 GEMM: the accumulators go through LDS as fp32 in up to
 // four passes in which only the waves of one or two wave-rows write while the others wait, and every thread then walks 16 dependent rounds of
@@ -322,11 +359,14 @@ constexpr int epi_lds_bytes(int BM, int BN, int WAVES_M, int WG) { return WG * (
 // (tools/epi_ab.py compares the two forms; ODISE_EPI_OLD=1 in the tools build keeps the fp32-staged form).
 // Staging rows are (BN + 8) halves: 16-byte aligned for the copy's ds_read_b128; the quad writes of 16 consecutive rows land 2-way on the
 // banks (row pitch = 4 banks mod 32), which stays below the write instruction's own issue cost.
-template <int BM, int BN, int WAVES_M, int WAVES_N, int EW, bool HALO, bool STATS, bool GEGLU>
-__device__ __forceinline__ void gemm_epilogue_f16(const GemmArgs& g, f32x16 (&acc)[BM / WAVES_M / 32][BN / WAVES_N / 32], char* smem, int m0, int n0, int zb) {
+template <int BM, int BN, int WAVES_M, int WAVES_N, int EW, bool HALO, bool STATS, bool GEGLU, class ACC>
+__device__ __forceinline__ void gemm_epilogue_f16(const GemmArgs& g, ACC& acc, char* smem, int m0, int n0, int zb) {
     constexpr int NT = 64 * WAVES_M * WAVES_N;
     constexpr int WTM = BM / WAVES_M, WTN = BN / WAVES_N;
     constexpr int TM = WTM / 32, TN = WTN / 32;
+    static_assert(AccTraits<ACC>::TM == TM && AccTraits<ACC>::TN == TN, "accumulator array does not match the wave tile");
+    using FL = FragLayout<AccTraits<ACC>::L16>;
+    constexpr int NR = FL::NR, NC = FL::NC, TR = TM * NR;   // rows per lane: TR
     constexpr int ROWS = EW * WTM;                 // tile rows per pass
     constexpr int BNO = GEGLU ? BN / 2 : BN;       // output columns of the tile
     constexpr int PITCH = BN + 8;                  // halves per staging row
@@ -337,7 +377,6 @@ __device__ __forceinline__ void gemm_epilogue_f16(const GemmArgs& g, f32x16 (&ac
     const int lane = tid & 63;
     const int wave = tid >> 6;
     const int wm = wave / WAVES_N, wn = wave % WAVES_N;
-    const int hi = lane >> 5, l31 = lane & 31;
     f16* stg = reinterpret_cast<f16*>(smem);
     const int NO = GEGLU ? (g.N >> 1) : g.N;       // output columns of the problem
     const int no0 = GEGLU ? (n0 >> 1) : n0;
@@ -368,18 +407,18 @@ __device__ __forceinline__ void gemm_epilogue_f16(const GemmArgs& g, f32x16 (&ac
     for (int gp = 0; gp < WAVES_M / EW; ++gp) {
         if (gp > 0) lds_barrier();  // the copy reads of the previous pass are done
         if (wm / EW == gp) {
-            int mr[TM];
-            float alpha_r[TM], bm_r[TM];
-            unsigned grp_r[TM];
+            int mr[TR];
+            float alpha_r[TR], bm_r[TR];
+            unsigned grp_r[TR];
             // LayerNorm folded into this GEMM (gemm_ln).  With W' = W diag(gamma), b' = b + W beta and cs[n] = sum_k W'[n,k]:
             //   LN(x) W^T + b = rstd_m (x W'^T - mean_m cs) + b'  ->  v * rstd_m + (b'[n] + r1_m cs[n]),  r1_m = -mean_m rstd_m,
             // the row statistics coming as partial (sum, sum of squares) from the epilogue of the GEMM that produced x (ln_stats_out below).
             // In the swapped form (rows of W are the normalised tokens) the same with rows and columns exchanged, from finished (r1, rstd).
             constexpr int NPW = (WTN % kLnPartCols == 0) ? WTN / kLnPartCols : 1;   // statistics parts (kLnPartCols columns each) per wave column
-            float r1_r[TM], rs_r[TM], ps_r[TM][NPW], pq_r[TM][NPW];
+            float r1_r[TR], rs_r[TR], ps_r[TR][NPW], pq_r[TR][NPW];
 #pragma unroll
-            for (int p = 0; p < TM; ++p) {
-                const int m = row_to_m(wm * WTM + p * 32 + l31);
+            for (int p = 0; p < TR; ++p) {   // p = NR * (32-row block) + rr
+                const int m = row_to_m(wm * WTM + (p / NR) * 32 + FL::row(lane, p % NR));
                 mr[p] = m;
                 const bool ok = m < g.M;
                 float alpha = e.alpha;
@@ -396,7 +435,7 @@ __device__ __forceinline__ void gemm_epilogue_f16(const GemmArgs& g, f32x16 (&ac
                     const float rstd = rsqrtf(var + e.ln_eps);
                     alpha *= rstd;
                     r1_r[p] = -mean * rstd;
-                    if (ln_final_out && n0 == 0 && wn == 0 && hi == 0) {
+                    if (ln_final_out && n0 == 0 && wn == 0 && FL::leader(lane)) {
                         ln_final_out[2 * (int64_t)m] = r1_r[p];
                         ln_final_out[2 * (int64_t)m + 1] = rstd;
                     }
@@ -409,8 +448,8 @@ __device__ __forceinline__ void gemm_epilogue_f16(const GemmArgs& g, f32x16 (&ac
 #pragma unroll
             for (int j = 0; j < TN; ++j)
 #pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    const int cl = wn * WTN + j * 32 + 8 * q + 4 * hi;   // tile column of this lane's four values
+                for (int q = 0; q < NC; ++q) {
+                    const int cl = wn * WTN + j * 32 + FL::col(lane, q);   // tile column of this lane's four values
                     const int n = n0 + cl;
                     const bool nok = n < g.N;                            // N % 8 == 0 on this path: the four columns are in or out together
                     float4 bn = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -424,9 +463,10 @@ __device__ __forceinline__ void gemm_epilogue_f16(const GemmArgs& g, f32x16 (&ac
                     const float csv[4] = {cs4.x, cs4.y, cs4.z, cs4.w};
                     const float r1c[4] = {fa.x, fa.z, fb.x, fb.z}, rsc[4] = {fa.y, fa.w, fb.y, fb.w};
 #pragma unroll
-                    for (int p = 0; p < TM; ++p) {
+                    for (int p = 0; p < TR; ++p) {
                         const bool ok = nok && mr[p] < g.M;
-                        float v[4] = {acc[p][j][4 * q], acc[p][j][4 * q + 1], acc[p][j][4 * q + 2], acc[p][j][4 * q + 3]};
+                        const int r0 = 4 * ((p % NR) * NC + q);   // first register of quad (rr, q) of block (p / NR, j)
+                        float v[4] = {acc_get(acc, p / NR, j, r0), acc_get(acc, p / NR, j, r0 + 1), acc_get(acc, p / NR, j, r0 + 2), acc_get(acc, p / NR, j, r0 + 3)};
                         float b[4] = {0.f, 0.f, 0.f, 0.f};
                         if (e.bias_n) { b[0] = bn.x; b[1] = bn.y; b[2] = bn.z; b[3] = bn.w; }
                         if (e.rowgroup_add && ok) {
@@ -448,7 +488,7 @@ __device__ __forceinline__ void gemm_epilogue_f16(const GemmArgs& g, f32x16 (&ac
 #pragma unroll
                             for (int i = 0; i < 4; ++i) v[i] = v[i] * alpha_r[p] + b[i];
                         }
-                        const int rl = (wm % EW) * WTM + p * 32 + l31;   // staging row
+                        const int rl = (wm % EW) * WTM + (p / NR) * 32 + FL::row(lane, p % NR);   // staging row
                         if (GEGLU) {
                             // columns are (a, gate) pairs; the output has N/2 columns (no activation / residual on this path)
                             typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
@@ -488,11 +528,11 @@ __device__ __forceinline__ void gemm_epilogue_f16(const GemmArgs& g, f32x16 (&ac
                                   // the two lane halves hold the two 4-column halves of every 8
                 const int part0 = (n0 + wn * WTN) / kLnPartCols, parts = (g.N + kLnPartCols - 1) / kLnPartCols;
 #pragma unroll
-                for (int p = 0; p < TM; ++p)
+                for (int p = 0; p < TR; ++p)
 #pragma unroll
                     for (int u = 0; u < NPW; ++u) {
-                        const float s1 = ps_r[p][u] + __shfl_xor(ps_r[p][u], 32), s2 = pq_r[p][u] + __shfl_xor(pq_r[p][u], 32);
-                        if (hi == 0 && mr[p] < g.M && part0 + u < parts) {
+                        const float s1 = FL::row_sum(ps_r[p][u]), s2 = FL::row_sum(pq_r[p][u]);
+                        if (FL::leader(lane) && mr[p] < g.M && part0 + u < parts) {
                             float* o = ln_stats_out + ((int64_t)mr[p] * parts + part0 + u) * 2;
                             o[0] = s1;
                             o[1] = s2;
@@ -553,9 +593,9 @@ __device__ __forceinline__ void gemm_epilogue_f16(const GemmArgs& g, f32x16 (&ac
     }
 }
 
-template <int BM, int BN, int WAVES_M, int WAVES_N, int WG, bool HALO = false, bool STATS = false, bool PAIRS = true, int EW16 = 0, bool GEGLU_OK = false>
-__device__ __forceinline__ void gemm_epilogue(const GemmArgs& g, f32x16 (&acc)[BM / WAVES_M / 32][BN / WAVES_N / 32], char* smem, int m0, int n0,
-                                              int z, int zb, bool split) {
+template <int BM, int BN, int WAVES_M, int WAVES_N, int WG, bool HALO = false, bool STATS = false, bool PAIRS = true, int EW16 = 0, bool GEGLU_OK = false, class ACC>
+__device__ __forceinline__ void gemm_epilogue(const GemmArgs& g, ACC& acc, char* smem, int m0, int n0, int z, int zb, bool split) {
+    using FL = FragLayout<AccTraits<ACC>::L16>;
     if constexpr (EW16 > 0) {
         if (g.epi.f16path && !split && !ODISE_ABLATE(g, 8 | 32)) {   // tools: ODISE_EPI_OLD=1 (bit 32) keeps the fp32-staged form for A/B runs
             if constexpr (GEGLU_OK) {
@@ -572,7 +612,6 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& g, f32x16 (&acc)[B
     const int lane = tid & 63;
     const int wave = tid >> 6;
     const int wm = wave / WAVES_N, wn = wave % WAVES_N;
-    const int hi = lane >> 5, l31 = lane & 31;
     constexpr int LDS_LD = BN + 4;
     constexpr int CH = BN / 8;
     float* stg = reinterpret_cast<float*>(smem);
@@ -623,12 +662,16 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& g, f32x16 (&acc)[B
                     // bits - so the 32x32 tile sits TRANSPOSED in the registers: lane l owns row l & 31 and, per register quad q, the four
                     // consecutive columns 8q + 4(l >> 5) + (0..3).  A quad is one 16-byte staging write (32 ds_write_b128 per wave and tile
                     // instead of 128 ds_write_b32); eight consecutive rows of the padded staging image hit all 32 banks once ((BN + 4) % 32 == 4).
-                    const int row = (wm % WG) * WTM + p * 32 + l31;
 #pragma unroll
-                    for (int q = 0; q < 4; ++q) {
-                        const int col = wn * WTN + j * 32 + 8 * q + 4 * hi;
-                        *reinterpret_cast<float4*>(&stg[row * LDS_LD + col]) =
-                            make_float4(acc[p][j][4 * q], acc[p][j][4 * q + 1], acc[p][j][4 * q + 2], acc[p][j][4 * q + 3]);
+                    for (int rr = 0; rr < FL::NR; ++rr) {
+                        const int row = (wm % WG) * WTM + p * 32 + FL::row(lane, rr);
+#pragma unroll
+                        for (int q = 0; q < FL::NC; ++q) {
+                            const int col = wn * WTN + j * 32 + FL::col(lane, q);
+                            const int r0 = 4 * (rr * FL::NC + q);
+                            *reinterpret_cast<float4*>(&stg[row * LDS_LD + col]) =
+                                make_float4(acc_get(acc, p, j, r0), acc_get(acc, p, j, r0 + 1), acc_get(acc, p, j, r0 + 2), acc_get(acc, p, j, r0 + 3));
+                        }
                     }
                 }
         }
@@ -842,6 +885,49 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& g, f32x16 (&acc)[B
     }
 }
 
+// ---- MFMA shape of the main loops --------------------------------------------------------------------------------------------------
+// Every kernel below walks a 64-deep K-tile of a 32x32 output block in Frag::NSTEP steps; a step consumes Frag::PER fragments (16 bytes
+// per lane each) of the block's A rows and of its B rows:
+//   32x32x16: 4 steps of one MFMA; fragment = rows l & 31, 16-byte k-slot 2 st + (l >> 5)
+//   16x16x32: 2 steps of 2 x 2 MFMAs; fragment u = rows 16 u + (l & 15), k-slot 4 st + (l >> 4)
+// Same fragment bytes, LDS reads and FLOPs per block either way.  kL16 selects the shape for all of them (round 5: the 16x16x32
+// instruction sustains 1.95 PFLOP/s on operands that toggle like real data, 32x32x16 is power-bound at 1.62 - FragLayout above); the
+// k order inside a K-tile (steps ascending) is the same in every kernel, so kernels still agree bit for bit on a given K walk.
+#ifdef ODISE_MFMA32   // A/B build only (python -m odise_amd.build --m32): the MFMA shape of rounds 1-4
+constexpr bool kL16 = false;
+#else
+constexpr bool kL16 = true;
+#endif
+template <bool L16>
+struct Frag {
+    static constexpr int NSTEP = L16 ? 2 : 4;
+    static constexpr int PER = L16 ? 2 : 1;
+    static __device__ __forceinline__ int lrow(int lane) { return L16 ? (lane & 15) : (lane & 31); }
+    static __device__ __forceinline__ int lk(int lane) { return L16 ? (lane >> 4) : (lane >> 5); }
+    static __device__ __forceinline__ int kslot(int st, int lk) { return L16 ? st * 4 + lk : st * 2 + lk; }
+};
+template <bool L16> struct AccBlockT { typedef f32x16 type; };
+template <> struct AccBlockT<true> { typedef f32x4 type[4]; };
+template <bool L16> using AccBlock = typename AccBlockT<L16>::type;
+__device__ __forceinline__ void acc_zero(f32x16& a) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) a[r] = 0.f;
+}
+__device__ __forceinline__ void acc_zero(f32x4 (&a)[4]) {
+#pragma unroll
+    for (int t = 0; t < 4; ++t) a[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+}
+// one step of a 32x32 block; operands swapped (transposed tile in the registers, see gemm_epilogue)
+__device__ __forceinline__ void mma_step(f32x16& acc, const f16x8 (&b)[1], const f16x8 (&a)[1]) {
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(b[0], a[0], acc, 0, 0, 0);
+}
+__device__ __forceinline__ void mma_step(f32x4 (&acc)[4], const f16x8 (&b)[2], const f16x8 (&a)[2]) {
+#pragma unroll
+    for (int rt = 0; rt < 2; ++rt)
+#pragma unroll
+        for (int ct = 0; ct < 2; ++ct) acc[rt * 2 + ct] = __builtin_amdgcn_mfma_f32_16x16x32_f16(b[ct], a[rt], acc[rt * 2 + ct], 0, 0, 0);
+}
+
 template <int BM, int BN, int WAVES_M, int WAVES_N, bool CONV, bool INTERLEAVE>
 __global__ void __launch_bounds__(64 * WAVES_M * WAVES_N) gemm_kernel(GemmArgs g) {
     constexpr int BK = 64;
@@ -995,21 +1081,21 @@ __global__ void __launch_bounds__(64 * WAVES_M * WAVES_N) gemm_kernel(GemmArgs g
         for (int l = 0; l < NL; ++l) issue_load(l, stage);
     };
 
-    f32x16 acc[TM][TN];
+    AccBlock<kL16> acc[TM][TN];
 #pragma unroll
     for (int i = 0; i < TM; ++i)
 #pragma unroll
-        for (int j = 0; j < TN; ++j)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+        for (int j = 0; j < TN; ++j) acc_zero(acc[i][j]);
 
     // The swizzle key (r>>1)&7 of a fragment row r = wave_base + 32*tile + (lane&31) only depends on the lane (bases are
     // multiples of 32), so the four k-step slot offsets are shared by every A and B fragment of this lane.
-    int koff[4];
+    using FR = Frag<kL16>;
+    const int lrow = FR::lrow(lane), lkq = FR::lk(lane);
+    int koff[FR::NSTEP];   // 16-byte slot of step st, swizzled with the lane's row key (tile bases are multiples of 16 rows); fragment u: + u * 16 rows
 #pragma unroll
-    for (int s = 0; s < 4; ++s) koff[s] = ((s * 2 + hi) ^ ((l31 >> 1) & 7)) << 4;
-    const int a_lane_off = (wm * WTM + l31) * 128;
-    const int b_lane_off = (wn * WTN + l31) * 128;
+    for (int s = 0; s < FR::NSTEP; ++s) koff[s] = (FR::kslot(s, lkq) ^ ((lrow >> 1) & 7)) << 4;
+    const int a_lane_off = (wm * WTM + lrow) * 128;
+    const int b_lane_off = (wn * WTN + lrow) * 128;
 
     if (kt_begin < kt_end) issue_tile(kt_begin, 0);
 
@@ -1028,27 +1114,30 @@ __global__ void __launch_bounds__(64 * WAVES_M * WAVES_N) gemm_kernel(GemmArgs g
         // fragment reads: per-lane base + per-k-step swizzled slot offset (loop invariant) + compile-time tile offset
         const char* fa = smem + cur * STAGE_BYTES + a_lane_off;
         const char* fb = smem + cur * STAGE_BYTES + BM * BK * 2 + b_lane_off;
-        f16x8 af[TM], bf[TN];
+        f16x8 af[TM][FR::PER], bf[TN][FR::PER];
 #pragma unroll
-        for (int s = 0; s < 4; ++s) {
+        for (int s = 0; s < FR::NSTEP; ++s) {
             if (!(ODISE_ABLATE(g, 2)) || (kt == kt_begin && s == 0)) {
 #pragma unroll
-                for (int i = 0; i < TM; ++i) af[i] = *reinterpret_cast<const f16x8*>(fa + koff[s] + i * 4096);
+                for (int i = 0; i < TM; ++i)
 #pragma unroll
-                for (int j = 0; j < TN; ++j) bf[j] = *reinterpret_cast<const f16x8*>(fb + koff[s] + j * 4096);
+                    for (int u = 0; u < FR::PER; ++u) af[i][u] = *reinterpret_cast<const f16x8*>(fa + koff[s] + i * 4096 + u * 2048);
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+#pragma unroll
+                    for (int u = 0; u < FR::PER; ++u) bf[j][u] = *reinterpret_cast<const f16x8*>(fb + koff[s] + j * 4096 + u * 2048);
             }
 #pragma unroll
             for (int i = 0; i < TM; ++i)
 #pragma unroll
-                for (int j = 0; j < TN; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bf[j], af[i], acc[i][j], 0, 0, 0);  // operands swapped: transposed tile (see gemm_epilogue)
+                for (int j = 0; j < TN; ++j) mma_step(acc[i][j], bf[j], af[i]);  // operands swapped: transposed tile (see gemm_epilogue)
             if (INTERLEAVE) {
                 // next tile's LDS-DMA loads are issued in the shadow of this k-step's MFMAs (the matrix pipe keeps
                 // draining the queued MFMAs while the wave issues address math + global_load_lds)
                 if (dma) {
 #pragma unroll
                     for (int l = 0; l < NL; ++l)
-                        if ((l * 4) / NL == s) issue_load(l, cur ^ 1);
+                        if ((l * FR::NSTEP) / NL == s) issue_load(l, cur ^ 1);
                 }
                 __builtin_amdgcn_sched_barrier(0);
             }
@@ -1243,19 +1332,19 @@ __global__ void __launch_bounds__(512) gemm_pp_kernel(GemmArgs g) {
         glds16(src, smem + stage * STAGE_BYTES + A_BYTES + b_lds0 + j * RB * 128);
     };
 
-    f32x16 acc[TM][TN];
+    AccBlock<kL16> acc[TM][TN];
 #pragma unroll
     for (int i = 0; i < TM; ++i)
 #pragma unroll
-        for (int j = 0; j < TN; ++j)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+        for (int j = 0; j < TN; ++j) acc_zero(acc[i][j]);
 
-    int koff[4];
+    using FR = Frag<kL16>;
+    const int lrow = FR::lrow(lane), lkq = FR::lk(lane);
+    int koff[FR::NSTEP];   // 16-byte slot of step st, swizzled with the lane's row key (tile bases are multiples of 16 rows); fragment u: + u * 16 rows
 #pragma unroll
-    for (int s = 0; s < 4; ++s) koff[s] = ((s * 2 + hi) ^ ((l31 >> 1) & 7)) << 4;
-    const int a_lane_off = (wm * 64 + l31) * 128;
-    const int b_lane_off = A_BYTES + (wn * WTN + l31) * 128;
+    for (int s = 0; s < FR::NSTEP; ++s) koff[s] = (FR::kslot(s, lkq) ^ ((lrow >> 1) & 7)) << 4;
+    const int a_lane_off = (wm * 64 + lrow) * 128;
+    const int b_lane_off = A_BYTES + (wn * WTN + lrow) * 128;
 
     // load l of a K-tile: l < JA -> A piece l, else B piece l-JA; issued in slot l / LPP of the tile (see the schedule above)
     auto issue = [&](int l, int stage, const TileK& t) {
@@ -1285,7 +1374,7 @@ __global__ void __launch_bounds__(512) gemm_pp_kernel(GemmArgs g) {
     __builtin_amdgcn_s_barrier();
     if (grp == 1) __builtin_amdgcn_s_barrier();  // stagger: group 1 runs one barrier interval behind group 0
 
-    f16x8 af[TM][4], bf[PT][4];
+    f16x8 af[TM][FR::NSTEP][FR::PER], bf[PT][FR::NSTEP][FR::PER];
     for (int kt = kt_begin; kt < kt_end; ++kt) {
         const int cur = (kt - kt_begin) & 1;
         const bool has1 = (kt + 1) < kt_end && !(ODISE_ABLATE(g, 1)), has2 = (kt + 2) < kt_end && !(ODISE_ABLATE(g, 1));  // dbg 1: ablate the DMA
@@ -1302,13 +1391,17 @@ __global__ void __launch_bounds__(512) gemm_pp_kernel(GemmArgs g) {
 #pragma unroll
                     for (int i = 0; i < TM; ++i)
 #pragma unroll
-                        for (int s = 0; s < 4; ++s) af[i][s] = *reinterpret_cast<const f16x8*>(fa + koff[s] + i * 4096);
+                        for (int s = 0; s < FR::NSTEP; ++s)
+#pragma unroll
+                            for (int u = 0; u < FR::PER; ++u) af[i][s][u] = *reinterpret_cast<const f16x8*>(fa + koff[s] + i * 4096 + u * 2048);
                 }
 #pragma unroll
                 for (int jj = 0; jj < PT; ++jj)
                     if (jj < nj && rd) {
 #pragma unroll
-                        for (int s = 0; s < 4; ++s) bf[jj][s] = *reinterpret_cast<const f16x8*>(fb + koff[s] + (j0 + jj) * 4096);
+                        for (int s = 0; s < FR::NSTEP; ++s)
+#pragma unroll
+                            for (int u = 0; u < FR::PER; ++u) bf[jj][s][u] = *reinterpret_cast<const f16x8*>(fb + koff[s] + (j0 + jj) * 4096 + u * 2048);
                     }
             };
             read_frags();
@@ -1367,13 +1460,12 @@ __global__ void __launch_bounds__(512) gemm_pp_kernel(GemmArgs g) {
             // -------- MFMA segment
             __builtin_amdgcn_s_setprio(1);
 #pragma unroll
-            for (int s = 0; s < 4; ++s)
+            for (int s = 0; s < FR::NSTEP; ++s)
 #pragma unroll
                 for (int jj = 0; jj < PT; ++jj)
                     if (jj < nj) {
 #pragma unroll
-                        for (int i = 0; i < TM; ++i)
-                            acc[i][j0 + jj] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bf[jj][s], af[i][s], acc[i][j0 + jj], 0, 0, 0);  // transposed tile (see gemm_epilogue)
+                        for (int i = 0; i < TM; ++i) mma_step(acc[i][j0 + jj], bf[jj][s], af[i][s]);  // transposed tile (see gemm_epilogue)
                     }
             __builtin_amdgcn_s_setprio(0);
             __builtin_amdgcn_sched_barrier(0);
@@ -1594,19 +1686,19 @@ __global__ void __launch_bounds__(512) gemm_pp2_kernel(GemmArgs g) {
         glds16(src, smem + stage * STAGE_BYTES + A_BYTES + b_lds0 + j * RB * 128);
     };
 
-    f32x16 acc[TM][TN];
+    AccBlock<kL16> acc[TM][TN];
 #pragma unroll
     for (int i = 0; i < TM; ++i)
 #pragma unroll
-        for (int j = 0; j < TN; ++j)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+        for (int j = 0; j < TN; ++j) acc_zero(acc[i][j]);
 
-    int koff[4];
+    using FR = Frag<kL16>;
+    const int lrow = FR::lrow(lane), lkq = FR::lk(lane);
+    int koff[FR::NSTEP];   // 16-byte slot of step st, swizzled with the lane's row key (tile bases are multiples of 16 rows); fragment u: + u * 16 rows
 #pragma unroll
-    for (int s = 0; s < 4; ++s) koff[s] = ((s * 2 + hi) ^ ((l31 >> 1) & 7)) << 4;
-    const int a_lane_off = (wm * 64 + l31) * 128;
-    const int b_lane_off = A_BYTES + (wn * WTN + l31) * 128;
+    for (int s = 0; s < FR::NSTEP; ++s) koff[s] = (FR::kslot(s, lkq) ^ ((lrow >> 1) & 7)) << 4;
+    const int a_lane_off = (wm * 64 + lrow) * 128;
+    const int b_lane_off = A_BYTES + (wn * WTN + lrow) * 128;
 
     // issue every load of tile T whose slot is `sl` (program order = ascending l)
     auto issue_slot = [&](int sl, int stage, const TileK& t) {
@@ -1636,18 +1728,20 @@ __global__ void __launch_bounds__(512) gemm_pp2_kernel(GemmArgs g) {
     t2 = t1;
     advance(t2);
     __builtin_amdgcn_s_barrier();
-    f16x8 af[TM][4], bf[PT][4];
+    f16x8 af[TM][FR::NSTEP][FR::PER], bf[PT][FR::NSTEP][FR::PER];
     // fragments of phase (0,0)
     {
         const char* fa = smem + a_lane_off;
         const char* fb = smem + b_lane_off;
 #pragma unroll
-        for (int s = 0; s < 4; ++s) {
+        for (int s = 0; s < FR::NSTEP; ++s)
 #pragma unroll
-            for (int i = 0; i < TM; ++i) af[i][s] = *reinterpret_cast<const f16x8*>(fa + koff[s] + i * 4096);
+            for (int u = 0; u < FR::PER; ++u) {
 #pragma unroll
-            for (int jj = 0; jj < PT; ++jj) bf[jj][s] = *reinterpret_cast<const f16x8*>(fb + koff[s] + jj * 4096);
-        }
+                for (int i = 0; i < TM; ++i) af[i][s][u] = *reinterpret_cast<const f16x8*>(fa + koff[s] + i * 4096 + u * 2048);
+#pragma unroll
+                for (int jj = 0; jj < PT; ++jj) bf[jj][s][u] = *reinterpret_cast<const f16x8*>(fb + koff[s] + jj * 4096 + u * 2048);
+            }
     }
     if (grp == 1) __builtin_amdgcn_s_barrier();  // stagger: group 1 runs one barrier interval behind group 0
 
@@ -1677,19 +1771,21 @@ __global__ void __launch_bounds__(512) gemm_pp2_kernel(GemmArgs g) {
             const char* nfb = smem + (next_in_tile ? cur : (cur ^ 1)) * STAGE_BYTES + b_lane_off + (next_in_tile ? (j0 + PT) * 4096 : 0);
             __builtin_amdgcn_s_setprio(1);
 #pragma unroll
-            for (int s = 0; s < 4; ++s) {
+            for (int s = 0; s < FR::NSTEP; ++s) {
 #pragma unroll
                 for (int jj = 0; jj < PT; ++jj)
 #pragma unroll
-                    for (int i = 0; i < TM; ++i)
-                        acc[i][j0 + jj] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bf[jj][s], af[i][s], acc[i][j0 + jj], 0, 0, 0);  // transposed tile (see gemm_epilogue)
+                    for (int i = 0; i < TM; ++i) mma_step(acc[i][j0 + jj], bf[jj][s], af[i][s]);  // transposed tile (see gemm_epilogue)
                 if (have_next) {
-                    if (!next_in_tile) {
 #pragma unroll
-                        for (int i = 0; i < TM; ++i) af[i][s] = *reinterpret_cast<const f16x8*>(nfa + koff[s] + i * 4096);
+                    for (int u = 0; u < FR::PER; ++u) {
+                        if (!next_in_tile) {
+#pragma unroll
+                            for (int i = 0; i < TM; ++i) af[i][s][u] = *reinterpret_cast<const f16x8*>(nfa + koff[s] + i * 4096 + u * 2048);
+                        }
+#pragma unroll
+                        for (int jj = 0; jj < PT; ++jj) bf[jj][s][u] = *reinterpret_cast<const f16x8*>(nfb + koff[s] + jj * 4096 + u * 2048);
                     }
-#pragma unroll
-                    for (int jj = 0; jj < PT; ++jj) bf[jj][s] = *reinterpret_cast<const f16x8*>(nfb + koff[s] + jj * 4096);
                 }
             }
             __builtin_amdgcn_s_setprio(0);
@@ -1726,18 +1822,21 @@ __global__ void __launch_bounds__(512) gemm_pp2_kernel(GemmArgs g) {
 //     which is read from the next phase on; a buffer is restaged two phases after its last read (B0: one phase, its reads are retired by
 //     lgkmcnt(8) before phase 1's first barrier).
 // Rows beyond M / N and padded convolution taps read a zero line (no predication of the DMA, uniform vmcnt accounting).
-template <bool CONV>
+template <int BM, int BN, bool CONV, bool L16>
 __global__ void __launch_bounds__(512) gemm8_kernel(GemmArgs g) {
-    constexpr int BM = 256, BN = 256, BK = 64, WAVES_M = 2, WAVES_N = 4;
-    constexpr int HALF = 128 * BK * 2, STAGE = 4 * HALF;
-    constexpr int OFF_A0 = 0, OFF_A1 = HALF, OFF_B0 = 2 * HALF, OFF_B1 = 3 * HALF;
+    constexpr int BK = 64, WAVES_M = BM / 128, WAVES_N = BN / 64;
+    static_assert(WAVES_M * WAVES_N == 8 && BM % 128 == 0 && BN % 128 == 0, "8 waves of 128x64");
+    constexpr int JA = BM / 128, JB = BN / 128;                 // 64-row DMA pieces (one 16-byte load per thread) per A / B half-tile
+    constexpr int HALF_A = (BM / 2) * BK * 2, HALF_B = (BN / 2) * BK * 2, STAGE = 2 * HALF_A + 2 * HALF_B;
+    constexpr int OFF_A0 = 0, OFF_A1 = HALF_A, OFF_B0 = 2 * HALF_A, OFF_B1 = 2 * HALF_A + HALF_B;
+    constexpr int INFLIGHT = JA + 2 * JB;                       // loads issued after A1(t+1): B0, A0, B1 of K-tile t+2
     extern __shared__ __attribute__((aligned(16))) char smem[];
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wr = wave >> 2, wc = wave & 3;
-    const int hi = lane >> 5, l31 = lane & 31;
+    const int wm = wave / WAVES_N, wn = wave % WAVES_N;
+    const int grp = wave >> 2;   // waves w and w + 4 share a SIMD: the two groups run one barrier apart
     int bx, by;
     {
         const int nbx = gridDim.x, nb = gridDim.x * gridDim.y;
@@ -1764,18 +1863,18 @@ __global__ void __launch_bounds__(512) gemm8_kernel(GemmArgs g) {
     const f16* Ab = g.A + (int64_t)zb * g.strideA;
     const f16* Wb = g.W + (int64_t)zb * g.strideW;
 
-    // ---- staging descriptors: the thread fills physical 16-byte slot (lane & 7) of half-tile row i*64 + srow (piece i = 0, 1) and fetches
+    // ---- staging descriptors: the thread fills physical 16-byte slot (lane & 7) of half-tile row i*64 + srow (piece i) and fetches
     // logical slot ls (XOR swizzle on the source: the LDS image of a DMA instruction is lane-linear)
     const int srow = wave * 8 + (lane >> 3);
     const int ls = (lane & 7) ^ ((srow >> 1) & 7);
     // A half h, piece i: tile row i*128 + h*64 + srow.  Dense: one base pointer, row validity by compare.  Conv: per row the window's
     // top-left input coordinate (packed y << 16 | x & 0xffff; rows >= M get y far out of range) and a 32-bit element offset.
-    int a_yx[2][2], a_eoff[2][2];
-    bool a_ok[2][2];
+    int a_yx[2][JA], a_eoff[2][JA];
+    bool a_ok[2][JA];
 #pragma unroll
     for (int h = 0; h < 2; ++h)
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
+        for (int i = 0; i < JA; ++i) {
             const int m = m0 + i * 128 + h * 64 + srow;
             const bool ok = m < g.M;
             a_ok[h][i] = ok;
@@ -1798,11 +1897,11 @@ __global__ void __launch_bounds__(512) gemm8_kernel(GemmArgs g) {
     // B half h, piece i: tile row (i*2 + wave/4)*64 + h*32 + (wave%4)*8 + lane/8
     const int b_row = (wave >> 2) * 64 + (wave & 3) * 8 + (lane >> 3);
     const f16* const b_src = Wb + (int64_t)(n0 + b_row) * g.ldw + ls * 8;
-    bool b_ok[2][2];
+    bool b_ok[2][JB];
 #pragma unroll
     for (int h = 0; h < 2; ++h)
 #pragma unroll
-        for (int i = 0; i < 2; ++i) b_ok[h][i] = (n0 + b_row + i * 128 + h * 32) < g.N;
+        for (int i = 0; i < JB; ++i) b_ok[h][i] = (n0 + b_row + i * 128 + h * 32) < g.N;
     char* const lds_w = smem + wave * 1024;   // this wave's 8 rows inside a 64-row piece
 
     // K-tile position (wave-uniform, advanced incrementally; conv taps are whole 64-channel chunks walked chunk-major or tap-major: see gemm_kernel::prep_tile)
@@ -1863,7 +1962,7 @@ __global__ void __launch_bounds__(512) gemm8_kernel(GemmArgs g) {
     auto stage_A = [&](int h, int buf, const TileK& t) {
         char* d = lds_w + buf * STAGE + (h ? OFF_A1 : OFF_A0);
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
+        for (int i = 0; i < JA; ++i) {
             const f16* src;
             if (CONV) {
                 const int iy = (a_yx[h][i] >> 16) + t.ky, ix = (int)(short)(a_yx[h][i] & 0xffff) + t.kx;
@@ -1878,38 +1977,53 @@ __global__ void __launch_bounds__(512) gemm8_kernel(GemmArgs g) {
     auto stage_B = [&](int h, int buf, const TileK& t) {
         char* d = lds_w + buf * STAGE + (h ? OFF_B1 : OFF_B0);
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
+        for (int i = 0; i < JB; ++i) {
             const f16* src = b_ok[h][i] ? b_src + (int64_t)(i * 128 + h * 32) * g.ldw + t.kw : g.zeros;
             glds16(src, d + i * 8192);
         }
     };
 
-    f32x16 acc[4][2];
+    // ---- accumulators and fragments of the wave's 128x64 tile (FragLayout).  L16: 16-row tiles i = 0..3 of the 64-row sub-tile (block
+    // p = 2 ih + i / 2, row half i % 2), 16-column tiles jj = 0, 1 of the 32-column sub-tile, k-steps of 32; L32: 32-row tiles i = 0, 1, k-steps of 16
+    typedef typename std::conditional<L16, f32x4[4][2][4], f32x16[4][2]>::type AccT;
+    AccT acc;
 #pragma unroll
     for (int i = 0; i < 4; ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j)
+        for (int j = 0; j < 2; ++j) {
+            if constexpr (L16) {
 #pragma unroll
-            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-
-    // ---- fragment addresses: lane reads row (l & 31) of a 32-row tile, logical slot 2s + (l >> 5) of k-step s -> physical ^ ((row >> 1) & 7)
-    int koff[4];
+                for (int t = 0; t < 4; ++t) acc[i][j][t] = f32x4{0.f, 0.f, 0.f, 0.f};
+            } else {
 #pragma unroll
-    for (int s = 0; s < 4; ++s) koff[s] = ((s * 2 + hi) ^ ((l31 >> 1) & 7)) << 4;
-    const int a_lane = (wr * 64 + l31) * 128;   // + i * 4096 per 32-row tile of the sub-tile
-    const int b_lane = (wc * 32 + l31) * 128;
-    f16x8 af[2][4], b0f[4], b1f[4];
+                for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+            }
+        }
+    // lane reads row lrow of a tile, 16-byte slot kslot(s) of k-step s -> physical slot ^ ((row >> 1) & 7) (tile bases are multiples of 16 rows)
+    const int lrow = L16 ? (lane & 15) : (lane & 31);
+    const int lk = L16 ? (lane >> 4) : (lane >> 5);
+    constexpr int KS = L16 ? 2 : 4, KSLOTS = L16 ? 4 : 2;       // k-steps per K-tile, 16-byte slots per lane group and k-step
+    constexpr int MT = L16 ? 4 : 2, NT_ = L16 ? 2 : 1;          // row / column tiles per sub-tile
+    constexpr int TROWS = L16 ? 16 : 32;
+    int koff[KS];
+#pragma unroll
+    for (int s = 0; s < KS; ++s) koff[s] = ((s * KSLOTS + lk) ^ ((lrow >> 1) & 7)) << 4;
+    const int a_lane = (wm * 64 + lrow) * 128;
+    const int b_lane = (wn * 32 + lrow) * 128;
+    f16x8 af[MT][KS], b0f[NT_][KS], b1f[NT_][KS];
     auto read_A = [&](int h, int buf) {
         const char* p = smem + buf * STAGE + (h ? OFF_A1 : OFF_A0) + a_lane;
 #pragma unroll
-        for (int i = 0; i < 2; ++i)
+        for (int i = 0; i < MT; ++i)
 #pragma unroll
-            for (int s = 0; s < 4; ++s) af[i][s] = *reinterpret_cast<const f16x8*>(p + i * 4096 + koff[s]);
+            for (int s = 0; s < KS; ++s) af[i][s] = *reinterpret_cast<const f16x8*>(p + i * TROWS * 128 + koff[s]);
     };
-    auto read_B = [&](f16x8 (&bf)[4], int h, int buf) {
+    auto read_B = [&](f16x8 (&bf)[NT_][KS], int h, int buf) {
         const char* p = smem + buf * STAGE + (h ? OFF_B1 : OFF_B0) + b_lane;
 #pragma unroll
-        for (int s = 0; s < 4; ++s) bf[s] = *reinterpret_cast<const f16x8*>(p + koff[s]);
+        for (int j = 0; j < NT_; ++j)
+#pragma unroll
+            for (int s = 0; s < KS; ++s) bf[j][s] = *reinterpret_cast<const f16x8*>(p + j * TROWS * 128 + koff[s]);
     };
 #define G8_BAR()                               \
     do {                                       \
@@ -1917,17 +2031,25 @@ __global__ void __launch_bounds__(512) gemm8_kernel(GemmArgs g) {
         __builtin_amdgcn_s_barrier();          \
         __builtin_amdgcn_sched_barrier(0);     \
     } while (0)
-    // the 8 MFMAs of quadrant (ih, jh); operands swapped (transposed tile in the registers, see gemm_epilogue)
-#define G8_MMA(ih, bfr, jh)                                                                                                         \
-    do {                                                                                                                            \
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                                                          \
-        __builtin_amdgcn_sched_barrier(0);                                                                                          \
-        __builtin_amdgcn_s_setprio(1);                                                                                              \
-        _Pragma("unroll") for (int s = 0; s < 4; ++s)                                                                               \
-            _Pragma("unroll") for (int i = 0; i < 2; ++i)                                                                           \
-                acc[(ih) * 2 + i][jh] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bfr[s], af[i][s], acc[(ih) * 2 + i][jh], 0, 0, 0);   \
-        __builtin_amdgcn_s_setprio(0);                                                                                              \
-        G8_BAR();                                                                                                                   \
+    // the MFMAs of quadrant (ih, jh): 64 rows x 32 columns x the whole K-tile; operands swapped (transposed tile in the registers, see gemm_epilogue)
+#define G8_MMA(ih, bfr, jh)                                                                                                               \
+    do {                                                                                                                                  \
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                                                                \
+        __builtin_amdgcn_sched_barrier(0);                                                                                                \
+        __builtin_amdgcn_s_setprio(1);                                                                                                    \
+        if constexpr (L16) {                                                                                                              \
+            _Pragma("unroll") for (int s = 0; s < 2; ++s)                                                                                 \
+                _Pragma("unroll") for (int i = 0; i < 4; ++i)                                                                             \
+                    _Pragma("unroll") for (int jj = 0; jj < 2; ++jj)                                                                      \
+                        acc[(ih) * 2 + i / 2][jh][(i % 2) * 2 + jj] =                                                                     \
+                            __builtin_amdgcn_mfma_f32_16x16x32_f16(bfr[jj][s], af[i][s], acc[(ih) * 2 + i / 2][jh][(i % 2) * 2 + jj], 0, 0, 0); \
+        } else {                                                                                                                          \
+            _Pragma("unroll") for (int s = 0; s < 4; ++s)                                                                                 \
+                _Pragma("unroll") for (int i = 0; i < 2; ++i)                                                                             \
+                    acc[(ih) * 2 + i][jh] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bfr[0][s], af[i][s], acc[(ih) * 2 + i][jh], 0, 0, 0);  \
+        }                                                                                                                                 \
+        __builtin_amdgcn_s_setprio(0);                                                                                                    \
+        G8_BAR();                                                                                                                         \
     } while (0)
 
     TileK t1 = decode(kt_begin), t2;   // t1 / t2: K-tiles t+1 / t+2 of the tile being multiplied
@@ -1940,7 +2062,7 @@ __global__ void __launch_bounds__(512) gemm8_kernel(GemmArgs g) {
         read_A(0, buf);
         if (has1) stage_A(1, buf ^ 1, t1);
         __builtin_amdgcn_sched_barrier(0);
-        asm volatile("s_waitcnt lgkmcnt(8)" ::: "memory");
+        asm volatile("s_waitcnt lgkmcnt(8)" ::: "memory");   // retires the four B0 reads (issued first): B0 may be restaged in the next phase
         G8_BAR();
         G8_MMA(0, b0f, 0);
         // phase 2
@@ -1954,7 +2076,7 @@ __global__ void __launch_bounds__(512) gemm8_kernel(GemmArgs g) {
         G8_BAR();
         G8_MMA(1, b1f, 1);
         // phase 4
-        if (has2) { stage_B(1, buf, t2); wait_vmcnt<6>(); }
+        if (has2) { stage_B(1, buf, t2); wait_vmcnt<INFLIGHT>(); }
         else if (has1) wait_vmcnt<0>();
         G8_BAR();
         G8_MMA(1, b0f, 0);
@@ -1969,7 +2091,7 @@ __global__ void __launch_bounds__(512) gemm8_kernel(GemmArgs g) {
         stage_B(0, 0, t0); stage_A(0, 0, t0); stage_B(1, 0, t0); stage_A(1, 0, t0);
         if (nk > 1) {
             stage_B(0, 1, t1); stage_A(0, 1, t1); stage_B(1, 1, t1);
-            wait_vmcnt<6>();
+            wait_vmcnt<INFLIGHT>();
         } else {
             wait_vmcnt<0>();
         }
@@ -1977,7 +2099,7 @@ __global__ void __launch_bounds__(512) gemm8_kernel(GemmArgs g) {
     t2 = t1;
     advance(t2);
     G8_BAR();
-    if (wr == 1) G8_BAR();   // stagger: wave row 1 runs one barrier behind wave row 0
+    if (grp == 1) G8_BAR();   // stagger: the second wave group runs one barrier behind the first
 
     int kt = 0;
     for (; kt + 3 < nk; kt += 2) {   // steady state: two K-tiles per iteration, buffers and flags compile-time constants
@@ -1985,12 +2107,14 @@ __global__ void __launch_bounds__(512) gemm8_kernel(GemmArgs g) {
         ktile(1, true, true);
     }
     for (; kt < nk; ++kt) ktile(kt & 1, kt + 1 < nk, kt + 2 < nk);   // the last one to three K-tiles (kt is even here)
-    if (wr == 0) G8_BAR();   // re-align the two groups
+    if (grp == 0) G8_BAR();   // re-align the two groups
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
     __syncthreads();
 #undef G8_MMA
 #undef G8_BAR
+    if (ODISE_ABLATE(g, 4)) return;   // tools: main loop only
     constexpr int LDS = pp_lds_bytes(BM, BN, WAVES_M);
+    static_assert(LDS >= 2 * STAGE, "operand stages exceed the LDS request");
     gemm_epilogue<BM, BN, WAVES_M, WAVES_N, epi_wave_rows(BM, BN, WAVES_M, LDS), false, CONV, true, epi16_rows_if_enabled(BM, BN, WAVES_M, LDS), !CONV>(
         g, acc, smem, m0, n0, z, zb, split);
 }
@@ -2112,27 +2236,30 @@ __global__ void __launch_bounds__(512) conv3_halo_kernel(GemmArgs g) {
         finish(t);
     };
 
-    f32x16 acc[TM][TN];
+    AccBlock<kL16> acc[TM][TN];
 #pragma unroll
     for (int i = 0; i < TM; ++i)
 #pragma unroll
-        for (int j = 0; j < TN; ++j)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+        for (int j = 0; j < TN; ++j) acc_zero(acc[i][j]);
 
-    int koff[4];
+    using FR = Frag<kL16>;
+    const int lrow = FR::lrow(lane), lkq = FR::lk(lane);
+    int koff[FR::NSTEP];   // 16-byte slot of step st, swizzled with the lane's row key (tile bases are multiples of 16 rows); fragment u: + u * 16 rows
 #pragma unroll
-    for (int s = 0; s < 4; ++s) koff[s] = ((s * 2 + hi) ^ ((l31 >> 1) & 7)) << 4;
-    const int b_lane_off = (wn * WTN + l31) * 128;
-    const int a_pix0 = (wm * 4 + (l31 >> 4)) * HW_ + (l31 & 15);  // halo pixel of this lane's row of A tile i = 0 at tap (0,0); tile 1: +2 rows
+    for (int s = 0; s < FR::NSTEP; ++s) koff[s] = (FR::kslot(s, lkq) ^ ((lrow >> 1) & 7)) << 4;
+    const int b_lane_off = (wn * WTN + lrow) * 128;
+    const int a_pix0 = (wm * 4 + (lrow >> 4)) * HW_ + (lrow & 15);  // halo pixel of this lane's row of A tile i = 0, fragment 0 at tap (0,0); tile 1: +2 rows, fragment u: + u rows
 
     // A fragments of the K-tile at position t (chunk, tap) for k-step s, from the chunk's halo buffer
-    auto read_a = [&](const TileK& t, int s, f16x8 (&dst)[TM][4]) {
+    auto read_a = [&](const TileK& t, int s, f16x8 (&dst)[TM][FR::NSTEP][FR::PER]) {
         const char* ha = smem + HALO0 + (t.chunk & 1) * HALO_BYTES;
         const int pix = a_pix0 + t.ky * HW_ + t.kx;
-        const int key = (((l31 & 15) + t.kx) >> 1) & 7;  // swizzle key = halo COLUMN / 2 (see the header)
+        const int key = (((lrow & 15) + t.kx) >> 1) & 7;  // swizzle key = halo COLUMN / 2 (see the header)
 #pragma unroll
-        for (int i = 0; i < TM; ++i) dst[i][s] = *reinterpret_cast<const f16x8*>(ha + (pix + i * 2 * HW_) * 128 + (((s * 2 + hi) ^ key) << 4));
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int u = 0; u < FR::PER; ++u)
+                dst[i][s][u] = *reinterpret_cast<const f16x8*>(ha + (pix + (i * 2 + u) * HW_) * 128 + ((FR::kslot(s, lkq) ^ key) << 4));
     };
     // ---- prologue: halo of the first chunk, B of tile 0, first half of B of tile 1; everything of tile 0 lands before the first reads
     TileK t0;
@@ -2157,14 +2284,16 @@ __global__ void __launch_bounds__(512) conv3_halo_kernel(GemmArgs g) {
     advance(t2);
     __builtin_amdgcn_s_barrier();
     TileK tc = t0;  // position of the K-tile being multiplied
-    f16x8 af[TM][4], bf[PT][4];
+    f16x8 af[TM][FR::NSTEP][FR::PER], bf[PT][FR::NSTEP][FR::PER];
     {   // fragments of phase (0,0)
         const char* fb = smem + b_lane_off;
 #pragma unroll
-        for (int s = 0; s < 4; ++s) {
+        for (int s = 0; s < FR::NSTEP; ++s) {
             read_a(tc, s, af);
 #pragma unroll
-            for (int jj = 0; jj < PT; ++jj) bf[jj][s] = *reinterpret_cast<const f16x8*>(fb + koff[s] + jj * 4096);
+            for (int jj = 0; jj < PT; ++jj)
+#pragma unroll
+                for (int u = 0; u < FR::PER; ++u) bf[jj][s][u] = *reinterpret_cast<const f16x8*>(fb + koff[s] + jj * 4096 + u * 2048);
         }
     }
     if (grp == 1) __builtin_amdgcn_s_barrier();  // stagger: group 1 runs one barrier interval behind group 0
@@ -2209,16 +2338,17 @@ __global__ void __launch_bounds__(512) conv3_halo_kernel(GemmArgs g) {
             const char* nfb = smem + (next_in_tile ? cur : (cur ^ 1)) * B_BYTES + b_lane_off + (next_in_tile ? (j0 + PT) * 4096 : 0);
             __builtin_amdgcn_s_setprio(1);
 #pragma unroll
-            for (int s = 0; s < 4; ++s) {
+            for (int s = 0; s < FR::NSTEP; ++s) {
 #pragma unroll
                 for (int jj = 0; jj < PT; ++jj)
 #pragma unroll
-                    for (int i = 0; i < TM; ++i)
-                        acc[i][j0 + jj] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bf[jj][s], af[i][s], acc[i][j0 + jj], 0, 0, 0);  // transposed tile (see gemm_epilogue)
+                    for (int i = 0; i < TM; ++i) mma_step(acc[i][j0 + jj], bf[jj][s], af[i][s]);  // transposed tile (see gemm_epilogue)
                 if (have_next) {
                     if (!next_in_tile) read_a(t1, s, af);
 #pragma unroll
-                    for (int jj = 0; jj < PT; ++jj) bf[jj][s] = *reinterpret_cast<const f16x8*>(nfb + koff[s] + jj * 4096);
+                    for (int jj = 0; jj < PT; ++jj)
+#pragma unroll
+                        for (int u = 0; u < FR::PER; ++u) bf[jj][s][u] = *reinterpret_cast<const f16x8*>(nfb + koff[s] + jj * 4096 + u * 2048);
                 }
             }
             __builtin_amdgcn_s_setprio(0);
@@ -2329,19 +2459,19 @@ __global__ void __launch_bounds__(256, 2) conv3_halo4_kernel(GemmArgs g) {
         }
     };
 
-    f32x16 acc[TM][TN];
+    AccBlock<kL16> acc[TM][TN];
 #pragma unroll
     for (int i = 0; i < TM; ++i)
 #pragma unroll
-        for (int j = 0; j < TN; ++j)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+        for (int j = 0; j < TN; ++j) acc_zero(acc[i][j]);
 
-    int koff[4];
+    using FR = Frag<kL16>;
+    const int lrow = FR::lrow(lane), lkq = FR::lk(lane);
+    int koff[FR::NSTEP];   // 16-byte slot of step st, swizzled with the lane's row key (tile bases are multiples of 16 rows); fragment u: + u * 16 rows
 #pragma unroll
-    for (int s = 0; s < 4; ++s) koff[s] = ((s * 2 + hi) ^ ((l31 >> 1) & 7)) << 4;
-    const int b_lane_off = l31 * 128;
-    const int a_pix0 = (wm * 4 + (l31 >> 4)) * HW_ + (l31 & 15);  // halo pixel of this lane's row of A tile 0 at tap (0,0); tile 1: +2 patch rows
+    for (int s = 0; s < FR::NSTEP; ++s) koff[s] = (FR::kslot(s, lkq) ^ ((lrow >> 1) & 7)) << 4;
+    const int b_lane_off = lrow * 128;
+    const int a_pix0 = (wm * 4 + (lrow >> 4)) * HW_ + (lrow & 15);  // halo pixel of this lane's row of A tile 0, fragment 0 at tap (0,0); tile 1: +2 patch rows, fragment u: + u
 
     // K-tile position: chunk-major (tap inner); kw = element offset inside a weight row [Cout][ky][kx][Cin]
     int ky = 0, kx = 0, chunk = kt_begin / 9;
@@ -2362,26 +2492,28 @@ __global__ void __launch_bounds__(256, 2) conv3_halo4_kernel(GemmArgs g) {
         const char* ha = smem + HALO0;
         const char* fb = smem + cur * B_BYTES + b_lane_off;
         const int pix = a_pix0 + ky * HW_ + kx;
-        const int key = (((l31 & 15) + kx) >> 1) & 7;  // swizzle key = halo COLUMN / 2 (see conv3_halo_kernel)
+        const int key = (((lrow & 15) + kx) >> 1) & 7;  // swizzle key = halo COLUMN / 2 (see conv3_halo_kernel)
         // fragments double-buffered in registers: the reads of k-step s + 1 are issued before the MFMAs of k-step s (counted lgkmcnt), so a
         // lone wave does not sit out an LDS round trip per k-step while its SIMD partner (the other block's wave) is in a barrier or a wait
-        f16x8 af[2][TM], bf[2][TN];
+        f16x8 af[2][TM][FR::PER], bf[2][TN][FR::PER];
         auto read_frags = [&](int s, int b) {
 #pragma unroll
-            for (int i = 0; i < TM; ++i) af[b][i] = *reinterpret_cast<const f16x8*>(ha + (pix + i * 2 * HW_) * 128 + (((s * 2 + hi) ^ key) << 4));
+            for (int u = 0; u < FR::PER; ++u) {
 #pragma unroll
-            for (int j = 0; j < TN; ++j) bf[b][j] = *reinterpret_cast<const f16x8*>(fb + koff[s] + j * 4096);
+                for (int i = 0; i < TM; ++i) af[b][i][u] = *reinterpret_cast<const f16x8*>(ha + (pix + (i * 2 + u) * HW_) * 128 + ((FR::kslot(s, lkq) ^ key) << 4));
+#pragma unroll
+                for (int j = 0; j < TN; ++j) bf[b][j][u] = *reinterpret_cast<const f16x8*>(fb + koff[s] + j * 4096 + u * 2048);
+            }
         };
         read_frags(0, 0);
 #pragma unroll
-        for (int s = 0; s < 4; ++s) {
-            if (s + 1 < 4) read_frags(s + 1, (s + 1) & 1);
+        for (int s = 0; s < FR::NSTEP; ++s) {
+            if (s + 1 < FR::NSTEP) read_frags(s + 1, (s + 1) & 1);
             __builtin_amdgcn_sched_barrier(0);   // keep the prefetch ahead of the MFMAs (the scheduler otherwise sinks it to save registers)
 #pragma unroll
             for (int j = 0; j < TN; ++j)
 #pragma unroll
-                for (int i = 0; i < TM; ++i)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bf[s & 1][j], af[s & 1][i], acc[i][j], 0, 0, 0);  // transposed tile (see gemm_epilogue)
+                for (int i = 0; i < TM; ++i) mma_step(acc[i][j], bf[s & 1][j], af[s & 1][i]);  // transposed tile (see gemm_epilogue)
             __builtin_amdgcn_sched_barrier(0);
         }
         if (more && nchunk != chunk) {
@@ -2488,15 +2620,14 @@ static int launch_gemm_pp2(odise_hip_ctx* ctx, GemmArgs& g, int batch) {
     return ODISE_OK;
 }
 
-template <bool CONV>
+template <int BM, int BN, bool CONV, bool L16>
 static int launch_gemm8(odise_hip_ctx* ctx, GemmArgs& g, int batch) {
-    constexpr int lds = pp_lds_bytes(256, 256, 2);
-    static_assert(lds >= 2 * 4 * 128 * 64 * 2, "operand stages exceed the LDS request");
-    static_assert(epi_lds_bytes(256, 256, 2, epi_wave_rows(256, 256, 2, lds)) <= lds, "epilogue staging exceeds the LDS request");
-    auto kern = gemm8_kernel<CONV>;
+    constexpr int lds = pp_lds_bytes(BM, BN, BM / 128);
+    static_assert(epi_lds_bytes(BM, BN, BM / 128, epi_wave_rows(BM, BN, BM / 128, lds)) <= lds, "epilogue staging exceeds the LDS request");
+    auto kern = gemm8_kernel<BM, BN, CONV, L16>;
     static LdsAttrOnce once;  // per instantiation; tracked per device inside
     ODISE_TRY(ensure_dyn_lds(ctx, once, (const void*)kern, lds));
-    dim3 grid((unsigned)ceil_div(g.N, 256), (unsigned)ceil_div(g.M, 256), (unsigned)(g.splitk > 1 ? g.splitk : batch));
+    dim3 grid((unsigned)ceil_div(g.N, BN), (unsigned)ceil_div(g.M, BM), (unsigned)(g.splitk > 1 ? g.splitk : batch));
     hipLaunchKernelGGL(kern, grid, dim3(512), lds, ctx->stream, g);
     ODISE_CHECK_HIP(hipGetLastError());
     if (g.splitk > 1) {
@@ -2583,25 +2714,31 @@ static const TileCost kTileCost[kNumTiles] = {
     {2.10, 15.0, 1},  // 256x256 (plain kernel)
     {1.42, 6.0, 1},   // 256x128
     {2.25, 12.0, 1},  // 512x128 (ping-pong kernel only)
-    {1.92, 12.0, 1},  // halo 256 pixels x 256 channels (measured 7 % under the im2col ping-pong tile on the 512-channel VAE layers)
+    {1.43, 21.0, 1},  // halo 256 pixels x 256 channels (round 5, 16x16x32 MFMAs: the dominant convolution 995 us = 8 rounds of 72 K-tiles, 256 -> 256 at
+                      // 256^2 1164 us = 16 rounds of 36 - ahead of every other tile on all convolutions with 256 or more output channels)
     {1.12, 9.0, 1},   // halo 256 pixels x 128 channels (re-fitted in round 2: 28 us per block of 18 K-tiles on the 128-channel VAE level, where
                       // the im2col 512x128 tile takes 65 us per block of twice the size: 1.80 vs 2.07 ms per launch, tools/halo512_probe.py)
-    {2.00, 9.0, 2},   // the same tile as four waves, two blocks per CU (a block's K-tile takes about twice as long beside its partner)
+    {1.65, 12.5, 2},  // the same tile as four waves, two blocks per CU (round 5 refit: 128 -> 128 at 512^2 1348 us = 32 rounds of 18, the dominant
+                      // convolution 1049 us = 8 rounds of 72)
 };
 // (Round 3: on launches of at least two full rounds a refit of this tile, {1.78, 12.0}, also takes the 256- / 512-channel VAE layers from the
 // 256-channel halo tile - isolated they run 2-6 % faster on it although every patch's halo is then fetched by Cout / 128 column blocks
 // (tools/conv_tiles.py) - but the two-lane step did not get faster, 87.0 / 87.4 ms against 86.9 / 86.8 ms: not adopted.)
 // the 256-row tiles as run by the ping-pong kernel (K % 64 == 0; conv: Cin % 64 == 0, no fused upsample)
 static const TileCost kTileCostPP[2] = {
-    {2.55, 16.0, 1},  // 256x320
-    {2.10, 12.0, 1},  // 256x256
+    {2.00, 16.0, 1},  // 256x320 (round 5 refit: 9344x4096x1024 93 us = 1.9 rounds of 16, conv 320 -> 320 at 64^2 108 us = one round of 45)
+    {2.10, 12.0, 1},  // 256x256 (only reached with the 8-phase kernel switched off)
 };
 // the 512x128 tile on implicit-GEMM convolutions: every input pixel passes the LDS-DMA path nine times (measured 61-65 us per block of
 // 18 K-tiles on the 128-channel VAE level; the dense fit above says 52 us).  Still ahead of the plain 256x128 tile on the stride-2 conv
 // of that level (622 vs 651 us), behind the halo tile on the stride-1 ones.
 static const TileCost kTileCostConv512 = {2.5, 16.0, 1};
-// the 256x256 tile as run by the 8-phase kernel (round 5; fitted on tools/gemm8p_bench.py: 4096^3 101 us = 64 K-tiles, 65536x512x4608 244 us = 2 rounds of 72)
-static const TileCost kTileCost8 = {1.50, 9.0, 1};
+// the 256x256 tile as run by the 8-phase kernel on v_mfma_f32_16x16x32_f16 (round 5; fitted on tools/g8_shapes.py, profiles/r05_gemm8_by_shape.txt:
+// 9344x1024x4096 93.5 us = one 58 % round of 64 K-tiles, 9344x4096x1024 122.7 us = 2.3 rounds of 16, the dominant convolution 989 us = 8 rounds of 72)
+static const TileCost kTileCost8 = {1.21, 24.0, 1};
+// ... and on implicit-GEMM convolutions (every input pixel passes the LDS-DMA path nine times; the dominant convolution 1037 us = 8 rounds of 72,
+// 256 -> 256 at 256^2 1263 us = 16 rounds of 36: profiles/r05_conv_tiles_l16.txt)
+static const TileCost kTileCost8Conv = {1.41, 28.0, 1};
 // previous fit (before the lean epilogue / ping-pong kernel), kept selectable for A/B runs: ODISE_GEMM_FLAGS=8
 static const TileCost kTileCostOld[kNumTiles] = {{1.68, 9.5, 2}, {1.58, 4.1, 3}, {1.28, 2.4, 4}, {3.04, 29.0, 1}, {2.58, 22.0, 1},
                                                  {1.75, 10.6, 1}, {2.25, 12.0, 1}, {1.92, 12.0, 1}, {1.32, 10.0, 1}, {2.64, 10.0, 2}};
@@ -2672,7 +2809,7 @@ static int launch_gemm_select(odise_hip_ctx* ctx, GemmArgs& g, int batch, int fo
         if (t == 6 && (!pp_ok || (flags & 16))) continue;
         if (t >= 7 && t <= 9 && (!halo_ok || !pp_ok || (flags & 64))) continue;  // ODISE_GEMM_FLAGS=64: never use the halo kernels
         if (t == 9 && (flags & 2048)) continue;                        // ODISE_GEMM_FLAGS=2048: never use the two-blocks-per-CU halo kernel
-        const TileCost& tc = (flags & 8) ? kTileCostOld[t] : (g8_ok && t == 4) ? kTileCost8 : (pp_ok && (t == 3 || t == 4)) ? kTileCostPP[t - 3] :
+        const TileCost& tc = (flags & 8) ? kTileCostOld[t] : (g8_ok && t == 4) ? (CONV ? kTileCost8Conv : kTileCost8) : (pp_ok && (t == 3 || t == 4)) ? kTileCostPP[t - 3] :
                              (CONV && t == 6) ? kTileCostConv512 : kTileCost[t];
         if (force_tile < 0) {
             if (kTileBM[t] > 64 && g.M <= kTileBM[t] / 2) continue;            // mostly-empty row tiles
@@ -2748,7 +2885,7 @@ static int launch_gemm_select(odise_hip_ctx* ctx, GemmArgs& g, int batch, int fo
         // epilogue), a column-chunk count that divides the thread count, and row blocks that never straddle two images
         const int ohw = CONV ? g.cg.OH * g.cg.OW : 0;
         // kernels instantiated with the statistics epilogue: halo tiles, pp2 conv (256x256) and the 512x128 conv tile
-        const bool pp2_used = (tile == 4) && pp_ok && (g8_ok || (flags & 512) || (!(flags & 1024) && CONV));   // gemm8_kernel<true> carries the statistics epilogue too
+        const bool pp2_used = (tile == 4) && pp_ok && (g8_ok || (flags & 512) || (!(flags & 1024) && CONV));   // gemm8_kernel<.., CONV = true> carries the statistics epilogue too
         bool ok = CONV && g.splitk == 1 && g.epi.fast && g.N % 8 == 0 && ((tile >= 7 && tile <= 9) || (tile == 6 && pp_ok && !(flags & 512)) || pp2_used);
         if (ok && tile >= 7) g.stats_blocks = g.cg.halo_tx * g.cg.halo_ty;
         else if (ok && ohw % kTileBM[tile] == 0) g.stats_blocks = ohw / kTileBM[tile];
@@ -2772,7 +2909,11 @@ static int launch_gemm_select(odise_hip_ctx* ctx, GemmArgs& g, int batch, int fo
     // second-generation ping-pong kernel (fragment reads under the MFMAs): measured +3..18 % on the implicit-GEMM convs and on
     // dense problems that do not fill the chip twice; the large dense GEMMs keep the first generation (-5..12 % there).
     // ODISE_GEMM_FLAGS: 512 forces it, 1024 forbids it.
-    if (tile == 4 && g8_ok) return launch_gemm8<CONV>(ctx, g, batch);
+    if ((tile == 4 || tile == 6) && g8_ok) {   // ODISE_GEMM_FLAGS 8192: the 8-phase 256x256 kernel on the OTHER MFMA shape (32x32x16 in the product build)
+        if (tile == 6) return launch_gemm8<512, 128, CONV, kL16>(ctx, g, batch);
+        if (flags & 8192) return launch_gemm8<256, 256, CONV, !kL16>(ctx, g, batch);
+        return launch_gemm8<256, 256, CONV, kL16>(ctx, g, batch);
+    }
     const bool pp2_auto = !(flags & 1024) && ((CONV && tile != 6) || (!CONV && blocks(tile) * (g.splitk > 1 ? g.splitk : 1) <= 2 * cus));
     if ((tile == 3 || tile == 4 || tile == 6) && pp_ok && ((flags & 512) || pp2_auto)) {
         if (tile == 6) return launch_gemm_pp2<512, 128, 1, 2, CONV>(ctx, g, batch);

@@ -795,6 +795,22 @@ extern "C" int odise_hip_backbone_forward(odise_hip_ctx* ctx, const float* image
     return backbone_forward(ctx, image, B, H, W, out4);
 }
 
+// test / attribution hook (include/odise_hip_tools.h): the s2..s5 maps of the last backbone pass that are still resident in the arena
+// (odise_hip_backbone_forward or odise_hip_infer; gone after the next call that resets it), converted to fp32 NCHW [B,C,h,w] device arrays
+extern "C" int odise_hip_backbone_maps(odise_hip_ctx* ctx, float** out4, int* shape_bchw4x4) {
+    ODISE_REQUIRE(ctx && out4, "backbone_maps: null argument");
+    ODISE_CHECK_HIP(hipSetDevice(ctx->device));
+    ModelStore* ms = store_of(ctx);
+    MaskGenModel* g = ms->maskgen;
+    ODISE_REQUIRE(g && g->feats[0].p != nullptr, "backbone_maps: no backbone features resident (run the backbone or odise_hip_infer first)");
+    for (int i = 0; i < 4; ++i) {
+        const Act& a = g->feats[i];
+        if (shape_bchw4x4) { shape_bchw4x4[4 * i] = a.n; shape_bchw4x4[4 * i + 1] = a.c; shape_bchw4x4[4 * i + 2] = a.h; shape_bchw4x4[4 * i + 3] = a.w; }
+        if (out4[i]) ODISE_TRY(odise_hip_nhwc_f16_to_nchw_f32(ctx, a.p, out4[i], a.n, a.c, a.h, a.w));
+    }
+    return ODISE_OK;
+}
+
 // feats4: s2,s3,s4,s5 fp32 NCHW [B,Cin,H/4..H/32,W/4..W/32] on the device, or NULL to use the maps of the last backbone_forward.
 // outputs (device, any may be NULL): pred_masks [B,Q,H/4,W/4] f32, mask_embed [B,Q,C] f32, mask_pooled [B,Q,C] f32; logit_scale (host)
 extern "C" int odise_hip_head_forward(odise_hip_ctx* ctx, const float* const* feats4, int B, int Cin, int H4, int W4, float* pred_masks,

@@ -73,6 +73,20 @@ class HipODISE:
         outs = self.backbone_device(self.ctx.to_device(np.asarray(image, np.float32)))
         return {k: o.numpy() for k, o in zip(("s2", "s3", "s4", "s5"), outs)}
 
+    def backbone_maps(self) -> Dict[str, np.ndarray]:
+        """The s2..s5 maps of the LAST backbone pass (`backbone_device` or a whole `infer_device` call) as the device holds them, fp32 NCHW on
+        the host.  Test / attribution hook: valid until the next call that resets the activation arena."""
+        shp = (C.c_int * 16)()
+        none = (C.c_void_p * 4)()
+        check(self.ctx.lib.odise_hip_backbone_maps(self.ctx.h, none, shp), "backbone_maps")
+        outs = [self.ctx.empty(tuple(shp[4 * i:4 * i + 4]), np.float32) for i in range(4)]
+        arr = (C.c_void_p * 4)(*[o.ptr for o in outs])
+        check(self.ctx.lib.odise_hip_backbone_maps(self.ctx.h, arr, None), "backbone_maps")
+        res = {k: o.numpy() for k, o in zip(("s2", "s3", "s4", "s5"), outs)}
+        for o in outs:
+            o.free()
+        return res
+
     # ---- MaskFormerHead.layers ------------------------------------------------------------------------------------------------
     def head_device(self, feats: Optional[list], B: int, H4: int, W4: int, cin: int = 512, want_outputs: bool = True):
         Q, Cd = self.num_queries, self.hidden_dim

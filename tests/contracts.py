@@ -74,8 +74,17 @@ def end_to_end_contract(got, ref, cls_ref, k, things, tag="", size=1024, segment
         assert info == info_ref, (tag, info, info_ref)
         assert agree > 0.99, (tag, agree)                    # measured 0.9968-0.9989: the pixels inside the fp16 band of a mask boundary
     else:
-        print(tag, "segments_info not decided by the reference's margins at the measured error; identical anyway:", info == info_ref)
-        assert agree > 0.97 or info != info_ref, (tag, agree)
+        # the reference's own table is not fixed by its margins at the measured error (margins.segments_decided): the two tables may differ by the
+        # segments next to a threshold - but only by those.  Hard floor whatever the tables say: per-pixel CATEGORY agreement (segment ids are
+        # arbitrary labels, categories are not), and a bound on how many segments came or went.
+        cat_got, cat_ref = category_map(pan, info), category_map(pan_ref.numpy(), info_ref)
+        cat_agree = float((cat_got == cat_ref).mean())
+        from collections import Counter
+        c_got, c_ref = Counter(s["category_id"] for s in info), Counter(s["category_id"] for s in info_ref)
+        changed = sum(((c_got - c_ref) + (c_ref - c_got)).values())
+        print(tag, "segments_info not decided by the reference's margins at the measured error; identical anyway:", info == info_ref,
+              "| per-pixel category agreement", cat_agree, "| segments that came or went", changed)
+        assert (agree > 0.99 if info == info_ref else (cat_agree > 0.9 and changed <= 3)), (tag, agree, cat_agree, changed)
     # sem_seg = sum_q P[q,k] sigmoid(mask_q) carries the class-probability error; its per-pixel argmax is identical wherever the reference decides by
     # more than that error, and the undecided rest (near-ties between two of the class scores) stays a small fraction
     assert serr < max(TAU_SEM, tau) and same[decided].all() and sagree > 0.98, (tag, serr, sagree)
@@ -90,20 +99,23 @@ def end_to_end_contract(got, ref, cls_ref, k, things, tag="", size=1024, segment
     return dict(segments=len(info), panoptic_agreement=agree, sem_err=serr, sem_agreement=sagree, instances=len(key_got), worst_iou=float(worst))
 
 
-MAX_REDECIDED = 3    # queries per picture whose class distribution may move by more than TAU_PROB (see class_probability_contract)
-TAU_REDECIDED = 0.2  # ... and by how much at most
+MAX_REDECIDED = 3    # sanity bound on the queries per picture whose class distribution moves by more than TAU_PROB against the pure oracle ...
+TAU_REDECIDED = 0.2  # ... and by how much (both only REPORT how the reference's own decision chain reacts to the device's ~3e-3 feature error)
 
 
-def class_probability_contract(got_logp, ref_logp, k, tag="", min_decided=50, min_same=93):
-    """Class log-probabilities [Q, K+1] of one image against the oracle's.  Per query q the error e_q = max_k |p_got - p_ref|:
-      * REGULAR queries (e_q < TAU_PROB; measured 0.5-2.6e-2 at logit scale 100) - all but at most MAX_REDECIDED;
-      * a RE-DECIDED query is one whose mask went the other way at one of the masked decoder's hard decisions (attention masks `sigmoid < 0.5`
-        at 9 layers, MaskCLIP's per-patch visibility bits): its mask-pooled embedding, hence its class distribution, moves by more than rounding
-        noise (tools/oracle_sensitivity.py shows the fp32 oracle doing the same under fp16-sized perturbations; which query it hits is a draw
-        that changes with any change of summation order).  They are counted, bounded in number and size, and - like every query - held to
-        their own margin:
-      * the arg-max label is identical on EVERY query whose reference top-2 margin exceeds twice that query's own measured error.
-    Returns the per-query errors e_q."""
+def class_probability_contract(got_logp, ref_logp, k, tag="", min_decided=50, min_same=93, ideal=None):
+    """Class log-probabilities [Q, K+1] of one image against the oracle's.  Per query q the error e_q = max_k |p_got - p_ref|.
+
+    STRICT: every query within TAU_PROB of the reference (measured 0.5-2.6e-2 at logit scale 100) - or, for a query beyond it, within TAU_PROB of
+    `ideal`: the fp32 ORACLE head + classifier run on the DEVICE's own backbone features of this picture (tests/fullsize.py
+    ideal_on_device_features; array [Q, K+1] or a callable that computes it - only evaluated when a query exceeds the bound).  Round 5 measured
+    where such queries come from (tools/parity_attribution.py, profiles/r05_parity_attribution.txt): the ideal fp32 head on the device's
+    features reproduces them (picture 1: 6.40e-2 against the device's 6.37e-2 on the same query), while the device head against the ideal head
+    on the same features stays at 1.1-1.5e-2 on all 100 queries.  They are the reference's own chain of hard decisions (attention masks
+    `sigmoid < 0.5` at 9 layers, MaskCLIP's visibility bits) reacting to a 3e-3 feature perturbation, not an error of the device's head -
+    so the device is held STRICTLY (all queries, no exceptions) to what an exact head makes of its features, and without `ideal` to the pure
+    oracle.  Labels: identical on every query whose reference top-2 margin exceeds twice that query's own measured error.
+    Returns the per-query errors e_q against the pure oracle."""
     p_ref, p_got = np.exp(np.asarray(ref_logp, np.float64).reshape(-1, k + 1)), np.exp(np.asarray(got_logp, np.float64).reshape(-1, k + 1))
     eprob = np.abs(p_got - p_ref).max(-1)
     perr = float(eprob.max())
@@ -112,14 +124,32 @@ def class_probability_contract(got_logp, ref_logp, k, tag="", min_decided=50, mi
     margin = top2[:, 1] - top2[:, 0]
     decided = margin > 2 * np.maximum(eprob, TAU_PROB)
     same = p_got.argmax(-1) == p_ref.argmax(-1)
-    print(f"{tag} class prob max abs err {perr:.3e} (regular bound {TAU_PROB}; re-decided queries {int((~regular).sum())}/{len(regular)}, the regular ones' max "
+    print(f"{tag} class prob max abs err {perr:.3e} (bound {TAU_PROB}; queries beyond it {int((~regular).sum())}/{len(regular)}, the others' max "
           f"{float(eprob[regular].max()):.3e}); labels: {len(set(p_ref.argmax(-1).tolist()))} distinct, {int((p_ref.argmax(-1) == k).sum())} null; queries decided by "
           f"their margin: {int(decided.sum())}/{len(same)}; label agreement {int(same.sum())}/{len(same)}; undecided {int((~decided).sum())}, of which differing "
           f"{int((~same & ~decided).sum())}")
-    assert (~regular).sum() <= MAX_REDECIDED and perr < TAU_REDECIDED, (tag, int((~regular).sum()), perr)
+    if not regular.all():
+        assert ideal is not None, (f"{tag}: {int((~regular).sum())} queries beyond TAU_PROB ({perr:.3e}) and no attribution reference (the fp32 oracle head on the "
+                                   "device's own features) to hold them to")
+        p_ideal = np.exp(np.asarray(ideal() if callable(ideal) else ideal, np.float64).reshape(-1, k + 1))
+        e_attr = np.abs(p_got - p_ideal).max(-1)
+        e_feat = np.abs(p_ideal - p_ref).max(-1)
+        print(f"{tag} attribution: device vs the fp32 oracle head on the device's own features: max {float(e_attr.max()):.3e} over ALL queries (bound {TAU_PROB}); "
+              f"that ideal head vs the pure oracle on the queries beyond the bound: {np.round(e_feat[~regular], 4).tolist()} (device: {np.round(eprob[~regular], 4).tolist()})")
+        assert e_attr.max() < TAU_PROB, f"{tag}: the device's head / classifier differs from the fp32 oracle on the SAME features by {float(e_attr.max()):.3e}"
+        assert (~regular).sum() <= MAX_REDECIDED and perr < TAU_REDECIDED, (tag, int((~regular).sum()), perr)
     assert same[decided].all(), f"{tag}: argmax label differs on a query whose reference margin exceeds twice its measured error"
     assert decided.sum() >= min_decided and same.sum() >= min_same, (tag, int(decided.sum()), int(same.sum()))
     return eprob
+
+
+def category_map(pan, info):
+    """Panoptic map + segments_info -> per-pixel category id (-1 = void): what two tables that name their segments differently still share."""
+    lut = np.full(int(max([s["id"] for s in info] + [0])) + 1, -1, np.int64)
+    for s in info:
+        lut[s["id"]] = s["category_id"]
+    pan = np.asarray(pan)
+    return lut[np.clip(pan, 0, len(lut) - 1)]
 
 
 def device_pair_report(a, b, logp_a, logp_b, k, tag=""):

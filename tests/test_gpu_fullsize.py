@@ -24,7 +24,7 @@ import pytest
 import torch
 
 from contracts import TAU_PROB, class_probability_contract, end_to_end_contract
-from fullsize import build_models, category_head_state, reference
+from fullsize import build_models, category_head_state, ideal_on_device_features, reference
 from oracle import odise_model as om
 
 pytestmark = pytest.mark.gpu
@@ -189,10 +189,13 @@ def test_end_to_end_contract(full, ctx, vocab, overlap_threshold):
         use_vocabulary(full, vocab)
         dev = ctx.to_device(np.ascontiguousarray(img.numpy()))
         hip.infer_device([dev], 1, [(1024, 1024)], [(1024, 1024)], to_host=False, mask_cls_out=cls_got)     # the same call again for its class probabilities
+        maps = hip.backbone_maps()        # the backbone features this very call computed: what a query beyond the bound is attributed with
     finally:
         hip.overlap_threshold = 0.8
         use_vocabulary(full, "coco133")
-    perr = class_probability_contract(cls_got.numpy()[0], cls_ref[0].numpy(), k, tag=f"vocabulary {vocab} overlap {overlap_threshold}:")
+    ext, _, head = build_models(k)
+    perr = class_probability_contract(cls_got.numpy()[0], cls_ref[0].numpy(), k, tag=f"vocabulary {vocab} overlap {overlap_threshold}:",
+                                      ideal=lambda: ideal_on_device_features(ext, head, heads, maps, img)["mask_cls"][0].numpy())
     end_to_end_contract(got, ref, cls_ref, k, things, tag=f"vocabulary {vocab} overlap {overlap_threshold}:", perr=perr)
 
 

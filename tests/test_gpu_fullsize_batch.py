@@ -20,7 +20,7 @@ import pytest
 import torch
 
 from contracts import TAU_PROB, class_probability_contract, device_pair_report, end_to_end_contract, launch_choice_diff
-from fullsize import build_models, category_head_state, reference, reference_with
+from fullsize import build_models, category_head_state, ideal_on_device_features, reference, reference_with
 from margins import segments_decided, upsampled_reference_logits
 from oracle import odise_model as om
 
@@ -88,8 +88,16 @@ def _activate(hip, name, size):
     return (ext, bb, head), heads, things, k
 
 
-def _run(ctx, hip, imgs, size, log=False):
-    """One call over `imgs` -> (results with host arrays, class log-probabilities [B, Q, K+1], launch log or None)."""
+def _ideal(models, heads, maps, imgs, i):
+    """Lazy attribution reference of picture i of the batch whose backbone maps are `maps` (contracts.class_probability_contract `ideal`)."""
+    ext, _, head = models
+    one = {k: v[i:i + 1] for k, v in maps.items()}
+    return lambda: ideal_on_device_features(ext, head, heads, one, imgs[i])["mask_cls"][0].numpy()
+
+
+def _run(ctx, hip, imgs, size, log=False, want_maps=False):
+    """One call over `imgs` -> (results with host arrays, class log-probabilities [B, Q, K+1], launch log or None); with want_maps the call's
+    backbone features are left in `_run.maps` (dict s2..s5 of [B, 512, h, w] fp32)."""
     n = len(imgs)
     cls = ctx.empty((n, hip.num_queries, hip.num_classes + 1), np.float32)
     dev = [ctx.to_device(np.ascontiguousarray(i.numpy())) for i in imgs]      # uint8 CHW (layout 1)
@@ -98,6 +106,7 @@ def _run(ctx, hip, imgs, size, log=False):
     try:
         res = hip.infer_device(dev, 1, [(size, size)] * n, [(size, size)] * n, to_host=True, mask_cls_out=cls)
         rec = ctx.launch_log_read() if log else None
+        _run.maps = hip.backbone_maps() if want_maps else None     # the backbone features of THIS call (attribution of re-decided queries)
     finally:
         if log:
             ctx.launch_log(False)
@@ -117,7 +126,8 @@ def test_batch_of_four_1024_matches_oracle_and_single_runs(ctx, fullsize_model):
     refs = [reference_with(bb, head, ext, 1024, heads, s) for s in seeds]
     imgs = [r[0] for r in refs]
     assert ctx.get_option(ctx.OPT_CLIP_LN_FOLD) == 0, "the library's own rule must decide the LayerNorm form"
-    batch, cls_b, log_b = _run(ctx, hip, imgs, 1024, log=True)
+    batch, cls_b, log_b = _run(ctx, hip, imgs, 1024, log=True, want_maps=True)
+    maps = _run.maps
     merr = _mask_errors(hip, refs, 1024)
     # ---- every picture of the batch against ITS oracle pass
     strict = []
@@ -125,7 +135,7 @@ def test_batch_of_four_1024_matches_oracle_and_single_runs(ctx, fullsize_model):
         regular = merr[i] < TAU_MASK
         print(f"batch of 4, picture {i}: mask logits within {TAU_MASK} of max|logit| on {int(regular.sum())}/100 queries (worst {merr[i].max():.3e}, median {np.median(merr[i]):.2e})")
         assert regular.sum() >= 100 - MAX_MASK_REDECIDED and merr[i].max() < 8e-2, (i, int(regular.sum()), float(merr[i].max()))
-        perr = class_probability_contract(cls_b[i], r["mask_cls"][0].numpy(), k, tag=f"batch of 4, picture {i}:")
+        perr = class_probability_contract(cls_b[i], r["mask_cls"][0].numpy(), k, tag=f"batch of 4, picture {i}:", ideal=_ideal(models, heads, maps, imgs, i))
         ref = om.postprocess(r["mask_cls"], r["pred_masks"], (1024, 1024), [(1024, 1024)], [(1024, 1024)], k, things, 0.8)[0]
         up = upsampled_reference_logits(r["pred_masks"][0], (1024, 1024), (1024, 1024), (1024, 1024))
         strict.append(_segments_strict(i, cls_b[i], r, k, things, 1024, elogit_rel=merr[i], up=up))
@@ -176,11 +186,12 @@ def test_batch_of_eight_1024_ade150(ctx, fullsize_model):
     imgs = [r[0] for r in refs] + [image_u8(1024, 1024, s) for s in (4, 5, 6, 7)]
     hip.semantic_on = False           # keeps the host copies of this test at 8 x 0.4 GB; the semantic head at 32 crops adds nothing the 16-crop test has not run
     try:
-        batch, cls_b, _ = _run(ctx, hip, imgs, 1024)
+        batch, cls_b, _ = _run(ctx, hip, imgs, 1024, want_maps=True)
+        maps = _run.maps
         merr = _mask_errors(hip, refs, 1024, batch=len(imgs))
         undecided = set()
         for i, (img, r) in enumerate(refs):
-            class_probability_contract(cls_b[i], r["mask_cls"][0].numpy(), k, tag=f"batch of 8, picture {i}:")
+            class_probability_contract(cls_b[i], r["mask_cls"][0].numpy(), k, tag=f"batch of 8, picture {i}:", ideal=_ideal(models, heads, maps, imgs, i))
             ref = om.postprocess(r["mask_cls"], r["pred_masks"], (1024, 1024), [(1024, 1024)], [(1024, 1024)], k, things, 0.8)[0]
             info = batch[i]["panoptic_seg"][1]
             agree = float((batch[i]["panoptic_seg"][0] == ref["panoptic_seg"][0].numpy()).mean())
@@ -211,11 +222,13 @@ def test_batch_of_two_1280_ade847_fused_argmax(ctx, fullsize_model):
     hip.panoptic_on = hip.instance_on = False
     try:
         hip.semantic_argmax = True
-        batch, cls_b, log_b = _run(ctx, hip, imgs, S, log=True)
+        batch, cls_b, log_b = _run(ctx, hip, imgs, S, log=True, want_maps=True)
+        maps = _run.maps
         hip.semantic_argmax = False
         scores = []
         for i, (img, r) in enumerate(refs):
-            class_probability_contract(cls_b[i], r["mask_cls"][0].numpy(), k, tag=f"batch of 2 x 1280, picture {i}:", min_decided=40, min_same=90)
+            class_probability_contract(cls_b[i], r["mask_cls"][0].numpy(), k, tag=f"batch of 2 x 1280, picture {i}:", min_decided=40, min_same=90,
+                                       ideal=_ideal(models, heads, maps, imgs, i))
             one, _, _ = _run(ctx, hip, [img], S)                               # the device's own [K, S, S] scores of this picture (alone): the error bound
             scores.append(one[0]["sem_seg"])
         hip.semantic_argmax = True

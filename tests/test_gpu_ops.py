@@ -106,12 +106,21 @@ def test_gemm_plain(ctx, M, N, K, tile, split):
     close(out32, ref.numpy(), rtol=1e-4, atol=1e-4 * float(ref.abs().max()), what="gemm f32 out")
 
 
-# ---- the 8-phase 256x256 kernel (gemm8_kernel, round 5: tile 4 wherever K % 64 == 0) against the ping-pong kernel it replaces on that tile
-# (odise_hip_gemm_debug 1024 << 4 names it): same MFMA shape, same k order -> the same bits.  Ragged M / N (zero-line rows), one to many
-# K-tiles with odd and even counts (the tail of one to three K-tiles), split-K, batched, every epilogue family.
-@pytest.mark.parametrize("M,N,K,split,batch", [(256, 256, 64, 1, 1), (256, 256, 128, 1, 1), (512, 512, 192, 1, 1), (300, 330, 256, 1, 1), (1000, 264, 320, 1, 1),
-                                               (2720, 1024, 1024, 1, 1), (512, 256, 1536, 3, 1), (700, 300, 448, 2, 1), (256, 512, 512, 1, 3), (9344, 1024, 1024, 1, 1)])
-def test_gemm8_bit_identical_to_pingpong(ctx, M, N, K, split, batch):
+# ---- the 8-phase kernels (gemm8_kernel, round 5: tiles 4 = 256x256 and 6 = 512x128 wherever K % 64 == 0) against the ping-pong kernels
+# they replace on those tiles (odise_hip_gemm_debug 1024 << 4 names those).  Every main loop of csrc/gemm.hip multiplies with
+# v_mfma_f32_16x16x32_f16 and takes the k-steps of a K-tile in the same order: the same bits.  The 8-phase 256x256 kernel also exists on
+# v_mfma_f32_32x32x16_f16 (8192 << 4, the A/B form of tools/g8_shapes.py: another rounding sequence, the same error bound): held to the
+# fp32 reference and to the default form within one fp16 step of the largest output.
+# Ragged M / N (zero-line rows), one to many K-tiles with odd and even counts (the tail of one to three K-tiles), split-K, batched,
+# every epilogue family.
+G8, G8_M32, PP = 0, 8192 << 4, 1024 << 4
+
+
+@pytest.mark.parametrize("M,N,K,split,batch,tile", [(256, 256, 64, 1, 1, 4), (256, 256, 128, 1, 1, 4), (512, 512, 192, 1, 1, 4), (300, 330, 256, 1, 1, 4),
+                                                    (1000, 264, 320, 1, 1, 4), (2720, 1024, 1024, 1, 1, 4), (512, 256, 1536, 3, 1, 4), (700, 300, 448, 2, 1, 4),
+                                                    (256, 512, 512, 1, 3, 4), (9344, 1024, 1024, 1, 1, 4),
+                                                    (512, 128, 64, 1, 1, 6), (1100, 136, 320, 1, 1, 6), (4096, 128, 1152, 1, 1, 6), (1024, 256, 512, 2, 1, 6)])
+def test_gemm8_against_pingpong_and_reference(ctx, M, N, K, split, batch, tile):
     g = torch.Generator().manual_seed(M + 3 * N + 7 * K + split)
     shp = (lambda r, c: (batch, r, c)) if batch > 1 else (lambda r, c: (r, c))
     A = h(torch.randn(*shp(M, K), generator=g))
@@ -122,23 +131,27 @@ def test_gemm8_bit_identical_to_pingpong(ctx, M, N, K, split, batch):
     dr = ctx.to_device(res.half().numpy()) if batch == 1 else None
     outs = {}
     try:
-        for name, flags in (("g8", 0), ("pp", 1024 << 4)):
+        for name, flags in (("g8", G8), ("g8m32", G8_M32), ("pp", PP)):
             ctx.lib.odise_hip_gemm_debug(flags)
-            outs[name] = [ctx.gemm(dA, dW, bias_n=db, act=_lib.ACT_SILU, residual=dr, force_tile=4, force_split=split).numpy(),
-                          ctx.gemm(dA, dW, out_dtype=np.float32, force_tile=4, force_split=split).numpy()]
+            outs[name] = [ctx.gemm(dA, dW, bias_n=db, act=_lib.ACT_SILU, residual=dr, force_tile=tile, force_split=split).numpy(),
+                          ctx.gemm(dA, dW, out_dtype=np.float32, force_tile=tile, force_split=split).numpy()]
             if batch == 1 and N % 16 == 0:
-                outs[name].append(ctx.gemm(dA, dW, bias_n=db, geglu=True, force_tile=4, force_split=split).numpy())
+                outs[name].append(ctx.gemm(dA, dW, bias_n=db, geglu=True, force_tile=tile, force_split=split).numpy())
     finally:
         ctx.lib.odise_hip_gemm_debug(0)
     ref = (A @ W.transpose(-1, -2)).numpy()
-    close(outs["g8"][1], ref, rtol=1e-4, atol=1e-4 * float(np.abs(ref).max()), what=f"gemm8 {M}x{N}x{K} f32 out")
+    close(outs["g8"][1], ref, rtol=1e-4, atol=1e-4 * float(np.abs(ref).max()), what=f"gemm8 {M}x{N}x{K} tile {tile} f32 out")
     for a, b in zip(outs["g8"], outs["pp"]):
-        assert np.array_equal(a, b), f"gemm8 differs bitwise from the ping-pong kernel at {M}x{N}x{K} split {split} batch {batch}"
+        assert np.array_equal(a, b), f"gemm8 differs bitwise from the ping-pong kernel at {M}x{N}x{K} tile {tile} split {split} batch {batch}"
+    for a, b in zip(outs["g8m32"], outs["g8"]):     # (tile 6 has no 32x32x16 form: the flag leaves it as it is)
+        a, b = a.astype(np.float32), b.astype(np.float32)
+        assert np.abs(a - b).max() <= 2.0 ** -10 * max(np.abs(b).max(), 1.0), f"gemm8 on 32x32x16 vs 16x16x32 at {M}x{N}x{K} tile {tile}: {np.abs(a - b).max()}"
 
 
-@pytest.mark.parametrize("N,H,W,Cin,Cout,k,stride,split", [(2, 16, 16, 128, 256, 3, 1, 1), (1, 33, 17, 64, 300, 3, 1, 1), (2, 32, 32, 192, 256, 3, 1, 2),
-                                                           (1, 32, 32, 128, 256, 1, 1, 1), (2, 32, 32, 64, 512, 3, 2, 1), (1, 24, 40, 320, 320, 3, 1, 1)])
-def test_conv_gemm8_bit_identical_to_pingpong(ctx, N, H, W, Cin, Cout, k, stride, split):
+@pytest.mark.parametrize("N,H,W,Cin,Cout,k,stride,split,tile", [(2, 16, 16, 128, 256, 3, 1, 1, 4), (1, 33, 17, 64, 300, 3, 1, 1, 4), (2, 32, 32, 192, 256, 3, 1, 2, 4),
+                                                                (1, 32, 32, 128, 256, 1, 1, 1, 4), (2, 32, 32, 64, 512, 3, 2, 1, 4), (1, 24, 40, 320, 320, 3, 1, 1, 4),
+                                                                (2, 32, 32, 128, 128, 3, 1, 1, 6), (1, 33, 17, 64, 136, 3, 1, 1, 6), (1, 64, 64, 128, 128, 3, 2, 1, 6)])
+def test_conv_gemm8_against_pingpong_and_reference(ctx, N, H, W, Cin, Cout, k, stride, split, tile):
     g = torch.Generator().manual_seed(N + H + Cin + Cout + k)
     x = h(torch.randn(N, H, W, Cin, generator=g))
     w = h(torch.randn(Cout, k, k, Cin, generator=g) / (k * k * Cin) ** 0.5)
@@ -146,14 +159,15 @@ def test_conv_gemm8_bit_identical_to_pingpong(ctx, N, H, W, Cin, Cout, k, stride
     dx, dw, db = ctx.to_device(x.half().numpy()), ctx.to_device(w.half().numpy()), ctx.to_device(b)
     outs = {}
     try:
-        for name, flags in (("g8", 0), ("pp", 1024 << 4)):
+        for name, flags in (("g8", G8), ("g8m32", G8_M32), ("pp", PP)):
             ctx.lib.odise_hip_gemm_debug(flags)
-            outs[name] = ctx.conv2d(dx, dw, bias=db, stride=stride, act=_lib.ACT_SILU, force_tile=4, force_split=split).numpy()
+            outs[name] = ctx.conv2d(dx, dw, bias=db, stride=stride, act=_lib.ACT_SILU, force_tile=tile, force_split=split).numpy()
     finally:
         ctx.lib.odise_hip_gemm_debug(0)
     ref = F.silu(_conv_ref(x, w, stride, k // 2, b)).numpy()
-    close(outs["g8"], ref, what=f"conv gemm8 {N}x{H}x{W}x{Cin}->{Cout} k{k} s{stride}")
+    close(outs["g8"], ref, what=f"conv gemm8 {N}x{H}x{W}x{Cin}->{Cout} k{k} s{stride} tile {tile}")
     assert np.array_equal(outs["g8"], outs["pp"]), "gemm8 conv differs bitwise from the ping-pong kernel"
+    assert np.abs(outs["g8m32"].astype(np.float32) - outs["g8"].astype(np.float32)).max() <= 2.0 ** -10 * max(np.abs(ref).max(), 1.0)
 
 
 def test_gemm_asymmetric_identity(ctx):

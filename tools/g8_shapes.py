@@ -3,7 +3,8 @@
 
     old    odise_hip_gemm_debug(4096 << 4): the round-4 selection (ping-pong / halo kernels), tile chosen by its cost model
     new    the current selection (cost model free to take the 8-phase tile)
-    g8     tile 4 forced (8-phase kernel wherever its preconditions hold)
+    g8     tile 4 forced (8-phase 256x256 kernel, v_mfma_f32_16x16x32_f16);  g8m32: the same on v_mfma_f32_32x32x16_f16
+    t6     tile 6 forced (8-phase 512x128 kernel), for N <= 256
 
 Prints time (min over rounds), TFLOP/s, the tile | split-K each variant ran on, and max |difference| of `new` / `g8` against `old`.
     python tools/g8_shapes.py [gemm|conv|all]"""
@@ -64,7 +65,9 @@ def gemm_case(M, N, K, batch=1, act=0, bias=True, residual=False, geglu=False):
     def run(flags, tile):
         ctx.lib.odise_hip_gemm_debug(flags)
         return ctx.gemm(A, W, force_tile=tile, **kw)
-    fns = [("old", lambda: run(NO_G8, -1)), ("new", lambda: run(0, -1)), ("g8", lambda: run(0, 4))]
+    fns = [("old", lambda: run(NO_G8, -1)), ("new", lambda: run(0, -1)), ("g8", lambda: run(0, 4)), ("g8m32", lambda: run(8192 << 4, 4))]
+    if N <= 256:
+        fns.append(("t6", lambda: run(0, 6)))
     flop = 2.0 * batch * M * N * K
     bench(f"gemm {M}x{N}x{K} b{batch}{' act' if act else ''}{' res' if residual else ''}{' geglu' if geglu else ''}", flop, fns, max(3, int(4e12 / flop)))
     for a in (A, W, O, b, R):
@@ -87,6 +90,10 @@ def conv_case(B, H, W_, Cin, Cout, stride=1, act=0, residual=False):
         ctx.lib.odise_hip_gemm_debug(flags)
         return ctx.conv2d(X, Wt, force_tile=tile, **kw)
     fns = [("old", lambda: run(NO_G8, -1)), ("new", lambda: run(0, -1)), ("g8", lambda: run(0, 4))]
+    if Cout <= 256:
+        fns.append(("t6", lambda: run(0, 6)))
+    if stride == 1 and Cin % 64 == 0:
+        fns += [("t7", lambda: run(0, 7)), ("t9", lambda: run(0, 9))]
     flop = 2.0 * B * OH * OW * Cout * 9 * Cin
     bench(f"conv {B}x{H}x{W_} {Cin}->{Cout} s{stride}{' res' if residual else ''}", flop, fns, max(3, int(6e12 / flop)))
     for a in (X, Wt, O, b, R):
@@ -94,6 +101,13 @@ def conv_case(B, H, W_, Cin, Cout, stride=1, act=0, residual=False):
             a.free()
 
 
+if what == "epi":      # what the epilogue's terms cost on the CLIP c_fc shape (the yardstick kernel of tools/gemm8p_bench.py: 83 us without any)
+    gemm_case(9344, 4096, 1024, bias=False)
+    gemm_case(9344, 4096, 1024)
+    gemm_case(9344, 4096, 1024, act=ACT_QUICKGELU)
+    gemm_case(9344, 4096, 1024, residual=True)
+    gemm_case(9344, 1024, 4096, bias=False)
+    gemm_case(9344, 1024, 4096, residual=True)
 if what in ("gemm", "all"):
     gemm_case(9344, 4096, 1024, act=ACT_QUICKGELU)         # CLIP c_fc
     gemm_case(9344, 2048, 1024)                            # CLIP q|k
