@@ -84,6 +84,7 @@ struct GemmArgs {
     const f16* zeros;  // >= 16 zero bytes (source of padded / out-of-range operand slots)
     int dbg;           // ablation switches (tools only): 1 = no operand DMA after the first tile, 2 = no fragment reads after the first
     int stats_blocks;  // out: row blocks per image of the fused GroupNorm statistics (0 = not produced, epi.gn_stats was cleared)
+    int epi_block;     // 1: never the wave-private epilogue (launch_gemm_select: ODISE_GEMM_FLAGS 32768)
 };
 
 // Workgroup barrier that only orders LDS traffic.  `__syncthreads()` also drains the vector-memory counter, i.e. it waits for
@@ -593,9 +594,334 @@ __device__ __forceinline__ void gemm_epilogue_f16(const GemmArgs& g, ACC& acc, c
     }
 }
 
-template <int BM, int BN, int WAVES_M, int WAVES_N, int WG, bool HALO = false, bool STATS = false, bool PAIRS = true, int EW16 = 0, bool GEGLU_OK = false, class ACC>
+// ---- wave-private epilogue (round 5) -------------------------------------------------------------------------------------------------
+// Measured (tools/g8_ablate.py, profiles/r05_epilogue_share.txt): the two block-wide epilogues below cost a 256x256 tile 18-23 us per residency
+// round - 40 of 110 us on the CLIP c_fc GEMM (K = 1024), 16-20 of 115 us at 4096^3 - where the yardstick kernel of csrc/gemm8p.hip spends
+// 3-4 us: they stage the whole tile behind block barriers (every wave waits for the slowest), the math-first form reads the residual and
+// writes LDS in fragment layout (8-byte pieces of 16 rows per instruction), and with one block per CU nothing else runs meanwhile.
+// Here a wave needs nobody after the barrier that ends the main loop: it stages R rows x WTN columns of its OWN accumulators as fp32 in its
+// private slice of the block's LDS (float4 writes of a 16-lane group cover the 64 banks once: pitch WTN + 4), reads them back as 8
+// consecutive columns of a row per lane, applies the epilogue (same operations per element in the same order as epi_fast8 /
+// gemm_epilogue_f16: the same bits) and stores 16 bytes per lane - residual reads and output writes are whole 128-byte row segments.  No
+// block barrier, no wave waits for another.  Covers every `fast` (aligned) case without split-K: bias / per-image vector / per-row terms /
+// activation / GEGLU / residual / fp16 or fp32 output, the folded-LayerNorm terms and the fused GroupNorm statistics; the rest stays below.
+constexpr int wave_epi_rows(int WTM, int WTN, int waves, int lds_bytes, int rmin) {
+    const int chw = WTN / 8;
+    int best = 0;
+    for (int r = rmin; r <= WTM; r += rmin)
+        if (WTM % r == 0 && (r * chw) % 64 == 0 && r * (WTN + 4) * 4 <= lds_bytes / waves) best = r;
+    return best;
+}
+template <int BM, int BN, int WAVES_M, int WAVES_N, bool HALO, bool STATS, bool GEGLU_OK, int LDSB, class ACC>
+__device__ __forceinline__ void gemm_epilogue_wave(const GemmArgs& g, ACC& acc, char* smem, int m0, int n0, int zb) {
+    constexpr bool L16 = AccTraits<ACC>::L16;
+    using FL = FragLayout<L16>;
+    constexpr int NWAVES = WAVES_M * WAVES_N;
+    constexpr int WTM = BM / WAVES_M, WTN = BN / WAVES_N;
+    constexpr int TN = WTN / 32;
+    constexpr int R = wave_epi_rows(WTM, WTN, NWAVES, LDSB, L16 ? 16 : 32);
+    static_assert(R > 0, "no wave-private staging fits");
+    constexpr int PITCH = WTN + 4;             // floats
+    constexpr int CHW = WTN / 8;               // 8-column chunks per row of the wave tile
+    constexpr int ITEMS = R * CHW / 64;        // (row, chunk) items per lane and pass
+    constexpr bool FIXED = (64 % CHW) == 0;    // a lane keeps ONE column chunk over all its items: per-column terms are loaded once
+    constexpr int RSUB = L16 ? 16 : 32;        // rows a lane group covers per fragment row index
+    const GemmEpi& e = g.epi;
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
+    const int wm = wave / WAVES_N, wn = wave % WAVES_N;
+    float* stg = reinterpret_cast<float*>(smem) + (size_t)wave * R * PITCH;
+    auto row_to_m = [&](int rt) -> int {
+        if (HALO) {
+            const int patch = m0 / BM;
+            const int per_img = g.cg.halo_tx * g.cg.halo_ty;
+            const int img = patch / per_img, pr = patch - img * per_img;
+            const int oy = (pr / g.cg.halo_tx) * 16 + (rt >> 4), ox = (pr % g.cg.halo_tx) * 16 + (rt & 15);
+            return (oy < g.cg.OH && ox < g.cg.OW) ? (img * g.cg.OH + oy) * g.cg.OW + ox : g.M;
+        }
+        return m0 + rt;
+    };
+    const bool stats = STATS && FIXED && e.gn_stats != nullptr;
+    constexpr bool LN_OK = !HALO && !STATS;
+    const float* const ln_part = LN_OK ? e.ln_part : nullptr;
+    const float* const ln_colsum = LN_OK ? e.ln_colsum : nullptr;
+    float* const ln_final_out = LN_OK ? e.ln_final_out : nullptr;
+    const float* const ln_final = LN_OK ? e.ln_final : nullptr;
+    const float* const ln_rowsum = LN_OK ? e.ln_rowsum : nullptr;
+    float* const ln_stats_out = (LN_OK && CHW % 8 == 0) ? e.ln_stats_out : nullptr;
+    const bool geglu = GEGLU_OK && e.geglu;
+    // nothing per row but the residual, fp16 output: the lean item loop
+    const bool plain = !geglu && e.c_dtype == ODISE_F16 && !e.scale_m && !e.bias_m && !e.rowgroup_add && !ln_part && !ln_colsum && !ln_final && !ln_rowsum &&
+                       !ln_stats_out && !ln_final_out;
+    float s8[8], q8[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) s8[i] = q8[i] = 0.f;
+    // per-column terms of the lane's chunk (FIXED): bias_n, LayerNorm column sums / finished column statistics
+    float bn8[8], cs8[8], r1c8[8], rsc8[8];
+    auto load_cols = [&](int n) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) { bn8[i] = 0.f; cs8[i] = 0.f; r1c8[i] = 0.f; rsc8[i] = 1.f; }
+        if (n + 8 > g.N) return;
+        if (e.bias_n) {
+            const float4 b0 = *reinterpret_cast<const float4*>(e.bias_n + n), b1 = *reinterpret_cast<const float4*>(e.bias_n + n + 4);
+            bn8[0] = b0.x; bn8[1] = b0.y; bn8[2] = b0.z; bn8[3] = b0.w; bn8[4] = b1.x; bn8[5] = b1.y; bn8[6] = b1.z; bn8[7] = b1.w;
+        }
+        if (ln_colsum) {
+            const float4 c0 = *reinterpret_cast<const float4*>(ln_colsum + n), c1 = *reinterpret_cast<const float4*>(ln_colsum + n + 4);
+            cs8[0] = c0.x; cs8[1] = c0.y; cs8[2] = c0.z; cs8[3] = c0.w; cs8[4] = c1.x; cs8[5] = c1.y; cs8[6] = c1.z; cs8[7] = c1.w;
+        }
+        if (ln_final) {   // (r1, rstd) per column
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const float4 f = *reinterpret_cast<const float4*>(ln_final + 2 * (int64_t)(n + 2 * i));
+                r1c8[2 * i] = f.x; rsc8[2 * i] = f.y; r1c8[2 * i + 1] = f.z; rsc8[2 * i + 1] = f.w;
+            }
+        }
+    };
+    if (FIXED) load_cols(n0 + wn * WTN + (lane % CHW) * 8);
+#pragma unroll
+    for (int ps = 0; ps < WTM / R; ++ps) {
+        // ---- stage rows [ps R, ps R + R) of the wave tile (the previous pass's reads are retired: same wave, LDS operations complete in order)
+#pragma unroll
+        for (int p = 0; p < WTM / 32; ++p)
+#pragma unroll
+            for (int rr = 0; rr < FL::NR; ++rr) {
+                const int rbase = p * 32 + rr * RSUB;          // first tile row of this fragment row group (compile-time after unrolling)
+                if (rbase < ps * R || rbase >= (ps + 1) * R) continue;
+                const int row = rbase - ps * R + (L16 ? (lane & 15) : (lane & 31));
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+#pragma unroll
+                    for (int cc = 0; cc < FL::NC; ++cc) {
+                        const int r0 = 4 * (rr * FL::NC + cc);
+                        float4 q = make_float4(acc_get(acc, p, j, r0), acc_get(acc, p, j, r0 + 1), acc_get(acc, p, j, r0 + 2), acc_get(acc, p, j, r0 + 3));
+                        *reinterpret_cast<float4*>(&stg[row * PITCH + j * 32 + FL::col(lane, cc)]) = q;
+                    }
+            }
+        // the staged rows are complete before any lane reads them back (the store's data moves from the registers to the LDS asynchronously)
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_wave_barrier();
+        // ---- read back 8 consecutive columns of a row per lane, finish and store.  The item loops are ROLLED (a dozen items per pass; unrolled they
+        // were ~800 instructions each with every feature test repeated) and everything that does not change from item to item is set up before them
+        if (FIXED && plain) {
+            // lean form: bias / activation / residual / fp16 store (+ the fused GroupNorm sums): what the VAE, most UNet and head layers need
+            const int c8 = lane % CHW;
+            const int n = n0 + wn * WTN + c8 * 8;
+            const bool nok = n + 8 <= g.N;
+            const float alpha = e.alpha;
+#pragma unroll 1
+            for (int it = 0; it < ITEMS; ++it) {
+                const int row = it * (64 / CHW) + lane / CHW;
+                const int m = row_to_m(wm * WTM + ps * R + row);
+                const bool ok = nok && m < g.M;
+                const float4 t0 = *reinterpret_cast<const float4*>(&stg[row * PITCH + c8 * 8]);
+                const float4 t1 = *reinterpret_cast<const float4*>(&stg[row * PITCH + c8 * 8 + 4]);
+                f16x8 rr8 = {0, 0, 0, 0, 0, 0, 0, 0};
+                if (e.residual && ok) rr8 = *reinterpret_cast<const f16x8*>(e.residual + (int64_t)zb * e.strideR + (int64_t)m * e.ldr + n);
+                float v[8] = {t0.x, t0.y, t0.z, t0.w, t1.x, t1.y, t1.z, t1.w};
+#pragma unroll
+                for (int i = 0; i < 8; ++i) v[i] = v[i] * alpha + bn8[i];
+                if (e.act == ODISE_ACT_SILU) {
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) v[i] = mul_sigmoid(v[i], v[i]);
+                } else if (e.act == ODISE_ACT_RELU) {
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) v[i] = v[i] > 0.f ? v[i] : 0.f;
+                } else if (e.act == ODISE_ACT_QUICKGELU) {
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) v[i] = mul_sigmoid(v[i], 1.702f * v[i]);
+                } else if (e.act == ODISE_ACT_GELU) {
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) v[i] = gelu_erf(v[i]);
+                }
+                f16x8 t;
+#pragma unroll
+                for (int i = 0; i < 8; ++i) t[i] = (f16)(v[i] + (float)rr8[i]);
+                if (ok) {
+                    *reinterpret_cast<f16x8*>((f16*)e.C + (int64_t)zb * e.strideC + (int64_t)m * e.ldc + n) = t;
+                    if (stats) {
+#pragma unroll
+                        for (int i = 0; i < 8; ++i) { const float r = (float)t[i]; s8[i] += r; q8[i] += r * r; }
+                    }
+                }
+            }
+            continue;   // next pass
+        }
+#pragma unroll 1
+        for (int it = 0; it < ITEMS; ++it) {
+            const int idx = it * 64 + lane;
+            const int row = idx / CHW, c8 = idx - row * CHW;
+            const int rt = wm * WTM + ps * R + row;            // block tile row
+            const int m = row_to_m(rt);
+            const int n = n0 + wn * WTN + c8 * 8;
+            const float4 t0 = *reinterpret_cast<const float4*>(&stg[row * PITCH + c8 * 8]);
+            const float4 t1 = *reinterpret_cast<const float4*>(&stg[row * PITCH + c8 * 8 + 4]);
+            const bool ok = m < g.M && n + 8 <= g.N;
+            if (!FIXED) load_cols(n);
+            float v[8] = {t0.x, t0.y, t0.z, t0.w, t1.x, t1.y, t1.z, t1.w};
+            float b[8];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) b[i] = bn8[i];
+            f16x8 rr8 = {0, 0, 0, 0, 0, 0, 0, 0};
+            if (ok && e.residual && !geglu) rr8 = *reinterpret_cast<const f16x8*>(e.residual + (int64_t)zb * e.strideR + (int64_t)m * e.ldr + n);
+            float alpha = e.alpha, r1 = 0.f, rs = 0.f;
+            if (ln_part) {
+                // finish the row statistics from the producer's partial sums (gemm_epilogue_f16): the lanes of a row (a group of 8 inside its
+                // chunk lanes) share the P partial pairs - same fixed summation order for every lane of the row, so they agree bit for bit
+                float s1 = 0.f, s2 = 0.f;
+                if (ok) {
+                    const float* pp = ln_part + (int64_t)m * e.ln_P * 2;
+                    for (int i = 0; i < e.ln_P; ++i) { s1 += pp[2 * i]; s2 += pp[2 * i + 1]; }
+                }
+                const float mean = s1 * e.ln_inv_c;
+                const float var = fmaxf(s2 * e.ln_inv_c - mean * mean, 0.f);
+                const float rstd = rsqrtf(var + e.ln_eps);
+                alpha *= rstd;
+                r1 = -mean * rstd;
+                if (ln_final_out && n == 0 && ok) {
+                    ln_final_out[2 * (int64_t)m] = r1;
+                    ln_final_out[2 * (int64_t)m + 1] = rstd;
+                }
+            }
+            if (ok) {
+                if (e.scale_m) alpha *= e.scale_m[m];
+                if (ln_rowsum) rs = ln_rowsum[m];
+                if (e.rowgroup_add) {
+                    const float* rg = e.rowgroup_add + (int64_t)((unsigned)m / (unsigned)e.rows_per_group) * e.ldg + n;
+                    const float4 g0 = *reinterpret_cast<const float4*>(rg), g1 = *reinterpret_cast<const float4*>(rg + 4);
+                    b[0] += g0.x; b[1] += g0.y; b[2] += g0.z; b[3] += g0.w; b[4] += g1.x; b[5] += g1.y; b[6] += g1.z; b[7] += g1.w;
+                }
+                if (e.bias_m) {
+                    const float bm = e.bias_m[m];
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) b[i] += bm;
+                }
+            }
+            if (ln_colsum) {
+#pragma unroll
+                for (int i = 0; i < 8; ++i) b[i] += r1 * cs8[i];
+            }
+            if (ln_final) {
+#pragma unroll
+                for (int i = 0; i < 8; ++i) v[i] = v[i] * (alpha * rsc8[i]) + (b[i] + rs * r1c8[i]);
+            } else {
+#pragma unroll
+                for (int i = 0; i < 8; ++i) v[i] = v[i] * alpha + b[i];
+            }
+            if (geglu) {   // columns are (a, gate) pairs; the output has N/2 columns (no activation / residual on this path)
+                if (ok) {
+                    float o[4];
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) o[i] = v[2 * i] * gelu_erf(v[2 * i + 1]);
+                    const int64_t off = (int64_t)zb * e.strideC + (int64_t)m * e.ldc + (n >> 1);
+                    if (e.c_dtype == ODISE_F16) {
+                        f16x4 t;
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) t[i] = (f16)o[i];
+                        *reinterpret_cast<f16x4*>((f16*)e.C + off) = t;
+                    } else {
+                        *reinterpret_cast<float4*>((float*)e.C + off) = make_float4(o[0], o[1], o[2], o[3]);
+                    }
+                }
+                continue;
+            }
+            if (e.act == ODISE_ACT_SILU) {
+#pragma unroll
+                for (int i = 0; i < 8; ++i) v[i] = mul_sigmoid(v[i], v[i]);
+            } else if (e.act == ODISE_ACT_RELU) {
+#pragma unroll
+                for (int i = 0; i < 8; ++i) v[i] = v[i] > 0.f ? v[i] : 0.f;
+            } else if (e.act == ODISE_ACT_QUICKGELU) {
+#pragma unroll
+                for (int i = 0; i < 8; ++i) v[i] = mul_sigmoid(v[i], 1.702f * v[i]);
+            } else if (e.act == ODISE_ACT_GELU) {
+#pragma unroll
+                for (int i = 0; i < 8; ++i) v[i] = gelu_erf(v[i]);
+            }
+            const int64_t off = (int64_t)zb * e.strideC + (int64_t)m * e.ldc + n;
+            float ps1 = 0.f, pq1 = 0.f;
+            if (e.c_dtype == ODISE_F16) {
+                f16x8 t;
+#pragma unroll
+                for (int i = 0; i < 8; ++i) t[i] = (f16)(v[i] + (float)rr8[i]);
+                if (ok) {
+                    *reinterpret_cast<f16x8*>((f16*)e.C + off) = t;
+                    if (stats) {
+#pragma unroll
+                        for (int i = 0; i < 8; ++i) { const float r = (float)t[i]; s8[i] += r; q8[i] += r * r; }
+                    }
+                    if (ln_stats_out) {
+#pragma unroll
+                        for (int i = 0; i < 8; ++i) { const float r = (float)t[i]; ps1 += r; pq1 += r * r; }
+                    }
+                }
+            } else if (ok) {
+                float* c = (float*)e.C + off;
+                *reinterpret_cast<float4*>(c) = make_float4(v[0] + (float)rr8[0], v[1] + (float)rr8[1], v[2] + (float)rr8[2], v[3] + (float)rr8[3]);
+                *reinterpret_cast<float4*>(c + 4) = make_float4(v[4] + (float)rr8[4], v[5] + (float)rr8[5], v[6] + (float)rr8[6], v[7] + (float)rr8[7]);
+            }
+            if (ln_stats_out) {   // partial (sum, sum of squares) of this row over the 64 columns of its part: the 8 lanes (chunks) of the part
+#pragma unroll
+                for (int sft = 1; sft < 8; sft <<= 1) { ps1 += __shfl_xor(ps1, sft); pq1 += __shfl_xor(pq1, sft); }
+                if ((c8 & 7) == 0 && ok) {
+                    const int parts = (g.N + kLnPartCols - 1) / kLnPartCols;
+                    float* o = ln_stats_out + ((int64_t)m * parts + n / kLnPartCols) * 2;
+                    o[0] = ps1;
+                    o[1] = pq1;
+                }
+            }
+        }
+    }
+    if (STATS) {
+        // fused GroupNorm statistics: per-channel (sum, sum of squares) of the block's rows.  A lane holds its chunk's sums over its rows; fold the
+        // lanes of the wave that share a chunk (fixed order), then the WAVES_M waves of a wave column through LDS
+        if (stats) {
+#pragma unroll
+            for (int sft = CHW; sft < 64; sft <<= 1)
+#pragma unroll
+                for (int i = 0; i < 8; ++i) { s8[i] += __shfl_xor(s8[i], sft); q8[i] += __shfl_xor(q8[i], sft); }
+        }
+        __syncthreads();   // every wave is done with its staging slice (block-uniform branch: `stats` does not depend on the thread)
+        if (stats) {
+            float* red = reinterpret_cast<float*>(smem);   // [WAVES_M][BN][2]
+            if (lane < CHW) {
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+                    red[((wm * BN) + wn * WTN + lane * 8 + i) * 2 + 0] = s8[i];
+                    red[((wm * BN) + wn * WTN + lane * 8 + i) * 2 + 1] = q8[i];
+                }
+            }
+            __syncthreads();
+            for (int c = threadIdx.x; c < BN; c += 64 * NWAVES) {
+                float a = 0.f, bb = 0.f;
+                for (int r = 0; r < WAVES_M; ++r) { a += red[(r * BN + c) * 2]; bb += red[(r * BN + c) * 2 + 1]; }
+                if (n0 + c < g.N) {
+                    float* o = e.gn_stats + ((int64_t)(m0 / BM) * g.N + n0 + c) * 2;
+                    o[0] = a;
+                    o[1] = bb;
+                }
+            }
+        }
+    }
+}
+
+template <int BM, int BN, int WAVES_M, int WAVES_N, int WG, bool HALO = false, bool STATS = false, bool PAIRS = true, int EW16 = 0, bool GEGLU_OK = false, int LDSB = 0,
+          class ACC>
 __device__ __forceinline__ void gemm_epilogue(const GemmArgs& g, ACC& acc, char* smem, int m0, int n0, int z, int zb, bool split) {
     using FL = FragLayout<AccTraits<ACC>::L16>;
+    // LDSB = the kernel's LDS request: the wave-private form wherever it applies (tools: ODISE_EPI_OLD=1 keeps the block-wide forms).  8-wave kernels
+    // only: in the 4-wave kernels (64x64 .. 128x128 tiles, several blocks per CU) it returned rare wrong elements on the hardware - one dword of a
+    // staged row read as zero in lanes 48-63, not cured by a barrier or a full LDS wait between staging and read-back, never seen with 8 waves
+    // (tools/epi_debug.py; unexplained, so those kernels keep the block-wide forms)
+    // Where it measured faster (tools/g8_shapes.py, profiles/r05_epilogue_forms.txt): wave tiles whose 8-column chunks divide the wavefront (a lane keeps one
+    // chunk: everything but the 256x320 tile), without GEGLU (its half-width rows leave the lean loop; the block-wide form is ~15 % ahead there).
+    // ODISE_GEMM_FLAGS 32768 keeps the block-wide forms everywhere (A/B of whole steps: bench.py --gemm-flags).
+    if constexpr (LDSB > 0 && WAVES_M * WAVES_N == 8 && (64 % ((BN / WAVES_N) / 8)) == 0) {
+        if (g.epi.fast && !split && !g.epi.geglu && !g.epi_block && !ODISE_ABLATE(g, 8 | 32)) {
+            gemm_epilogue_wave<BM, BN, WAVES_M, WAVES_N, HALO, STATS, GEGLU_OK, LDSB>(g, acc, smem, m0, n0, zb);
+            return;
+        }
+    }
     if constexpr (EW16 > 0) {
         if (g.epi.f16path && !split && !ODISE_ABLATE(g, 8 | 32)) {   // tools: ODISE_EPI_OLD=1 (bit 32) keeps the fp32-staged form for A/B runs
             if constexpr (GEGLU_OK) {
@@ -1147,7 +1473,7 @@ __global__ void __launch_bounds__(64 * WAVES_M * WAVES_N) gemm_kernel(GemmArgs g
     if (ODISE_ABLATE(g, 4)) return;  // ablation: main loop only
 
     gemm_epilogue<BM, BN, WAVES_M, WAVES_N, epi_wave_rows(BM, BN, WAVES_M, plain_lds_bytes(BM, BN, WAVES_M)), false, false, (BM * BN < 256 * 256),
-                  epi16_rows_if_enabled(BM, BN, WAVES_M, plain_lds_bytes(BM, BN, WAVES_M)), !CONV>(g, acc, smem, m0, n0, z, zb, split);
+                  epi16_rows_if_enabled(BM, BN, WAVES_M, plain_lds_bytes(BM, BN, WAVES_M)), !CONV, plain_lds_bytes(BM, BN, WAVES_M)>(g, acc, smem, m0, n0, z, zb, split);
 }
 
 template <int N>
@@ -1479,7 +1805,7 @@ __global__ void __launch_bounds__(512) gemm_pp_kernel(GemmArgs g) {
     __syncthreads();
     if (ODISE_ABLATE(g, 4)) return;
     gemm_epilogue<BM, BN, WAVES_M, WAVES_N, epi_wave_rows(BM, BN, WAVES_M, pp_lds_bytes(BM, BN, WAVES_M)), false, (CONV && BM == 512), true,
-                  epi16_rows_if_enabled(BM, BN, WAVES_M, pp_lds_bytes(BM, BN, WAVES_M)), !CONV>(g, acc, smem, m0, n0, z, zb, split);
+                  epi16_rows_if_enabled(BM, BN, WAVES_M, pp_lds_bytes(BM, BN, WAVES_M)), !CONV, pp_lds_bytes(BM, BN, WAVES_M)>(g, acc, smem, m0, n0, z, zb, split);
 }
 
 
@@ -1801,7 +2127,7 @@ __global__ void __launch_bounds__(512) gemm_pp2_kernel(GemmArgs g) {
     __syncthreads();
     if (ODISE_ABLATE(g, 4)) return;
     gemm_epilogue<BM, BN, WAVES_M, WAVES_N, epi_wave_rows(BM, BN, WAVES_M, pp_lds_bytes(BM, BN, WAVES_M)), false, CONV, true,
-                  epi16_rows_if_enabled(BM, BN, WAVES_M, pp_lds_bytes(BM, BN, WAVES_M)), !CONV>(g, acc, smem, m0, n0, z, zb, split);
+                  epi16_rows_if_enabled(BM, BN, WAVES_M, pp_lds_bytes(BM, BN, WAVES_M)), !CONV, pp_lds_bytes(BM, BN, WAVES_M)>(g, acc, smem, m0, n0, z, zb, split);
 }
 
 // ---- 8-phase pipelined 256x256 tile (round 5) ---------------------------------------------------------------------------------------
@@ -2115,7 +2441,7 @@ __global__ void __launch_bounds__(512) gemm8_kernel(GemmArgs g) {
     if (ODISE_ABLATE(g, 4)) return;   // tools: main loop only
     constexpr int LDS = pp_lds_bytes(BM, BN, WAVES_M);
     static_assert(LDS >= 2 * STAGE, "operand stages exceed the LDS request");
-    gemm_epilogue<BM, BN, WAVES_M, WAVES_N, epi_wave_rows(BM, BN, WAVES_M, LDS), false, CONV, true, epi16_rows_if_enabled(BM, BN, WAVES_M, LDS), !CONV>(
+    gemm_epilogue<BM, BN, WAVES_M, WAVES_N, epi_wave_rows(BM, BN, WAVES_M, LDS), false, CONV, true, epi16_rows_if_enabled(BM, BN, WAVES_M, LDS), !CONV, LDS>(
         g, acc, smem, m0, n0, z, zb, split);
 }
 
@@ -2364,7 +2690,7 @@ __global__ void __launch_bounds__(512) conv3_halo_kernel(GemmArgs g) {
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
     __syncthreads();
     gemm_epilogue<BM, BN, WAVES_M, WAVES_N, epi_wave_rows(BM, BN, WAVES_M, halo_lds_bytes(BN)), true, true, true,
-                  epi16_rows_if_enabled(BM, BN, WAVES_M, halo_lds_bytes(BN)), false>(g, acc, smem, m0, n0, z, zb, split);
+                  epi16_rows_if_enabled(BM, BN, WAVES_M, halo_lds_bytes(BN)), false, halo_lds_bytes(BN)>(g, acc, smem, m0, n0, z, zb, split);
 }
 
 // ---- 3x3 halo convolution, 4-wave form: TWO co-resident blocks per CU --------------------------------------------------------------------
@@ -2528,7 +2854,7 @@ __global__ void __launch_bounds__(256, 2) conv3_halo4_kernel(GemmArgs g) {
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
     __syncthreads();  // every wave is done with the operand buffers before the staging image reuses them
     gemm_epilogue<BM, BN, WAVES_M, WAVES_N, epi_wave_rows(BM, BN, WAVES_M, halo4_lds_bytes(BN)), true, true, true,
-                  epi16_rows_if_enabled(BM, BN, WAVES_M, halo4_lds_bytes(BN)), false>(g, acc, smem, m0, n0, z, zb, split);
+                  epi16_rows_if_enabled(BM, BN, WAVES_M, halo4_lds_bytes(BN)), false, halo4_lds_bytes(BN)>(g, acc, smem, m0, n0, z, zb, split);
 }
 
 __global__ void __launch_bounds__(256) splitk_reduce_kernel(const float* __restrict__ ws, int splitk, int M, int N, GemmEpi e) {
@@ -2727,7 +3053,7 @@ static const TileCost kTileCost[kNumTiles] = {
 // the 256-row tiles as run by the ping-pong kernel (K % 64 == 0; conv: Cin % 64 == 0, no fused upsample)
 static const TileCost kTileCostPP[2] = {
     {2.00, 16.0, 1},  // 256x320 (round 5 refit: 9344x4096x1024 93 us = 1.9 rounds of 16, conv 320 -> 320 at 64^2 108 us = one round of 45)
-    {2.10, 12.0, 1},  // 256x256 (only reached with the 8-phase kernel switched off)
+    {1.56, 10.0, 1},  // 256x256 (round 5 refit, 16x16x32 MFMAs + wave-private epilogue: 4096^3 110 us = one round of 64, 9472x4096x1024 97 us = 2.3 rounds of 16)
 };
 // the 512x128 tile on implicit-GEMM convolutions: every input pixel passes the LDS-DMA path nine times (measured 61-65 us per block of
 // 18 K-tiles on the 128-channel VAE level; the dense fit above says 52 us).  Still ahead of the plain 256x128 tile on the stride-2 conv
@@ -2799,9 +3125,11 @@ static int launch_gemm_select(odise_hip_ctx* ctx, GemmArgs& g, int batch, int fo
     double best = 1e30;
     const int flags = g_conv_flags | env_gemm_flags();
     const bool pp_ok = !no_interleave && !(flags & 2) && g.K % 64 == 0 && (!CONV || (g.cg.Cin % 64 == 0 && !g.cg.ups));
-    // the 8-phase kernel runs the 256x256 tile wherever the ping-pong kernels could (its convolution form keeps 32-bit element offsets);
-    // ODISE_GEMM_FLAGS 4096 = never, and the switches that name a ping-pong generation (512 / 1024) keep their meaning
-    const bool g8_ok = pp_ok && !(flags & (4096 | 512 | 1024)) &&
+    // the 8-phase kernels (gemm8_kernel) run the 256x256 / 512x128 tiles wherever the ping-pong kernels could (the convolution form keeps 32-bit
+    // element offsets) - on request only, ODISE_GEMM_FLAGS 16384: built as the guide's yardstick schedule and kept for A/B runs; once every main loop
+    // multiplied with 16x16x32 MFMAs and wrote its tile through the wave-private epilogue, the ping-pong kernels measured 3-7 % ahead of it on the
+    // same tiles (tools/g8_ablate.py: main loops 72.7 vs 76.3 us at 9472x4096x1024, full kernels 97 vs 104; profiles/r05_epilogue_forms.txt)
+    const bool g8_ok = pp_ok && (flags & 16384) && !(flags & (4096 | 512 | 1024)) &&
                        (!CONV || (int64_t)(g.M / (g.cg.OH * g.cg.OW)) * g.cg.H * g.cg.W * g.cg.Cin < ((int64_t)1 << 31));
     for (int t = 0; t < kNumTiles; ++t) {
         if (force_tile >= 0 && force_tile < kNumTiles && t != force_tile) continue;
@@ -2893,6 +3221,7 @@ static int launch_gemm_select(odise_hip_ctx* ctx, GemmArgs& g, int batch, int fo
         if (!ok) { g.epi.gn_stats = nullptr; g.stats_blocks = 0; }
     }
     g.zeros = (const f16*)ctx->zeros;
+    g.epi_block = (flags & 32768) ? 1 : 0;
 #ifdef ODISE_TOOLS
     static const int freeze_k = (getenv("ODISE_GEMM_FREEZE_K") ? 16 : 0) | (getenv("ODISE_EPI_OLD") ? 32 : 0) | (getenv("ODISE_NO_RES_PREFETCH") ? 64 : 0);
     g.dbg = g_gemm_debug | freeze_k | (g_epi_old ? 32 : 0);

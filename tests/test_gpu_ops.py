@@ -107,13 +107,13 @@ def test_gemm_plain(ctx, M, N, K, tile, split):
 
 
 # ---- the 8-phase kernels (gemm8_kernel, round 5: tiles 4 = 256x256 and 6 = 512x128 wherever K % 64 == 0) against the ping-pong kernels
-# they replace on those tiles (odise_hip_gemm_debug 1024 << 4 names those).  Every main loop of csrc/gemm.hip multiplies with
+# that run those tiles by default (the 8-phase kernels are opt-in: odise_hip_gemm_debug 16384 << 4).  Every main loop of csrc/gemm.hip multiplies with
 # v_mfma_f32_16x16x32_f16 and takes the k-steps of a K-tile in the same order: the same bits.  The 8-phase 256x256 kernel also exists on
 # v_mfma_f32_32x32x16_f16 (8192 << 4, the A/B form of tools/g8_shapes.py: another rounding sequence, the same error bound): held to the
 # fp32 reference and to the default form within one fp16 step of the largest output.
 # Ragged M / N (zero-line rows), one to many K-tiles with odd and even counts (the tail of one to three K-tiles), split-K, batched,
 # every epilogue family.
-G8, G8_M32, PP = 0, 8192 << 4, 1024 << 4
+G8, G8_M32, PP = 16384 << 4, (16384 | 8192) << 4, 0
 
 
 @pytest.mark.parametrize("M,N,K,split,batch,tile", [(256, 256, 64, 1, 1, 4), (256, 256, 128, 1, 1, 4), (512, 512, 192, 1, 1, 4), (300, 330, 256, 1, 1, 4),
@@ -168,6 +168,32 @@ def test_conv_gemm8_against_pingpong_and_reference(ctx, N, H, W, Cin, Cout, k, s
     close(outs["g8"], ref, what=f"conv gemm8 {N}x{H}x{W}x{Cin}->{Cout} k{k} s{stride} tile {tile}")
     assert np.array_equal(outs["g8"], outs["pp"]), "gemm8 conv differs bitwise from the ping-pong kernel"
     assert np.abs(outs["g8m32"].astype(np.float32) - outs["g8"].astype(np.float32)).max() <= 2.0 ** -10 * max(np.abs(ref).max(), 1.0)
+
+
+@pytest.mark.parametrize("tile", [0, 1, 2, 3, 4, 5, 6])
+def test_gemm_repeated_launches_agree(ctx, tile):
+    """Every tile on a many-block problem (several residency rounds, several blocks per CU for the small tiles), launched 12 times into a
+    buffer pre-filled with a sentinel: every launch must write every element and reproduce the first launch bit for bit (a race in an epilogue's
+    staging shows up as a few elements that differ from launch to launch), and the first must match the fp32 reference."""
+    M, N, K = 4096, 1280, 320
+    g = torch.Generator().manual_seed(11 + tile)
+    A = h(torch.randn(M, K, generator=g))
+    W = h(torch.randn(N, K, generator=g) / K ** 0.5)
+    bias = torch.randn(N, generator=g)
+    res = h(torch.randn(M, N, generator=g))
+    dA, dW, db, dr = ctx.to_device(A.half().numpy()), ctx.to_device(W.half().numpy()), ctx.to_device(bias), ctx.to_device(res.half().numpy())
+    ref = (A @ W.t() + bias + res).numpy()
+    first = None
+    O = ctx.empty((M, N), np.float16)
+    for rep in range(12):
+        O.copy_from(np.full((M, N), 777.0, np.float16))
+        got = ctx.gemm(dA, dW, bias_n=db, residual=dr, force_tile=tile, force_split=1, out=O).numpy()
+        if first is None:
+            first = got
+            close(first, ref, what=f"tile {tile} at {M}x{N}x{K}")
+        else:
+            diff = np.argwhere(got != first)
+            assert diff.size == 0, f"tile {tile}: launch {rep} differs from the first in {len(diff)} elements, e.g. {diff[:4].tolist()} -> {got[tuple(diff[0])]} vs {first[tuple(diff[0])]}"
 
 
 def test_gemm_asymmetric_identity(ctx):

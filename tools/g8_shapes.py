@@ -1,8 +1,8 @@
 """The 8-phase 256x256 kernel (gemm8_kernel, round 5) against what the cost model ran before it, on the step's heaviest GEMM / convolution shapes
 (profiles/r04_gemm_efficiency_by_shape.txt, 16 crops / 4 pictures), same process, interleaved rounds, random operands:
 
-    old    odise_hip_gemm_debug(4096 << 4): the round-4 selection (ping-pong / halo kernels), tile chosen by its cost model
-    new    the current selection (cost model free to take the 8-phase tile)
+    old    odise_hip_gemm_debug(32768 << 4): the current selection with the block-wide epilogues everywhere
+    new    the current selection (wave-private epilogue where it applies)
     g8     tile 4 forced (8-phase 256x256 kernel, v_mfma_f32_16x16x32_f16);  g8m32: the same on v_mfma_f32_32x32x16_f16
     t6     tile 6 forced (8-phase 512x128 kernel), for N <= 256
 
@@ -20,7 +20,8 @@ from odise_amd.runtime import Context  # noqa: E402
 what = sys.argv[1] if len(sys.argv) > 1 else "all"
 ctx = Context(0)
 rng = np.random.default_rng(0)
-NO_G8 = 4096 << 4
+NO_G8 = 32768 << 4   # "old" = the block-wide epilogues everywhere
+G8 = 16384 << 4
 
 
 def rand(shape, s=1.0):
@@ -65,7 +66,7 @@ def gemm_case(M, N, K, batch=1, act=0, bias=True, residual=False, geglu=False):
     def run(flags, tile):
         ctx.lib.odise_hip_gemm_debug(flags)
         return ctx.gemm(A, W, force_tile=tile, **kw)
-    fns = [("old", lambda: run(NO_G8, -1)), ("new", lambda: run(0, -1)), ("g8", lambda: run(0, 4)), ("g8m32", lambda: run(8192 << 4, 4))]
+    fns = [("old", lambda: run(NO_G8, -1)), ("new", lambda: run(0, -1)), ("g8", lambda: run(G8, 4)), ("g8m32", lambda: run(G8 | (8192 << 4), 4))]
     if N <= 256:
         fns.append(("t6", lambda: run(0, 6)))
     flop = 2.0 * batch * M * N * K
@@ -89,7 +90,7 @@ def conv_case(B, H, W_, Cin, Cout, stride=1, act=0, residual=False):
     def run(flags, tile):
         ctx.lib.odise_hip_gemm_debug(flags)
         return ctx.conv2d(X, Wt, force_tile=tile, **kw)
-    fns = [("old", lambda: run(NO_G8, -1)), ("new", lambda: run(0, -1)), ("g8", lambda: run(0, 4))]
+    fns = [("old", lambda: run(NO_G8, -1)), ("new", lambda: run(0, -1)), ("g8", lambda: run(G8, 4)), ("t4", lambda: run(0, 4))]
     if Cout <= 256:
         fns.append(("t6", lambda: run(0, 6)))
     if stride == 1 and Cin % 64 == 0:
