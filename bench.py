@@ -194,7 +194,7 @@ def dominant_kernel_isolated(ctx, n):
         ctx.conv2d(X, Wt, out=O)
     us = ctx.timer_stop() / it * 1e3
     tile = ctx.lib.odise_hip_last_tile() & 255            # what the library's cost model ran this shape on (gemm.hip kTileBM / kTileBN)
-    kernel = {4: "gemm8_kernel<256,256,conv,16x16x32>", 7: "conv3_halo_kernel<256,2>", 8: "conv3_halo_kernel<128,1>", 9: "conv3_halo4_kernel<128>"}.get(tile, f"tile {tile}")
+    kernel = {4: "gemm_pp2_kernel<256,256,2,2,conv>", 7: "conv3_halo_kernel<256,2>", 8: "conv3_halo_kernel<128,1>", 9: "conv3_halo4_kernel<128>"}.get(tile, f"tile {tile}")
     flops = 2.0 * n * hw * hw * cout * 9 * cin
     for a in (X, Wt, O):
         a.free()

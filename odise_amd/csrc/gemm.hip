@@ -3040,12 +3040,13 @@ static const TileCost kTileCost[kNumTiles] = {
     {2.10, 15.0, 1},  // 256x256 (plain kernel)
     {1.42, 6.0, 1},   // 256x128
     {2.25, 12.0, 1},  // 512x128 (ping-pong kernel only)
-    {1.43, 21.0, 1},  // halo 256 pixels x 256 channels (round 5, 16x16x32 MFMAs: the dominant convolution 995 us = 8 rounds of 72 K-tiles, 256 -> 256 at
-                      // 256^2 1164 us = 16 rounds of 36 - ahead of every other tile on all convolutions with 256 or more output channels)
+    {1.47, 22.5, 1},  // halo 256 pixels x 256 channels (round 5, 16x16x32 MFMAs + wave-private epilogue: the dominant convolution 1027 us = 8 rounds of 72
+                      // K-tiles, 256 -> 256 at 256^2 1208 us = 16 rounds of 36 - 2-5 % ahead of every other tile on all convolutions with 256 or more
+                      // output channels, profiles/r05_conv_tiles_final.txt)
     {1.12, 9.0, 1},   // halo 256 pixels x 128 channels (re-fitted in round 2: 28 us per block of 18 K-tiles on the 128-channel VAE level, where
                       // the im2col 512x128 tile takes 65 us per block of twice the size: 1.80 vs 2.07 ms per launch, tools/halo512_probe.py)
-    {1.65, 12.5, 2},  // the same tile as four waves, two blocks per CU (round 5 refit: 128 -> 128 at 512^2 1348 us = 32 rounds of 18, the dominant
-                      // convolution 1049 us = 8 rounds of 72)
+    {1.70, 12.0, 2},  // the same tile as four waves, two blocks per CU (round 5 refit: 128 -> 128 at 512^2 1365 us = 32 rounds of 18; only offered for
+                      // N <= 128 now - with more column blocks every block re-fetches the patch and the 256-channel halo tile is 4-8 % ahead)
 };
 // (Round 3: on launches of at least two full rounds a refit of this tile, {1.78, 12.0}, also takes the 256- / 512-channel VAE layers from the
 // 256-channel halo tile - isolated they run 2-6 % faster on it although every patch's halo is then fetched by Cout / 128 column blocks
@@ -3059,6 +3060,8 @@ static const TileCost kTileCostPP[2] = {
 // 18 K-tiles on the 128-channel VAE level; the dense fit above says 52 us).  Still ahead of the plain 256x128 tile on the stride-2 conv
 // of that level (622 vs 651 us), behind the halo tile on the stride-1 ones.
 static const TileCost kTileCostConv512 = {2.5, 16.0, 1};
+// the 256x256 ping-pong tile on implicit-GEMM convolutions (round 5: the dominant convolution 1063 us = 8 rounds of 72, 256 -> 256 at 256^2 1267 us = 16 of 36)
+static const TileCost kTileCostPPConv256 = {1.49, 25.5, 1};
 // the 256x256 tile as run by the 8-phase kernel on v_mfma_f32_16x16x32_f16 (round 5; fitted on tools/g8_shapes.py, profiles/r05_gemm8_by_shape.txt:
 // 9344x1024x4096 93.5 us = one 58 % round of 64 K-tiles, 9344x4096x1024 122.7 us = 2.3 rounds of 16, the dominant convolution 989 us = 8 rounds of 72)
 static const TileCost kTileCost8 = {1.21, 24.0, 1};
@@ -3137,7 +3140,9 @@ static int launch_gemm_select(odise_hip_ctx* ctx, GemmArgs& g, int batch, int fo
         if (t == 6 && (!pp_ok || (flags & 16))) continue;
         if (t >= 7 && t <= 9 && (!halo_ok || !pp_ok || (flags & 64))) continue;  // ODISE_GEMM_FLAGS=64: never use the halo kernels
         if (t == 9 && (flags & 2048)) continue;                        // ODISE_GEMM_FLAGS=2048: never use the two-blocks-per-CU halo kernel
-        const TileCost& tc = (flags & 8) ? kTileCostOld[t] : (g8_ok && t == 4) ? (CONV ? kTileCost8Conv : kTileCost8) : (pp_ok && (t == 3 || t == 4)) ? kTileCostPP[t - 3] :
+        if (t == 9 && force_tile < 0 && g.N > 128) continue;           // (see kTileCost[9])
+        const TileCost& tc = (flags & 8) ? kTileCostOld[t] : (g8_ok && t == 4) ? (CONV ? kTileCost8Conv : kTileCost8) : (CONV && pp_ok && t == 4) ? kTileCostPPConv256 :
+                             (pp_ok && (t == 3 || t == 4)) ? kTileCostPP[t - 3] :
                              (CONV && t == 6) ? kTileCostConv512 : kTileCost[t];
         if (force_tile < 0) {
             if (kTileBM[t] > 64 && g.M <= kTileBM[t] / 2) continue;            // mostly-empty row tiles
