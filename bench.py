@@ -71,6 +71,11 @@ def parse():
     p.add_argument("--clip-ln-fold", type=int, default=0, choices=[0, 1, 2], help="A/B: the CLIP towers' LayerNorm fold, 0 = the library's rule, 1 = always, 2 = never")
     p.add_argument("--vae-chunk-mb", type=float, default=None, help="A/B: ODISE_OPT_VAE_CHUNK_BYTES in MiB (0 = all crops per launch; default: the library's)")
     p.add_argument("--attn-kvres", type=int, default=1, choices=[0, 1], help="A/B: 0 = the CLIP towers' attention on the tiled kernel instead of the K/V-resident one")
+    p.add_argument("--pipeline", action="store_true", help="encoder prefetch (odise_hip_infer_prefetch): the steps alternate between two resident sets of "
+                   "--images pictures, and every model call enqueues the OTHER set's input side + VAE encoder behind its own VAE lane on a low-priority "
+                   "stream; the next call starts from that latent.  Outputs are bit-identical to the plain call; every step is still one synchronous call")
+    p.add_argument("--prefetch-cus", type=int, default=0, help="with --pipeline: ODISE_OPT_PREFETCH_CU_EIGHTHS (1..7 of every 8 CUs for the prefetch stream; 0 = no mask)")
+    p.add_argument("--prefetch-start", type=int, default=1, choices=[0, 1], help="with --pipeline: ODISE_OPT_PREFETCH_START (0 = behind the VAE lane, 1 = behind the backbone)")
     p.add_argument("--gemm-flags", type=int, default=0, help="A/B: kernel-selection switches of the GEMM / convolution library (csrc/gemm.hip launch_gemm_select; "
                    "4096 = never the 8-phase kernels, 8192 = the 8-phase kernels on 32x32x16 MFMAs), process-wide")
     p.add_argument("--no-cpu-baseline", action="store_true")
@@ -310,6 +315,9 @@ def main():
     ctx.set_option(ctx.OPT_CLIP_LN_FOLD, args.clip_ln_fold)
     if args.gemm_flags:
         ctx.lib.odise_hip_gemm_debug(args.gemm_flags << 4)
+    if args.pipeline:
+        ctx.set_option(ctx.OPT_PREFETCH_CU_EIGHTHS, args.prefetch_cus)
+        ctx.set_option(ctx.OPT_PREFETCH_START, args.prefetch_start)
     if not args.attn_kvres:
         ctx.set_option(ctx.OPT_ATTN_KV_RESIDENT, 2)
     if args.vae_chunk_mb is not None:
@@ -356,6 +364,10 @@ def main():
         exchange = D.Exchange(ctx, rank, world, D.gloo_broadcast if world > 1 else None)
         # further batches in flight: a model instance of their own (same weights, same calibration -> identical state), their own pictures
         slots = [{"ctx": ctx, "hip": hip, "img": d_img}]
+        if args.pipeline:   # a second resident set of pictures: the steps alternate, each call prefetching the other set's encoder
+            assert args.in_flight == 1, "--pipeline is the one-context form; --in-flight runs whole contexts side by side"
+            slots[0]["img_alt"] = [ctx.to_device(image_u8(S, (world + rank) * B + b)) for b in range(B)]
+            slots[0]["turn"] = 0
         for k in range(1, max(1, args.in_flight)):
             c2 = Context(local_rank)
             h2, _ = calibrated_model(c2, image_u8(S, 0), S, K, K_TOT, set(range(N_THINGS)), None if K <= 200 else 188)
@@ -378,7 +390,15 @@ def main():
             # one model call (synchronous at its API edge: the tables are read back) + the one exchange step of the path, which then
             # runs on the library's exchange stream while the next call's kernels execute.  With several batches in flight the one
             # communicator is used in global step order (`ticket`), the same order on every rank.
-            sl["res"] = sl["hip"].infer_device(sl["img"], 0, hw, hw, to_host=False, pan_out=sl["pan_out"])
+            imgs = sl["img"]
+            if args.pipeline:
+                cur, nxt = (sl["img"], sl["img_alt"]) if sl["turn"] == 0 else (sl["img_alt"], sl["img"])
+                sl["turn"] ^= 1
+                sl["left"] = sl.get("left", 1 << 30) - 1
+                if sl["left"] > 0:                            # (the LAST timed step prepares nothing: K timed steps run exactly K encoders)
+                    sl["hip"].prefetch_device(nxt, 0, hw)    # registered before the call that will enqueue it behind its own VAE lane
+                imgs = cur
+            sl["res"] = sl["hip"].infer_device(imgs, 0, hw, hw, to_host=False, pan_out=sl["pan_out"])
             if hip.panoptic_on:
                 if ticket is None:
                     exchange.allgather(sl["local"], sl["allrec"])
@@ -464,6 +484,7 @@ def main():
         if probe is not None:
             ctx.probe_arm(True, *probe["shape"], max_launches=4096)
         t0 = time.perf_counter()
+        slots[0]["left"] = args.steps
         ctx.timer_start()
         for _ in range(args.steps):
             step()
@@ -564,7 +585,8 @@ def main():
                                        f"exchange stream)") if gather else f"dp{world}",
                        "rccl_ranks": rccl_ranks, "batches_in_flight": n_fly, "one_batch_alone_ms": single_ms,
                        "vae_chunk_bytes": ctx.get_option(ctx.OPT_VAE_CHUNK_BYTES), "clip_ln_fold": ctx.get_option(ctx.OPT_CLIP_LN_FOLD),
-                       "gemm_flags": args.gemm_flags},
+                       "gemm_flags": args.gemm_flags,
+                       "pipeline": (f"encoder-prefetch (start {args.prefetch_start}, {args.prefetch_cus or 8}/8 CUs)" if args.pipeline else None)},
             "roofline": {"bound": "mfma", "achieved": achieved, "peak": MFMA_F16_PEAK / 1e12, "unit": "TFLOP/s", "frac": achieved * 1e12 / MFMA_F16_PEAK,
                          "traffic": None,
                          "kernel": "whole step (all kernels; per-kernel times in profiles/)",

@@ -67,10 +67,15 @@ int odise_hip_device_info(odise_hip_ctx* ctx, char* name_buf, int buf_len, int* 
  *   ODISE_OPT_VAE_CHUNK_BYTES  > 0: the AutoencoderKL levels (ldm.py:493-533, 585-606) run over as many crops per launch as keep one activation
  *                              tensor below this many bytes (a smaller working set and arena); 0 (default) = all crops of a call at once, which
  *                              measured faster on MI355X (profiles/r04_vae_chunking_experiment.txt).  Per-crop arithmetic is unchanged.
+ *   ODISE_OPT_PREFETCH_CU_EIGHTHS  1..7: the encoder-prefetch stream (odise_hip_infer_prefetch) is created with a CU mask of that many of every 8
+ *                              compute units, so the batch in progress always finds free CUs for its small dependent launches; 0 / 8 (default 0) =
+ *                              no mask.  Read when the stream is first created.
+ *   ODISE_OPT_PREFETCH_START   where the next batch's encoder is enqueued: 0 = behind the current batch's VAE lane, 1 (default) = behind its
+ *                              backbone, i.e. beside the serial tail of small launches (pixel decoder .. post-processing)
  *   ODISE_OPT_ATTN_KV_RESIDENT 0 (default) = attention with d_head 64 and at most 608 keys runs the K / V^T-resident kernel where (head, image)
  *                              pairs fill the chip in whole rounds (the CLIP tower of 16 / 32 crops), the tiled kernel elsewhere; 2 = always the
  *                              tiled kernel.  The two forms step the running softmax maximum per 32 / per 64 keys: results agree to fp32 rounding. */
-enum { ODISE_OPT_CLIP_LN_FOLD = 1, ODISE_OPT_VAE_CHUNK_BYTES = 2, ODISE_OPT_ATTN_KV_RESIDENT = 3 };
+enum { ODISE_OPT_CLIP_LN_FOLD = 1, ODISE_OPT_VAE_CHUNK_BYTES = 2, ODISE_OPT_ATTN_KV_RESIDENT = 3, ODISE_OPT_PREFETCH_CU_EIGHTHS = 4, ODISE_OPT_PREFETCH_START = 5 };
 int odise_hip_set_option(odise_hip_ctx* ctx, int option, int64_t value);
 int odise_hip_get_option(odise_hip_ctx* ctx, int option, int64_t* value);
 /* Launch probe (measurement, bench.py's `roofline`): HIP events around every launch of ONE shape - conv != 0: the implicit GEMM of a convolution
@@ -329,6 +334,14 @@ typedef struct {
     odise_post_desc post;
 } odise_infer_desc;
 int odise_hip_infer(odise_hip_ctx* ctx, const odise_infer_desc* d);
+/* Encoder prefetch for a stream of batches (the reference's evaluation loop consumes a prefetching loader: odise/evaluation/evaluator.py:
+ * 87-126, odise/data/build.py:138-151).  Registers the NEXT batch (only B / images / image_layout / img_hw of `next` are read; the image
+ * buffers must stay valid and unchanged until that batch's own odise_hip_infer returns): the following odise_hip_infer call, once the VAE
+ * lane of ITS batch is done, enqueues the next batch's normalise / pad, window extraction, VAE encoder and latent on a lowest-priority
+ * stream into a side arena, and the odise_hip_infer of exactly that batch (same pointers, layout and sizes) starts from the stored latent
+ * and encoder taps.  Same kernels on the same shapes: every output is bit-identical to the call without prefetch.  A prefetched batch that
+ * is not the next one inferred is dropped.  next == NULL cancels a registration. */
+int odise_hip_infer_prefetch(odise_hip_ctx* ctx, const odise_infer_desc* next);
 
 /* ---- input resize and evaluator reductions of the eval loop --------------------------------------------
  * Replaces, on device buffers: detectron2 T.ResizeShortestEdge -> PIL.Image.resize(BILINEAR) of the DatasetMapper

@@ -71,6 +71,10 @@ extern "C" int odise_hip_destroy(odise_hip_ctx* ctx) {
     odise::stage_log_release(ctx);
     if (ctx->ws) (void)hipFree(ctx->ws);
     if (ctx->ws2) (void)hipFree(ctx->ws2);
+    if (ctx->ws3) (void)hipFree(ctx->ws3);
+    if (ctx->ev_pf_go) (void)hipEventDestroy(ctx->ev_pf_go);
+    if (ctx->ev_pf_done) (void)hipEventDestroy(ctx->ev_pf_done);
+    if (ctx->stream3) (void)hipStreamDestroy(ctx->stream3);
     if (ctx->ev_fork) (void)hipEventDestroy(ctx->ev_fork);
     if (ctx->ev_mid) (void)hipEventDestroy(ctx->ev_mid);
     if (ctx->ev_join) (void)hipEventDestroy(ctx->ev_join);
@@ -177,6 +181,15 @@ extern "C" int odise_hip_set_option(odise_hip_ctx* ctx, int option, int64_t valu
             ODISE_REQUIRE(value >= 0, "set_option: VAE_CHUNK_BYTES must be >= 0");
             ctx->vae_chunk_bytes = value;
             return ODISE_OK;
+        case ODISE_OPT_PREFETCH_CU_EIGHTHS:
+            ODISE_REQUIRE(value >= 0 && value <= 8, "set_option: PREFETCH_CU_EIGHTHS takes 0..8");
+            ODISE_REQUIRE(!ctx->stream3, "set_option: PREFETCH_CU_EIGHTHS must be set before the first prefetch (the stream exists already)");
+            ctx->prefetch_cu_eighths = (int)value;
+            return ODISE_OK;
+        case ODISE_OPT_PREFETCH_START:
+            ODISE_REQUIRE(value == 0 || value == 1, "set_option: PREFETCH_START takes 0 (behind the VAE lane) or 1 (behind the backbone)");
+            ctx->prefetch_start = (int)value;
+            return ODISE_OK;
         default:
             set_error("set_option: unknown option %d", option);
             return ODISE_ERR_ARG;
@@ -188,6 +201,8 @@ extern "C" int odise_hip_get_option(odise_hip_ctx* ctx, int option, int64_t* val
         case ODISE_OPT_CLIP_LN_FOLD: *value = ctx->clip_ln_fold; return ODISE_OK;
         case ODISE_OPT_VAE_CHUNK_BYTES: *value = ctx->vae_chunk_bytes; return ODISE_OK;
         case ODISE_OPT_ATTN_KV_RESIDENT: *value = ctx->attn_kv_resident; return ODISE_OK;
+        case ODISE_OPT_PREFETCH_CU_EIGHTHS: *value = ctx->prefetch_cu_eighths; return ODISE_OK;
+        case ODISE_OPT_PREFETCH_START: *value = ctx->prefetch_start; return ODISE_OK;
         default:
             set_error("get_option: unknown option %d", option);
             return ODISE_ERR_ARG;

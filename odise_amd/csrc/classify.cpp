@@ -591,6 +591,16 @@ extern "C" int odise_hip_infer(odise_hip_ctx* ctx, const odise_infer_desc* d) {
         if (!same) ODISE_TRY(launch_image_pad(ctx, d->images[b], d->image_layout, h, w, img01 + (size_t)b * 3 * H * W, H, W));
     }
     stage_mark(ctx, "infer: inputs padded");
+    {   // encoder prefetch: is this the batch the previous call prepared?  (anything else that was prepared is dropped: its stream is drained first)
+        Prefetch& pf = ms->pf;
+        PrefetchKey key;
+        key.B = B; key.layout = d->image_layout;
+        key.images.assign(d->images, d->images + B);
+        key.hw.assign(d->img_hw, d->img_hw + 2 * B);
+        pf.use_now = pf.has_ready && pf.ready == key;
+        if (pf.has_ready && !pf.use_now && ctx->stream3) ODISE_CHECK_HIP(hipStreamSynchronize(ctx->stream3));
+        pf.has_ready = false;   // consumed (or dropped) by this call
+    }
     ODISE_TRY(odise_hip_backbone_forward(ctx, padded, B, Hp, Wp, nullptr));
     stage_mark(ctx, "backbone done (taps projected + stitched)");
     ODISE_TRY(odise_hip_head_forward(ctx, nullptr, B, 0, Hp / 4, Wp / 4, nullptr, nullptr, nullptr, nullptr));
@@ -602,6 +612,20 @@ extern "C" int odise_hip_infer(odise_hip_ctx* ctx, const odise_infer_desc* d) {
     const int rc = odise_hip_postprocess_batch(ctx, &p);
     stage_mark(ctx, "post-processing done");
     return rc;
+}
+
+extern "C" int odise_hip_infer_prefetch(odise_hip_ctx* ctx, const odise_infer_desc* next) {
+    ODISE_REQUIRE(ctx, "infer_prefetch: null context");
+    ModelStore* ms = store_of(ctx);
+    Prefetch& pf = ms->pf;
+    if (!next) { pf.has_pending = false; return ODISE_OK; }   // cancel
+    ODISE_REQUIRE(next->images && next->img_hw && next->B >= 1 && next->image_layout >= 0 && next->image_layout <= 2, "infer_prefetch: bad descriptor");
+    pf.pending.B = next->B;
+    pf.pending.layout = next->image_layout;
+    pf.pending.images.assign(next->images, next->images + next->B);
+    pf.pending.hw.assign(next->img_hw, next->img_hw + 2 * next->B);
+    pf.has_pending = true;
+    return ODISE_OK;
 }
 
 extern "C" int odise_hip_sem_tile(int tile) { odise::g_sem_tile = tile; return 0; }

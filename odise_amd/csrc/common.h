@@ -100,6 +100,13 @@ struct odise_hip_ctx {
     void* ws2 = nullptr;
     hipEvent_t ev_fork = nullptr, ev_mid = nullptr, ev_join = nullptr;
     int lanes = 2;  // 1 = everything on the one stream (tools A/B: odise_hip_set_lanes)
+    // encoder prefetch (engine.h Prefetch, odise_hip_infer_prefetch): a third, lowest-priority stream with its own split-K workspace; the next
+    // batch's VAE encoder runs there behind ev_pf_go (recorded when the current batch's VAE lane is done) and publishes ev_pf_done
+    int prefetch_cu_eighths = 0;     // ODISE_OPT_PREFETCH_CU_EIGHTHS
+    int prefetch_start = 1;          // ODISE_OPT_PREFETCH_START
+    hipStream_t stream3 = nullptr;
+    void* ws3 = nullptr;
+    hipEvent_t ev_pf_go = nullptr, ev_pf_done = nullptr;
     void* comm = nullptr;  // odise::Comm* (comm.cpp): RCCL communicator + exchange stream, created by odise_hip_comm_init
     // per-context execution options (odise_hip_set_option, include/odise_hip.h); read on the host when a stage is enqueued
     int clip_ln_fold = 0;            // ODISE_OPT_CLIP_LN_FOLD: 0 = by token count, 1 = always, 2 = never

@@ -34,8 +34,41 @@ void models_destroy(odise_hip_ctx* ctx) {
     for (void* p : ms->dev_allocs) (void)hipFree(p);
     if (ms->arena.base) (void)hipFree(ms->arena.base);
     if (ms->arena2.base) (void)hipFree(ms->arena2.base);
+    for (Arena& a : ms->pf.arena)
+        if (a.base) (void)hipFree(a.base);
     delete ms;
     ctx->models = nullptr;
+}
+
+int ensure_prefetch_lane(odise_hip_ctx* ctx, ModelStore* ms, int slot, size_t arena_bytes) {
+    if (!ctx->stream3) {
+        int lo = 0, hi = 0;   // (least, greatest) priority
+        ODISE_CHECK_HIP(hipDeviceGetStreamPriorityRange(&lo, &hi));
+        const int e8 = ctx->prefetch_cu_eighths;
+        if (e8 >= 1 && e8 <= 7) {
+            // a CU-masked stream: e8 of every 8 compute units (bit i of the mask = CU i; the same pattern in every byte spreads over the XCDs /
+            // shader engines whatever the enumeration), so the batch in progress always finds CUs no prefetch workgroup occupies
+            uint32_t mask[8];
+            const uint32_t byte = (1u << e8) - 1u;
+            for (uint32_t& m : mask) m = byte * 0x01010101u;
+            ODISE_CHECK_HIP(hipExtStreamCreateWithCUMask(&ctx->stream3, 8, mask));
+        } else {
+            ODISE_CHECK_HIP(hipStreamCreateWithPriority(&ctx->stream3, hipStreamNonBlocking, lo));   // never ahead of the batch in progress
+        }
+        ODISE_CHECK_HIP(hipMalloc(&ctx->ws3, ctx->ws_bytes));
+        ODISE_CHECK_HIP(hipEventCreateWithFlags(&ctx->ev_pf_go, hipEventDisableTiming));
+        ODISE_CHECK_HIP(hipEventCreateWithFlags(&ctx->ev_pf_done, hipEventDisableTiming));
+    }
+    Arena& a = ms->pf.arena[slot];
+    if (a.cap < arena_bytes) {
+        ODISE_CHECK_HIP(hipStreamSynchronize(ctx->stream3));
+        ODISE_CHECK_HIP(hipStreamSynchronize(ctx->stream));
+        if (a.base) ODISE_CHECK_HIP(hipFree(a.base));
+        a = Arena();
+        ODISE_CHECK_HIP(hipMalloc((void**)&a.base, arena_bytes));
+        a.cap = arena_bytes;
+    }
+    return ODISE_OK;
 }
 
 int ensure_lane2(odise_hip_ctx* ctx, ModelStore* ms, size_t arena_bytes) {

@@ -71,6 +71,33 @@ struct NormW {
 
 struct UNetModel;
 
+// ---- encoder prefetch ------------------------------------------------------------------------------------------------------------------
+// The reference's evaluation loop is a stream of batches with the loader prefetching (odise/evaluation/evaluator.py:87-126, odise/data/build.py:
+// 138-151).  Here the NEXT batch's input side - normalise / pad, window extraction, VAE encoder, latent - can be enqueued while the current
+// batch still runs: odise_hip_infer_prefetch registers the next batch (`pending`); the following odise_hip_infer enqueues that work on the
+// context's lowest-priority stream once its own VAE lane is done (its second stream is then idle and its tail is a chain of small launches),
+// into one of two side arenas; the odise_hip_infer of exactly that batch (`ready`) starts from the stored latent and encoder taps.  Same
+// kernels on the same shapes: the results are bit-identical to the unpipelined call (tests/test_gpu_fullsize_batch.py).
+struct EncoderOut {
+    Act tap0, tap1;   // inputs of encoder blocks 5 / 7 (ldm.py:437-438)
+    Act xt, zdec;     // q_sample(t = 0) of the scaled posterior mean; post_quant_conv input of the decoder
+};
+struct PrefetchKey {
+    int B = 0, layout = 0;
+    std::vector<const void*> images;
+    std::vector<int> hw;
+    bool operator==(const PrefetchKey& o) const { return B == o.B && layout == o.layout && images == o.images && hw == o.hw; }
+};
+struct Prefetch {
+    bool has_pending = false, has_ready = false;
+    PrefetchKey pending, ready;
+    int ready_slot = 0;           // side arena that holds `ready`'s tensors (the slots alternate: the call in progress may still read the other one)
+    EncoderOut out;               // of `ready`
+    int crops = 0;                // crops (B x windows) the stored tensors cover
+    bool use_now = false;         // set by odise_hip_infer for the call in progress: extractor_launch consumes `out`
+    Arena arena[2];
+};
+
 struct ModelStore {
     std::map<std::string, HostTensor> host;
     std::vector<void*> dev_allocs;              // weights that live as long as the context
@@ -78,6 +105,7 @@ struct ModelStore {
     void track(void* p) { (alloc_sink ? *alloc_sink : dev_allocs).push_back(p); }
     Arena arena;
     Arena arena2;   // activations of the second lane (Lane2)
+    Prefetch pf;    // encoder prefetch of the next batch (odise_hip_infer_prefetch)
     UNetModel* unet = nullptr;
     struct ExtractorModel* extractor = nullptr;
     struct MaskGenModel* maskgen = nullptr;
@@ -154,6 +182,30 @@ struct Lane2 {
     }
 };
 
+// While a PrefetchLane lives, everything enqueued through the context goes to the prefetch stream (created on first use, lowest priority),
+// allocates from side arena `slot` and uses the third split-K workspace.
+int ensure_prefetch_lane(odise_hip_ctx* ctx, ModelStore* ms, int slot, size_t arena_bytes);
+struct PrefetchLane {
+    odise_hip_ctx* ctx;
+    ModelStore* ms;
+    int slot;
+    hipStream_t s0;
+    void* w0;
+    void* stages0;
+    PrefetchLane(odise_hip_ctx* c, ModelStore* m, int sl) : ctx(c), ms(m), slot(sl), s0(c->stream), w0(c->ws), stages0(c->stages) {
+        ctx->stream = ctx->stream3;
+        ctx->ws = ctx->ws3;
+        ctx->stages = nullptr;     // the stage timeline describes the batch in progress only
+        std::swap(ms->arena, ms->pf.arena[slot]);
+    }
+    ~PrefetchLane() {
+        ctx->stream = s0;
+        ctx->ws = w0;
+        ctx->stages = stages0;
+        std::swap(ms->arena, ms->pf.arena[slot]);
+    }
+};
+
 // ---- stage entry points shared between translation units --------------------------------------------------------
 int ensure_arena(odise_hip_ctx* ctx, ModelStore* ms, size_t bytes);
 int unet_build(odise_hip_ctx* ctx, const char* prefix);
@@ -166,6 +218,8 @@ const Act* extractor_taps(ModelStore* ms);
 bool extractor_ready(ModelStore* ms);
 int extractor_launch(odise_hip_ctx* ctx, ModelStore* ms, const float* image, int B, int H, int W, bool standalone, bool join = true);
 int extractor_join(odise_hip_ctx* ctx);
+int extractor_encoder_only(odise_hip_ctx* ctx, ModelStore* ms, const float* image, int B, int H, int W, EncoderOut& out);   // the VAE encoder + latent of `image` on the current stream / arena
+size_t encoder_arena_bytes(int B, int H, int W);
 
 // misc.hip
 struct LatentW {

@@ -17,6 +17,7 @@
 #include <math.h>
 #include <string.h>
 
+#include <functional>
 #include "engine.h"
 
 namespace odise {
@@ -594,6 +595,96 @@ size_t extractor_arena_bytes(int B, int H, int W) {
 const Act* extractor_taps(ModelStore* ms) { return ms->extractor ? ms->extractor->taps : nullptr; }
 bool extractor_ready(ModelStore* ms) { return ms->extractor && ms->extractor->built; }
 
+// ---- VAE encoder + latent heads (ldm.py:424-467, 543-566): shared by the call in progress and the prefetch of the next batch ------------------
+// `after_level0` (optional) is called once the first level is enqueued (the two-lane step feeds its second lane there, see extractor_launch)
+static int run_vae_encoder(Exec& ex, ExtractorModel* e, const float* image, int B, int H, int W, EncoderOut& out, const std::function<int()>* after_level0) {
+    odise_hip_ctx* ctx = ex.ctx;
+    const int lh = H / 8, lw = W / 8;
+    // ---- VAE encoder ------------------------------------------------------------------------------------------------
+    Act x;
+    ODISE_TRY(ex.alloc(x, B, H, W, 8));
+    {
+        const float sc[3] = {2.f, 2.f, 2.f}, sh[3] = {-1.f, -1.f, -1.f};  // (img - 0.5) / 0.5  (ldm.py:556)
+        ODISE_TRY(launch_image_to_nhwc(ctx, image, x.p, B, 3, H * W, 8, sc, sh));
+    }
+    // One level = [conv_in] -> two ResBlocks -> [downsample], run over `chunk` crops at a time (vae_chunk): the level's input and output are
+    // batched tensors, everything between them lives in the chunk's scope of the arena - the same addresses for every chunk, so the working
+    // set of a level is a handful of <= 64 MiB tensors that stay in the Infinity Cache between producer and consumer.  Per-crop arithmetic is
+    // what it was (same kernels, same K order; only the row-block partition of the fused GroupNorm sums can follow a different tile choice).
+    Act cur = x;
+    int flat = 0;
+    auto encoder_level = [&](int l) -> int {
+        const int h = H >> l, w = W >> l;
+        const int cout = e->enc_blocks[l][1].c1.cout;
+        const int chunk = vae_chunk(ctx, B, (size_t)h * w * cout * 2);
+        const bool tap0 = flat <= 5 && 5 < flat + 2, tap1 = flat <= 7 && 7 < flat + 2;   // the input of block 5 / 7 (ldm.py:437-438) is a batched output
+        Act nxt, mid;      // mid: the tensor between the two blocks, batched only when it is a tap
+        if (l < 3) ODISE_TRY(ex.alloc(nxt, B, h / 2, w / 2, e->enc_down[l].cout));
+        else ODISE_TRY(ex.alloc(nxt, B, h, w, cout));
+        const bool scoped = chunk < B;   // all crops at once: nothing is released (the statistics of the level's output feed the next block)
+        const bool mid_is_tap = (tap0 && flat + 1 == 5) || (tap1 && flat + 1 == 7);
+        if (mid_is_tap) ODISE_TRY(ex.alloc(mid, B, h, w, e->enc_blocks[l][0].c1.cout));
+        if (mid_is_tap) (flat + 1 == 5 ? out.tap0 : out.tap1) = mid;
+        for (int n0 = 0; n0 < B; n0 += chunk) {
+            const int n = std::min(chunk, B - n0);
+            const size_t mk = ex.ms->arena.mark();
+            Act c0 = crop_slice(cur, n0, n);
+            if (l == 0) {
+                Act t;
+                ODISE_TRY(ex.conv(c0, e->enc_conv_in, t, 1, 1));
+                c0 = t;
+            }
+            Act b0 = mid_is_tap ? crop_slice(mid, n0, n) : Act();
+            ODISE_TRY(run_vae_res(ex, e->enc_blocks[l][0], c0, b0));
+            if (l < 3) {
+                Act b1, d = crop_slice(nxt, n0, n);
+                ODISE_TRY(run_vae_res(ex, e->enc_blocks[l][1], b0, b1));
+                // F.pad (0,1,0,1) + conv3x3 stride 2 pad 0
+                ODISE_TRY(ex.conv(b1, e->enc_down[l], d, 2, 0, false, nullptr, nullptr, 0, ODISE_ACT_NONE, 0, 0, h / 2, w / 2));
+            } else {
+                Act b1 = crop_slice(nxt, n0, n);
+                ODISE_TRY(run_vae_res(ex, e->enc_blocks[l][1], b0, b1));
+                if (!scoped) nxt = b1;    // keeps the fused GroupNorm statistics for mid.block_1
+            }
+            // the chunk's temporaries (and the statistics buffers of its slices) are released; batched outputs were allocated below the mark
+            if (scoped) ex.ms->arena.release(mk);
+        }
+        cur = nxt;
+        if (scoped || l < 3) { cur.gn_part = nullptr; cur.gn_blocks = 0; }
+        flat += 2;
+        return ODISE_OK;
+    };
+    ODISE_TRY(encoder_level(0));
+    if (after_level0) ODISE_TRY((*after_level0)());
+    for (int l = 1; l < 4; ++l) ODISE_TRY(encoder_level(l));
+    {
+        Act a, b2, c, nrm, h8;
+        ODISE_TRY(run_vae_res(ex, e->enc_mid1, cur, a));
+        ODISE_TRY(run_vae_attn(ex, e->enc_attn, a, b2));
+        ODISE_TRY(run_vae_res(ex, e->enc_mid2, b2, c));
+        ODISE_TRY(ex.group_norm(c, e->enc_norm_out, nrm, 1e-6f, ODISE_ACT_SILU));
+        ODISE_TRY(ex.conv(nrm, e->enc_conv_out, h8, 1, 1));
+        cur = h8;  // [B, lh, lw, 8]
+    }
+    // ---- latent: posterior mean * scale, q_sample(t=0), post_quant_conv -----------------------------------------------
+    if (e->noise_hw != lh * lw) {
+        set_error("extractor: latent %dx%d differs from the shared-noise size (%d elements); only the reference crop size is supported", lh, lw,
+                  e->noise_hw);
+        return ODISE_ERR_ARG;
+    }
+    ODISE_TRY(ex.alloc(out.xt, B, lh, lw, 8));
+    ODISE_TRY(ex.alloc(out.zdec, B, lh, lw, 8));
+    ODISE_TRY(launch_latent_heads(ctx, cur.p, e->noise, out.xt.p, out.zdec.p, nullptr, B, lh * lw, e->lat));
+    return ODISE_OK;
+}
+
+size_t encoder_arena_bytes(int B, int H, int W) { return ((size_t)H * W * 128 * 2 * 6 + ((size_t)160 << 20)) * B + ((size_t)256 << 20); }
+
+int extractor_encoder_only(odise_hip_ctx* ctx, ModelStore* ms, const float* image, int B, int H, int W, EncoderOut& out) {
+    Exec ex{ctx, ms};
+    return run_vae_encoder(ex, ms->extractor, image, B, H, W, out, nullptr);
+}
+
 // standalone=false: called from the backbone stage, which owns the arena and the MAC counter
 // The UNet taps (2..5) are produced on the second lane: a caller that passed join = false consumes the VAE taps (0, 1, 6, 7) first and calls
 // this before it touches a UNet tap (stream-side wait, the host never blocks)
@@ -669,87 +760,28 @@ int extractor_launch(odise_hip_ctx* ctx, ModelStore* ms, const float* image, int
     if (!two) ODISE_TRY(conditioning());
     if (two && !vae_first) ODISE_TRY(clip_on_lane2());
 
-    // ---- VAE encoder ------------------------------------------------------------------------------------------------
-    Act x;
-    ODISE_TRY(ex.alloc(x, B, H, W, 8));
-    {
-        const float sc[3] = {2.f, 2.f, 2.f}, sh[3] = {-1.f, -1.f, -1.f};  // (img - 0.5) / 0.5  (ldm.py:556)
-        ODISE_TRY(launch_image_to_nhwc(ctx, image, x.p, B, 3, H * W, 8, sc, sh));
-    }
-    // One level = [conv_in] -> two ResBlocks -> [downsample], run over `chunk` crops at a time (vae_chunk): the level's input and output are
-    // batched tensors, everything between them lives in the chunk's scope of the arena - the same addresses for every chunk, so the working
-    // set of a level is a handful of <= 64 MiB tensors that stay in the Infinity Cache between producer and consumer.  Per-crop arithmetic is
-    // what it was (same kernels, same K order; only the row-block partition of the fused GroupNorm sums can follow a different tile choice).
-    Act cur = x;
-    int flat = 0;
-    auto encoder_level = [&](int l) -> int {
-        const int h = H >> l, w = W >> l;
-        const int cout = e->enc_blocks[l][1].c1.cout;
-        const int chunk = vae_chunk(ctx, B, (size_t)h * w * cout * 2);
-        const bool tap0 = flat <= 5 && 5 < flat + 2, tap1 = flat <= 7 && 7 < flat + 2;   // the input of block 5 / 7 (ldm.py:437-438) is a batched output
-        Act nxt, mid;      // mid: the tensor between the two blocks, batched only when it is a tap
-        if (l < 3) ODISE_TRY(ex.alloc(nxt, B, h / 2, w / 2, e->enc_down[l].cout));
-        else ODISE_TRY(ex.alloc(nxt, B, h, w, cout));
-        const bool scoped = chunk < B;   // all crops at once: nothing is released (the statistics of the level's output feed the next block)
-        const bool mid_is_tap = (tap0 && flat + 1 == 5) || (tap1 && flat + 1 == 7);
-        if (mid_is_tap) ODISE_TRY(ex.alloc(mid, B, h, w, e->enc_blocks[l][0].c1.cout));
-        if (mid_is_tap) e->taps[flat + 1 == 5 ? 0 : 1] = mid;
-        for (int n0 = 0; n0 < B; n0 += chunk) {
-            const int n = std::min(chunk, B - n0);
-            const size_t mk = ex.ms->arena.mark();
-            Act c0 = crop_slice(cur, n0, n);
-            if (l == 0) {
-                Act t;
-                ODISE_TRY(ex.conv(c0, e->enc_conv_in, t, 1, 1));
-                c0 = t;
+    // ---- VAE encoder + latent: computed here, or taken from the prefetch the previous call ran for this batch ---------------------------
+    EncoderOut enc;
+    const bool prefetched = ms->pf.use_now && !standalone && ms->pf.crops == B;
+    if (prefetched) {
+        enc = ms->pf.out;
+        ODISE_CHECK_HIP(hipStreamWaitEvent(ctx->stream, ctx->ev_pf_done, 0));
+        if (two && vae_first) { ODISE_TRY(clip_on_lane2()); clip_enqueued = true; }
+    } else {
+        // the CLIP branch is enqueued behind the first level when the levels run in crop chunks: that level is then ~200 launches (a few ms of
+        // host time, ~25 ms of device time), so the second lane's ~450 CLIP launches reach the device while the first is still busy with it
+        std::function<int()> hook = [&]() -> int {
+            if (two && vae_first && vae_chunk(ctx, B, (size_t)H * W * 128 * 2) < B) {
+                ODISE_TRY(clip_on_lane2());
+                clip_enqueued = true;
             }
-            Act b0 = mid_is_tap ? crop_slice(mid, n0, n) : Act();
-            ODISE_TRY(run_vae_res(ex, e->enc_blocks[l][0], c0, b0));
-            if (l < 3) {
-                Act b1, d = crop_slice(nxt, n0, n);
-                ODISE_TRY(run_vae_res(ex, e->enc_blocks[l][1], b0, b1));
-                // F.pad (0,1,0,1) + conv3x3 stride 2 pad 0
-                ODISE_TRY(ex.conv(b1, e->enc_down[l], d, 2, 0, false, nullptr, nullptr, 0, ODISE_ACT_NONE, 0, 0, h / 2, w / 2));
-            } else {
-                Act b1 = crop_slice(nxt, n0, n);
-                ODISE_TRY(run_vae_res(ex, e->enc_blocks[l][1], b0, b1));
-                if (!scoped) nxt = b1;    // keeps the fused GroupNorm statistics for mid.block_1
-            }
-            // the chunk's temporaries (and the statistics buffers of its slices) are released; batched outputs were allocated below the mark
-            if (scoped) ex.ms->arena.release(mk);
-        }
-        cur = nxt;
-        if (scoped || l < 3) { cur.gn_part = nullptr; cur.gn_blocks = 0; }
-        flat += 2;
-        return ODISE_OK;
-    };
-    ODISE_TRY(encoder_level(0));
-    // the CLIP branch is enqueued behind the first level: in chunks that level is ~200 launches (a few ms of host time, ~25 ms of device time),
-    // so the second lane's ~450 CLIP launches reach the device while the first is still busy with it
-    if (two && vae_first && vae_chunk(ctx, B, (size_t)H * W * 128 * 2) < B) {
-        ODISE_TRY(clip_on_lane2());
-        clip_enqueued = true;
+            return ODISE_OK;
+        };
+        ODISE_TRY(run_vae_encoder(ex, e, image, B, H, W, enc, &hook));
     }
-    for (int l = 1; l < 4; ++l) ODISE_TRY(encoder_level(l));
-    {
-        Act a, b2, c, nrm, h8;
-        ODISE_TRY(run_vae_res(ex, e->enc_mid1, cur, a));
-        ODISE_TRY(run_vae_attn(ex, e->enc_attn, a, b2));
-        ODISE_TRY(run_vae_res(ex, e->enc_mid2, b2, c));
-        ODISE_TRY(ex.group_norm(c, e->enc_norm_out, nrm, 1e-6f, ODISE_ACT_SILU));
-        ODISE_TRY(ex.conv(nrm, e->enc_conv_out, h8, 1, 1));
-        cur = h8;  // [B, lh, lw, 8]
-    }
-    // ---- latent: posterior mean * scale, q_sample(t=0), post_quant_conv -----------------------------------------------
-    if (e->noise_hw != lh * lw) {
-        set_error("extractor: latent %dx%d differs from the shared-noise size (%d elements); only the reference crop size is supported", lh, lw,
-                  e->noise_hw);
-        return ODISE_ERR_ARG;
-    }
-    Act xt, zdec;
-    ODISE_TRY(ex.alloc(xt, B, lh, lw, 8));
-    ODISE_TRY(ex.alloc(zdec, B, lh, lw, 8));
-    ODISE_TRY(launch_latent_heads(ctx, cur.p, e->noise, xt.p, zdec.p, nullptr, B, lh * lw, e->lat));
+    e->taps[0] = enc.tap0;
+    e->taps[1] = enc.tap1;
+    const Act xt = enc.xt, zdec = enc.zdec;
     auto unet_on_lane2 = [&]() -> int {   // waits for the latent on the device; its ~540 launches take the host ~10 ms
         Lane2 lane(ctx, ms);
         ODISE_CHECK_HIP(hipStreamWaitEvent(ctx->stream, ctx->ev_mid, 0));
@@ -760,10 +792,11 @@ int extractor_launch(odise_hip_ctx* ctx, ModelStore* ms, const float* image, int
         return ODISE_OK;
     };
     stage_mark(ctx, "extractor: VAE encoder + latent done");
+    bool unet_enqueued = false;   // (the CLIP branch may already sit on the second lane - crop chunks, prefetched encoder: then the UNet follows it here, once)
     if (two) {
         ODISE_CHECK_HIP(hipEventRecord(ctx->ev_mid, ctx->stream));            // the latent is ready
         if (vae_first && !clip_enqueued) ODISE_TRY(clip_on_lane2());
-        else ODISE_TRY(unet_on_lane2());
+        else { ODISE_TRY(unet_on_lane2()); unet_enqueued = true; }
     } else {
         // ---- UNet (t = 0), single lane: before the decoder, as the reference orders its modules
         ODISE_TRY(unet_launch(ctx, ms, ms->unet, nullptr, xt.p, cond_inputs, cond_emb, B, lh, lw, false));
@@ -796,7 +829,7 @@ int extractor_launch(odise_hip_ctx* ctx, ModelStore* ms, const float* image, int
         e->taps[7] = m1;  // input of up block 5
     }
     // ---- UNet (t = 0), second lane: enqueued last
-    if (two && vae_first) ODISE_TRY(unet_on_lane2());
+    if (two && vae_first && !unet_enqueued) ODISE_TRY(unet_on_lane2());
     {
         const Act* ut = unet_taps(ms);
         for (int i = 0; i < 4; ++i) e->taps[2 + i] = ut[i];

@@ -315,6 +315,62 @@ static const int kFeatStride[8] = {4, 8, 32, 32, 16, 8, 8, 4};  // LdmExtractor 
 static const int kGroups[4][3] = {{0, 7, -1}, {1, 5, 6}, {4, -1, -1}, {2, 3, -1}};  // s2, s3, s4, s5 in summation order
 static const int kGroupStride[4] = {4, 8, 16, 32};
 
+// slide-window boxes of an H x W image (feature_extractor.py:197-222): stride = window, the last row / column shifted inwards
+static void window_boxes(int H, int W, int cs, std::vector<int>& boxes) {
+    const int hg = (std::max(H - cs + cs - 1, 0)) / cs + 1, wg = (std::max(W - cs + cs - 1, 0)) / cs + 1;
+    for (int hi = 0; hi < hg; ++hi)
+        for (int wi = 0; wi < wg; ++wi) {
+            const int y2 = std::min(hi * cs + cs, H), x2 = std::min(wi * cs + cs, W);
+            boxes.push_back(std::max(y2 - cs, 0));
+            boxes.push_back(std::max(x2 - cs, 0));
+        }
+}
+
+// Encoder prefetch (engine.h Prefetch): enqueue the registered next batch's input padding, window extraction, VAE encoder and latent on the
+// prefetch stream, behind everything the main stream holds so far (= the current batch's VAE lane).  Only batches of the current padded size
+// are prefetched (the window table of that size is resident); anything else is dropped and simply computed by its own call.
+static int prefetch_enqueue(odise_hip_ctx* ctx, ModelStore* ms, MaskGenModel* g) {
+    Prefetch& pf = ms->pf;
+    const PrefetchKey key = pf.pending;
+    pf.has_pending = false;
+    const int B = key.B;
+    int H = 0, W = 0;
+    for (int b = 0; b < B; ++b) { H = std::max(H, key.hw[2 * b]); W = std::max(W, key.hw[2 * b + 1]); }
+    const int Hp = (int)round_up(H, 64), Wp = (int)round_up(W, 64);
+    const int S = 512, cs = std::min(S, std::min(Hp, Wp));
+    MaskGenModel::BoxEntry* hit = nullptr;
+    for (auto& e : g->box_cache)
+        if (e.H == Hp && e.W == Wp) hit = &e;
+    if (!hit || cs != S) return ODISE_OK;   // not this size class: no prefetch
+    const int K = hit->K, n = B * K;
+    const int slot = 1 - pf.ready_slot;   // strictly alternating: the batch in progress may have come from the other slot and still reads it
+    ODISE_TRY(ensure_prefetch_lane(ctx, ms, slot, encoder_arena_bytes(n, S, S) + (size_t)B * 3 * Hp * Wp * 4 + (size_t)n * 3 * S * S * 4));
+    ODISE_CHECK_HIP(hipEventRecord(ctx->ev_pf_go, ctx->stream));
+    const double macs0 = ms->macs;
+    {
+        PrefetchLane lane(ctx, ms, slot);
+        ODISE_CHECK_HIP(hipStreamWaitEvent(ctx->stream, ctx->ev_pf_go, 0));
+        ms->arena.reset();
+        Exec ex{ctx, ms};
+        float* padded = (float*)ex.alloc_bytes((size_t)B * 3 * Hp * Wp * 4);
+        float* crops = (float*)ex.alloc_bytes((size_t)n * 3 * S * S * 4);
+        if (!padded || !crops) return ODISE_ERR_NOMEM;
+        for (int b = 0; b < B; ++b)
+            ODISE_TRY(launch_image_pad(ctx, key.images[b], key.layout, key.hw[2 * b], key.hw[2 * b + 1], padded + (size_t)b * 3 * Hp * Wp, Hp, Wp));
+        ODISE_TRY(launch_crop_extract(ctx, padded, crops, B, 3, Hp, Wp, S, K, hit->dev));
+        EncoderOut out;
+        ODISE_TRY(extractor_encoder_only(ctx, ms, crops, n, S, S, out));
+        ODISE_CHECK_HIP(hipEventRecord(ctx->ev_pf_done, ctx->stream));
+        pf.out = out;
+    }
+    ms->macs = macs0;   // the MAC counter describes the call in progress
+    pf.ready = key;
+    pf.ready_slot = slot;
+    pf.crops = n;
+    pf.has_ready = true;
+    return ODISE_OK;
+}
+
 static int backbone_forward(odise_hip_ctx* ctx, const float* image, int B, int H, int W, float** out4) {
     ModelStore* ms = store_of(ctx);
     MaskGenModel* g = ms->maskgen;
@@ -394,6 +450,8 @@ static int backbone_forward(odise_hip_ctx* ctx, const float* image, int B, int H
     stage_mark(ctx, "backbone: crops extracted");
     ODISE_TRY(extractor_launch(ctx, ms, crops, B * K, S, S, false, /*join=*/!defer_join));
     stage_mark(ctx, "extractor: VAE lane done (main stream; the CLIP -> UNet lane is joined later)");
+    ms->pf.use_now = false;
+    if (ms->pf.has_pending && ctx->prefetch_start == 0) ODISE_TRY(prefetch_enqueue(ctx, ms, g));   // the NEXT batch's encoder behind this batch's VAE lane
     const Act* taps = extractor_taps(ms);
     bool joined = false;
     for (int gi = 0; gi < 4; ++gi) {
@@ -424,6 +482,8 @@ static int backbone_forward(odise_hip_ctx* ctx, const float* image, int B, int H
                                 H / stride, W / stride, g->proj_dim));
     }
     if (!joined) ODISE_TRY(extractor_join(ctx));
+    // ... or (default) behind the whole backbone: beside the serial tail of small launches (head, MaskCLIP, post-processing)
+    if (ms->pf.has_pending) ODISE_TRY(prefetch_enqueue(ctx, ms, g));
     ms->arena.release(mk);
     g->last_macs = ms->macs;
     (void)kFeatStride;

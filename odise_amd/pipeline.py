@@ -349,6 +349,21 @@ class HipCategoryODISE(HipODISE):
         check(self.ctx.lib.odise_hip_postprocess_batch(self.ctx.h, C.byref(d)), "postprocess_batch")
         return self._collect(bufs, sizes, to_host)
 
+    def prefetch_device(self, images, layout: int, img_hw) -> None:
+        """Register the NEXT batch (`odise_hip_infer_prefetch`): the following `infer_device` call enqueues this batch's input side and VAE
+        encoder behind its own VAE lane, and the `infer_device` of exactly these pictures starts from the stored latent.  `images=None` cancels.
+        The image buffers must stay alive and unchanged until their own `infer_device` call has returned."""
+        if images is None:
+            check(self.ctx.lib.odise_hip_infer_prefetch(self.ctx.h, None), "infer_prefetch")
+            return
+        n = len(images)
+        from ._lib import InferDesc
+        d = InferDesc()
+        ptrs = (C.c_void_p * n)(*[(im.ptr if isinstance(im, DeviceArray) else im) for im in images])
+        iarr = (C.c_int * (2 * n))(*[int(v) for s in img_hw for v in s])
+        d.B, d.images, d.image_layout, d.img_hw = n, C.cast(ptrs, C.c_void_p), layout, C.cast(iarr, C.c_void_p)
+        check(self.ctx.lib.odise_hip_infer_prefetch(self.ctx.h, C.byref(d)), "infer_prefetch")
+
     def infer_device(self, images, layout: int, img_hw, out_sizes, to_host: bool = False, pan_out=None, mask_cls_out=None, alloc=None) -> list:
         """One `odise_hip_infer` call: `images` = device pointers (DeviceArray or int) of uint8 HWC (layout 0) / uint8 CHW (1) / fp32 CHW
         0..255 (2) pictures with sizes img_hw [(h, w)]."""

@@ -257,3 +257,52 @@ def test_batch_of_two_1280_ade847_fused_argmax(ctx, fullsize_model):
     finally:
         hip.panoptic_on = hip.instance_on = True
         hip.semantic_argmax = False
+
+
+def test_encoder_prefetch_is_bit_identical(ctx, fullsize_model):
+    """odise_hip_infer_prefetch: the next batch's input side + VAE encoder run on a low-priority stream behind the current
+    batch's VAE lane, and the next call starts from that latent.  Same kernels on the same shapes: every output of a pipelined call - class
+    log-probabilities, semantic scores, panoptic map and table, instance masks and scores - must equal the plain call's bit for bit; a
+    prefetched batch that is not the next one inferred is dropped without a trace."""
+    from fullsize import image_u8
+    hip = fullsize_model
+    _activate(hip, "coco133", 1024)
+    S, n = 1024, 2
+    sets = {name: [ctx.to_device(np.ascontiguousarray(image_u8(S, S, seed).numpy())) for seed in seeds] for name, seeds in (("A", (0, 1)), ("B", (2, 3)))}
+    hw = [(S, S)] * n
+
+    def call(name):
+        cls = ctx.empty((n, hip.num_queries, hip.num_classes + 1), np.float32)
+        res = hip.infer_device(sets[name], 1, hw, hw, to_host=True, mask_cls_out=cls)
+        out = cls.numpy()
+        cls.free()
+        return res, out
+
+    def same(a, b, what):
+        (ra, ca), (rb, cb) = a, b
+        assert np.array_equal(ca, cb), f"{what}: class log-probabilities differ ({np.abs(ca - cb).max()})"
+        for i in range(n):
+            assert np.array_equal(ra[i]["sem_seg"], rb[i]["sem_seg"]), f"{what}: sem_seg of picture {i}"
+            assert np.array_equal(ra[i]["panoptic_seg"][0], rb[i]["panoptic_seg"][0]) and ra[i]["panoptic_seg"][1] == rb[i]["panoptic_seg"][1], f"{what}: panoptic {i}"
+            for k in ("pred_masks", "scores", "pred_classes"):
+                assert np.array_equal(np.asarray(ra[i]["instances"][k]), np.asarray(rb[i]["instances"][k])), f"{what}: instances[{k}] of picture {i}"
+
+    plain = {name: call(name) for name in ("A", "B")}
+    # the pipeline: every call prepares the other set
+    hip.prefetch_device(sets["B"], 1, hw)
+    first = call("A")                        # computes A itself, enqueues B's encoder behind its VAE lane
+    hip.prefetch_device(sets["A"], 1, hw)
+    second = call("B")                       # starts from the prefetched latent of B, prepares A
+    third = call("A")                        # starts from the prefetched latent of A, prepares nothing
+    same(first, plain["A"], "call that only prepares the next batch")
+    same(second, plain["B"], "call on a prefetched batch")
+    same(third, plain["A"], "second call on a prefetched batch")
+    # a prepared batch that is not the next one is dropped
+    hip.prefetch_device(sets["B"], 1, hw)
+    call("A")
+    same(call("A"), plain["A"], "call after a dropped prefetch")
+    hip.prefetch_device(None, 1, hw)
+    same(call("B"), plain["B"], "plain call after the pipeline")
+    for s in sets.values():
+        for d in s:
+            d.free()

@@ -18,6 +18,9 @@ def main():
     ap.add_argument("--images", type=int, default=4)
     ap.add_argument("--reps", type=int, default=3)
     ap.add_argument("--lanes", type=int, default=2)
+    ap.add_argument("--pipeline", action="store_true", help="encoder prefetch: the calls alternate between two sets of pictures, each preparing the other")
+    ap.add_argument("--prefetch-start", type=int, default=1)
+    ap.add_argument("--prefetch-cus", type=int, default=0)
     args = ap.parse_args()
     from odise_amd.runtime import Context
     ctx = Context(0)
@@ -28,13 +31,27 @@ def main():
     hip, _ = bench.calibrated_model(ctx, u8[0], S, 133, 254, set(range(80)), None)
     d_img = [ctx.to_device(u) for u in u8]
     hw = [(S, S)] * B
+    sets = [d_img]
+    if args.pipeline:
+        ctx.set_option(ctx.OPT_PREFETCH_CU_EIGHTHS, args.prefetch_cus)
+        ctx.set_option(ctx.OPT_PREFETCH_START, args.prefetch_start)
+        sets.append([ctx.to_device(bench.image_u8(S, B + b)) for b in range(B)])
+    turn = [0]
+
+    def call():
+        cur = sets[turn[0] % len(sets)]
+        turn[0] += 1
+        if args.pipeline:
+            hip.prefetch_device(sets[turn[0] % len(sets)], 0, hw)
+        hip.infer_device(cur, 0, hw, hw, to_host=False)
+
     for _ in range(2):
-        hip.infer_device(d_img, 0, hw, hw, to_host=False)
+        call()
     ctx.sync()
     rows = None
     for _ in range(args.reps):
         ctx.stage_timeline(True)
-        hip.infer_device(d_img, 0, hw, hw, to_host=False)
+        call()
         ctx.sync()
         t = ctx.stage_timeline_read()
         rows = t if rows is None else [(a[0], a[1] + b[1], a[2] + b[2]) for a, b in zip(rows, t)]
