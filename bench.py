@@ -84,11 +84,19 @@ def parse():
 
 
 def _threads():
+    """Host threads of THIS rank: the host's cores are shared by the ranks of the node (8 ranks x 16 threads of set-up work - 1.1 G synthetic
+    parameters each, packed to fp16 - would oversubscribe a 128-thread host), and torch's intra-op pool stops scaling far below a 256-thread host."""
     try:
         avail = len(os.sched_getaffinity(0))
     except AttributeError:
         avail = os.cpu_count() or 1
-    return max(1, min(avail, 16))  # torch's intra-op pool stops scaling (and thrashes) far below a 256-thread host
+    world = max(1, int(os.environ.get("WORLD_SIZE", "1")))
+    return max(1, min(avail // world if world > 1 else avail, 16))
+
+
+def _peak_rss_gb():
+    import resource
+    return resource.getrusage(resource.RUSAGE_SELF).ru_maxrss / (1 << 20)   # Linux: kilobytes
 
 
 def image_u8(size, seed):
@@ -254,7 +262,11 @@ def inclusive_rates(ctx, hip, u8, S, B, sizes, steps):
     return out
 
 
-def calibrated_model(ctx, first_image_u8, S, K, K_TOT, things, anchored):
+MASK_POSITIVE = 0.01   # (0.15, what the parity tests use, leaves every picture ONE panoptic segment at overlap threshold 0.8; 0.01 keeps
+                       # 2-18 per picture, 5-7 of them stuff - tools/segments_calib.py, profiles/r05_bench_segments_calibration.txt)  # fraction of the mask logits that is positive after calibration (odise_amd/synthetic.py mask_bias_shift)
+
+
+def calibrated_model(ctx, first_image_u8, S, K, K_TOT, things, anchored, positive_fraction=None, anchor_images=None):
     """HipCategoryODISE on synthetic weights with NON-DEGENERATE decisions (module docstring; odise_amd/synthetic.py): branch gain, mask
     logits centred from the device's own head outputs on `first_image_u8` (two rounds, each a reload of the 28 M-parameter head), text
     banks spread over the device's own mask / MaskCLIP embeddings.  Everything here happens before the timed region."""
@@ -279,15 +291,28 @@ def calibrated_model(ctx, first_image_u8, S, K, K_TOT, things, anchored):
 
     for _ in range(2):
         pm, _, mf_h = head_pass()
-        shift = syn.mask_bias_shift(syn.mask_embeddings_from(pm, mf_h), pm)
+        shift = syn.mask_bias_shift(syn.mask_embeddings_from(pm, mf_h), pm, MASK_POSITIVE if positive_fraction is None else positive_fraction)
         state["sem_seg_head.pixel_decoder.mask_features.bias"] = (state["sem_seg_head.pixel_decoder.mask_features.bias"] + shift).astype(np.float32)
         hip.reload_head(state)
     pm, me, _ = head_pass()
     for f in feats:
         f.free()
     _, ce = hip.classify_device(img01, want_clip_embed=True)
-    t1, t2, null = syn.spread_vocabulary(me, ce.numpy()[0], sizes, state["category_head.text_proj.weight"], state["category_head.text_proj.bias"],
-                                         anchored=anchored)
+    me_all, ce_all = [me], [ce.numpy()[0]]
+    # `anchor_images` (optional): the text banks' anchor queries drawn from SEVERAL pictures' embeddings.  Measured (tools/segments_calib.py): the tables
+    # get more even but smaller ([2, 4, 6, 3] segments against [18, 4, 2, 12] with picture 0 alone at 1 % positive logits), so the bench does not use it
+    for u in (anchor_images or []):
+        x = ctx.to_device(np.ascontiguousarray(u.transpose(2, 0, 1)[None].astype(np.float32) / 255.0))
+        fx = hip.backbone_device(x)
+        _, me_x, _, _ = hip.head_device(fx, 1, S // 4, S // 4)
+        _, ce_x = hip.classify_device(x, want_clip_embed=True)
+        me_all.append(me_x.numpy()[0])
+        ce_all.append(ce_x.numpy()[0])
+        for f in fx:
+            f.free()
+        x.free()
+    t1, t2, null = syn.spread_vocabulary(np.concatenate(me_all), np.concatenate(ce_all), sizes, state["category_head.text_proj.weight"],
+                                         state["category_head.text_proj.bias"], anchored=anchored, null_queries=6 * len(me_all))
     state["category_head.null_embed"] = null
     hip.load_category_head(state)
     hip.set_vocabulary(t1, t2, sizes, overlap, things, 0.3, 0.7)
@@ -303,6 +328,7 @@ def main():
     os.environ["NCCL_DEBUG"] = os.environ.get("ODISE_NCCL_DEBUG", "WARN")
     rank, world, local_rank = launch.world_from_env()
 
+    t_setup0 = time.perf_counter()
     import torch
     torch.set_num_threads(_threads())
     dist = None
@@ -442,6 +468,8 @@ def main():
             # the vocabulary is spread over the FIRST image's queries: that image must produce segments (the other pictures of the batch are
             # reported; at overlap threshold 0.8 a picture with every mask contested can legitimately keep none)
             assert counts[0] > 0 and sum(counts) > 0, f"empty segment tables: {counts} (degenerate decisions)"
+            if S == 1024 and args.vocab == "coco133" and B >= 4:     # the headline configuration: the decision kernels are timed on real tables
+                assert min(counts) >= 2 and sum(counts) >= 5 * B, f"near-degenerate segment tables: {counts}"
             report.update({"segments_per_image": counts, "segments_image0": counts[0], "records_bytes_per_rank": int(B * rec * 4)})
             return report
         ncrops = (-(-S // 512)) ** 2                                       # slide windows of 512 (feature_extractor.py:197-222): 4 at 1024, 9 at 1280
@@ -466,6 +494,10 @@ def main():
         if dist is not None:
             dist.barrier()
 
+    # set-up is over (weights generated, packed, uploaded and calibrated on every rank): one line per rank, so that a multi-GPU run that dies or crawls
+    # in set-up leaves its cause behind (never exercised at 8 concurrent ranks on one host)
+    print(f"[bench rank {rank}/{world}] set-up {time.perf_counter() - t_setup0:.1f} s, peak host RSS {_peak_rss_gb():.1f} GB, {_threads()} host threads",
+          file=sys.stderr, flush=True)
     n_fly = len(slots) if args.stage == "full" else 1
     single_ms = None
     probe = None

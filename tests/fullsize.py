@@ -284,3 +284,33 @@ def ideal_on_device_features(ext, head, heads, feats_dev, img, tag=None):
     r = dict(_MEMO[key])
     r["mask_cls"] = classify_reference(heads, r)
     return r
+
+
+def reference_instability(ext, head, heads, feats_dev, feats_ref, img, trials=4, seed=1234):
+    """How far the REFERENCE's own class probabilities move, per query, when its backbone features are perturbed by errors of exactly the device's
+    size: the fp32 oracle head + classifier on `feats_ref + s * (feats_dev - feats_ref)` for `trials` random sign patterns s (element-wise +-1;
+    s = +1 everywhere is ideal_on_device_features), against its output on the unperturbed features.  A query whose distribution moves under such
+    a perturbation sits on one of the decoder's hard decisions (attention masks `sigmoid < 0.5` at 9 layers, MaskCLIP's visibility bits): any error
+    of that size - the backbone's or the head's own rounding - can send it either way, in the reference as on the device.
+    feats_*: dict s2..s5 [1, 512, h, w] fp32 (numpy / torch).  -> [Q] max over the trials of max_k |p_perturbed - p_unperturbed|."""
+    img01 = img.float()[None] / 255.0
+    g = torch.Generator().manual_seed(seed)
+
+    def run(feats):
+        with torch.no_grad():
+            out = head(feats)
+            ce = om.mask_clip_embed(ext.clip, img01, out["pred_masks"])
+            r = {"mask_embed": out["mask_embed"], "clip_embed": ce, "logit_scale": float(out["logit_scale"])}
+            return torch.exp(classify_reference(heads, r)[0].double())
+
+    ref = {k: torch.as_tensor(np.ascontiguousarray(feats_ref[k]), dtype=torch.float32) for k in ("s2", "s3", "s4", "s5")}
+    dev = {k: torch.as_tensor(np.ascontiguousarray(feats_dev[k]), dtype=torch.float32) for k in ("s2", "s3", "s4", "s5")}
+    p0 = run(ref)
+    move = torch.zeros(p0.shape[0], dtype=torch.float64)
+    for _ in range(trials):
+        pert = {}
+        for k in ref:
+            sign = torch.randint(0, 2, ref[k].shape, generator=g, dtype=torch.int8).float() * 2 - 1
+            pert[k] = ref[k] + sign * (dev[k] - ref[k])
+        move = torch.maximum(move, (run(pert) - p0).abs().amax(-1))
+    return move.numpy()

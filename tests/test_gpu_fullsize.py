@@ -24,7 +24,7 @@ import pytest
 import torch
 
 from contracts import TAU_PROB, class_probability_contract, end_to_end_contract
-from fullsize import build_models, category_head_state, ideal_on_device_features, reference
+from fullsize import build_models, category_head_state, ideal_on_device_features, reference, reference_instability
 from oracle import odise_model as om
 
 pytestmark = pytest.mark.gpu
@@ -195,7 +195,8 @@ def test_end_to_end_contract(full, ctx, vocab, overlap_threshold):
         use_vocabulary(full, "coco133")
     ext, _, head = build_models(k)
     perr = class_probability_contract(cls_got.numpy()[0], cls_ref[0].numpy(), k, tag=f"vocabulary {vocab} overlap {overlap_threshold}:",
-                                      ideal=lambda: ideal_on_device_features(ext, head, heads, maps, img)["mask_cls"][0].numpy())
+                                      ideal=lambda: ideal_on_device_features(ext, head, heads, maps, img)["mask_cls"][0].numpy(),
+                                      instability=lambda: reference_instability(ext, head, heads, maps, {kk: out_ref[kk] for kk in ("s2", "s3", "s4", "s5")}, img))
     end_to_end_contract(got, ref, cls_ref, k, things, tag=f"vocabulary {vocab} overlap {overlap_threshold}:", perr=perr)
 
 
