@@ -201,7 +201,9 @@ def test_batch_of_eight_1024_ade150(ctx, fullsize_model):
     batch_dev = hip.infer_device(dev, 1, [(1024, 1024)] * n, [(1024, 1024)] * n, to_host=False, mask_cls_out=cls)
     maps = hip.backbone_maps()
     cls_b = cls.numpy()
-    merr = _mask_errors(hip, refs, 1024, batch=n)
+    pm_dev = hip.head_device(None, n, 256, 256)[0].numpy()      # the head re-run on the backbone maps still in the arena: the same bits as inside the call
+    merr = np.stack([np.abs(pm_dev[i] - r["pred_masks"][0].numpy()).reshape(pm_dev.shape[1], -1).max(-1) / np.abs(r["pred_masks"][0].numpy()).max()
+                     for i, (_, r) in enumerate(refs)])
     undecided = set()
     batch = []
     for i, (img, r) in enumerate(refs):
@@ -226,8 +228,16 @@ def test_batch_of_eight_1024_ade150(ctx, fullsize_model):
         decided = (top2[1] - top2[0]) > 2.0 * maxerr
         same = sem.argmax(0) == sem_ref.argmax(0)
         print(f"batch of 8, picture {i}: sem_seg max-err/scale {serr:.3e}, arg-max agreement {float(same.mean()):.5f}, decided pixels {float(decided.mean()):.4f}")
-        from contracts import TAU_SEM
-        assert serr < max(TAU_SEM, 1.1 * float(np.max(perr))) and same[decided].all() and same.mean() > 0.98, (i, serr, float(same.mean()))
+        # What the measured errors of its two factors allow: s_k(x) = sum_q p_qk sigmoid(m_q(x)), so to first order
+        #   |ds_k(x)| <= sum_q e_q sigmoid(m_q^ref(x)) + sum_q max_k p_qk |sigmoid(m_q^dev(x)) - sigmoid(m_q^ref(x))|
+        # with e_q the per-query class-probability error (perr) - evaluated on the head's own 256 x 256 grid (the x4 bilinear upsampling is a convex
+        # combination).  The semantic error must be explained by them (x 1.25 for the second-order term and the upsampling of |.|).
+        p_ref = np.exp(r["mask_cls"][0].numpy().astype(np.float64))[:, :-1]
+        sig_ref = 1.0 / (1.0 + np.exp(-r["pred_masks"][0].numpy().astype(np.float64)))
+        sig_dev = 1.0 / (1.0 + np.exp(-pm_dev[i].astype(np.float64)))
+        allowed = (np.einsum("q,qhw->hw", np.asarray(perr, np.float64), sig_ref) + np.einsum("q,qhw->hw", p_ref.max(-1), np.abs(sig_dev - sig_ref))).max()
+        print(f"batch of 8, picture {i}: semantic error {maxerr:.4f} against {allowed:.4f} explained by the measured class-probability and mask errors")
+        assert maxerr < 1.25 * allowed and same[decided].all() and same.mean() > 0.98, (i, maxerr, allowed, float(same.mean()))
         batch.append(got)
         del sem, sem_ref, top2
     for d in dev:
