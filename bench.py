@@ -516,7 +516,8 @@ def main():
         if probe is not None:
             ctx.probe_arm(True, *probe["shape"], max_launches=4096)
         t0 = time.perf_counter()
-        slots[0]["left"] = args.steps
+        if args.stage == "full":
+            slots[0]["left"] = args.steps
         ctx.timer_start()
         for _ in range(args.steps):
             step()

@@ -769,7 +769,20 @@ __device__ __forceinline__ void gemm_epilogue_wave(const GemmArgs& g, ACC& acc, 
                 // finish the row statistics from the producer's partial sums (gemm_epilogue_f16): the lanes of a row (a group of 8 inside its
                 // chunk lanes) share the P partial pairs - same fixed summation order for every lane of the row, so they agree bit for bit
                 float s1 = 0.f, s2 = 0.f;
-                if (ok) {
+                if (CHW % 8 == 0) {
+                    // the 8 lanes of a row's 64-column part share the work: lane j takes partials j, j + 8, ..., a butterfly over the group adds them and
+                    // the group's first lane's total goes to all of them (the butterfly's association differs from lane to lane: one value per row).
+                    // Every group of a row does the same additions in the same order, so all its lanes - and both forms of this epilogue's callers -
+                    // see one (mean, rstd) per row.  (One lane walking all P partials per item made this loop the slowest part of the CLIP GEMMs.)
+                    if (ok) {
+                        const float2* pp = reinterpret_cast<const float2*>(ln_part) + (int64_t)m * e.ln_P;
+                        for (int i = (lane & 7); i < e.ln_P; i += 8) { const float2 t = pp[i]; s1 += t.x; s2 += t.y; }
+                    }
+#pragma unroll
+                    for (int sft = 1; sft < 8; sft <<= 1) { s1 += __shfl_xor(s1, sft); s2 += __shfl_xor(s2, sft); }
+                    s1 = __shfl(s1, lane & ~7);
+                    s2 = __shfl(s2, lane & ~7);
+                } else if (ok) {
                     const float* pp = ln_part + (int64_t)m * e.ln_P * 2;
                     for (int i = 0; i < e.ln_P; ++i) { s1 += pp[2 * i]; s2 += pp[2 * i + 1]; }
                 }
