@@ -679,6 +679,36 @@ __device__ __forceinline__ void gemm_epilogue_wave(const GemmArgs& g, ACC& acc, 
         }
     };
     if (FIXED) load_cols(n0 + wn * WTN + (lane % CHW) * 8);
+    // Folded LayerNorm, consumer side: finish the statistics of the wave tile's rows ONCE, before the passes - lane l takes rows l, l + 64, ... and
+    // walks the producer's P partial pairs of its row in the fixed order of gemm_epilogue_f16 (the same bits in both forms and in every wave
+    // and block that covers the row).  The item loop fetches a row's pair from the lane that holds it.  (Finished per item - two dependent
+    // global loads in a rolled loop, 16 times per wave tile - this was 35-50 us of the 110-150 us CLIP GEMMs that read LN(x).)
+    constexpr int NH = (WTM + 63) / 64;
+    float ln_rs[NH], ln_r1[NH];
+#pragma unroll
+    for (int h = 0; h < NH; ++h) ln_rs[h] = ln_r1[h] = 0.f;
+    if (ln_part) {
+#pragma unroll
+        for (int h = 0; h < NH; ++h) {
+            const int rw = h * 64 + lane;
+            const int m = m0 + wm * WTM + rw;          // LN_OK: never a halo tile
+            if (rw < WTM && m < g.M) {
+                const float2* pp = reinterpret_cast<const float2*>(ln_part) + (int64_t)m * e.ln_P;
+                float s1 = 0.f, s2 = 0.f;
+#pragma unroll 8
+                for (int i = 0; i < e.ln_P; ++i) { const float2 t = pp[i]; s1 += t.x; s2 += t.y; }
+                const float mean = s1 * e.ln_inv_c;
+                const float var = fmaxf(s2 * e.ln_inv_c - mean * mean, 0.f);
+                const float rstd = rsqrtf(var + e.ln_eps);
+                ln_rs[h] = rstd;
+                ln_r1[h] = -mean * rstd;
+                if (ln_final_out && n0 + wn * WTN == 0) {
+                    ln_final_out[2 * (int64_t)m] = ln_r1[h];
+                    ln_final_out[2 * (int64_t)m + 1] = rstd;
+                }
+            }
+        }
+    }
 #pragma unroll
     for (int ps = 0; ps < WTM / R; ++ps) {
         // ---- stage rows [ps R, ps R + R) of the wave tile (the previous pass's reads are retired: same wave, LDS operations complete in order)
@@ -766,35 +796,15 @@ __device__ __forceinline__ void gemm_epilogue_wave(const GemmArgs& g, ACC& acc, 
             if (ok && e.residual && !geglu) rr8 = *reinterpret_cast<const f16x8*>(e.residual + (int64_t)zb * e.strideR + (int64_t)m * e.ldr + n);
             float alpha = e.alpha, r1 = 0.f, rs = 0.f;
             if (ln_part) {
-                // finish the row statistics from the producer's partial sums (gemm_epilogue_f16): the lanes of a row (a group of 8 inside its
-                // chunk lanes) share the P partial pairs - same fixed summation order for every lane of the row, so they agree bit for bit
-                float s1 = 0.f, s2 = 0.f;
-                if (CHW % 8 == 0) {
-                    // the 8 lanes of a row's 64-column part share the work: lane j takes partials j, j + 8, ..., a butterfly over the group adds them and
-                    // the group's first lane's total goes to all of them (the butterfly's association differs from lane to lane: one value per row).
-                    // Every group of a row does the same additions in the same order, so all its lanes - and both forms of this epilogue's callers -
-                    // see one (mean, rstd) per row.  (One lane walking all P partials per item made this loop the slowest part of the CLIP GEMMs.)
-                    if (ok) {
-                        const float2* pp = reinterpret_cast<const float2*>(ln_part) + (int64_t)m * e.ln_P;
-                        for (int i = (lane & 7); i < e.ln_P; i += 8) { const float2 t = pp[i]; s1 += t.x; s2 += t.y; }
-                    }
+                // this row's (rstd, -mean rstd) sit in the lane that finished them before the first pass (ln_rs / ln_r1 above)
+                const int rw = ps * R + row;
+                float rstd = 0.f;
 #pragma unroll
-                    for (int sft = 1; sft < 8; sft <<= 1) { s1 += __shfl_xor(s1, sft); s2 += __shfl_xor(s2, sft); }
-                    s1 = __shfl(s1, lane & ~7);
-                    s2 = __shfl(s2, lane & ~7);
-                } else if (ok) {
-                    const float* pp = ln_part + (int64_t)m * e.ln_P * 2;
-                    for (int i = 0; i < e.ln_P; ++i) { s1 += pp[2 * i]; s2 += pp[2 * i + 1]; }
+                for (int h = 0; h < NH; ++h) {
+                    const float t = __shfl(ln_rs[h], rw & 63), u = __shfl(ln_r1[h], rw & 63);
+                    if ((rw >> 6) == h) { rstd = t; r1 = u; }
                 }
-                const float mean = s1 * e.ln_inv_c;
-                const float var = fmaxf(s2 * e.ln_inv_c - mean * mean, 0.f);
-                const float rstd = rsqrtf(var + e.ln_eps);
                 alpha *= rstd;
-                r1 = -mean * rstd;
-                if (ln_final_out && n == 0 && ok) {
-                    ln_final_out[2 * (int64_t)m] = r1;
-                    ln_final_out[2 * (int64_t)m + 1] = rstd;
-                }
             }
             if (ok) {
                 if (e.scale_m) alpha *= e.scale_m[m];
