@@ -37,11 +37,14 @@ struct DecLayerW {
     NormW ffn_norm;
 };
 
-struct MaskGenModel {
-    std::vector<void*> owned_backbone, owned_head;   // device weights of the two separately (re)buildable halves (AllocScope)
-    bool backbone_built = false, head_built = false;
+// Device weights of the two separately (re)buildable halves.  Kept as base structs of the model so that a rebuild can assemble a complete new
+// set on the side and put it in place only when every key was found and every upload succeeded: a failed reload (a checkpoint with a missing
+// or misshapen tensor) leaves the previous weights in place and usable.
+struct BackboneW {
     BottleneckW proj[8];
     int proj_dim = 512;
+};
+struct HeadW {
     // pixel decoder
     ConvW in_proj[3];
     NormW in_proj_gn[3];
@@ -60,6 +63,13 @@ struct MaskGenModel {
     NormW pool_ln, post_ln;
     float logit_scale = 0.f;
     int Q = 100, dec_heads = 8;
+    bool has_class_embed = false;  // CaptionODISE: learned Linear(C, 2) on the decoder output (mask2former_transformer_decoder.py:333)
+    LinW class_embed;
+};
+
+struct MaskGenModel : BackboneW, HeadW {
+    std::vector<void*> owned_backbone, owned_head;   // what the two halves allocated on the device (AllocScope)
+    bool backbone_built = false, head_built = false;
     // Per-size device tables, kept in small LRU caches keyed by the EXACT shapes: a dataset evaluation sees many aspect ratios, and every
     // size used to cost a fresh hipMalloc that was never freed (40 MB of positional tables per size change at 1024^2).  A hit costs nothing;
     // a miss uploads one set and, beyond kSizeCache entries, frees the least recently used one (after a stream sync: queued kernels may
@@ -95,8 +105,6 @@ struct MaskGenModel {
     f16* pred_masks = nullptr;   // [B, Q, H4*W4] logits
     f16* mask_embed = nullptr;   // [B, Q, C]
     f16* mask_pooled = nullptr;  // [B, Q, C]
-    bool has_class_embed = false;  // CaptionODISE: learned Linear(C, 2) on the decoder output (mask2former_transformer_decoder.py:333)
-    LinW class_embed;
     float* class_logits = nullptr;  // [B, Q, 2] of the final prediction head
     int out_B = 0, out_h = 0, out_w = 0;
     double last_macs = 0.0;
@@ -152,12 +160,8 @@ static int build_mha(Packer& pk, const std::string& key, MhaW& m, int C, bool st
     return ODISE_OK;
 }
 
-static int maskgen_build_backbone(odise_hip_ctx* ctx) {
-    ModelStore* ms = store_of(ctx);
-    MaskGenModel* g = maskgen_of(ms);
-    g->backbone_built = false;
-    free_allocs(g->owned_backbone);   // a rebuild (reload of the projections) replaces the previous weights
-    AllocScope scope(ms, g->owned_backbone);
+static int build_backbone_weights(odise_hip_ctx* ctx, ModelStore* ms, BackboneW* g, std::vector<void*>& owned) {
+    AllocScope scope(ms, owned);
     Packer pk{ctx, ms, "backbone.feature_projections.", ""};
     for (int i = 0; i < 8; ++i) {
         const std::string k = std::to_string(i) + ".0";
@@ -169,16 +173,28 @@ static int maskgen_build_backbone(odise_hip_ctx* ctx) {
         if (b.has_sc) ODISE_TRY(build_convnorm(pk, k + ".shortcut", b.sc, b.nsc));
     }
     g->proj_dim = g->proj[0].c3.cout;
+    return ODISE_OK;
+}
+
+static int maskgen_build_backbone(odise_hip_ctx* ctx) {
+    ModelStore* ms = store_of(ctx);
+    MaskGenModel* g = maskgen_of(ms);
+    BackboneW fresh;
+    std::vector<void*> owned;
+    const int rc = build_backbone_weights(ctx, ms, &fresh, owned);
+    if (rc != ODISE_OK) {   // the previous projections (if any) stay in place
+        free_allocs(owned);
+        return rc;
+    }
+    free_allocs(g->owned_backbone);   // device-synchronising: nothing queued still reads the weights this rebuild replaces
+    g->owned_backbone.swap(owned);
+    static_cast<BackboneW&>(*g) = fresh;
     g->backbone_built = true;
     return ODISE_OK;
 }
 
-static int maskgen_build_head(odise_hip_ctx* ctx) {
-    ModelStore* ms = store_of(ctx);
-    MaskGenModel* g = maskgen_of(ms);
-    g->head_built = false;
-    free_allocs(g->owned_head);       // reload_head(): the previous head's ~56 MB of weights are released, not kept until the context dies
-    AllocScope scope(ms, g->owned_head);
+static int build_head_weights(odise_hip_ctx* ctx, ModelStore* ms, HeadW* g, std::vector<void*>& owned) {
+    AllocScope scope(ms, owned);
     Packer pk{ctx, ms, "sem_seg_head.pixel_decoder.", ""};
     for (int i = 0; i < 3; ++i) {
         ODISE_TRY(pk.conv("input_proj." + std::to_string(i) + ".0", g->in_proj[i]));
@@ -187,8 +203,6 @@ static int maskgen_build_head(odise_hip_ctx* ctx) {
     g->C = g->in_proj[0].cout;
     const int C = g->C;
     ODISE_TRY(pk.vec_f32("transformer.level_embed", &g->enc_level_embed, 3 * C));
-    ODISE_CHECK_HIP(hipStreamSynchronize(ctx->stream));
-    g->drop_size_caches();  // PE + level_embed tables are derived from these weights: a rebuilt head must not reuse the previous model's
     g->enc_layers.clear();
     for (int i = 0;; ++i) {
         const std::string k = "transformer.encoder.layers." + std::to_string(i);
@@ -267,6 +281,23 @@ static int maskgen_build_head(odise_hip_ctx* ctx) {
         return ODISE_ERR_STATE;
     }
     g->logit_scale = std::min(expf(ls->data[0]), 100.0f);  // torch.clamp(logit_scale.exp(), max=100)  (odise.py:1004)
+    return ODISE_OK;
+}
+
+static int maskgen_build_head(odise_hip_ctx* ctx) {
+    ModelStore* ms = store_of(ctx);
+    MaskGenModel* g = maskgen_of(ms);
+    HeadW fresh;
+    std::vector<void*> owned;
+    const int rc = build_head_weights(ctx, ms, &fresh, owned);
+    if (rc != ODISE_OK) {   // reload_head() with an incomplete checkpoint: the previous head stays in place and usable
+        free_allocs(owned);
+        return rc;
+    }
+    free_allocs(g->owned_head);   // device-synchronising; the previous head's ~56 MB of weights are released, not kept until the context dies
+    g->owned_head.swap(owned);
+    g->drop_size_caches();        // PE + level_embed tables are derived from these weights: a rebuilt head must not reuse the previous model's
+    static_cast<HeadW&>(*g) = std::move(fresh);
     g->head_built = true;
     return ODISE_OK;
 }

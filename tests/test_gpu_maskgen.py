@@ -8,6 +8,7 @@ import numpy as np
 import pytest
 import torch
 
+from odise_amd._lib import check
 from odise_amd.pipeline import HipODISE
 from oracle.backbone import FeatureExtractorBackbone, crop_boxes
 from oracle.ldm_extractor import ImplicitCaptionerExtractor
@@ -94,3 +95,29 @@ def test_small_backbone_then_head_end_to_end(small_models):
     got = hip.head(None, image_hw=(1, 512, 1024))
     _cmp("e2e pred_masks", got["pred_masks"], ref["pred_masks"].numpy(), tol=8e-2, cos_min=0.99)
     _cmp("e2e mask_embed", got["mask_embed"], ref["mask_embed"].numpy(), tol=8e-2, cos_min=0.99)
+
+
+def test_failed_head_reload_keeps_the_previous_head(small_models):
+    """reload_head() with an incomplete checkpoint (a missing key used to leave the context without a head): the library assembles
+    the new weights on the side and swaps them in only when every tensor was found, so the previous head keeps answering - bit for bit - and a
+    complete reload afterwards works; the same for the tap projections."""
+    _, head, hip = small_models
+    g = torch.Generator().manual_seed(11)
+    feats = {k: torch.randn(1, 512, 64 >> i, 64 >> i, generator=g).numpy() for i, k in enumerate(("s2", "s3", "s4", "s5"))}
+    before = hip.head(feats)
+    full = {"sem_seg_head." + k: v for k, v in head.state_dict().items()}
+    broken = {k: v for k, v in full.items() if "post_mask_embed.logit_scale" not in k}     # the LAST tensor the build asks for: everything else uploads first
+    with pytest.raises(RuntimeError, match="logit_scale"):
+        hip.reload_head(broken)
+    hip.ctx.lib.odise_hip_clear_host_weights(hip.ctx.h)
+    after = hip.head(feats)
+    for k in ("pred_masks", "mask_embed", "mask_pooled_features"):
+        assert np.array_equal(before[k], after[k]), k
+    hip.reload_head(full)
+    again = hip.head(feats)
+    for k in ("pred_masks", "mask_embed", "mask_pooled_features"):
+        assert np.array_equal(before[k], again[k]), k
+    with pytest.raises(RuntimeError):      # no backbone.feature_projections.* in the host store: the projections in place must survive
+        check(hip.ctx.lib.odise_hip_backbone_build(hip.ctx.h), "backbone_build")
+    img = _image(1, 256, 256, seed=3)
+    assert np.isfinite(hip.backbone(img.numpy())["s2"]).all()
