@@ -1,5 +1,6 @@
-"""The bench line the driver parses: every committed `profiles/r04_bench_*.json` (rank 0's one JSON line of a `bench.py` run on an MI355X, final
-round-4 binary) carries the keys of the measurement contract, with consistent arithmetic.  CPU only: guards the format, not the numbers."""
+"""The bench line the driver parses: every committed `profiles/r04_bench_*.json` / `r05_bench_*.json` (rank 0's one JSON line of a `bench.py` run on
+an MI355X, final binaries of the two rounds) carries the keys of the measurement contract, with consistent arithmetic.  CPU only: guards the
+format, not the numbers."""
 import glob
 import json
 import os
@@ -7,12 +8,12 @@ import os
 import pytest
 
 ROOT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..")
-LINES = sorted(glob.glob(os.path.join(ROOT, "profiles", "r04_bench_*.json")))
+LINES = sorted(glob.glob(os.path.join(ROOT, "profiles", "r04_bench_*.json")) + glob.glob(os.path.join(ROOT, "profiles", "r05_bench_*.json")))
 
 
 def test_profiles_present():
     """Its own test, not a condition inside the parametrized one: a missing or renamed profile set must fail, not generate zero cases."""
-    assert len(LINES) >= 8, LINES
+    assert len(LINES) >= 8 + 12, LINES
 
 
 @pytest.mark.parametrize("path", LINES, ids=[os.path.basename(p) for p in LINES])
@@ -61,3 +62,21 @@ def test_in_flight_line_says_so():
     d = json.load(open(os.path.join(ROOT, "profiles", "r04_bench_full_b4_1024_in_flight2.json")))
     assert d["config"]["batches_in_flight"] == 2 and d["config"]["one_batch_alone_ms"] > 0
     assert "in_flight_1" in d["exchange"]
+
+
+def test_round5_headline_and_its_same_box_variants():
+    """Round 5: the headline line, the two same-box A/B lines (block-wide epilogues; round 4's MFMA shape) and the encoder-prefetch line say what
+    they are in `config`, and the decisions the timed kernels made cover several segments per picture (bench.py check_exchange)."""
+    load = lambda n: json.load(open(os.path.join(ROOT, "profiles", n)))
+    d = load("r05_bench_full_b4_1024.json")
+    assert d["config"]["gemm_flags"] == 0 and d["config"]["pipeline"] is None and d["config"]["batches_in_flight"] == 1
+    assert d["config"]["vae_chunk_bytes"] == 0 and d["config"]["clip_ln_fold"] == 0
+    seg = d["exchange"]["segments_per_image"]
+    assert len(seg) == 4 and min(seg) >= 2 and sum(seg) >= 5 * 4, seg
+    c = d["cpu_baseline"]
+    assert c["kind"] == "port" and 0 < c["value"] < d["value"] / 100                      # the GPU / CPU ratio is reported, not the target
+    blk, m32, pf = (load("r05_bench_full_b4_1024_" + n + ".json") for n in ("block_epilogues", "mfma32_block_epilogues", "encoder_prefetch"))
+    assert blk["config"]["gemm_flags"] == 32768 and m32["config"]["gemm_flags"] == 32768
+    assert m32["ms_per_step"] > blk["ms_per_step"] > d["ms_per_step"]                     # what each of the two kernel changes is worth, one box
+    assert pf["config"]["pipeline"].startswith("encoder-prefetch") and pf["config"]["batches_in_flight"] == 1
+    assert 0.95 * d["ms_per_step"] < pf["ms_per_step"] < d["ms_per_step"]                 # work-conserving: a percent, not the idle lane's 14 ms
