@@ -180,7 +180,8 @@ static int build_clip_block(Packer& pk, const std::string& key, ClipBlock& b, in
 
 static int extractor_build(odise_hip_ctx* ctx) {
     ModelStore* ms = store_of(ctx);
-    extractor_destroy(ms);
+    extractor_destroy(ms);   // (device-synchronising: a prefetch in flight has finished)
+    ms->pf.has_pending = ms->pf.has_ready = ms->pf.use_now = false;   // an encoder result of the previous weights must not be consumed
     ExtractorModel* e = new ExtractorModel();
     ms->extractor = e;
     // ---- UNet --------------------------------------------------------------------------------------------------
@@ -763,6 +764,7 @@ int extractor_launch(odise_hip_ctx* ctx, ModelStore* ms, const float* image, int
     // ---- VAE encoder + latent: computed here, or taken from the prefetch the previous call ran for this batch ---------------------------
     EncoderOut enc;
     const bool prefetched = ms->pf.use_now && !standalone && ms->pf.crops == B;
+    ms->pf.use_now = false;   // consumed once, whatever happens below
     if (prefetched) {
         enc = ms->pf.out;
         ODISE_CHECK_HIP(hipStreamWaitEvent(ctx->stream, ctx->ev_pf_done, 0));
