@@ -117,7 +117,10 @@ def class_probability_contract(got_logp, ref_logp, k, tag="", min_decided=50, mi
     oracle.  One exception, with proof: a query beyond TAU_PROB against the ideal head too must be one the REFERENCE ITSELF does not decide stably -
     `instability` (array [Q] or callable): how far the fp32 oracle's own probabilities move under backbone perturbations of exactly the device's
     size in random directions (fullsize.reference_instability); every such query must move by more than TAU_PROB / 2 there.
-    Labels: identical on every query whose reference top-2 margin exceeds twice that query's own measured error.
+    Labels: identical on every query whose reference top-2 margin exceeds twice that query's own measured error - which follows from the error
+    bound itself (two probabilities that move by at most e cannot swap across a gap of more than 2 e), so that assertion only guards the
+    bookkeeping; what it adds is `min_decided`: the reference must decide at least that many queries by such a margin, i.e. the error bound
+    must actually pin their labels (a reference of near-ties would satisfy every bound and test nothing).
     Returns the per-query errors e_q against the pure oracle."""
     p_ref, p_got = np.exp(np.asarray(ref_logp, np.float64).reshape(-1, k + 1)), np.exp(np.asarray(got_logp, np.float64).reshape(-1, k + 1))
     eprob = np.abs(p_got - p_ref).max(-1)
