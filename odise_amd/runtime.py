@@ -129,8 +129,8 @@ class Context:
 
     def stage_timeline_read(self):
         """[(name, gpu_ms, host_ms)] of the stage boundaries since stage_timeline(True), relative to the first."""
-        cap = 512
-        names = C.create_string_buffer(1 << 16)
+        cap = 8192
+        names = C.create_string_buffer(1 << 20)
         g = (C.c_float * cap)()
         h = (C.c_double * cap)()
         n = C.c_int()
