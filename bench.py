@@ -71,6 +71,7 @@ def parse():
     p.add_argument("--clip-ln-fold", type=int, default=0, choices=[0, 1, 2], help="A/B: the CLIP towers' LayerNorm fold, 0 = the library's rule, 1 = always, 2 = never")
     p.add_argument("--vae-chunk-mb", type=float, default=None, help="A/B: ODISE_OPT_VAE_CHUNK_BYTES in MiB (0 = all crops per launch; default: the library's)")
     p.add_argument("--attn-kvres", type=int, default=1, choices=[0, 1], help="A/B: 0 = the CLIP towers' attention on the tiled kernel instead of the K/V-resident one")
+    p.add_argument("--attn-sa", type=int, default=1, choices=[0, 1], help="A/B: 0 = the UNet's self-attention on the tiled kernel instead of the software-pipelined one")
     p.add_argument("--pipeline", action="store_true", help="encoder prefetch (odise_hip_infer_prefetch): the steps alternate between two resident sets of "
                    "--images pictures, and every model call enqueues the OTHER set's input side + VAE encoder behind its own VAE lane on a low-priority "
                    "stream; the next call starts from that latent.  Outputs are bit-identical to the plain call; every step is still one synchronous call")
@@ -393,8 +394,8 @@ def main():
     if args.pipeline:
         ctx.set_option(ctx.OPT_PREFETCH_CU_EIGHTHS, args.prefetch_cus)
         ctx.set_option(ctx.OPT_PREFETCH_START, args.prefetch_start)
-    if not args.attn_kvres:
-        ctx.set_option(ctx.OPT_ATTN_KV_RESIDENT, 2)
+    if not args.attn_kvres or not args.attn_sa:
+        ctx.set_option(ctx.OPT_ATTN_KV_RESIDENT, (0 if args.attn_kvres else 2) | (0 if args.attn_sa else 4))
     if args.vae_chunk_mb is not None:
         ctx.set_option(ctx.OPT_VAE_CHUNK_BYTES, int(args.vae_chunk_mb * (1 << 20)))
     B = args.images if args.images is not None else (4 if args.stage == "full" else 1)

@@ -73,8 +73,11 @@ int odise_hip_device_info(odise_hip_ctx* ctx, char* name_buf, int buf_len, int* 
  *   ODISE_OPT_PREFETCH_START   where the next batch's encoder is enqueued: 0 = behind the current batch's VAE lane, 1 (default) = behind its
  *                              backbone, i.e. beside the serial tail of small launches (pixel decoder .. post-processing)
  *   ODISE_OPT_ATTN_KV_RESIDENT 0 (default) = attention with d_head 64 and at most 608 keys runs the K / V^T-resident kernel where (head, image)
- *                              pairs fill the chip in whole rounds (the CLIP tower of 16 / 32 crops), the tiled kernel elsewhere; 2 = always the
- *                              tiled kernel.  The two forms step the running softmax maximum per 32 / per 64 keys: results agree to fp32 rounding. */
+ *                              pairs fill the chip in whole rounds (the CLIP tower of 16 / 32 crops), unmasked self-attention over whole
+ *                              128-query / 64-key tiles (the SD UNet's 64^2 and 32^2 levels) the software-pipelined kernel, the tiled kernel
+ *                              elsewhere; 2 = never the K / V^T-resident kernel, 4 = never the pipelined one, 6 = always the tiled kernel.  The
+ *                              resident form steps the running softmax maximum per 32 instead of 64 keys (results agree to fp32 rounding);
+ *                              the pipelined form is bit-identical to the tiled one. */
 enum { ODISE_OPT_CLIP_LN_FOLD = 1, ODISE_OPT_VAE_CHUNK_BYTES = 2, ODISE_OPT_ATTN_KV_RESIDENT = 3, ODISE_OPT_PREFETCH_CU_EIGHTHS = 4, ODISE_OPT_PREFETCH_START = 5 };
 int odise_hip_set_option(odise_hip_ctx* ctx, int option, int64_t value);
 int odise_hip_get_option(odise_hip_ctx* ctx, int option, int64_t* value);

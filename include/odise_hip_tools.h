@@ -52,6 +52,11 @@ int odise_hip_sem_tile(int tile);
 int odise_hip_stage_timeline(odise_hip_ctx* ctx, int on);
 int odise_hip_stage_timeline_read(odise_hip_ctx* ctx, char* names, int names_cap, float* gpu_ms, double* host_ms, int cap, int* n);
 
+/* encoder prefetch (odise_hip_infer_prefetch), what happened so far on this context: encoders enqueued ahead of their batch, prefetched results the
+ * next odise_hip_infer consumed (hits), prepared results that were dropped because another batch came next, registrations that could not be
+ * enqueued (the call in progress is unaffected).  Any pointer may be NULL.  tests/test_gpu_fullsize_batch.py asserts hit / drop per call. */
+int odise_hip_prefetch_stats(odise_hip_ctx* ctx, int* enqueued, int* hits, int* dropped, int* failed);
+
 /* per-context log of every GEMM / convolution launch the cost model decided (tests print which choices differ between two batch sizes):
  * odise_hip_launch_log(ctx, 1) starts / clears it, (ctx, 0) drops it; _read copies records of 6 ints (conv, M, N, K, tile id, split-K factor) */
 int odise_hip_launch_log(odise_hip_ctx* ctx, int on);

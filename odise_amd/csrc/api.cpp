@@ -174,7 +174,7 @@ extern "C" int odise_hip_set_option(odise_hip_ctx* ctx, int option, int64_t valu
             ctx->clip_ln_fold = (int)value;
             return ODISE_OK;
         case ODISE_OPT_ATTN_KV_RESIDENT:
-            ODISE_REQUIRE(value == 0 || value == 2, "set_option: ATTN_KV_RESIDENT takes 0 (the library's rule) or 2 (never)");
+            ODISE_REQUIRE(value >= 0 && value <= 7 && !(value & 1), "set_option: ATTN_KV_RESIDENT takes 0 (the library's rules), 2 (never the K/V-resident kernel), 4 (never the pipelined self-attention kernel) or 6");
             ctx->attn_kv_resident = (int)value;
             return ODISE_OK;
         case ODISE_OPT_VAE_CHUNK_BYTES:

@@ -475,7 +475,7 @@ __global__ void __launch_bounds__(64 * KVR_WAVES) attn_kvres_kernel(AttnArgs a, 
 // 148 KB prologue per block for too few query tiles (MaskCLIP on 4 pictures): the tiled kernel keeps those (tools/attn_bench.py).
 static bool attn_kvres_ok(const odise_hip_ctx* ctx, const AttnArgs& a) {
     const int cus = ctx->cu_count;
-    if (ctx->attn_kv_resident == 2) return false;   // ODISE_OPT_ATTN_KV_RESIDENT: never
+    if (ctx->attn_kv_resident & 2) return false;   // ODISE_OPT_ATTN_KV_RESIDENT bit 1: never
     if (ctx->max_lds_optin < KVR_LDS) return false; // a device (or partition) that cannot give one block 152.5 KiB of LDS keeps the tiled kernel
     if (!(a.D == 64 && a.Lk >= 256 && a.Lk <= KVR_LKP && a.Lq >= 256)) return false;
     const int64_t pairs = (int64_t)a.B * a.H;
@@ -499,6 +499,240 @@ static int launch_attn_kvres(odise_hip_ctx* ctx, AttnArgs& a) {
     hipLaunchKernelGGL(attn_kvres_kernel<KVR_WAVES>, grid, dim3(64 * KVR_WAVES), KVR_LDS, ctx->stream, a, qsplit);
     ODISE_CHECK_HIP(hipGetLastError());
     return ODISE_OK;
+}
+
+// ---- software-pipelined self-attention (round 6): UNet SpatialTransformer self-attention, 4096 / 1024 tokens, d_head 40 / 80 ---------------
+// The tiled kernel above runs a wave's tile as a serial chain - stage, barrier, S^T MFMAs, softmax on the VALU, O^T MFMAs, barrier - and at
+// d_head 40 the VALU part alone (32 scores per lane and 64-key tile: max3, packed scale, v_exp_f32 at quarter rate, packed sum, packed
+// convert: ~800 issue cycles) is 1.8x the 14 MFMAs (448 cycles): measured 886 us on the 16-crop 64^2 level, i.e. ~1700 cycles per wave
+// tile - VALU, MFMA, LDS round trips and two barriers back to back.  Here the S^T MFMAs of tile t+1 are issued BEFORE the softmax of tile
+// t (a second accumulator set, +32 VGPRs) and the O^T MFMAs of tile t right after it, so the matrix pipe works underneath the VALU stretch
+// of the same wave instead of between two of them; K is double- and V^T triple-buffered in LDS so that ONE barrier per tile orders
+// everything: at the top of iteration t every wave has finished iteration t-1 (its reads of K[t] and V[t-1]), tile t+2 goes from the
+// prefetch registers into the buffers those reads released, and tile t+3's global loads are issued.  Same arithmetic per score in the
+// same order as attn_kernel (bit-identical results).  Preconditions (attn_sa_ok): no mask, no key split, Lk % 128 == 0,
+// Lq % 128 == 0.
+template <int DPAD>
+__global__ void __launch_bounds__(256) attn_sa_kernel(AttnArgs a) {
+    constexpr int KS = DPAD / 16;          // MFMA k-steps of QK^T
+    constexpr int DT = (DPAD + 31) / 32;   // 32-row d tiles of O^T
+    constexpr int KROW = DPAD + 8;         // halves per K row in LDS
+    constexpr int VROW = 64 + 4;           // halves per V^T row in LDS
+    constexpr int KSLOTS = DPAD / 8;       // 16-byte slots per K row
+    constexpr int KHALVES = 64 * KROW, VHALVES = DT * 32 * VROW;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    f16* Ks = reinterpret_cast<f16*>(smem);                  // [2][64][KROW]
+    f16* Vs = Ks + 2 * KHALVES;                              // [3][DT*32][VROW]
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int hi = lane >> 5, l31 = lane & 31;
+    const int b = blockIdx.z, h = blockIdx.y;
+    const int q = blockIdx.x * 128 + wave * 32 + l31;  // this lane's query (always < Lq)
+    const int D = a.D;
+    const f16* Qb = a.Q + (int64_t)b * a.strideQ + (int64_t)h * D;
+    const f16* Kb = a.K + (int64_t)b * a.strideK + (int64_t)h * D;
+    const f16* Vb = a.Vt + (int64_t)b * a.strideVt + (int64_t)h * D * a.ldvt;
+    const f16x8 zero8 = {0, 0, 0, 0, 0, 0, 0, 0};
+
+    f16x8 qf[KS];
+#pragma unroll
+    for (int s = 0; s < KS; ++s) {
+        const int d0 = s * 16 + hi * 8;
+        qf[s] = zero8;
+        if (d0 < D) qf[s] = *reinterpret_cast<const f16x8*>(Qb + (int64_t)q * a.ldq + d0);
+    }
+    f32x16 ot[DT];
+#pragma unroll
+    for (int t = 0; t < DT; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) ot[t][r] = 0.f;
+    float m_run = -INFINITY, l_run = 0.f;
+    const int ntiles = a.Lk >> 6;
+
+    constexpr int NKR = (64 * KSLOTS + 255) / 256;  // 16-byte K slots per thread
+    constexpr int NVR = DT;                         // 16-byte V^T slots per thread
+    f16x8 kreg[NKR], vreg[NVR];
+    // Unconditional loads from clamped (always valid) addresses, zeroed by a select: a branch per load would make the compiler wait for
+    // each load before it issues the next one.  The pad slots (d >= D) are staged as zeros every tile.
+    int64_t koff[NKR], voff[NVR];
+    bool kval[NKR], vval[NVR];
+#pragma unroll
+    for (int u = 0; u < NKR; ++u) {
+        const int c = tid + u * 256;
+        const int key = c / KSLOTS, sl = c - key * KSLOTS;
+        kval[u] = c < 64 * KSLOTS && sl * 8 < D;
+        koff[u] = (int64_t)min(key, 63) * a.ldk + min(sl * 8, D - 8);
+    }
+#pragma unroll
+    for (int u = 0; u < NVR; ++u) {
+        const int c = tid + u * 256;
+        const int d = c >> 3, sl = c & 7;
+        vval[u] = d < D;
+        voff[u] = (int64_t)min(d, D - 1) * a.ldvt + sl * 8;
+    }
+    auto fetch = [&](int kt) {
+        const f16* Kt = Kb + (int64_t)kt * 64 * a.ldk;
+        const f16* Vt_ = Vb + kt * 64;
+#pragma unroll
+        for (int u = 0; u < NKR; ++u) kreg[u] = *reinterpret_cast<const f16x8*>(Kt + koff[u]);
+#pragma unroll
+        for (int u = 0; u < NVR; ++u) vreg[u] = *reinterpret_cast<const f16x8*>(Vt_ + voff[u]);
+    };
+    auto stage = [&](f16* Kd, f16* Vd) {
+#pragma unroll
+        for (int u = 0; u < NKR; ++u) {
+            const int c = tid + u * 256;
+            const int key = c / KSLOTS, sl = c - key * KSLOTS;
+            if (c < 64 * KSLOTS) *reinterpret_cast<f16x8*>(Kd + key * KROW + sl * 8) = kval[u] ? kreg[u] : zero8;   // (wave-uniform predicate)
+        }
+#pragma unroll
+        for (int u = 0; u < NVR; ++u) {
+            const int c = tid + u * 256;
+            const int d = c >> 3, sl = c & 7;
+            const f16x8 v = vval[u] ? vreg[u] : zero8;
+            const f16x4 lo4 = {v[0], v[1], v[2], v[3]}, hi4 = {v[4], v[5], v[6], v[7]};
+            *reinterpret_cast<f16x4*>(Vd + d * VROW + sl * 8) = lo4;       // V^T rows are 136 B apart: two 8-byte halves
+            *reinterpret_cast<f16x4*>(Vd + d * VROW + sl * 8 + 4) = hi4;
+        }
+    };
+    // S^T = K Q^T for the two 32-key halves of a tile
+    auto qk = [&](const f16* Kt, f32x16 (&st)[2]) {
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) st[t][r] = 0.f;
+#pragma unroll
+            for (int s = 0; s < KS; ++s) {
+                const f16x8 kf = *reinterpret_cast<const f16x8*>(Kt + (t * 32 + l31) * KROW + s * 16 + hi * 8);
+                st[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf, qf[s], st[t], 0, 0, 0);
+            }
+        }
+    };
+    typedef float f32x2 __attribute__((ext_vector_type(2)));
+    // online softmax of one tile's scores (this lane: one query, 32 of the 64 keys) and O^T += V^T P^T
+    auto softmax_pv = [&](f32x16 (&st)[2], const f16* Vt_) {
+        float mx = fmaxf(fmaxf(st[0][0], st[0][1]), st[0][2]);
+#pragma unroll
+        for (int r = 3; r < 15; r += 2) mx = fmaxf(fmaxf(mx, st[0][r]), st[0][r + 1]);
+        mx = fmaxf(fmaxf(mx, st[0][15]), st[1][0]);
+#pragma unroll
+        for (int r = 1; r < 15; r += 2) mx = fmaxf(fmaxf(mx, st[1][r]), st[1][r + 1]);
+        mx = fmaxf(mx, st[1][15]);
+        mx = fmaxf(mx, __shfl_xor(mx, 32)) * a.scale_log2e;
+        const float m_new = fmaxf(m_run, mx);
+        const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);  // m_run = -inf -> 0 (m_new is finite: no mask)
+        const f32x2 sc2 = {a.scale_log2e, a.scale_log2e}, nm2 = {-m_new, -m_new};
+        f32x2 ps2 = {0.f, 0.f};
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int r = 0; r < 16; r += 2) {
+                const f32x2 x = {st[t][r], st[t][r + 1]};
+                const f32x2 y = __builtin_elementwise_fma(x, sc2, nm2);
+                const f32x2 p = {__builtin_amdgcn_exp2f(y[0]), __builtin_amdgcn_exp2f(y[1])};
+                st[t][r] = p[0];
+                st[t][r + 1] = p[1];
+                ps2 += p;
+            }
+        l_run = l_run * alpha + (ps2[0] + ps2[1]);
+        m_run = m_new;
+        if (__builtin_amdgcn_ballot_w64(alpha != 1.0f) != 0) {
+#pragma unroll
+            for (int t = 0; t < DT; ++t)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) ot[t][r] *= alpha;
+        }
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+#pragma unroll
+            for (int s2 = 0; s2 < 2; ++s2) {
+                f16x8 pf;
+#pragma unroll
+                for (int i = 0; i < 8; ++i) pf[i] = (f16)st[t][8 * s2 + i];
+                const int kA = t * 32 + 16 * s2 + 4 * hi, kB = kA + 8;
+#pragma unroll
+                for (int dt = 0; dt < DT; ++dt) {
+                    const f16* vr = Vt_ + (dt * 32 + l31) * VROW;
+                    const f16x4 va = *reinterpret_cast<const f16x4*>(vr + kA);
+                    const f16x4 vb = *reinterpret_cast<const f16x4*>(vr + kB);
+                    const f16x8 vf = {va[0], va[1], va[2], va[3], vb[0], vb[1], vb[2], vb[3]};
+                    ot[dt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf, pf, ot[dt], 0, 0, 0);
+                }
+            }
+        }
+    };
+
+    // ---- prologue: tiles 0 and 1 into LDS, tile 2 into the prefetch registers, S^T of tile 0
+    fetch(0);
+    stage(Ks, Vs);
+    fetch(1);
+    stage(Ks + KHALVES, Vs + VHALVES);
+    fetch(min(2, ntiles - 1));
+    __syncthreads();
+    f32x16 sa[2], sb[2];
+    qk(Ks, sa);
+    // iteration t: scores of tile t are in `cur` (issued one iteration ago), tile t+1 is computed into `nxt`.  vcur / vfree: the V^T buffers of
+    // tile t and of tile t+2 (= the one tile t-1 released), walked as run-time offsets so that the loop is NOT unrolled by its buffer period
+    // (2 x 3 copies of a 600-instruction body would not fit the instruction cache)
+    int vcur = 0, vfree = 2 * VHALVES;
+    auto iteration = [&](int t, f32x16 (&cur)[2], f32x16 (&nxt)[2]) {
+        __syncthreads();   // every wave is done with iteration t-1: K[t] (buffer t & 1) and V[t-1] are free, K / V of tile t+1 are visible
+        // The body is branch-free: in the last iterations the staging writes land in buffers nobody reads any more, the prefetch re-reads the
+        // last tile and the S^T of the tile "after the last" is computed from stale (finite) LDS and never used - cheaper than the loop
+        // versions the compiler builds around three conditions (19k lines of ISA, beyond the instruction cache).
+        stage(Ks + (t & 1) * KHALVES, Vs + vfree);
+        fetch(min(t + 3, ntiles - 1));
+        qk(Ks + ((t + 1) & 1) * KHALVES, nxt);
+        __builtin_amdgcn_sched_barrier(0);   // the S^T MFMAs of tile t+1 stay ahead of the softmax of tile t
+        softmax_pv(cur, Vs + vcur);
+        vfree = vcur;                         // V[t] is released when every wave has passed the next barrier; tile t+3 goes there
+        vcur = vcur + VHALVES == 3 * VHALVES ? 0 : vcur + VHALVES;
+    };
+#pragma unroll 1
+    for (int t = 0; t < ntiles; t += 2) {     // Lk % 128 == 0: whole pairs of tiles
+        iteration(t, sa, sb);
+        iteration(t + 1, sb, sa);
+    }
+
+    const float l_tot = l_run + __shfl_xor(l_run, 32);
+    const float inv = l_tot > 0.f ? 1.f / l_tot : 0.f;
+    f16* Ob = a.O + (int64_t)b * a.strideO + (int64_t)q * a.ldo + (int64_t)h * D;
+#pragma unroll
+    for (int dt = 0; dt < DT; ++dt) {
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const int d0 = dt * 32 + 8 * g + 4 * hi;
+            if (d0 < D) {
+                f16x4 o;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) o[i] = (f16)(ot[dt][4 * g + i] * inv);
+                *reinterpret_cast<f16x4*>(Ob + d0) = o;
+            }
+        }
+    }
+}
+
+template <int DPAD>
+static int launch_attn_sa(odise_hip_ctx* ctx, AttnArgs& a) {
+    constexpr int DT = (DPAD + 31) / 32;
+    constexpr int LDS = 2 * 64 * (DPAD + 8) * 2 + 3 * DT * 32 * 68 * 2;
+    a.nsplit = 1;
+    a.part = nullptr;
+    dim3 grid((unsigned)(a.Lq / 128), (unsigned)a.H, (unsigned)a.B);
+    hipLaunchKernelGGL((attn_sa_kernel<DPAD>), grid, dim3(256), LDS, ctx->stream, a);
+    ODISE_CHECK_HIP(hipGetLastError());
+    return ODISE_OK;
+}
+// the pipelined kernel takes the self-attention shapes that fill the chip: whole 128-query blocks and 64-key tiles, no mask
+static bool attn_sa_ok(const odise_hip_ctx* ctx, const AttnArgs& a) {
+    if (ctx->attn_kv_resident & 4) return false;   // ODISE_OPT_ATTN_KV_RESIDENT bit 2: never (A/B, tests)
+    if (a.mask || a.Lq % 128 != 0 || a.Lk % 128 != 0 || a.Lk < 256 || a.D > 80 || a.D <= 32) return false;
+    // Measured (tools/attn_unet_bench.py, profiles/r06_attention_pipelined.txt): with up to ~8 blocks per CU the pipelined kernel wins (61.6 against 75.5 us
+    // on one crop's 64^2 level, 78.3 against 84.7 on 16 crops' 32^2 level); on the 16-crop 64^2 level (16 blocks per CU) the tiled kernel's third wave
+    // per SIMD (138 against 190 VGPRs) is worth more than the overlap inside a wave (717 against 750 us): both sit on the VALU + MFMA issue time
+    // of the scores (~44 cycles per 64 scores and SIMD), which neither form overlaps.
+    const int64_t blocks = (int64_t)(a.Lq / 128) * a.H * a.B;
+    return blocks >= ctx->cu_count && blocks <= 8 * (int64_t)ctx->cu_count;
 }
 
 // O[q] = sum_s O_s 2^(m_s - M) / sum_s l_s 2^(m_s - M): one thread per (row, 4 channels)
@@ -589,6 +823,11 @@ extern "C" int odise_hip_attention(odise_hip_ctx* ctx, const odise_attn_desc* d)
     // 16 waves per block (four per SIMD) measured best: 48.1 us against 52.2 (8 waves), 51.4 (12) and 54.4 (tiled kernel) on the 16-crop tower, 91.1
     // against 96.6 (tiled) on 32 crops (tools/attn_bench.py, profiles/r04_attention_kv_resident.txt); only that form is instantiated
     if (attn_kvres_ok(ctx, a)) return launch_attn_kvres<16>(ctx, a);
+    if (attn_sa_ok(ctx, a)) {
+        if (D <= 48) return launch_attn_sa<48>(ctx, a);
+        if (D <= 64) return launch_attn_sa<64>(ctx, a);
+        return launch_attn_sa<80>(ctx, a);
+    }
     if (D <= 32) return launch_attn<32>(ctx, a);
     if (D <= 48) return launch_attn<48>(ctx, a);
     if (D <= 64) return launch_attn<64>(ctx, a);

@@ -502,10 +502,15 @@ extern "C" int odise_hip_postprocess_batch(odise_hip_ctx* ctx, const odise_post_
         int* amax = (want_sem && d->sem_argmax) ? d->sem_argmax[b] : nullptr;
         int* pan = want_pan ? d->panoptic[b] : nullptr;
         const bool inst = want_inst;
-        const bool need_S = sem || amax || inst;
-        if (!need_S && !pan) continue;
+        // the semantic scores come out of the pixel pass itself where its tiled form applies (an exact 4x upsampling, <= 112 queries): no
+        // pixel-major matrix S is written for them; S is still produced for the instance statistics, the fused arg-max and the GEMM fallback
+        const bool fused_sem = sem && g_sem_tile < 0 && postprocess_pixels_fuses_semantic(g);
+        const bool need_S = (sem && !fused_sem) || amax || inst;
+        if (!need_S && !pan && !sem) continue;
         ODISE_TRY(join_side());
-        ODISE_TRY(launch_postprocess_pixels(ctx, logits, kscore + (size_t)b * Q, need_S ? S : nullptr, pan ? ids : nullptr, counts + (size_t)b * 3 * Q, g));
+        if (fused_sem) ms->macs += (double)K * npix * Qpad;
+        ODISE_TRY(launch_postprocess_pixels(ctx, logits, kscore + (size_t)b * Q, need_S ? S : nullptr, pan ? ids : nullptr, counts + (size_t)b * 3 * Q, g,
+                                            fused_sem ? semT + (size_t)b * K * Qpad : nullptr, fused_sem ? sem : nullptr, fused_sem ? K : 0));
         auto decisions = [&]() -> int {
             if (inst) ODISE_TRY(launch_column_stats(ctx, S, partial, stats + (size_t)b * 2 * Qpad, npix, Qpad));
             if (pan) {
@@ -525,7 +530,7 @@ extern "C" int odise_hip_postprocess_batch(odise_hip_ctx* ctx, const odise_post_
             }
             side_pending = true;
         }
-        if (sem) {   // sem_seg[c, p] = sum_q softmax(mask_cls)[q, c] * sigmoid(mask)[q, p]  (maskformer_model.py:280-284) as an MFMA GEMM
+        if (sem && !fused_sem) {   // sem_seg[c, p] = sum_q softmax(mask_cls)[q, c] * sigmoid(mask)[q, p]  (maskformer_model.py:280-284) as an MFMA GEMM
             odise_gemm_desc gd;
             memset(&gd, 0, sizeof(gd));
             gd.M = K; gd.N = npix; gd.K = Qpad;
@@ -598,10 +603,15 @@ extern "C" int odise_hip_infer(odise_hip_ctx* ctx, const odise_infer_desc* d) {
         key.images.assign(d->images, d->images + B);
         key.hw.assign(d->img_hw, d->img_hw + 2 * B);
         pf.use_now = pf.has_ready && pf.ready == key;
+        if (pf.has_ready) ++(pf.use_now ? pf.n_hits : pf.n_dropped);
         if (pf.has_ready && !pf.use_now && ctx->stream3) ODISE_CHECK_HIP(hipStreamSynchronize(ctx->stream3));
         pf.has_ready = false;   // consumed (or dropped) by this call
     }
-    ODISE_TRY(odise_hip_backbone_forward(ctx, padded, B, Hp, Wp, nullptr));
+    {
+        const int rc_bb = odise_hip_backbone_forward(ctx, padded, B, Hp, Wp, nullptr);
+        ms->pf.use_now = false;   // on every exit path: a stored latent must never be consumed by a later, unrelated backbone call
+        if (rc_bb != ODISE_OK) return rc_bb;
+    }
     stage_mark(ctx, "backbone done (taps projected + stitched)");
     ODISE_TRY(odise_hip_head_forward(ctx, nullptr, B, 0, Hp / 4, Wp / 4, nullptr, nullptr, nullptr, nullptr));
     ODISE_TRY(odise_hip_classify(ctx, img01, B, H, W, mask_cls, nullptr));
@@ -625,6 +635,16 @@ extern "C" int odise_hip_infer_prefetch(odise_hip_ctx* ctx, const odise_infer_de
     pf.pending.images.assign(next->images, next->images + next->B);
     pf.pending.hw.assign(next->img_hw, next->img_hw + 2 * next->B);
     pf.has_pending = true;
+    return ODISE_OK;
+}
+
+extern "C" int odise_hip_prefetch_stats(odise_hip_ctx* ctx, int* enqueued, int* hits, int* dropped, int* failed) {
+    ODISE_REQUIRE(ctx, "prefetch_stats: null context");
+    const Prefetch& pf = store_of(ctx)->pf;
+    if (enqueued) *enqueued = pf.n_enqueued;
+    if (hits) *hits = pf.n_hits;
+    if (dropped) *dropped = pf.n_dropped;
+    if (failed) *failed = pf.n_failed;
     return ODISE_OK;
 }
 

@@ -346,9 +346,17 @@ __global__ void __launch_bounds__(256) postprocess_pixels_x4_kernel(const f16* _
 // four query slices through LDS (ties to the lowest query, like the sequential walk), the area counters as before.
 constexpr int PT_PIX = 256;          // pixels of a tile
 constexpr int PT_CELLS = 64;         // cell columns of a tile (one per lane)
+// Round 6: the semantic head rides in the same kernel (`sem` != nullptr).  sem_seg[c, p] = sum_q P[q, c] sigmoid(mask)[q, p]
+// (maskformer_model.py:280-284) was a GEMM over the pixel-major matrix S this kernel had just written: 218 MB out, 218 MB back in, then 558 MB
+// of scores per 1024^2 picture - 353 us at 1.8 TB/s behind the 204 us pixel pass.  The tile's S rows are still in LDS when the block is done
+// with them: every wave takes 64 of the tile's pixels as the column operand of v_mfma_f32_32x32x16_f16 (their S rows in registers, exactly the
+// operand form of semantic_argmax_kernel below: same products, same order), walks the class tiles of PT = P^T [K, Qpad] from the L2 and stores
+// whole 128-byte lines of the class rows.  S is still written when the instance head needs it (column_stats_kernel).
+template <int KS>   // k-steps of 16 of the fused semantic product: Qpad <= 16 * KS (KS = 0: no semantic epilogue compiled in)
 __global__ void __launch_bounds__(256) postprocess_pixels_x4_tiled_kernel(const f16* __restrict__ logits, const float* __restrict__ kscore,
                                                                          f16* __restrict__ S, int* __restrict__ ids, int* __restrict__ counts,
-                                                                         PostGeom g, int tiles_per_row) {
+                                                                         PostGeom g, int tiles_per_row, const f16* __restrict__ PT,
+                                                                         float* __restrict__ sem, int K) {
     extern __shared__ __attribute__((aligned(16))) char psm[];
     const int Q = g.Q, Qpad = g.Qpad;
     const int pitch = Qpad * 2 + 8;                      // bytes per pixel row of the LDS image: 8-byte aligned, rows 4 pixels apart fall 2-way on the banks
@@ -410,7 +418,7 @@ __global__ void __launch_bounds__(256) postprocess_pixels_x4_tiled_kernel(const 
                 if (ks >= 0.f && lane == 0 && npos) atomicAdd(&hist[Q + q], npos);
             }
         }
-        if (S) {
+        if (S || (KS > 0 && sem)) {
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
                 typedef _Float16 f16x4v __attribute__((ext_vector_type(4)));
@@ -459,6 +467,48 @@ __global__ void __launch_bounds__(256) postprocess_pixels_x4_tiled_kernel(const 
             const f16x4v lo = *reinterpret_cast<const f16x4v*>(src), hi = *reinterpret_cast<const f16x4v*>(src + 8);
             f16x8 o = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
             *reinterpret_cast<f16x8*>(dst + (int64_t)j * 8) = o;
+        }
+    }
+    // ---- semantic scores of the tile's pixels from the LDS image (the tile is complete since the barrier above)
+    if (KS > 0 && sem) {
+        const int hi = lane >> 5, l31 = lane & 31;
+        const int64_t npix = (int64_t)g.oh * g.ow;
+#pragma unroll 1
+        for (int half = 0; half < 2; ++half) {
+            const int pxl = slice * 64 + half * 32 + l31;          // pixel of the tile
+            const int px = 4 * cx0 + pxl;                          // output column
+            const bool pok = px < g.ow;
+            f16x8 pf[KS > 0 ? KS : 1];
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) {
+                const int ko = ks * 16 + hi * 8;
+                pf[ks] = f16x8{0, 0, 0, 0, 0, 0, 0, 0};
+                if (pok && ko + 8 <= Qpad) {
+                    typedef _Float16 f16x4v __attribute__((ext_vector_type(4)));
+                    const char* src = tile + (size_t)pxl * pitch + ko * 2;
+                    const f16x4v lo = *reinterpret_cast<const f16x4v*>(src), hh = *reinterpret_cast<const f16x4v*>(src + 8);
+                    pf[ks] = f16x8{lo[0], lo[1], lo[2], lo[3], hh[0], hh[1], hh[2], hh[3]};
+                }
+            }
+            float* out = sem + (int64_t)oy * g.ow + px;
+            for (int c0 = 0; c0 < K; c0 += 32) {
+                const int c = c0 + l31;
+                f32x16 acc;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+#pragma unroll
+                for (int ks = 0; ks < KS; ++ks) {
+                    const int ko = ks * 16 + hi * 8;
+                    f16x8 cf = {0, 0, 0, 0, 0, 0, 0, 0};
+                    if (c < K && ko + 8 <= Qpad) cf = *reinterpret_cast<const f16x8*>(PT + (int64_t)c * Qpad + ko);
+                    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(cf, pf[ks], acc, 0, 0, 0);
+                }
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int cls = c0 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+                    if (cls < K && pok) __builtin_nontemporal_store(acc[r], out + (int64_t)cls * npix);   // lanes 0..31: 32 consecutive pixels of one class row = one 128-byte line
+                }
+            }
         }
     }
     __syncthreads();
@@ -876,14 +926,24 @@ int launch_classify_rows(odise_hip_ctx* ctx, const float* L1, const float* L2, c
     ODISE_CHECK_HIP(hipGetLastError());
     return ODISE_OK;
 }
-int launch_postprocess_pixels(odise_hip_ctx* ctx, const f16* logits, const float* kscore, f16* S, int* ids, int* counts, const PostGeom& g) {
+// true when the pixel pass of this geometry can also produce the semantic scores (the tiled x4 form with Qpad <= 112): the caller then passes
+// PT / sem to launch_postprocess_pixels and skips the semantic GEMM
+bool postprocess_pixels_fuses_semantic(const PostGeom& g) {
+    const size_t lds = (size_t)PT_PIX * (g.Qpad * 2 + 8) + 8 * (size_t)PT_PIX * 4 + 3 * (size_t)g.Q * sizeof(int);
+    return g.oh == g.ih && g.ow == g.iw && g.ph == 4 * g.h4 && g.pw == 4 * g.w4 && g_post_generic == 0 && lds <= 64 * 1024 && g.Qpad <= 112 && g.ow % 32 == 0;
+}
+int launch_postprocess_pixels(odise_hip_ctx* ctx, const f16* logits, const float* kscore, f16* S, int* ids, int* counts, const PostGeom& g, const f16* PT,
+                              float* sem, int K) {
     const int npix = g.oh * g.ow;
+    ODISE_REQUIRE(!sem || (PT && K > 0 && postprocess_pixels_fuses_semantic(g)), "postprocess_pixels: this geometry cannot fuse the semantic head");
     if (g.oh == g.ih && g.ow == g.iw && g.ph == 4 * g.h4 && g.pw == 4 * g.w4 && g_post_generic != 1) {
         const size_t lds = (size_t)PT_PIX * (g.Qpad * 2 + 8) + 8 * (size_t)PT_PIX * 4 + 3 * (size_t)g.Q * sizeof(int);
         if (g_post_generic != 2 && lds <= 64 * 1024) {   // tiled form (two blocks per CU); odise_hip_post_generic(2) keeps the thread-per-cell-column form
             const int tiles_per_row = (int)ceil_div((g.ow + 3) / 4, PT_CELLS);
-            hipLaunchKernelGGL(postprocess_pixels_x4_tiled_kernel, dim3((unsigned)(g.oh * tiles_per_row)), dim3(256), lds, ctx->stream, logits, kscore, S, ids,
-                               counts, g, tiles_per_row);
+            if (sem) hipLaunchKernelGGL(postprocess_pixels_x4_tiled_kernel<7>, dim3((unsigned)(g.oh * tiles_per_row)), dim3(256), lds, ctx->stream, logits, kscore, S,
+                                        ids, counts, g, tiles_per_row, PT, sem, K);
+            else hipLaunchKernelGGL(postprocess_pixels_x4_tiled_kernel<0>, dim3((unsigned)(g.oh * tiles_per_row)), dim3(256), lds, ctx->stream, logits, kscore, S, ids,
+                                    counts, g, tiles_per_row, nullptr, nullptr, 0);
             ODISE_CHECK_HIP(hipGetLastError());
             return ODISE_OK;
         }

@@ -110,7 +110,8 @@ struct odise_hip_ctx {
     void* comm = nullptr;  // odise::Comm* (comm.cpp): RCCL communicator + exchange stream, created by odise_hip_comm_init
     // per-context execution options (odise_hip_set_option, include/odise_hip.h); read on the host when a stage is enqueued
     int clip_ln_fold = 0;            // ODISE_OPT_CLIP_LN_FOLD: 0 = by token count, 1 = always, 2 = never
-    int attn_kv_resident = 0;        // ODISE_OPT_ATTN_KV_RESIDENT: 0 = by the library's rule (attn.hip attn_kvres_ok), 2 = never (tiled kernel)
+    int attn_kv_resident = 0;        // ODISE_OPT_ATTN_KV_RESIDENT: 0 = by the library's rules (attn.hip attn_kvres_ok / attn_sa_ok), bit 1 (2) = never the K/V-resident
+                                     // kernel, bit 2 (4) = never the pipelined self-attention kernel
     int64_t vae_chunk_bytes = 0;     // ODISE_OPT_VAE_CHUNK_BYTES: crops per VAE launch so that one activation stays below this (0 = all crops at once, the default)
     void* probe = nullptr;           // odise::LaunchProbe* (api.cpp): HIP events around the launches of one kernel shape (odise_hip_probe_*)
     void* stages = nullptr;          // odise::StageLog* while odise_hip_stage_timeline is on: (name, HIP event on the current stream, host clock) at stage boundaries

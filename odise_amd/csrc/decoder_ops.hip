@@ -138,6 +138,13 @@ __global__ void __launch_bounds__(256) add_vec_table_kernel(const f16* __restric
     }
 }
 
+// y[b, :] = x[:] for b < B (16-byte pieces): the learned queries broadcast over the batch (odise.py:663-664) in ONE launch - four
+// hipMemcpyAsync device-to-device copies of 51 KB cost ~60 us each through the blit path
+__global__ void __launch_bounds__(256) broadcast_rows_kernel(const f16* __restrict__ x, f16* __restrict__ y, int64_t n8, int64_t total) {
+    for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * blockDim.x)
+        reinterpret_cast<f16x8*>(y)[idx] = reinterpret_cast<const f16x8*>(x)[idx % n8];
+}
+
 struct MsdaPrep {
     int L, P, M;
     int H[8], W[8], start[8];
@@ -335,6 +342,12 @@ int launch_stitch(odise_hip_ctx* ctx, const f16* feat, f16* out, float* out_nchw
                   int OW, int C) {
     const int64_t total = (int64_t)B * OH * OW * (C / 8);
     hipLaunchKernelGGL(stitch_kernel, dim3(g1(total)), dim3(256), 0, ctx->stream, feat, out, out_nchw, K, boxes_dev, ch, cw, OH, OW, C / 8, total);
+    ODISE_CHECK_HIP(hipGetLastError());
+    return ODISE_OK;
+}
+int launch_broadcast_rows(odise_hip_ctx* ctx, const f16* x, f16* y, int64_t n, int B) {   // n % 8 == 0, 16-byte aligned
+    const int64_t n8 = n / 8, total = n8 * B;
+    hipLaunchKernelGGL(broadcast_rows_kernel, dim3(g1(total)), dim3(256), 0, ctx->stream, x, y, n8, total);
     ODISE_CHECK_HIP(hipGetLastError());
     return ODISE_OK;
 }

@@ -42,22 +42,38 @@ void models_destroy(odise_hip_ctx* ctx) {
 
 int ensure_prefetch_lane(odise_hip_ctx* ctx, ModelStore* ms, int slot, size_t arena_bytes) {
     if (!ctx->stream3) {
+        // all or nothing: the lane's four resources are created into locals and committed together, so a failure half way (the workspace is
+        // ws_bytes of HBM) leaves no half-initialised lane behind for the next call to mistake for a complete one
         int lo = 0, hi = 0;   // (least, greatest) priority
         ODISE_CHECK_HIP(hipDeviceGetStreamPriorityRange(&lo, &hi));
         const int e8 = ctx->prefetch_cu_eighths;
+        hipStream_t st = nullptr;
+        void* ws = nullptr;
+        hipEvent_t go = nullptr, done = nullptr;
+        hipError_t err;
         if (e8 >= 1 && e8 <= 7) {
             // a CU-masked stream: e8 of every 8 compute units (bit i of the mask = CU i; the same pattern in every byte spreads over the XCDs /
-            // shader engines whatever the enumeration), so the batch in progress always finds CUs no prefetch workgroup occupies
+            // shader engines whatever the enumeration), so the batch in progress always finds CUs no prefetch workgroup occupies.  HIP offers no
+            // priority or flags with a CU mask: this stream has NORMAL priority and default flags (it synchronises with the legacy NULL stream)
             uint32_t mask[8];
             const uint32_t byte = (1u << e8) - 1u;
             for (uint32_t& m : mask) m = byte * 0x01010101u;
-            ODISE_CHECK_HIP(hipExtStreamCreateWithCUMask(&ctx->stream3, 8, mask));
+            err = hipExtStreamCreateWithCUMask(&st, 8, mask);
         } else {
-            ODISE_CHECK_HIP(hipStreamCreateWithPriority(&ctx->stream3, hipStreamNonBlocking, lo));   // never ahead of the batch in progress
+            err = hipStreamCreateWithPriority(&st, hipStreamNonBlocking, lo);   // never ahead of the batch in progress
         }
-        ODISE_CHECK_HIP(hipMalloc(&ctx->ws3, ctx->ws_bytes));
-        ODISE_CHECK_HIP(hipEventCreateWithFlags(&ctx->ev_pf_go, hipEventDisableTiming));
-        ODISE_CHECK_HIP(hipEventCreateWithFlags(&ctx->ev_pf_done, hipEventDisableTiming));
+        if (err == hipSuccess) err = hipMalloc(&ws, ctx->ws_bytes);
+        if (err == hipSuccess) err = hipEventCreateWithFlags(&go, hipEventDisableTiming);
+        if (err == hipSuccess) err = hipEventCreateWithFlags(&done, hipEventDisableTiming);
+        if (err != hipSuccess) {
+            if (done) (void)hipEventDestroy(done);
+            if (go) (void)hipEventDestroy(go);
+            if (ws) (void)hipFree(ws);
+            if (st) (void)hipStreamDestroy(st);
+            set_error("prefetch lane: %s", hipGetErrorString(err));
+            return ODISE_ERR_HIP;
+        }
+        ctx->stream3 = st; ctx->ws3 = ws; ctx->ev_pf_go = go; ctx->ev_pf_done = done;
     }
     Arena& a = ms->pf.arena[slot];
     if (a.cap < arena_bytes) {

@@ -95,6 +95,7 @@ struct Prefetch {
     EncoderOut out;               // of `ready`
     int crops = 0;                // crops (B x windows) the stored tensors cover
     bool use_now = false;         // set by odise_hip_infer for the call in progress: extractor_launch consumes `out`
+    int n_enqueued = 0, n_hits = 0, n_dropped = 0, n_failed = 0;   // odise_hip_prefetch_stats: encoders enqueued ahead / consumed by the next call / prepared but not consumed / could not be enqueued
     Arena arena[2];
 };
 
@@ -248,6 +249,7 @@ int launch_crop_resize_bicubic(odise_hip_ctx* ctx, const float* img, float* crop
 int launch_upsample_nearest(odise_hip_ctx* ctx, const f16* x, f16* y, int N, int H, int W, int OH, int OW, int C);
 int launch_stitch(odise_hip_ctx* ctx, const f16* feat, f16* out, float* out_nchw, int B, int K, const int* boxes_dev, int ch, int cw, int OH,
                   int OW, int C);
+int launch_broadcast_rows(odise_hip_ctx* ctx, const f16* x, f16* y, int64_t n, int B);
 int launch_add_vec_table(odise_hip_ctx* ctx, const f16* x, const float* vec, const float* table, f16* y, int64_t N, int P, int C);
 int launch_msda_prepare(odise_hip_ctx* ctx, const float* off, const float* aw, float* loc, float* w, int B, int Lq, int M, int L, int P,
                         const int* Hs, const int* Ws, const int* starts);
@@ -271,7 +273,9 @@ int launch_l2_normalize_f16(odise_hip_ctx* ctx, const f16* x, f16* y, int64_t ro
 int launch_l2_normalize_f32(odise_hip_ctx* ctx, const float* x, f16* y, int64_t rows, int C);
 int launch_classify_rows(odise_hip_ctx* ctx, const float* L1, const float* L2, const int* seg, const int* ovl, const float* binary, float* out, int64_t rows, int K,
                          int Ktot, float ls1, float ls2, float alpha, float beta);
-int launch_postprocess_pixels(odise_hip_ctx* ctx, const f16* logits, const float* kscore, f16* S, int* ids, int* counts, const PostGeom& g);
+int launch_postprocess_pixels(odise_hip_ctx* ctx, const f16* logits, const float* kscore, f16* S, int* ids, int* counts, const PostGeom& g, const f16* PT = nullptr,
+                              float* sem = nullptr, int K = 0);   // PT / sem: the semantic scores from the same pass (postprocess_pixels_fuses_semantic)
+bool postprocess_pixels_fuses_semantic(const PostGeom& g);
 int launch_column_stats(odise_hip_ctx* ctx, const f16* S, float* partial, float* out2, int npix, int Qpad);
 int launch_panoptic_write(odise_hip_ctx* ctx, const int* ids, const int* map, int* seg, int npix);
 int launch_instance_masks(odise_hip_ctx* ctx, const f16* logits, const int* idx, float* out, int n, const PostGeom& g, const int* n_dev = nullptr);

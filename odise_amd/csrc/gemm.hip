@@ -84,8 +84,7 @@ struct GemmArgs {
     const f16* zeros;  // >= 16 zero bytes (source of padded / out-of-range operand slots)
     int dbg;           // ablation switches (tools only): 1 = no operand DMA after the first tile, 2 = no fragment reads after the first
     int stats_blocks;  // out: row blocks per image of the fused GroupNorm statistics (0 = not produced, epi.gn_stats was cleared)
-    int epi_block;     // bit 0: never the wave-private epilogue (launch_gemm_select: ODISE_GEMM_FLAGS 32768); bit 1 (65536): the wave-private epilogue
-                       // without round 6's register pre-fold of the LayerNorm terms (round 5's general item loop), for same-box A/B runs
+    int epi_block;     // 1: never the wave-private epilogue (launch_gemm_select: ODISE_GEMM_FLAGS 32768)
 };
 
 // Workgroup barrier that only orders LDS traffic.  `__syncthreads()` also drains the vector-memory counter, i.e. it waits for
@@ -349,10 +348,6 @@ template <int TM, int TN>
 __device__ __forceinline__ float acc_get(const f32x16 (&a)[TM][TN], int p, int j, int r) { return a[p][j][r]; }
 template <int TM, int TN>
 __device__ __forceinline__ float acc_get(const f32x4 (&a)[TM][TN][4], int p, int j, int r) { return a[p][j][r >> 2][r & 3]; }
-template <int TM, int TN>
-__device__ __forceinline__ void acc_set(f32x16 (&a)[TM][TN], int p, int j, int r, float v) { a[p][j][r] = v; }
-template <int TM, int TN>
-__device__ __forceinline__ void acc_set(f32x4 (&a)[TM][TN][4], int p, int j, int r, float v) { a[p][j][r >> 2][r & 3] = v; }
 
 // ---- math-first epilogue for fp16 outputs ----------------------------------------------------------------------------------------------
 // The fp32-staged epilogue below costs a 256x256 tile ~12 us, a third of a K = 1024 GEMM: the accumulators go through LDS as fp32 in up to
@@ -655,19 +650,10 @@ __device__ __forceinline__ void gemm_epilogue_wave(const GemmArgs& g, ACC& acc, 
     const float* const ln_rowsum = LN_OK ? e.ln_rowsum : nullptr;
     float* const ln_stats_out = (LN_OK && CHW % 8 == 0) ? e.ln_stats_out : nullptr;
     const bool geglu = GEGLU_OK && e.geglu;
-    // Round 6: the folded-LayerNorm consumers (rows: ln_part + ln_colsum; swapped form: ln_final + ln_rowsum [+ bias_m]) take their per-row / per-column
-    // terms IN THE ACCUMULATOR REGISTERS before staging (`prefold` below: one pass of FMAs over the wave tile, the column terms loaded once per
-    // register quad), and the producers' row statistics (ln_stats_out) ride in the lean item loop - so every GEMM of a folded CLIP block runs the
-    // lean loop.  (Through the general loop below - per item: feature tests, two shuffles per row term, the 8-lane reduction - the four GEMM
-    // shapes of a block ran at 341-450 TFLOP/s against 650-800 for the same shapes with a plain epilogue, profiles/r05_gemm_efficiency_by_shape.txt.)
-    // Same operations per element in the same order as the general loop: the same bits.
-    const bool rowfold = ln_part && ln_colsum && !ln_final && !ln_rowsum && !e.bias_m;
-    const bool colfold = ln_final && ln_rowsum && !ln_part && !ln_colsum;
-    const bool r5 = (g.epi_block & 2) != 0;   // A/B: round 5's item loop
-    const bool prefold = !r5 && FIXED && !geglu && e.c_dtype == ODISE_F16 && !e.scale_m && !e.rowgroup_add && (rowfold || colfold);
-    // nothing per row but the residual (and the LayerNorm sums of the output rows), fp16 output: the lean item loop
-    const bool plain = !geglu && e.c_dtype == ODISE_F16 && !e.scale_m && !e.rowgroup_add &&
-                       (prefold || (!e.bias_m && !ln_part && !ln_colsum && !ln_final && !ln_rowsum)) && !(r5 && (ln_stats_out || ln_final_out));
+    // nothing per row but the residual, fp16 output: the lean item loop
+    // (round 6: the producers of the LayerNorm row statistics - out-proj / c_proj with ln_stats_out - stay in the lean loop too)
+    const bool plain = !geglu && e.c_dtype == ODISE_F16 && !e.scale_m && !e.bias_m && !e.rowgroup_add && !ln_part && !ln_colsum && !ln_final && !ln_rowsum &&
+                       !ln_final_out;
     float s8[8], q8[8];
 #pragma unroll
     for (int i = 0; i < 8; ++i) s8[i] = q8[i] = 0.f;
@@ -724,63 +710,6 @@ __device__ __forceinline__ void gemm_epilogue_wave(const GemmArgs& g, ACC& acc, 
             }
         }
     }
-    if (LN_OK && prefold) {
-        constexpr int TMB = WTM / 32, TR = TMB * FL::NR;          // rows of the wave tile a lane holds
-        float al_r[TR], r1_r[TR], rs_r[TR], bm_r[TR];
-#pragma unroll
-        for (int p = 0; p < TR; ++p) {
-            const int rw = (p / FL::NR) * 32 + FL::row(lane, p % FL::NR);   // row of the wave tile
-            const int m = m0 + wm * WTM + rw;
-            float alpha = e.alpha;
-            r1_r[p] = rs_r[p] = bm_r[p] = 0.f;
-            if (rowfold) {
-                float rstd = 0.f, r1 = 0.f;
-#pragma unroll
-                for (int h = 0; h < NH; ++h) {
-                    const float t = __shfl(ln_rs[h], rw & 63), u = __shfl(ln_r1[h], rw & 63);
-                    if ((rw >> 6) == h) { rstd = t; r1 = u; }
-                }
-                alpha *= rstd;
-                r1_r[p] = r1;
-            } else if (m < g.M) {
-                rs_r[p] = ln_rowsum[m];
-                if (e.bias_m) bm_r[p] = e.bias_m[m];
-            }
-            al_r[p] = alpha;
-        }
-#pragma unroll
-        for (int j = 0; j < TN; ++j)
-#pragma unroll
-            for (int cc = 0; cc < FL::NC; ++cc) {
-                const int n = n0 + wn * WTN + j * 32 + FL::col(lane, cc);
-                const bool nok = n + 4 <= g.N;
-                float4 bn = make_float4(0.f, 0.f, 0.f, 0.f), cs4 = bn, fa = bn, fb = bn;
-                if (e.bias_n && nok) bn = *reinterpret_cast<const float4*>(e.bias_n + n);
-                if (rowfold && nok) cs4 = *reinterpret_cast<const float4*>(ln_colsum + n);
-                if (colfold && nok) {   // (r1, rstd) of columns n, n + 1 | n + 2, n + 3
-                    fa = *reinterpret_cast<const float4*>(ln_final + 2 * (int64_t)n);
-                    fb = *reinterpret_cast<const float4*>(ln_final + 2 * (int64_t)n + 4);
-                }
-                const float bnv[4] = {bn.x, bn.y, bn.z, bn.w}, csv[4] = {cs4.x, cs4.y, cs4.z, cs4.w};
-                const float r1c[4] = {fa.x, fa.z, fb.x, fb.z}, rsc[4] = {fa.y, fa.w, fb.y, fb.w};
-#pragma unroll
-                for (int p = 0; p < TR; ++p) {
-                    const int r0 = 4 * ((p % FL::NR) * FL::NC + cc);
-#pragma unroll
-                    for (int i = 0; i < 4; ++i) {
-                        float v = acc_get(acc, p / FL::NR, j, r0 + i);
-                        float b = bnv[i];
-                        if (e.bias_m) b += bm_r[p];
-                        if (rowfold) b += r1_r[p] * csv[i];
-                        if (colfold) v = v * (al_r[p] * rsc[i]) + (b + rs_r[p] * r1c[i]);
-                        else v = v * al_r[p] + b;
-                        acc_set(acc, p / FL::NR, j, r0 + i, v);
-                    }
-                }
-            }
-#pragma unroll
-        for (int i = 0; i < 8; ++i) bn8[i] = 0.f;   // bias and scale are in the accumulators now: the lean loop adds nothing
-    }
 #pragma unroll
     for (int ps = 0; ps < WTM / R; ++ps) {
         // ---- stage rows [ps R, ps R + R) of the wave tile (the previous pass's reads are retired: same wave, LDS operations complete in order)
@@ -810,7 +739,7 @@ __device__ __forceinline__ void gemm_epilogue_wave(const GemmArgs& g, ACC& acc, 
             const int c8 = lane % CHW;
             const int n = n0 + wn * WTN + c8 * 8;
             const bool nok = n + 8 <= g.N;
-            const float alpha = prefold ? 1.f : e.alpha;     // (x * 1 + 0 is x: the pre-folded accumulators pass through unchanged)
+            const float alpha = e.alpha;
             const int ln_parts = (g.N + kLnPartCols - 1) / kLnPartCols;
 #pragma unroll 1
             for (int it = 0; it < ITEMS; ++it) {
@@ -1027,7 +956,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& g, ACC& acc, char*
     // chunk: everything but the 256x320 tile), without GEGLU (its half-width rows leave the lean loop; the block-wide form is ~15 % ahead there).
     // ODISE_GEMM_FLAGS 32768 keeps the block-wide forms everywhere (A/B of whole steps: bench.py --gemm-flags).
     if constexpr (LDSB > 0 && WAVES_M * WAVES_N == 8 && (64 % ((BN / WAVES_N) / 8)) == 0) {
-        if (g.epi.fast && !split && !g.epi.geglu && !(g.epi_block & 1) && !ODISE_ABLATE(g, 8 | 32)) {
+        if (g.epi.fast && !split && !g.epi.geglu && !g.epi_block && !ODISE_ABLATE(g, 8 | 32)) {
             gemm_epilogue_wave<BM, BN, WAVES_M, WAVES_N, HALO, STATS, GEGLU_OK, LDSB>(g, acc, smem, m0, n0, zb);
             return;
         }
@@ -3336,7 +3265,7 @@ static int launch_gemm_select(odise_hip_ctx* ctx, GemmArgs& g, int batch, int fo
         if (!ok) { g.epi.gn_stats = nullptr; g.stats_blocks = 0; }
     }
     g.zeros = (const f16*)ctx->zeros;
-    g.epi_block = ((flags & 32768) ? 1 : 0) | ((flags & 65536) ? 2 : 0);
+    g.epi_block = (flags & 32768) ? 1 : 0;
 #ifdef ODISE_TOOLS
     static const int freeze_k = (getenv("ODISE_GEMM_FREEZE_K") ? 16 : 0) | (getenv("ODISE_EPI_OLD") ? 32 : 0) | (getenv("ODISE_NO_RES_PREFETCH") ? 64 : 0);
     g.dbg = g_gemm_debug | freeze_k | (g_epi_old ? 32 : 0);

@@ -399,7 +399,18 @@ static int prefetch_enqueue(odise_hip_ctx* ctx, ModelStore* ms, MaskGenModel* g)
     pf.ready_slot = slot;
     pf.crops = n;
     pf.has_ready = true;
+    ++pf.n_enqueued;
     return ODISE_OK;
+}
+
+// The prefetch is an optimisation of the NEXT call: when it cannot be enqueued (a side arena that does not fit, a failed launch) the call in
+// progress must not fail with it - the registration is dropped, whatever reached the prefetch stream is never consumed (has_ready stays
+// false), and the next batch is simply computed by its own call.
+static void prefetch_try(odise_hip_ctx* ctx, ModelStore* ms, MaskGenModel* g) {
+    if (prefetch_enqueue(ctx, ms, g) != ODISE_OK) {
+        ms->pf.has_pending = ms->pf.has_ready = false;
+        ++ms->pf.n_failed;
+    }
 }
 
 static int backbone_forward(odise_hip_ctx* ctx, const float* image, int B, int H, int W, float** out4) {
@@ -482,7 +493,7 @@ static int backbone_forward(odise_hip_ctx* ctx, const float* image, int B, int H
     ODISE_TRY(extractor_launch(ctx, ms, crops, B * K, S, S, false, /*join=*/!defer_join));
     stage_mark(ctx, "extractor: VAE lane done (main stream; the CLIP -> UNet lane is joined later)");
     ms->pf.use_now = false;
-    if (ms->pf.has_pending && ctx->prefetch_start == 0) ODISE_TRY(prefetch_enqueue(ctx, ms, g));   // the NEXT batch's encoder behind this batch's VAE lane
+    if (ms->pf.has_pending && ctx->prefetch_start == 0) prefetch_try(ctx, ms, g);   // the NEXT batch's encoder behind this batch's VAE lane
     const Act* taps = extractor_taps(ms);
     bool joined = false;
     for (int gi = 0; gi < 4; ++gi) {
@@ -514,7 +525,7 @@ static int backbone_forward(odise_hip_ctx* ctx, const float* image, int B, int H
     }
     if (!joined) ODISE_TRY(extractor_join(ctx));
     // ... or (default) behind the whole backbone: beside the serial tail of small launches (head, MaskCLIP, post-processing)
-    if (ms->pf.has_pending) ODISE_TRY(prefetch_enqueue(ctx, ms, g));
+    if (ms->pf.has_pending) prefetch_try(ctx, ms, g);
     ms->arena.release(mk);
     g->last_macs = ms->macs;
     (void)kFeatStride;
@@ -738,8 +749,7 @@ static int predictor_forward(odise_hip_ctx* ctx, const PixDec& pd) {
         !mask_embed)
         return ODISE_ERR_NOMEM;
     // output = query_feat broadcast over the batch
-    for (int b = 0; b < B; ++b)
-        ODISE_CHECK_HIP(hipMemcpyAsync(out + (size_t)b * Q * C, g->query_feat16, (size_t)Q * C * 2, hipMemcpyDeviceToDevice, ctx->stream));
+    ODISE_TRY(launch_broadcast_rows(ctx, g->query_feat16, out, (int64_t)Q * C, B));
 
     auto prediction_heads = [&](int target_level) -> int {  // forward_prediction_heads (odise.py:729-776), mask branch only
         ODISE_TRY(ex.layer_norm(out, dn, MQ, g->decoder_norm, 1e-5f));

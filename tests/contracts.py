@@ -99,8 +99,9 @@ def end_to_end_contract(got, ref, cls_ref, k, things, tag="", size=1024, segment
     return dict(segments=len(info), panoptic_agreement=agree, sem_err=serr, sem_agreement=sagree, instances=len(key_got), worst_iou=float(worst))
 
 
-MAX_REDECIDED = 3    # sanity bound on the queries per picture whose class distribution moves by more than TAU_PROB against the pure oracle ...
-TAU_REDECIDED = 0.2  # ... and by how much (both only REPORT how the reference's own decision chain reacts to the device's ~3e-3 feature error)
+MAX_REDECIDED = 2    # bound on the queries per picture whose class distribution moves by more than TAU_PROB against the pure oracle (measured 0 or 1 over rounds 4-6;
+                     # the emulated fp16-storage oracle itself re-decides one query of picture 0, profiles/r06_feature_error_by_stage.txt section 4) ...
+TAU_REDECIDED = 0.1  # ... and by how much (measured <= 6.7e-2; round 5 allowed 3 queries at 0.2)
 
 
 def class_probability_contract(got_logp, ref_logp, k, tag="", min_decided=50, min_same=93, ideal=None, instability=None):

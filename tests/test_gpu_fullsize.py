@@ -127,7 +127,12 @@ def test_backbone_full_size(full, ctx, ln_fold):
     for k in ("s2", "s3", "s4", "s5"):
         err, cos, scale = _rel(got[k], feats_ref[k].numpy())
         print(f"backbone {k} {got[k].shape} max|ref| {scale:.3f} max-err/scale {err:.3e} cos {cos:.6f}")
-        assert err < 1e-2 and cos > 0.9999, (k, err, cos)
+        # Held to the FLOOR of fp16 storage, not to a loose bound (round 6, profiles/r06_feature_error_by_stage.txt): the fp32 oracle with its tensors
+        # rounded to fp16 where the device stores fp16 (tools/fp16_floor.py, policy `device`) is 2.4-3.25e-3 off the all-fp32 oracle on these maps, the
+        # device 2.0-3.1e-3 - at the floor at every stage (VAE encoder taps 1.2-1.3e-3 against an emulated 1.2-1.6e-3, UNet alone 1.6e-3 against
+        # 1.6-1.9e-3).  Weights alone in fp16 - the floor of ANY fp16-MFMA implementation - cost 1.0-1.7e-3: the 1e-3 VERDICT r05 asked for is below
+        # what the number format can give.  Bound = 1.25 x the emulated figure.
+        assert err < 4e-3 and cos > 0.99999, (k, err, cos)
 
 
 def test_head_full_size_from_reference_features(full):
@@ -215,4 +220,7 @@ def test_mask_iou_contract_at_output_resolution(full, ctx):
     # elements).  Contract: at most 5 re-decided queries, and they stay bounded; every other query as tight as the head alone.
     assert rep["regular"] >= 95 and rep["max"] < 6e-2 and rep["p999"] < 1.5e-2, rep
     assert rep["outside_regular"] == 0 and rep["iou_decided_min_regular"] == 1.0, "a mask pixel outside the fp16 band flipped on a regular query"
-    assert rep["iou_min_regular"] > 0.93 and rep["iou_med"] > 0.985 and rep["iou_min"] > 0.8, rep
+    # raw IoU: an IDEAL fp32 head on backbone features computed with nothing but fp16 WEIGHTS reaches a median of 0.9978 (0 of 100 queries >= 1 - 1e-3),
+    # with the device's storage format emulated 0.9949 and one re-decided query at 0.874 (tools/fp16_floor.py iou, profiles/r06_feature_error_by_stage.txt
+    # section 4); the device measures 0.9942: the median is held to that floor, the 1 - 1e-3 of the north star to the decided pixels (above)
+    assert rep["iou_min_regular"] > 0.93 and rep["iou_med"] > 0.99 and rep["iou_min"] > 0.8, rep

@@ -334,22 +334,53 @@ def test_encoder_prefetch_is_bit_identical(ctx, fullsize_model):
             for k in ("pred_masks", "scores", "pred_classes"):
                 assert np.array_equal(np.asarray(ra[i]["instances"][k]), np.asarray(rb[i]["instances"][k])), f"{what}: instances[{k}] of picture {i}"
 
+    import ctypes as C
+
+    def stats():
+        """(encoders enqueued ahead, consumed by their own call, prepared but dropped, failed) so far on this context (odise_hip_prefetch_stats)."""
+        v = [C.c_int() for _ in range(4)]
+        assert ctx.lib.odise_hip_prefetch_stats(ctx.h, *[C.byref(x) for x in v]) == 0
+        return tuple(x.value for x in v)
+
     plain = {name: call(name) for name in ("A", "B")}
-    # the pipeline: every call prepares the other set
+    s0 = stats()
+    delta = lambda: tuple(a - b for a, b in zip(stats(), s0))   # noqa: E731
+    # the pipeline: every call prepares the other set.  The counters prove that the prefetched path is the one taken (a prefetch that silently
+    # declined - size class, crop count, arena - would make every comparison below pass trivially; ADVICE r05)
     hip.prefetch_device(sets["B"], 1, hw)
     first = call("A")                        # computes A itself, enqueues B's encoder behind its VAE lane
+    assert delta() == (1, 0, 0, 0), delta()
     hip.prefetch_device(sets["A"], 1, hw)
     second = call("B")                       # starts from the prefetched latent of B, prepares A
+    assert delta() == (2, 1, 0, 0), delta()
     third = call("A")                        # starts from the prefetched latent of A, prepares nothing
+    assert delta() == (2, 2, 0, 0), delta()
     same(first, plain["A"], "call that only prepares the next batch")
     same(second, plain["B"], "call on a prefetched batch")
     same(third, plain["A"], "second call on a prefetched batch")
     # a prepared batch that is not the next one is dropped
     hip.prefetch_device(sets["B"], 1, hw)
     call("A")
+    assert delta() == (3, 2, 0, 0), delta()
     same(call("A"), plain["A"], "call after a dropped prefetch")
+    assert delta() == (3, 2, 1, 0), delta()
     hip.prefetch_device(None, 1, hw)
     same(call("B"), plain["B"], "plain call after the pipeline")
+    assert delta() == (3, 2, 1, 0), delta()
+    # The key of a prefetched batch is (pointers, layout, sizes): the CONTENTS must not change between the registration and the batch's own
+    # call (include/odise_hip.h).  Shown here: new pixels under the same pointers after the encoder ran give the OLD pictures' backbone.
+    hip.prefetch_device(sets["B"], 1, hw)
+    call("A")
+    keep = [ctx.to_device(d.numpy()) for d in sets["B"]]
+    for d, src in zip(sets["B"], sets["A"]):
+        d.copy_from(src.numpy())             # B's buffers now hold A's pixels
+    stale = call("B")
+    assert delta() == (4, 3, 1, 0), delta()
+    assert not np.array_equal(stale[1], plain["A"][1]), "a changed buffer was re-encoded: the documented contract (unchanged until its own call) would be stricter than needed"
+    for d, src in zip(sets["B"], keep):
+        d.copy_from(src.numpy())
+    for d in keep:
+        d.free()
     for s in sets.values():
         for d in s:
             d.free()

@@ -148,10 +148,14 @@ def test_postprocess_x4_kernel_matches_generic(models, h, w):
             other[mode] = hip.forward([{"image": img}])[0]
         finally:
             hip.ctx.lib.odise_hip_post_generic(0)
+    np.testing.assert_array_equal(other[1]["sem_seg"], other[2]["sem_seg"])     # the two GEMM-fed forms: bit for bit
     for mode, gen in other.items():
         np.testing.assert_array_equal(fast["panoptic_seg"][0], gen["panoptic_seg"][0])
         assert fast["panoptic_seg"][1] == gen["panoptic_seg"][1]
-        np.testing.assert_array_equal(fast["sem_seg"], gen["sem_seg"])
+        # the tiled pass produces the semantic scores itself (round 6: MFMA on the tile's S rows in LDS, v_mfma_f32_32x32x16_f16 chain over the
+        # queries); the other two forms run the semantic GEMM (16x16x32 MFMAs): the same fp16 products, summed in fp32 in another grouping
+        np.testing.assert_allclose(fast["sem_seg"], gen["sem_seg"], rtol=0, atol=2e-5)
+        assert np.array_equal(fast["sem_seg"].argmax(0), gen["sem_seg"].argmax(0)) or (fast["sem_seg"].argmax(0) != gen["sem_seg"].argmax(0)).mean() < 1e-4
         np.testing.assert_array_equal(fast["instances"]["pred_masks"], gen["instances"]["pred_masks"])
         np.testing.assert_array_equal(fast["instances"]["scores"], gen["instances"]["scores"])
 

@@ -477,6 +477,32 @@ def test_attention(ctx, B, H, Lq, Lk, D):
     close(out, ref.numpy(), rtol=5e-3, atol=3e-3, what=f"attention B{B} H{H} Lq{Lq} Lk{Lk} D{D}")
 
 
+@pytest.mark.parametrize("B,L,D", [(1, 4096, 40), (4, 1024, 80), (2, 2048, 64), (16, 256, 48)])
+def test_attention_pipelined_self_attention_is_bit_identical_to_the_tiled_kernel(ctx, B, L, D):
+    """attn_sa_kernel (round 6: S^T of tile t+1 issued before the softmax of tile t, K double- / V^T triple-buffered, one barrier per tile) takes
+    the unmasked self-attention launches made of whole 128-query / 128-key blocks that fill the chip - the SD UNet's 64^2 / 32^2 levels.  Same
+    arithmetic per score in the same order as the tiled kernel: bit-identical outputs, also through the online-softmax rescale (a late key with a
+    huge score) and with d_head below the padded MFMA depth; and against fp32 torch."""
+    g = torch.Generator().manual_seed(B * 7 + L + D)
+    H = 8
+    HD = H * D
+    Q, K, V = (h(torch.randn(B, L, HD, generator=g)) for _ in range(3))
+    K[:, L - 70] = Q[:, 5] * 3         # forces a rescale in the last-but-one tile
+    scale = D ** -0.5
+    q, k, v = (t.view(B, L, H, D).transpose(1, 2) for t in (Q, K, V))
+    ref = (torch.softmax(q @ k.transpose(-1, -2) * scale, -1) @ v).transpose(1, 2).reshape(B, L, HD)
+    dq, dk, dvt = ctx.to_device(Q.half().numpy()), ctx.to_device(K.half().numpy()), ctx.to_device(_vt(V.half().numpy(), L))
+    assert ctx.get_option(ctx.OPT_ATTN_KV_RESIDENT) == 0
+    out = ctx.attention(dq, dk, dvt, H, scale).numpy()
+    ctx.set_option(ctx.OPT_ATTN_KV_RESIDENT, 4)
+    try:
+        tiled = ctx.attention(dq, dk, dvt, H, scale).numpy()
+    finally:
+        ctx.set_option(ctx.OPT_ATTN_KV_RESIDENT, 0)
+    assert np.array_equal(out, tiled), f"pipelined and tiled attention differ (max {np.abs(out.astype(np.float32) - tiled.astype(np.float32)).max()})"
+    close(out, ref.numpy(), rtol=5e-3, atol=3e-3, what=f"pipelined self-attention B{B} L{L} D{D}")
+
+
 @pytest.mark.parametrize("Lk", [333, 2100])  # 2100 keys: the split-KV path (few query blocks, many key tiles) + combine kernel
 def test_attention_masked_and_spiked(ctx, Lk):
     g = torch.Generator().manual_seed(77)

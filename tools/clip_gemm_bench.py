@@ -1,7 +1,6 @@
 """The five GEMMs of one CLIP block with folded LayerNorms (extractor.cpp clip_tower) at the benchmarked 16-crop shape (M = 16 x 584 rows), each
-under three epilogue forms of the same binary: the default (round 6: LayerNorm terms folded into the accumulator registers, lean item loop),
-round 5's wave-private general item loop (`odise_hip_gemm_debug` 65536 << 4) and the block-wide math-first form (32768 << 4); plus the same
-shapes with a plain epilogue (no LayerNorm terms) as the yardstick.  Interleaved rounds, HIP-event timing on the context's stream.
+under the two epilogue forms of the same binary: the default wave-private item loop (round 6: the producers' row statistics ride in its lean form) and
+the block-wide math-first form (`odise_hip_gemm_debug` 32768 << 4); plus the same shapes with a plain epilogue (no LayerNorm terms) as the yardstick.  Interleaved rounds, HIP-event timing on the context's stream.
 
     python tools/clip_gemm_bench.py [rounds=5] [M=9344]          (GPU)"""
 import os
@@ -14,7 +13,7 @@ sys.path.insert(0, ROOT)
 from odise_amd import _lib  # noqa: E402
 from odise_amd.runtime import Context  # noqa: E402
 
-FORMS = (("r6 pre-fold", 0), ("r5 item loop", 65536), ("block-wide", 32768))
+FORMS = (("wave-private", 0), ("block-wide", 32768))
 
 
 def main():
@@ -74,7 +73,7 @@ def main():
             tot[fname] += us
             cells.append(f"{fname} {us:7.1f} ({flops / us / 1e6:6.0f})")
         print(f"  {name:66s} " + "   ".join(cells))
-    print("  sum of the five (one block):" + "".join(f"   {k} {v:7.1f} us" for k, v in tot.items()) + f"   x 23 folded blocks: r6 {tot['r6 pre-fold'] * 23 / 1e3:.2f} ms, r5 {tot['r5 item loop'] * 23 / 1e3:.2f} ms")
+    print("  sum of the five (one block):" + "".join(f"   {k} {v:7.1f} us" for k, v in tot.items()) + f"   x 23 folded blocks: {tot['wave-private'] * 23 / 1e3:.2f} ms")
     ctx.close()
 
 
