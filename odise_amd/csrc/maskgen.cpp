@@ -622,6 +622,8 @@ static int ensure_pe_tables(odise_hip_ctx* ctx, ModelStore* ms, MaskGenModel* g,
     return ODISE_OK;
 }
 
+static int g_msda_unfused = 0;   // tools hook (odise_hip_msda_unfused): 1 = prepare kernel + the native-op kernel, for bit-compare and A/B runs
+
 // MSDeformAttnPixelDecoder.forward_features (msdeformattn.py:314-358)
 static int pixel_decoder_forward(odise_hip_ctx* ctx, const Act feats[4], PixDec& pd) {
     ModelStore* ms = store_of(ctx);
@@ -663,8 +665,12 @@ static int pixel_decoder_forward(odise_hip_ctx* ctx, const Act feats[4], PixDec&
         ODISE_TRY(ex.linear(src, MT, L.value, val));
         ODISE_TRY(gemm_f32out(ex, qin, MT, L.off, off));
         ODISE_TRY(gemm_f32out(ex, qin, MT, L.aw, aw));
-        ODISE_TRY(launch_msda_prepare(ctx, off, aw, loc, wts, B, Lq, M8, 3, g->enc_points, hs, ws, starts));
-        ODISE_TRY(odise_hip_ms_deform_attn_forward(ctx, val, ss, ls, loc, wts, B, Lq, M8, C / M8, Lq, 3, g->enc_points, 128, ODISE_F16, samp));
+        if (msda_fused_ok(M8, C / M8, 3, g->enc_points) && !g_msda_unfused) {
+            ODISE_TRY(launch_msda_fused(ctx, val, off, aw, samp, hs, ws, starts, B, Lq, M8, Lq));
+        } else {
+            ODISE_TRY(launch_msda_prepare(ctx, off, aw, loc, wts, B, Lq, M8, 3, g->enc_points, hs, ws, starts));
+            ODISE_TRY(odise_hip_ms_deform_attn_forward(ctx, val, ss, ls, loc, wts, B, Lq, M8, C / M8, Lq, 3, g->enc_points, 128, ODISE_F16, samp));
+        }
         ms->macs += (double)MT * M8 * LP * 4 * (C / M8);                                           // bilinear taps
         ODISE_TRY(ex.linear(samp, MT, L.out, x1, ODISE_ACT_NONE, src));
         ODISE_TRY(ex.layer_norm(x1, src, MT, L.norm1, 1e-5f));
@@ -1032,3 +1038,5 @@ extern "C" int odise_hip_maskgen_info(odise_hip_ctx* ctx, int* num_queries, int*
     if (last_macs) *last_macs = g ? g->last_macs : 0.0;
     return ODISE_OK;
 }
+
+extern "C" int odise_hip_msda_unfused(int on) { odise::g_msda_unfused = on; return 0; }

@@ -12,7 +12,7 @@
 // a contiguous D*sizeof(T)-byte segment.  Sampling locations / weights of a (q,m) pair are read once
 // per lane group (same-address broadcast).  One launch for the whole batch: the reference's
 // im2col_step chunking only bounded its temporary; there is no temporary here.
-#include "common.h"
+#include "engine.h"
 
 namespace odise {
 
@@ -115,6 +115,123 @@ __global__ void __launch_bounds__(256) msda_forward_kernel(const T* __restrict__
     }
 }
 
+// ---- pixel-decoder form (round 6): softmax of the 12 attention logits and the sampling locations computed in the kernel ------------------
+// The encoder layer of msdeformattn.py:92-131 produces raw offsets [R, M, L, P, 2] and attention logits [R, M, L, P] (two GEMMs) and
+// MSDeformAttn.forward (ops/modules/ms_deform_attn.py:98-125) turns them into locations (reference point + offset / (W_l, H_l)) and softmax
+// weights before the native op.  That step was a kernel of its own (msda_prepare_kernel: 99 MB written and read back per layer at 1024^2 x 4).
+// Here the gather kernel does it per (query, head) - the 8 lanes that share a pair load the same 36 floats (one broadcast request each) -
+// with the prepare kernel's arithmetic in its order, then the reference's fixed summation order over (level, point, corner): bit-identical
+// to prepare + gather.  Blocks are renumbered so that each XCD (private 4 MiB L2; the dispatcher deals consecutive workgroups round-robin over
+// the 8 XCDs) walks ONE contiguous eighth of the query range: counters of round 4 showed 373 MB fetched per launch for a 44 MB value tensor -
+// every XCD's L2 pulled all of it, because neighbouring queries (which sample neighbouring pixels) sat on eight different L2s.
+template <int L, int P>
+__global__ void __launch_bounds__(256) msda_fused_kernel(const f16* __restrict__ value, const float* __restrict__ off, const float* __restrict__ aw,
+                                                        f16* __restrict__ out, MsdaLevels lv, int64_t total, int S, int M, int Lq) {
+    constexpr int D = 32, VEC = 4, dchunks = D / VEC, LP = L * P;
+    // XCD-aware block order (bijective for any grid size, as in gemm.hip)
+    const int nb = gridDim.x, bid = blockIdx.x;
+    const int qd = nb >> 3, r = nb & 7, xcd = bid & 7, bi = bid >> 3;
+    const int logical = (xcd < r ? xcd * (qd + 1) : r * (qd + 1) + (xcd - r) * qd) + bi;
+    const int64_t idx = (int64_t)logical * 256 + threadIdx.x;
+    if (idx >= total) return;
+    const int dc = (int)(idx % dchunks);
+    const int64_t qm = idx / dchunks;  // ((b*Lq + q)*M + m)
+    const int m = (int)(qm % M);
+    const int64_t bq = qm / M;
+    const int b = (int)(bq / Lq), q = (int)(bq - (int64_t)b * Lq);
+    // reference point: the centre of the query's own cell at its own level (valid ratios 1: identical for every sampled level)
+    int lvl = 0;
+#pragma unroll
+    for (int l = 1; l < L; ++l)
+        if (q >= lv.start[l]) lvl = l;
+    const int local = q - lv.start[lvl];
+    const float ref_y = ((float)(local / lv.W[lvl]) + 0.5f) / (float)lv.H[lvl];
+    const float ref_x = ((float)(local % lv.W[lvl]) + 0.5f) / (float)lv.W[lvl];
+    float e[LP], ov[2 * LP];
+    {
+        const float* a = aw + qm * LP;
+        const float* o = off + qm * LP * 2;
+#pragma unroll
+        for (int i = 0; i < LP; i += 4) {
+            const float4 t = *reinterpret_cast<const float4*>(a + i);
+            e[i] = t.x; e[i + 1] = t.y; e[i + 2] = t.z; e[i + 3] = t.w;
+        }
+#pragma unroll
+        for (int i = 0; i < 2 * LP; i += 4) {
+            const float4 t = *reinterpret_cast<const float4*>(o + i);
+            ov[i] = t.x; ov[i + 1] = t.y; ov[i + 2] = t.z; ov[i + 3] = t.w;
+        }
+    }
+    float mx = -INFINITY;
+#pragma unroll
+    for (int i = 0; i < LP; ++i) mx = fmaxf(mx, e[i]);
+    float sum = 0.f;
+#pragma unroll
+    for (int i = 0; i < LP; ++i) { e[i] = expf(e[i] - mx); sum += e[i]; }
+    const float inv = 1.f / sum;
+    const f16* vb = value + ((int64_t)b * S * M + m) * D + dc * VEC;
+    const int64_t pix_stride = (int64_t)M * D;
+    float acc[VEC] = {0.f, 0.f, 0.f, 0.f};
+    // Branch-free per level: the 16 corner loads of a level's four points are issued back to back from CLAMPED (always valid) addresses and an
+    // out-of-range corner / point gets weight 0 instead of being skipped (0 x finite = 0, and adding it leaves the sum's bits unchanged): the
+    // reference kernel's guarded loads (ms_deform_im2col_cuda.cuh:38-89) cost a divergent branch and a memory round trip per corner.
+#pragma unroll
+    for (int l = 0; l < L; ++l) {
+        const int Hl = lv.H[l], Wl = lv.W[l];
+        const f16* vl = vb + (int64_t)lv.start[l] * pix_stride;
+        f16x4 c[P][4];
+        float cw[P][4], pw[P];
+#pragma unroll
+        for (int p = 0; p < P; ++p) {
+            const int i = l * P + p;
+            const float lx = ref_x + ov[2 * i + 0] / (float)Wl;
+            const float ly = ref_y + ov[2 * i + 1] / (float)Hl;
+            const float h_im = ly * (float)Hl - 0.5f;
+            const float w_im = lx * (float)Wl - 0.5f;
+            const bool in = h_im > -1.f && w_im > -1.f && h_im < (float)Hl && w_im < (float)Wl;
+            const float hf = floorf(h_im), wf = floorf(w_im);
+            const int h_low = (int)fminf(fmaxf(hf, -1.f), (float)Hl), w_low = (int)fminf(fmaxf(wf, -1.f), (float)Wl);   // (clamped before the conversion: a far-off point must not overflow int)
+            const int h_high = h_low + 1, w_high = w_low + 1;
+            const float lh = h_im - hf, lw = w_im - wf;
+            const float hh = 1.f - lh, hw = 1.f - lw;
+            const bool t = h_low >= 0, bt = h_high <= Hl - 1, lf = w_low >= 0, rt = w_high <= Wl - 1;
+            const int hl = min(max(h_low, 0), Hl - 1), hh_i = min(max(h_high, 0), Hl - 1), wl = min(max(w_low, 0), Wl - 1), wh = min(max(w_high, 0), Wl - 1);
+            c[p][0] = *reinterpret_cast<const f16x4*>(vl + ((int64_t)hl * Wl + wl) * pix_stride);
+            c[p][1] = *reinterpret_cast<const f16x4*>(vl + ((int64_t)hl * Wl + wh) * pix_stride);
+            c[p][2] = *reinterpret_cast<const f16x4*>(vl + ((int64_t)hh_i * Wl + wl) * pix_stride);
+            c[p][3] = *reinterpret_cast<const f16x4*>(vl + ((int64_t)hh_i * Wl + wh) * pix_stride);
+            cw[p][0] = (in && t && lf) ? hh * hw : 0.f;
+            cw[p][1] = (in && t && rt) ? hh * lw : 0.f;
+            cw[p][2] = (in && bt && lf) ? lh * hw : 0.f;
+            cw[p][3] = (in && bt && rt) ? lh * lw : 0.f;
+            pw[p] = in ? e[i] * inv : 0.f;
+        }
+#pragma unroll
+        for (int p = 0; p < P; ++p)
+#pragma unroll
+            for (int k = 0; k < VEC; ++k) {
+                const float val = cw[p][0] * (float)c[p][0][k] + cw[p][1] * (float)c[p][1][k] + cw[p][2] * (float)c[p][2][k] + cw[p][3] * (float)c[p][3][k];
+                acc[k] += pw[p] * val;
+            }
+    }
+    VecIO<f16, VEC>::store(out + qm * D + dc * VEC, acc);
+}
+
+// value f16 [B, S, M, 32]; off f32 [B*Lq, M*L*P*2] and aw f32 [B*Lq, M*L*P] as the two projections leave them; out f16 [B*Lq, M*32].
+// L = 3 levels x P = 4 points (the released configuration); anything else: launch_msda_prepare + odise_hip_ms_deform_attn_forward
+bool msda_fused_ok(int M, int D, int L, int P) { return D == 32 && L == 3 && P == 4 && M >= 1; }
+int launch_msda_fused(odise_hip_ctx* ctx, const f16* value, const float* off, const float* aw, f16* out, const int* Hs, const int* Ws, const int* starts, int B,
+                      int S, int M, int Lq) {
+    MsdaLevels lv;
+    for (int l = 0; l < 3; ++l) { lv.H[l] = Hs[l]; lv.W[l] = Ws[l]; lv.start[l] = starts[l]; }
+    const int64_t total = (int64_t)B * Lq * M * 8;
+    if (total == 0) return ODISE_OK;
+    ODISE_REQUIRE(ceil_div(total, 256) < (1ll << 31), "msda: too many queries for one launch");
+    hipLaunchKernelGGL((msda_fused_kernel<3, 4>), dim3((unsigned)ceil_div(total, 256)), dim3(256), 0, ctx->stream, value, off, aw, out, lv, total, S, M, Lq);
+    ODISE_CHECK_HIP(hipGetLastError());
+    return ODISE_OK;
+}
+
 template <typename T>
 static int launch_msda(hipStream_t stream, const void* value, const float* loc, const float* attw, void* out,
                        const MsdaLevels& lv, int B, int S, int M, int D, int Lq, int L, int P) {
@@ -170,4 +287,20 @@ extern "C" int odise_hip_ms_deform_attn_forward(odise_hip_ctx* ctx, const void* 
     if (value_dtype == ODISE_F32)
         return launch_msda<float>(ctx->stream, value, sampling_loc, attn_weight, out, lv, B, S, M, D, Lq, L, P);
     return launch_msda<f16>(ctx->stream, value, sampling_loc, attn_weight, out, lv, B, S, M, D, Lq, L, P);
+}
+
+// test hook (include/odise_hip_tools.h): the pixel decoder's fused form on caller-provided raw projections, and the two-kernel form it replaces
+extern "C" int odise_hip_msda_fused_forward(odise_hip_ctx* ctx, const void* value, const float* off, const float* aw, const int* hs3, const int* ws3, int B, int M,
+                                            int fused, void* out, float* loc_scratch, float* w_scratch) {
+    using namespace odise;
+    ODISE_REQUIRE(ctx && value && off && aw && hs3 && ws3 && out && B >= 1 && M >= 1, "msda_fused_forward: bad argument");
+    ODISE_CHECK_HIP(hipSetDevice(ctx->device));
+    int starts[3], Lq = 0;
+    for (int l = 0; l < 3; ++l) { starts[l] = Lq; Lq += hs3[l] * ws3[l]; }
+    if (fused) return launch_msda_fused(ctx, (const f16*)value, off, aw, (f16*)out, hs3, ws3, starts, B, Lq, M, Lq);
+    ODISE_REQUIRE(loc_scratch && w_scratch, "msda_fused_forward: the two-kernel form needs loc / w scratch");
+    ODISE_TRY(launch_msda_prepare(ctx, off, aw, loc_scratch, w_scratch, B, Lq, M, 3, 4, hs3, ws3, starts));
+    int64_t ss[6], ls[3];
+    for (int l = 0; l < 3; ++l) { ss[2 * l] = hs3[l]; ss[2 * l + 1] = ws3[l]; ls[l] = starts[l]; }
+    return odise_hip_ms_deform_attn_forward(ctx, value, ss, ls, loc_scratch, w_scratch, B, Lq, M, 32, Lq, 3, 4, 128, ODISE_F16, out);
 }

@@ -159,6 +159,25 @@ def test_head_full_size_from_reference_features(full):
     assert rep["iou_min"] > 0.93 and rep["iou_med"] > 0.985
 
 
+def test_fused_msda_gather_against_prepare_plus_native_op_at_full_size(full, ctx):
+    """The pixel decoder's six MSDeformAttn layers run `msda_fused_kernel` (round 6: softmax of the 12 logits + sampling locations + a branch-free
+    gather in one kernel, XCD-aware block order); `odise_hip_msda_unfused(1)` restores `msda_prepare_kernel` + the native-op kernel (the form the
+    reference's ops/test.py vectors pin).  The two agree to the last fp16 bit of an output per layer (tests/test_gpu_ops.py, op level); through
+    six layers and the masked decoder's hard decisions that is the usual device-against-device spread, held to the head's own error bound."""
+    hip = full["hip"]
+    feats = {k: v.numpy() for k, v in full["ref"][0].items()}
+    a = hip.head(feats)
+    ctx.lib.odise_hip_msda_unfused(1)
+    try:
+        b = hip.head(feats)
+    finally:
+        ctx.lib.odise_hip_msda_unfused(0)
+    for k in ("pred_masks", "mask_embed", "mask_pooled_features"):
+        err, cos, scale = _rel(a[k], b[k])
+        print(f"fused vs two-kernel MSDeformAttn, {k}: max diff / scale {err:.3e} cos {cos:.7f}")
+        assert err < TAU_MASK and cos > 0.99999, (k, err, cos)
+
+
 def test_classification_full_size(coco, ctx, ln_fold):
     full = coco
     """CategoryEmbed + MaskCLIP (ViT-L/14@336, 100 mask tokens + 577 image tokens) + ensemble + null merge at K = 133 / 254 strings,

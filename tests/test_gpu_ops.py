@@ -72,6 +72,48 @@ def test_msda_linearity_and_empty(ctx):
     assert e.shape == (2, 0, 256)
 
 
+def test_msda_fused_gather_against_prepare_plus_native_op(ctx):
+    """msda_fused_kernel (round 6: softmax + sampling locations + branch-free gather, XCD-aware block order) against msda_prepare_kernel + the
+    native-op kernel on the same raw projections, offsets large enough that a fifth of the points leave the maps (zero padding outside
+    (-1, H) x (-1, W), ms_deform_im2col_cuda.cuh:38-89) - and both against the fp64 restatement of the reference op."""
+    import ctypes as C
+    from oracle.msda import msda_forward_torch
+    g = torch.Generator().manual_seed(11)
+    B, M, hs, ws = 2, 8, (8, 16, 32), (8, 16, 32)
+    Lq = sum(h_ * w_ for h_, w_ in zip(hs, ws))
+    value = h(torch.randn(B, Lq, M, 32, generator=g))
+    off = torch.randn(B * Lq, M * 12 * 2, generator=g) * 6.0
+    aw = torch.randn(B * Lq, M * 12, generator=g) * 2.0
+    dv, do, da = ctx.to_device(value.half().numpy()), ctx.to_device(off.numpy()), ctx.to_device(aw.numpy())
+    loc_s, w_s = ctx.empty((B * Lq * M * 24,), np.float32), ctx.empty((B * Lq * M * 12,), np.float32)
+    hs3, ws3 = (C.c_int * 3)(*hs), (C.c_int * 3)(*ws)
+    outs = {}
+    for fused in (1, 0):
+        o = ctx.empty((B * Lq, M * 32), np.float16)
+        _lib.check(ctx.lib.odise_hip_msda_fused_forward(ctx.h, dv, do, da, hs3, ws3, B, M, fused, o, loc_s, w_s), "msda_fused_forward")
+        outs[fused] = o.numpy().astype(np.float64)
+    # the reference op on the same locations / weights (fp64)
+    starts = np.cumsum([0] + [a * b for a, b in zip(hs, ws)])[:3]
+    q = torch.arange(Lq)
+    lvl = (q[:, None] >= torch.as_tensor(starts)[None]).sum(1) - 1
+    local = q - torch.as_tensor(starts)[lvl]
+    Wl, Hl = torch.as_tensor(ws)[lvl], torch.as_tensor(hs)[lvl]
+    ref_xy = torch.stack([((local % Wl).double() + 0.5) / Wl, ((local // Wl).double() + 0.5) / Hl], -1)               # [Lq, 2]
+    norm = torch.tensor([[w_, h_] for h_, w_ in zip(hs, ws)], dtype=torch.float64)                                    # [3, 2] = (W, H)
+    loc = ref_xy[None, :, None, None, None, :] + off.double().view(B, Lq, M, 3, 4, 2) / norm[None, None, None, :, None, :]
+    wts = torch.softmax(aw.double().view(B, Lq, M, 12), -1).view(B, Lq, M, 3, 4)
+    shp = torch.tensor([[h_, w_] for h_, w_ in zip(hs, ws)])
+    ref = msda_forward_torch(value.double(), shp, torch.as_tensor(starts), loc, wts).numpy().reshape(B * Lq, M * 32)
+    outside = float(((loc < 0) | (loc > 1)).any(-1).double().mean())
+    d = np.abs(outs[1] - outs[0]).max()
+    print(f"msda fused vs two-kernel: max diff {d:.3e}; vs fp64 reference: fused {np.abs(outs[1] - ref).max():.3e} two-kernel {np.abs(outs[0] - ref).max():.3e}; "
+          f"points outside [0, 1]: {outside:.2f}")
+    assert outside > 0.1
+    close(outs[1], ref, rtol=2e-3, atol=2e-3, what="fused msda vs fp64 reference")
+    close(outs[0], ref, rtol=2e-3, atol=2e-3, what="two-kernel msda vs fp64 reference")
+    assert d <= 2e-3, d      # both round their fp32 sums to fp16 once: they may differ in the last fp16 bit of an output, not more
+
+
 def test_msda_bad_im2col_step_raises(ctx):
     value, shp, start, loc, w = make_inputs(3, 2, 4, 5, [(4, 4)], 2, seed=23)
     with pytest.raises(RuntimeError):
