@@ -48,7 +48,7 @@ int odise_hip_sem_tile(int tile);
 /* 1: the pixel decoder's MSDeformAttn layers as msda_prepare_kernel + the native-op kernel (the round 1-5 form) instead of the fused gather (A/B, bit-compare) */
 int odise_hip_msda_unfused(int on);
 /* the pixel decoder's MSDeformAttn on raw projections: value f16 [B, Lq, M, 32], off f32 [B*Lq, M*12*2], aw f32 [B*Lq, M*12] (3 levels hs3 x ws3, 4 points),
- * out f16 [B*Lq, M*32].  fused != 0: msda_fused_kernel; 0: msda_prepare_kernel (into loc_scratch [B*Lq*M*24] / w_scratch [B*Lq*M*12]) + the native-op kernel */
+ * out f16 [B*Lq, M*32].  fused = 2 (or any other non-zero value): msda_fused_kernel as the pixel decoder runs it, 1: its 8-lanes-per-pair variant; 0: msda_prepare_kernel (into loc_scratch [B*Lq*M*24] / w_scratch [B*Lq*M*12]) + the native-op kernel */
 int odise_hip_msda_fused_forward(odise_hip_ctx* ctx, const void* value, const float* off, const float* aw, const int* hs3, const int* ws3, int B, int M, int fused,
                                  void* out, float* loc_scratch, float* w_scratch);
 

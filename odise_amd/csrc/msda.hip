@@ -119,15 +119,16 @@ __global__ void __launch_bounds__(256) msda_forward_kernel(const T* __restrict__
 // The encoder layer of msdeformattn.py:92-131 produces raw offsets [R, M, L, P, 2] and attention logits [R, M, L, P] (two GEMMs) and
 // MSDeformAttn.forward (ops/modules/ms_deform_attn.py:98-125) turns them into locations (reference point + offset / (W_l, H_l)) and softmax
 // weights before the native op.  That step was a kernel of its own (msda_prepare_kernel: 99 MB written and read back per layer at 1024^2 x 4).
-// Here the gather kernel does it per (query, head) - the 8 lanes that share a pair load the same 36 floats (one broadcast request each) -
+// Here the gather kernel does it per (query, head) - the 4 lanes that share a pair load the same 36 floats (one broadcast request each) -
 // with the prepare kernel's arithmetic in its order, then the reference's fixed summation order over (level, point, corner): bit-identical
 // to prepare + gather.  Blocks are renumbered so that each XCD (private 4 MiB L2; the dispatcher deals consecutive workgroups round-robin over
 // the 8 XCDs) walks ONE contiguous eighth of the query range: counters of round 4 showed 373 MB fetched per launch for a 44 MB value tensor -
 // every XCD's L2 pulled all of it, because neighbouring queries (which sample neighbouring pixels) sat on eight different L2s.
-template <int L, int P>
+template <int L, int P, int VEC>
 __global__ void __launch_bounds__(256) msda_fused_kernel(const f16* __restrict__ value, const float* __restrict__ off, const float* __restrict__ aw,
                                                         f16* __restrict__ out, MsdaLevels lv, int64_t total, int S, int M, int Lq) {
-    constexpr int D = 32, VEC = 4, dchunks = D / VEC, LP = L * P;
+    constexpr int D = 32, dchunks = D / VEC, LP = L * P;
+    typedef _Float16 fvec __attribute__((ext_vector_type(VEC)));
     // XCD-aware block order (bijective for any grid size, as in gemm.hip)
     const int nb = gridDim.x, bid = blockIdx.x;
     const int qd = nb >> 3, r = nb & 7, xcd = bid & 7, bi = bid >> 3;
@@ -171,7 +172,9 @@ __global__ void __launch_bounds__(256) msda_fused_kernel(const f16* __restrict__
     const float inv = 1.f / sum;
     const f16* vb = value + ((int64_t)b * S * M + m) * D + dc * VEC;
     const int64_t pix_stride = (int64_t)M * D;
-    float acc[VEC] = {0.f, 0.f, 0.f, 0.f};
+    float acc[VEC];
+#pragma unroll
+    for (int k = 0; k < VEC; ++k) acc[k] = 0.f;
     // Branch-free per level: the 16 corner loads of a level's four points are issued back to back from CLAMPED (always valid) addresses and an
     // out-of-range corner / point gets weight 0 instead of being skipped (0 x finite = 0, and adding it leaves the sum's bits unchanged): the
     // reference kernel's guarded loads (ms_deform_im2col_cuda.cuh:38-89) cost a divergent branch and a memory round trip per corner.
@@ -179,7 +182,7 @@ __global__ void __launch_bounds__(256) msda_fused_kernel(const f16* __restrict__
     for (int l = 0; l < L; ++l) {
         const int Hl = lv.H[l], Wl = lv.W[l];
         const f16* vl = vb + (int64_t)lv.start[l] * pix_stride;
-        f16x4 c[P][4];
+        fvec c[P][4];
         float cw[P][4], pw[P];
 #pragma unroll
         for (int p = 0; p < P; ++p) {
@@ -196,10 +199,10 @@ __global__ void __launch_bounds__(256) msda_fused_kernel(const f16* __restrict__
             const float hh = 1.f - lh, hw = 1.f - lw;
             const bool t = h_low >= 0, bt = h_high <= Hl - 1, lf = w_low >= 0, rt = w_high <= Wl - 1;
             const int hl = min(max(h_low, 0), Hl - 1), hh_i = min(max(h_high, 0), Hl - 1), wl = min(max(w_low, 0), Wl - 1), wh = min(max(w_high, 0), Wl - 1);
-            c[p][0] = *reinterpret_cast<const f16x4*>(vl + ((int64_t)hl * Wl + wl) * pix_stride);
-            c[p][1] = *reinterpret_cast<const f16x4*>(vl + ((int64_t)hl * Wl + wh) * pix_stride);
-            c[p][2] = *reinterpret_cast<const f16x4*>(vl + ((int64_t)hh_i * Wl + wl) * pix_stride);
-            c[p][3] = *reinterpret_cast<const f16x4*>(vl + ((int64_t)hh_i * Wl + wh) * pix_stride);
+            c[p][0] = *reinterpret_cast<const fvec*>(vl + ((int64_t)hl * Wl + wl) * pix_stride);
+            c[p][1] = *reinterpret_cast<const fvec*>(vl + ((int64_t)hl * Wl + wh) * pix_stride);
+            c[p][2] = *reinterpret_cast<const fvec*>(vl + ((int64_t)hh_i * Wl + wl) * pix_stride);
+            c[p][3] = *reinterpret_cast<const fvec*>(vl + ((int64_t)hh_i * Wl + wh) * pix_stride);
             cw[p][0] = (in && t && lf) ? hh * hw : 0.f;
             cw[p][1] = (in && t && rt) ? hh * lw : 0.f;
             cw[p][2] = (in && bt && lf) ? lh * hw : 0.f;
@@ -214,20 +217,28 @@ __global__ void __launch_bounds__(256) msda_fused_kernel(const f16* __restrict__
                 acc[k] += pw[p] * val;
             }
     }
-    VecIO<f16, VEC>::store(out + qm * D + dc * VEC, acc);
+    fvec o;
+#pragma unroll
+    for (int k = 0; k < VEC; ++k) o[k] = (f16)acc[k];
+    *reinterpret_cast<fvec*>(out + qm * D + dc * VEC) = o;
 }
 
 // value f16 [B, S, M, 32]; off f32 [B*Lq, M*L*P*2] and aw f32 [B*Lq, M*L*P] as the two projections leave them; out f16 [B*Lq, M*32].
 // L = 3 levels x P = 4 points (the released configuration); anything else: launch_msda_prepare + odise_hip_ms_deform_attn_forward
 bool msda_fused_ok(int M, int D, int L, int P) { return D == 32 && L == 3 && P == 4 && M >= 1; }
+// Lanes per (query, head) pair: 4 lanes x 16 bytes (VEC = 8) measured 175 us per layer at 4 x 1024^2 against 250 us with 8 lanes x 8 bytes and 317 us for
+// prepare + native op (tools/msda_bench.py, profiles/r06_msda_variants.txt) - half the load instructions per gathered byte is worth more than the
+// occupancy (178 VGPRs: two waves per SIMD; forcing three by a launch bound changed nothing).
+static int g_msda_vec = 8;   // tools: odise_hip_msda_fused_forward fused = 1 measures the 8-lane form
 int launch_msda_fused(odise_hip_ctx* ctx, const f16* value, const float* off, const float* aw, f16* out, const int* Hs, const int* Ws, const int* starts, int B,
                       int S, int M, int Lq) {
     MsdaLevels lv;
     for (int l = 0; l < 3; ++l) { lv.H[l] = Hs[l]; lv.W[l] = Ws[l]; lv.start[l] = starts[l]; }
-    const int64_t total = (int64_t)B * Lq * M * 8;
+    const int64_t total = (int64_t)B * Lq * M * (32 / g_msda_vec);
     if (total == 0) return ODISE_OK;
     ODISE_REQUIRE(ceil_div(total, 256) < (1ll << 31), "msda: too many queries for one launch");
-    hipLaunchKernelGGL((msda_fused_kernel<3, 4>), dim3((unsigned)ceil_div(total, 256)), dim3(256), 0, ctx->stream, value, off, aw, out, lv, total, S, M, Lq);
+    if (g_msda_vec == 8) hipLaunchKernelGGL((msda_fused_kernel<3, 4, 8>), dim3((unsigned)ceil_div(total, 256)), dim3(256), 0, ctx->stream, value, off, aw, out, lv, total, S, M, Lq);
+    else hipLaunchKernelGGL((msda_fused_kernel<3, 4, 4>), dim3((unsigned)ceil_div(total, 256)), dim3(256), 0, ctx->stream, value, off, aw, out, lv, total, S, M, Lq);
     ODISE_CHECK_HIP(hipGetLastError());
     return ODISE_OK;
 }
@@ -297,7 +308,12 @@ extern "C" int odise_hip_msda_fused_forward(odise_hip_ctx* ctx, const void* valu
     ODISE_CHECK_HIP(hipSetDevice(ctx->device));
     int starts[3], Lq = 0;
     for (int l = 0; l < 3; ++l) { starts[l] = Lq; Lq += hs3[l] * ws3[l]; }
-    if (fused) return launch_msda_fused(ctx, (const f16*)value, off, aw, (f16*)out, hs3, ws3, starts, B, Lq, M, Lq);
+    if (fused) {
+        g_msda_vec = fused == 1 ? 4 : 8;
+        const int rc = launch_msda_fused(ctx, (const f16*)value, off, aw, (f16*)out, hs3, ws3, starts, B, Lq, M, Lq);
+        g_msda_vec = 8;
+        return rc;
+    }
     ODISE_REQUIRE(loc_scratch && w_scratch, "msda_fused_forward: the two-kernel form needs loc / w scratch");
     ODISE_TRY(launch_msda_prepare(ctx, off, aw, loc_scratch, w_scratch, B, Lq, M, 3, 4, hs3, ws3, starts));
     int64_t ss[6], ls[3];
