@@ -314,10 +314,23 @@ def calibrated_model(ctx, first_image_u8, S, K, K_TOT, things, anchored, positiv
     banks spread over the device's own mask / MaskCLIP embeddings.  Everything here happens before the timed region."""
     from odise_amd import synthetic as syn
     from odise_amd.pipeline import HipCategoryODISE
-    state = syn.synthetic_state()
+    # several ranks on one host (--gpus N): ONE fp32 copy of the 1.28 G synthetic parameters in /dev/shm, mapped by every rank, instead of N
+    # private 5.1 GB copies generated N times (VERDICT r05: the 8-rank set-up had never run anywhere; tests/test_launch_cpu.py rehearses it)
+    shared = None
+    if int(os.environ.get("WORLD_SIZE", "1")) > 1:
+        state, shared = syn.synthetic_state_shared()
+        state = dict(state)
+    else:
+        state = syn.synthetic_state()
     syn.apply_branch_gain(state)
     hip = HipCategoryODISE(ctx, state, overlap_threshold=0.8)
-    state = {k: v for k, v in state.items() if k.startswith(("sem_seg_head.", "category_head."))}   # the frozen towers are on the device now
+    state = {k: np.array(v) for k, v in state.items() if k.startswith(("sem_seg_head.", "category_head."))}   # the frozen towers are on the device now
+    if shared is not None:   # every rank has mapped the file and handed the weights to its library: the local leader removes it
+        import torch.distributed as dist
+        syn.release_shared(shared, unlink=False)
+        dist.barrier()
+        if int(os.environ.get("LOCAL_RANK", "0")) == 0:
+            syn.release_shared(shared, unlink=True)
     cat, clp, sizes, overlap = syn.synthetic_vocabulary(K, K_TOT, 768)
     hip.set_vocabulary(cat, clp, sizes, overlap, things, 0.3, 0.7)              # provisional (random) banks: the calibration pass needs one
     img01 = ctx.to_device(np.ascontiguousarray(first_image_u8.transpose(2, 0, 1)[None].astype(np.float32) / 255.0))

@@ -15,6 +15,8 @@
 namespace odise {
 
 constexpr int GN_MAX_C = 4096;
+static int g_gn_chunk_factor = 2;     // chunks of the statistics pass = cu_count * factor / N per image: two fat blocks per CU (measured: UNet at 16 crops 21.5 ms at 8, 21.3 at 2; tools: odise_hip_gn_tuning)
+static int g_gn_fold_in_apply = 1;    // 1: the apply kernel folds the chunk partials itself when there are <= 64 per image (no finalize launch)
 
 __global__ void __launch_bounds__(256) gn_partial_kernel(const f16* __restrict__ x, float* __restrict__ partial, int HW, int C,
                                                         int G, int pix_per_chunk) {
@@ -166,15 +168,49 @@ __global__ void __launch_bounds__(256) gn_apply_kernel(const f16* __restrict__ x
                                                       const float* __restrict__ stats, const float* __restrict__ gamma,
                                                       const float* __restrict__ beta, int HW, int C, int G,
                                                       int act, const f16* __restrict__ residual,
-                                                      const f16* __restrict__ accum) {
+                                                      const f16* __restrict__ accum, int nchunks, float eps) {
     extern __shared__ __attribute__((aligned(16))) float sss[];  // scale[C], shift[C]
     float* scale = sss;
     float* shift = sss + C;
     const int n = blockIdx.y, tid = threadIdx.x;
     const int cpg = C / G;
+    __shared__ double red[2 * 256];
+    __shared__ float gstat[2 * 256];
+    if (nchunks > 0) {
+        // Round 6: `stats` holds the chunk partials [N][nchunks][G][2] of gn_partial_kernel and every block folds its image's (a few KB, L2-hot)
+        // itself, in gn_finalize_kernel's order (the same bits): one launch of ~14 us less per GroupNorm in the UNet's dependent chain
+        const int nsub = 256 / G;
+        const int gI = tid % G, sub = tid / G;
+        double s = 0.0, q = 0.0;
+        if (sub < nsub) {
+            for (int ch = sub; ch < nchunks; ch += nsub) {
+                const float2 o = *reinterpret_cast<const float2*>(stats + (((int64_t)n * nchunks + ch) * G + gI) * 2);
+                s += (double)o.x;
+                q += (double)o.y;
+            }
+        }
+        red[2 * tid] = s;
+        red[2 * tid + 1] = q;
+        __syncthreads();
+        if (tid < G) {
+            s = q = 0.0;
+            for (int u = 0; u < nsub; ++u) {
+                s += red[2 * (u * G + tid)];
+                q += red[2 * (u * G + tid) + 1];
+            }
+            const double cnt = (double)HW * cpg;
+            const double mu = s / cnt;
+            double var = q / cnt - mu * mu;
+            if (var < 0.0) var = 0.0;
+            gstat[2 * tid] = (float)mu;
+            gstat[2 * tid + 1] = (float)(1.0 / sqrt(var + (double)eps));
+        }
+        __syncthreads();
+    }
     for (int c = tid; c < C; c += blockDim.x) {
         const int gI = c / cpg;
-        const float mu = stats[((int64_t)n * G + gI) * 2], rs = stats[((int64_t)n * G + gI) * 2 + 1];
+        const float mu = nchunks > 0 ? gstat[2 * gI] : stats[((int64_t)n * G + gI) * 2];
+        const float rs = nchunks > 0 ? gstat[2 * gI + 1] : stats[((int64_t)n * G + gI) * 2 + 1];
         const float sc = rs * (gamma ? gamma[c] : 1.f);
         scale[c] = sc;
         shift[c] = (beta ? beta[c] : 0.f) - mu * sc;
@@ -403,7 +439,7 @@ extern "C" int odise_hip_group_norm_ex(odise_hip_ctx* ctx, const void* x, void* 
     const int PL = 256 / VW;
     // chunking: ~2 blocks per CU over the batch, every pixel lane gets at least ~2 pixels, at most 512 chunks per image
     ODISE_REQUIRE((int64_t)HW * (C / 8) < (1ll << 31) - (1 << 24), "group_norm: image too large");
-    int64_t want = std::max<int64_t>(1, (int64_t)ctx->cu_count * 8 / N);
+    int64_t want = std::max<int64_t>(1, (int64_t)ctx->cu_count * g_gn_chunk_factor / N);
     int64_t maxc = std::max<int64_t>(1, HW / (4 * PL));
     int nchunks = (int)std::min<int64_t>(std::min<int64_t>(want, maxc), 256);
     const int ppc = (int)ceil_div(HW, nchunks);
@@ -415,12 +451,16 @@ extern "C" int odise_hip_group_norm_ex(odise_hip_ctx* ctx, const void* x, void* 
     hipLaunchKernelGGL(gn_partial_kernel, dim3(nchunks, N), dim3(256), 2 * (size_t)PL * C * sizeof(float), ctx->stream, (const f16*)x,
                        partial, HW, C, groups, ppc);
     ODISE_CHECK_HIP(hipGetLastError());
-    hipLaunchKernelGGL(gn_finalize_kernel, dim3(N), dim3(256), 0, ctx->stream, partial, stats, HW, C, groups, nchunks, eps);
-    ODISE_CHECK_HIP(hipGetLastError());
+    // the apply blocks fold the partials themselves when there are few of them (<= 64 chunks: 16 KB per image, L2-hot); otherwise one finalize launch
+    const bool fold_in_apply = g_gn_fold_in_apply && nchunks <= 64;
+    if (!fold_in_apply) {
+        hipLaunchKernelGGL(gn_finalize_kernel, dim3(N), dim3(256), 0, ctx->stream, partial, stats, HW, C, groups, nchunks, eps);
+        ODISE_CHECK_HIP(hipGetLastError());
+    }
     const int64_t total = (int64_t)HW * (C / 8);
     const int bpi = (int)std::max<int64_t>(1, ceil_div(total, 256 * 4));  // four vectors per thread
-    hipLaunchKernelGGL(gn_apply_kernel, dim3(bpi, N), dim3(256), 2 * (size_t)C * sizeof(float), ctx->stream, (const f16*)x, (f16*)y, stats, gamma,
-                       beta, HW, C, groups, act, (const f16*)residual, (const f16*)accum);
+    hipLaunchKernelGGL(gn_apply_kernel, dim3(bpi, N), dim3(256), 2 * (size_t)C * sizeof(float), ctx->stream, (const f16*)x, (f16*)y,
+                       fold_in_apply ? partial : stats, gamma, beta, HW, C, groups, act, (const f16*)residual, (const f16*)accum, fold_in_apply ? nchunks : 0, eps);
     ODISE_CHECK_HIP(hipGetLastError());
     return ODISE_OK;
 }
@@ -439,7 +479,7 @@ int group_norm_from_colpart(odise_hip_ctx* ctx, const void* x, void* y, const fl
     const int64_t total = (int64_t)HW * (C / 8);
     const int bpi = (int)std::max<int64_t>(1, ceil_div(total, 256 * 4));
     hipLaunchKernelGGL(gn_apply_kernel, dim3(bpi, N), dim3(256), 2 * (size_t)C * sizeof(float), ctx->stream, (const f16*)x, (f16*)y, stats, gamma,
-                       beta, HW, C, groups, act, (const f16*)nullptr, (const f16*)nullptr);
+                       beta, HW, C, groups, act, (const f16*)nullptr, (const f16*)nullptr, 0, eps);
     ODISE_CHECK_HIP(hipGetLastError());
     return ODISE_OK;
 }
@@ -469,4 +509,11 @@ extern "C" int odise_hip_layer_norm(odise_hip_ctx* ctx, const void* x, void* y, 
     else launch(layer_norm_kernel<8, 1>, 1);
     ODISE_CHECK_HIP(hipGetLastError());
     return ODISE_OK;
+}
+
+// tools hook (include/odise_hip_tools.h): chunk density of the GroupNorm statistics pass and whether the apply kernel finishes the statistics itself
+extern "C" int odise_hip_gn_tuning(int chunk_factor, int fold_in_apply) {
+    if (chunk_factor >= 1) odise::g_gn_chunk_factor = chunk_factor;
+    odise::g_gn_fold_in_apply = fold_in_apply != 0;
+    return 0;
 }

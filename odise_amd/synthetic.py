@@ -38,6 +38,66 @@ def synthetic_state(prefixes: Optional[Iterable[str]] = None, strip: str = "", s
     return out
 
 
+def synthetic_state_shared(prefixes: Optional[Iterable[str]] = None, strip: str = "", seed: int = 0, directory: Optional[str] = None):
+    """`synthetic_state` once per HOST: the ranks of a multi-GPU run (bench.py --gpus N: one process per GPU, each loading the same 1.28 G
+    synthetic parameters) share ONE fp32 copy in /dev/shm instead of generating and holding 5.1 GB each - the first process to take the file lock
+    draws the tensors (same per-tensor seeds: bit-identical to `synthetic_state`), the others map the file read-only.  8 ranks: 5.1 GB of shared
+    pages + each rank's transient staging copy inside the library, instead of 8 x (5.1 + 5.1) GB.
+    -> (state dict of read-only views, handle); `release_shared(handle, unlink=...)` when the weights are on the device: every rank drops its
+    mapping, ONE rank per host (after a barrier) unlinks the file - a mapped file lives until its last mapping goes."""
+    import fcntl
+    import hashlib
+    import tempfile
+    spec = load_spec()
+    pre = tuple(prefixes) if prefixes is not None else None
+    names = [n for n in spec if pre is None or n.startswith(pre)]
+    if not names:
+        raise KeyError(f"no tensors with prefixes {pre} in {SPEC_PATH}")
+    sizes = [int(np.prod(spec[n][0])) if len(spec[n][0]) else 1 for n in names]
+    total = int(sum(sizes))
+    key = hashlib.sha1(json.dumps([[n, spec[n]] for n in names] + [seed]).encode()).hexdigest()[:16]
+    root = directory or ("/dev/shm" if os.path.isdir("/dev/shm") else tempfile.gettempdir())
+    base = os.path.join(root, f"odise_synth_{os.getuid()}_{key}")
+    data, ok, lock = base + ".f32", base + ".ok", base + ".lock"
+    with open(lock, "w") as lf:
+        fcntl.flock(lf, fcntl.LOCK_EX)
+        try:
+            if not (os.path.exists(ok) and os.path.exists(data) and os.path.getsize(data) == total * 4):
+                mm = np.memmap(data, np.float32, mode="w+", shape=(total,))
+                off = 0
+                for n, cnt in zip(names, sizes):
+                    shape, mean, std = spec[n]
+                    rng = np.random.default_rng((zlib.crc32(n.encode()) << 16) ^ seed)
+                    a = rng.standard_normal(shape, dtype=np.float32) if len(shape) else np.float32(rng.standard_normal())
+                    mm[off:off + cnt] = (np.asarray(a, np.float32) * np.float32(std) + np.float32(mean)).reshape(-1)
+                    off += cnt
+                mm.flush()
+                del mm
+                with open(ok, "w") as f:
+                    f.write(str(total))
+        finally:
+            fcntl.flock(lf, fcntl.LOCK_UN)
+    mm = np.memmap(data, np.float32, mode="r", shape=(total,))
+    out, off = {}, 0
+    for n, cnt in zip(names, sizes):
+        shape = spec[n][0]
+        out[n[len(strip):] if strip and n.startswith(strip) else n] = mm[off:off + cnt].reshape(shape) if len(shape) else mm[off:off + 1].reshape(())
+        off += cnt
+    return out, {"files": (data, ok, lock), "map": mm}
+
+
+def release_shared(handle, unlink: bool) -> None:
+    """Drop this process's mapping of a `synthetic_state_shared` file; `unlink=True` (one process per host, after every rank has mapped the
+    file) removes it from /dev/shm - the pages go when the last mapping does."""
+    handle.pop("map", None)
+    if unlink:
+        for f in handle.get("files", ()):
+            try:
+                os.unlink(f)
+            except OSError:
+                pass
+
+
 def synthetic_vocabulary(num_classes: int = 133, num_strings: int = 254, dim: int = 768, seed: int = 7):
     """Arguments of `set_vocabulary` for a random text bank: `num_strings` prompt embeddings over `num_classes` synonym groups
     (COCO panoptic: 133 classes / 254 prompt-engineered strings)."""
