@@ -87,7 +87,9 @@ def end_to_end_contract(got, ref, cls_ref, k, things, tag="", size=1024, segment
         assert (agree > 0.99 if info == info_ref else (cat_agree > 0.9 and changed <= 3)), (tag, agree, cat_agree, changed)
     # sem_seg = sum_q P[q,k] sigmoid(mask_q) carries the class-probability error; its per-pixel argmax is identical wherever the reference decides by
     # more than that error, and the undecided rest (near-ties between two of the class scores) stays a small fraction
-    assert serr < max(TAU_SEM, tau) and same[decided].all() and sagree > 0.98, (tag, serr, sagree)
+    # (a re-decided query's probability error enters the score of its class times a sigmoid <= 1, on top of the mask-logit share that TAU_SEM covers:
+    # first-order bound 1.25 x the measured error, as tests/test_gpu_fullsize_batch.py::test_batch_of_eight_ade150 derives it)
+    assert serr < max(TAU_SEM, 1.25 * float(eq.max())) and same[decided].all() and sagree > 0.98, (tag, serr, sagree)
     assert inst["pred_masks"].shape[1:] == (size, size)
     for q, c in set(key_ref) ^ set(key_got):    # entries may only differ at the selection boundary of the top-k
         assert abs(float(scores_flat[q * k + c]) - kth) < tau, (tag, q, c)
