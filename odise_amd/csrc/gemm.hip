@@ -2563,8 +2563,11 @@ __global__ void __launch_bounds__(512) conv3_halo_kernel(GemmArgs g) {
         if (group < HGROUPS && hp < HPIX) {
             const int hy = hp / HW_, hx = hp - hy * HW_;
             const int iy = py0 + hy, ix = px0 + hx;
-            if ((unsigned)iy < (unsigned)g.cg.H && (unsigned)ix < (unsigned)g.cg.W)
-                h_off[h] = (((int64_t)img * g.cg.H + iy) * g.cg.W + ix) * g.cg.Cin + (((lane & 7) ^ ((hx >> 1) & 7)) << 3);
+            // fused nearest-2x upsample (round 6): the patch is the UPSAMPLED input's - pixel (iy, ix) of it is source pixel (iy / 2, ix / 2); the
+            // duplicates come out of the L2 and the nine taps read the patch exactly as for a plain 3x3 convolution
+            const int up = g.cg.ups ? 1 : 0;
+            if ((unsigned)iy < (unsigned)(g.cg.H << up) && (unsigned)ix < (unsigned)(g.cg.W << up))
+                h_off[h] = (((int64_t)img * g.cg.H + (iy >> up)) * g.cg.W + (ix >> up)) * g.cg.Cin + (((lane & 7) ^ ((hx >> 1) & 7)) << 3);
         }
     }
     auto issue_halo = [&](int chunk) {
@@ -2799,8 +2802,9 @@ __global__ void __launch_bounds__(256, 2) conv3_halo4_kernel(GemmArgs g) {
         if (group < HGROUPS && hp < HPIX) {
             const int hy = hp / HW_, hx = hp - hy * HW_;
             const int iy = py0 + hy, ix = px0 + hx;
-            if ((unsigned)iy < (unsigned)g.cg.H && (unsigned)ix < (unsigned)g.cg.W)
-                h_off[h] = (iy * g.cg.W + ix) * g.cg.Cin + (((lane & 7) ^ ((hx >> 1) & 7)) << 3);
+            const int up = g.cg.ups ? 1 : 0;   // fused nearest-2x upsample: see conv3_halo_kernel
+            if ((unsigned)iy < (unsigned)(g.cg.H << up) && (unsigned)ix < (unsigned)(g.cg.W << up))
+                h_off[h] = ((iy >> up) * g.cg.W + (ix >> up)) * g.cg.Cin + (((lane & 7) ^ ((hx >> 1) & 7)) << 3);
         }
     }
     auto issue_halo = [&](int chunk) {
@@ -3144,6 +3148,7 @@ static int launch_gemm(odise_hip_ctx* ctx, GemmArgs& g, int batch, int force_til
     return rc;
 }
 
+static int flags_early() { return g_conv_flags | env_gemm_flags(); }   // (ODISE_GEMM_FLAGS 131072: no halo tile for the fused-upsample convolutions, A/B)
 template <bool CONV>
 static int launch_gemm_select(odise_hip_ctx* ctx, GemmArgs& g, int batch, int force_tile, int force_split, unsigned tile_mask) {
     const int64_t cus = ctx->cu_count;
@@ -3152,8 +3157,11 @@ static int launch_gemm_select(odise_hip_ctx* ctx, GemmArgs& g, int batch, int fo
     bool halo_ok = false;
     int64_t halo_patches = 0;
     if (CONV) {
-        halo_ok = g.cg.KH == 3 && g.cg.KW == 3 && g.cg.stride == 1 && g.cg.pad_t == 1 && g.cg.pad_l == 1 && !g.cg.ups && g.cg.Cin % 64 == 0 &&
-                  g.cg.OH == g.cg.H && g.cg.OW == g.cg.W && batch == 1;
+        // (round 6: also with the fused nearest-2x upsample - the halo patch is gathered from the half-size source, everything after it is the
+        // plain kernel; the decoder's 512 -> 512 upsampling convolution ran 2.4 ms on the un-pipelined implicit GEMM, the UNet's three likewise)
+        const int up = g.cg.ups ? 1 : 0;
+        halo_ok = g.cg.KH == 3 && g.cg.KW == 3 && g.cg.stride == 1 && g.cg.pad_t == 1 && g.cg.pad_l == 1 && g.cg.Cin % 64 == 0 &&
+                  g.cg.OH == (g.cg.H << up) && g.cg.OW == (g.cg.W << up) && batch == 1 && !(up && (flags_early() & 131072));
         g.cg.halo_tx = (int)ceil_div(g.cg.OW, 16);
         g.cg.halo_ty = (int)ceil_div(g.cg.OH, 16);
         halo_patches = (int64_t)(g.M / (g.cg.OH * g.cg.OW)) * g.cg.halo_tx * g.cg.halo_ty;
@@ -3166,7 +3174,8 @@ static int launch_gemm_select(odise_hip_ctx* ctx, GemmArgs& g, int batch, int fo
     int tile = 2, best_split = 1;
     double best = 1e30;
     const int flags = g_conv_flags | env_gemm_flags();
-    const bool pp_ok = !no_interleave && !(flags & 2) && g.K % 64 == 0 && (!CONV || (g.cg.Cin % 64 == 0 && !g.cg.ups));
+    const bool pp_base = !no_interleave && !(flags & 2) && g.K % 64 == 0 && (!CONV || g.cg.Cin % 64 == 0);   // what the halo tiles need (they gather the fused upsample themselves)
+    const bool pp_ok = pp_base && !(CONV && g.cg.ups);
     // the 8-phase kernels (gemm8_kernel) run the 256x256 / 512x128 tiles wherever the ping-pong kernels could (the convolution form keeps 32-bit
     // element offsets) - on request only, ODISE_GEMM_FLAGS 16384: built as the guide's yardstick schedule and kept for A/B runs; once every main loop
     // multiplied with 16x16x32 MFMAs and wrote its tile through the wave-private epilogue, the ping-pong kernels measured 3-7 % ahead of it on the
@@ -3177,7 +3186,7 @@ static int launch_gemm_select(odise_hip_ctx* ctx, GemmArgs& g, int batch, int fo
         if (force_tile >= 0 && force_tile < kNumTiles && t != force_tile) continue;
         if (!((tile_mask >> t) & 1)) continue;
         if (t == 6 && (!pp_ok || (flags & 16))) continue;
-        if (t >= 7 && t <= 9 && (!halo_ok || !pp_ok || (flags & 64))) continue;  // ODISE_GEMM_FLAGS=64: never use the halo kernels
+        if (t >= 7 && t <= 9 && (!halo_ok || !pp_base || (flags & 64))) continue;  // ODISE_GEMM_FLAGS=64: never use the halo kernels
         if (t == 9 && (flags & 2048)) continue;                        // ODISE_GEMM_FLAGS=2048: never use the two-blocks-per-CU halo kernel
         if (t == 9 && force_tile < 0 && g.N > 128) continue;           // (see kTileCost[9])
         const TileCost& tc = (flags & 8) ? kTileCostOld[t] : (g8_ok && t == 4) ? (CONV ? kTileCost8Conv : kTileCost8) : (CONV && pp_ok && t == 4) ? kTileCostPPConv256 :
@@ -3208,7 +3217,7 @@ static int launch_gemm_select(odise_hip_ctx* ctx, GemmArgs& g, int batch, int fo
             if (t_us < best) { best = t_us; tile = t; best_split = eff_sp; }
         }
     }
-    if (force_tile >= 0 && force_tile < kNumTiles && !(force_tile == 6 && !pp_ok) && !(force_tile >= 7 && force_tile <= 9 && !(halo_ok && pp_ok)))
+    if (force_tile >= 0 && force_tile < kNumTiles && !(force_tile == 6 && !pp_ok) && !(force_tile >= 7 && force_tile <= 9 && !(halo_ok && pp_base)))
         tile = force_tile;
     g.splitk = 1;
     g.ktiles_per_split = nk;

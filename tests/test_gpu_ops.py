@@ -451,6 +451,27 @@ def test_conv_fused_upsample_residual_timeemb(ctx):
     close(out, ref.numpy(), what="conv + temb + residual")
 
 
+@pytest.mark.parametrize("N,H,W,Cin,Cout,tile", [(2, 16, 16, 128, 256, 7), (1, 20, 12, 64, 128, 8), (2, 24, 40, 128, 128, 9), (1, 32, 32, 512, 512, -1)])
+def test_conv_fused_upsample_on_the_halo_tiles(ctx, N, H, W, Cin, Cout, tile):
+    """Upsample = nearest 2x + 3x3 conv (ldm Upsample, ldm.py:493-533 / 469-491) on the halo kernels (round 6): the 18 x 18 patch of the UPSAMPLED
+    input is gathered from the half-size source (pixel (y, x) <- (y / 2, x / 2)), everything after is the plain halo convolution.  Odd patch
+    counts, borders, and the cost model's own choice (tile -1: at 512 -> 512 it must now be a halo tile, not the un-pipelined implicit GEMM)."""
+    g = torch.Generator().manual_seed(N + H + W + Cin + Cout)
+    x = h(torch.randn(N, H, W, Cin, generator=g))
+    w = h(torch.randn(Cout, 3, 3, Cin, generator=g) / (9 * Cin) ** 0.5)
+    b = torch.randn(Cout, generator=g)
+    up = F.interpolate(x.permute(0, 3, 1, 2), scale_factor=2, mode="nearest").permute(0, 2, 3, 1)
+    ref = _conv_ref(up, w, 1, 1, b).numpy()
+    dx, dw, db = ctx.to_device(x.half().numpy()), ctx.to_device(w.half().numpy()), ctx.to_device(b)
+    out = ctx.conv2d(dx, dw, upsample2x=True, bias=db, force_tile=tile).numpy()
+    ran = ctx.lib.odise_hip_last_tile() & 255
+    assert ran in (7, 8, 9) and (tile < 0 or ran == tile), (tile, ran)
+    close(out, ref, what=f"fused-upsample halo tile {ran}")
+    plain = ctx.conv2d(dx, dw, upsample2x=True, bias=db, force_tile=0).numpy()      # the implicit-GEMM form of the same convolution
+    assert (ctx.lib.odise_hip_last_tile() & 255) == 0
+    close(out, plain, rtol=2e-3, what="halo vs implicit GEMM with the fused upsample")
+
+
 # ---------------------------------------------------------------------------------------------------------------
 # Norms
 # ---------------------------------------------------------------------------------------------------------------
