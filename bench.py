@@ -222,7 +222,7 @@ def profiled_traffic():
     """HBM bytes per launch of the dominant kernel from the separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes committed under profiles/
     (tools/one_conv.py; FETCH doubled as the guide's gfx950 correction prescribes).  NOT measured in this run: the line carries it as a pointer
     (`traffic_profiled`), `roofline.traffic` itself stays null."""
-    for name in ("r05_dominant_conv_traffic.json", "r04_dominant_conv_traffic.json", "r03_dominant_conv_traffic.json"):
+    for name in ("r06_dominant_conv_traffic.json", "r05_dominant_conv_traffic.json", "r04_dominant_conv_traffic.json", "r03_dominant_conv_traffic.json"):
         tp = os.path.join(ROOT, "profiles", name)
         if os.path.exists(tp):
             with open(tp) as f:

@@ -68,8 +68,9 @@ int odise_hip_device_info(odise_hip_ctx* ctx, char* name_buf, int buf_len, int* 
  *                              tensor below this many bytes (a smaller working set and arena); 0 (default) = all crops of a call at once, which
  *                              measured faster on MI355X (profiles/r04_vae_chunking_experiment.txt).  Per-crop arithmetic is unchanged.
  *   ODISE_OPT_PREFETCH_CU_EIGHTHS  1..7: the encoder-prefetch stream (odise_hip_infer_prefetch) is created with a CU mask of that many of every 8
- *                              compute units, so the batch in progress always finds free CUs for its small dependent launches; 0 / 8 (default 0) =
- *                              no mask.  Read when the stream is first created.
+ *                              compute units, so the batch in progress always finds free CUs for its small dependent launches - a CU-masked stream
+ *                              has NORMAL priority and default flags (HIP offers neither with a mask); 0 / 8 (default 0) = no mask, lowest
+ *                              priority, non-blocking.  Read when the stream is first created.
  *   ODISE_OPT_PREFETCH_START   where the next batch's encoder is enqueued: 0 = behind the current batch's VAE lane, 1 (default) = behind its
  *                              backbone, i.e. beside the serial tail of small launches (pixel decoder .. post-processing)
  *   ODISE_OPT_ATTN_KV_RESIDENT 0 (default) = attention with d_head 64 and at most 608 keys runs the K / V^T-resident kernel where (head, image)

@@ -8,12 +8,13 @@ import os
 import pytest
 
 ROOT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..")
-LINES = sorted(glob.glob(os.path.join(ROOT, "profiles", "r04_bench_*.json")) + glob.glob(os.path.join(ROOT, "profiles", "r05_bench_*.json")))
+LINES = sorted(glob.glob(os.path.join(ROOT, "profiles", "r04_bench_*.json")) + glob.glob(os.path.join(ROOT, "profiles", "r05_bench_*.json")) +
+               glob.glob(os.path.join(ROOT, "profiles", "r06_bench_*.json")))
 
 
 def test_profiles_present():
     """Its own test, not a condition inside the parametrized one: a missing or renamed profile set must fail, not generate zero cases."""
-    assert len(LINES) >= 8 + 12, LINES
+    assert len(LINES) >= 8 + 12 + 10, LINES
 
 
 @pytest.mark.parametrize("path", LINES, ids=[os.path.basename(p) for p in LINES])
@@ -33,7 +34,8 @@ def test_bench_line_contract(path):
         assert r["where"].startswith("in the timed step")
         assert abs(r["achieved"] - r["algorithmic_flops_per_launch"] / (r["launch_us"] * 1e-6) / 1e12) < 1e-6 * r["achieved"]
         assert r["launch_us_min"] <= r["launch_us"] <= r["launch_us_max"] and r["launches_timed"] >= d["steps"]
-        assert r["traffic"] is None and r["traffic_profiled"]["hbm_bytes_per_launch"] > 541e6   # not measured in this run: a pointer to the PMC passes
+        tp = r["traffic_profiled"]   # not measured in this run: a pointer to the PMC passes (the previous round's tree was run from a copy without profiles/)
+        assert r["traffic"] is None and (tp["hbm_bytes_per_launch"] > 541e6 if tp is not None else "previous_round_tree" in path)
         iso = r["isolated"]
         assert iso["launch_us"] < r["launch_us"] and abs(iso["frac"] - iso["achieved"] / 2500.0) < 1e-9   # alone on the idle chip it is faster
         assert 0.0 < r["step_frac"] < r["frac"] < iso["frac"] < 1.0
@@ -80,3 +82,26 @@ def test_round5_headline_and_its_same_box_variants():
     assert m32["ms_per_step"] > blk["ms_per_step"] > d["ms_per_step"]                     # what each of the two kernel changes is worth, one box
     assert pf["config"]["pipeline"].startswith("encoder-prefetch") and pf["config"]["batches_in_flight"] == 1
     assert 0.95 * d["ms_per_step"] < pf["ms_per_step"] < d["ms_per_step"]                 # work-conserving: a percent, not the idle lane's 14 ms
+
+
+def test_round6_line_carries_the_unet_share_and_the_host_fed_value():
+    """Round 6: the metric's second half - "UNet MFMA %peak" - is on the line the driver parses: the UNet stage as it runs inside
+    the timed step (stage marks) and alone after it, both as fractions of the 2.5 PFLOP/s peak; the evaluator-faithful rate (pictures from host
+    memory every step) as a top-level key next to `value`; and the same-box line of the previous round's tree beside the headline."""
+    load = lambda n: json.load(open(os.path.join(ROOT, "profiles", n)))
+    d = load("r06_bench_full_b4_1024.json")
+    assert d["metric"] == "panoptic-inference images/sec @1024x1024" and d["config"]["workload"].startswith("BASELINE configs[2]")
+    r = d["roofline"]
+    u, ui = r["unet"], r["unet_isolated"]
+    assert u["crops"] == ui["crops"] == 16 and u["steps"] == d["steps"] and u["where"].startswith("in the timed step")
+    for x in (u, ui):
+        assert abs(x["frac"] - x["crops"] * 0.7401e12 / (x["ms"] * 1e-3) / 2.5e15) < 1e-9 and abs(x["achieved"] - x["frac"] * 2500.0) < 1e-6
+    assert ui["ms"] < u["ms"] < d["ms_per_step"] and 0.1 < u["frac"] < ui["frac"] < 0.4        # alone it is faster; inside the step it shares the chip
+    assert 0 < d["value_host_fed"] < d["value"] and d["value_host_fed"] == d["inclusive"]["host_u8"]["value"]
+    seg = d["exchange"]["segments_per_image"]
+    assert len(seg) == 4 and min(seg) >= 2 and sum(seg) >= 20
+    prev = load("r06_bench_full_b4_1024_steps20_previous_round_tree.json")
+    now = [load("r06_bench_full_b4_1024_steps20.json"), load("r06_bench_full_b4_1024_steps20_again.json")]
+    assert all(n["ms_per_step"] < prev["ms_per_step"] for n in now) and "unet" not in prev["roofline"]          # the same box, the same hour
+    pf = load("r06_bench_full_b4_1024_encoder_prefetch.json")
+    assert pf["config"]["pipeline"].startswith("encoder-prefetch") and abs(pf["ms_per_step"] - now[0]["ms_per_step"]) < 0.02 * now[0]["ms_per_step"]
