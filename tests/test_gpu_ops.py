@@ -239,6 +239,33 @@ def test_gemm_repeated_launches_agree(ctx, tile):
             assert diff.size == 0, f"tile {tile}: launch {rep} differs from the first in {len(diff)} elements, e.g. {diff[:4].tolist()} -> {got[tuple(diff[0])]} vs {first[tuple(diff[0])]}"
 
 
+@pytest.mark.parametrize("tile,M,N,K", [(4, 1000, 768, 256), (4, 2304, 1024, 1024), (5, 1536, 384, 320), (6, 2048, 256, 512), (3, 1024, 640, 320)])
+def test_wave_private_epilogue_stress_against_the_block_wide_forms(ctx, tile, M, N, K):
+    """the wave-private epilogue (every 8-wave GEMM kernel's default since round 5) against the block-wide forms it replaced
+    (`odise_hip_gemm_debug` 32768 << 4), bit for bit, over random epilogue configurations and repeated launches - the 4-wave kernels showed rare
+    zeros in a staged dword with this code (they keep the block-wide form); nothing of the kind was ever seen with 8 waves, and this is the test
+    that would see it: 5 tiles x 6 configurations x 8 launches x up to 2.4 M elements each."""
+    g = torch.Generator().manual_seed(tile * 1000 + M)
+    A = ctx.to_device(h(torch.randn(M, K, generator=g)).half().numpy())
+    W = ctx.to_device(h(torch.randn(N, K, generator=g) / K ** 0.5).half().numpy())
+    bias = ctx.to_device(torch.randn(N, generator=g).numpy())
+    res = ctx.to_device(h(torch.randn(M, N, generator=g)).half().numpy())
+    configs = [dict(), dict(bias_n=bias), dict(bias_n=bias, act=_lib.ACT_SILU), dict(residual=res), dict(bias_n=bias, residual=res, act=_lib.ACT_QUICKGELU),
+               dict(bias_n=bias, out_dtype=np.float32)]
+    try:
+        for kw in configs:
+            ctx.lib.odise_hip_gemm_debug(32768 << 4)
+            ref = ctx.gemm(A, W, force_tile=tile, force_split=1, **kw).numpy()
+            ctx.lib.odise_hip_gemm_debug(0)
+            for rep in range(8):
+                out = ctx.gemm(A, W, force_tile=tile, force_split=1, **kw).numpy()
+                assert (ctx.lib.odise_hip_last_tile() & 255) == tile
+                bad = np.flatnonzero(out.reshape(-1) != ref.reshape(-1))
+                assert bad.size == 0, (tile, sorted(kw), rep, bad[:8].tolist(), out.reshape(-1)[bad[:8]].tolist(), ref.reshape(-1)[bad[:8]].tolist())
+    finally:
+        ctx.lib.odise_hip_gemm_debug(0)
+
+
 def test_gemm_asymmetric_identity(ctx):
     # transpose-detecting check (guide rule 16): A = I, W asymmetric -> C = W^T
     n = 128
