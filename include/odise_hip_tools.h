@@ -45,7 +45,7 @@ int odise_hip_gemm_debug(int flags);
 int odise_hip_post_generic(int on);
 /* force the tile of the semantic GEMM [K, pixels] = P^T S^T (A/B of the 256-row rule in odise_hip_postprocess_batch); -1 = the rule */
 int odise_hip_sem_tile(int tile);
-/* GroupNorm (csrc/norm.hip): chunks of the statistics pass per image = compute units * chunk_factor / images (default 2; < 1 keeps the current value);
+/* GroupNorm (csrc/norm.hip): chunks of the statistics pass per image = compute units * chunk_factor / images (default 2; 0 keeps the current value; a NEGATIVE value sets instead the row count from which LayerNorm takes 8 rows per wavefront to its magnitude);
  * fold_in_apply != 0 (default): with <= 64 chunks per image the apply kernel folds the partials itself and gn_finalize_kernel does not run */
 int odise_hip_gn_tuning(int chunk_factor, int fold_in_apply);
 /* 1: the pixel decoder's MSDeformAttn layers as msda_prepare_kernel + the native-op kernel (the round 1-5 form) instead of the fused gather (A/B, bit-compare) */

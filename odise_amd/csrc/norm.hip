@@ -16,6 +16,7 @@ namespace odise {
 
 constexpr int GN_MAX_C = 4096;
 static int g_gn_chunk_factor = 2;     // chunks of the statistics pass = cu_count * factor / N per image: two fat blocks per CU (measured: UNet at 16 crops 21.5 ms at 8, 21.3 at 2; tools: odise_hip_gn_tuning)
+static int g_ln_rows8 = 32768;        // rows from which a LayerNorm of C <= 512 takes 8 rows per wavefront (8 loads in flight per lane): UNet at 16 crops 20.94 -> 20.81 ms (tools: odise_hip_gn_tuning(-rows, ..))
 static int g_gn_fold_in_apply = 1;    // 1: the apply kernel folds the chunk partials itself when there are <= 64 per image (no finalize launch)
 
 __global__ void __launch_bounds__(256) gn_partial_kernel(const f16* __restrict__ x, float* __restrict__ partial, int HW, int C,
@@ -503,7 +504,7 @@ extern "C" int odise_hip_layer_norm(odise_hip_ctx* ctx, const void* x, void* y, 
     if (C <= 256) {   // a row fits half a wavefront: two rows per wave pass (layer_norm_half_kernel)
         if (many) hipLaunchKernelGGL(layer_norm_half_kernel<4>, dim3((unsigned)ceil_div(rows, 4 * 2 * 4)), dim3(256), 0, ctx->stream, (const f16*)x, (f16*)y, gamma, beta, rows, C, eps);
         else hipLaunchKernelGGL(layer_norm_half_kernel<1>, dim3((unsigned)ceil_div(rows, 4 * 2)), dim3(256), 0, ctx->stream, (const f16*)x, (f16*)y, gamma, beta, rows, C, eps);
-    } else if (C <= 512) { if (many) launch(layer_norm_kernel<1, 4>, 4); else launch(layer_norm_kernel<1, 1>, 1); }
+    } else if (C <= 512) { if (rows >= g_ln_rows8) launch(layer_norm_kernel<1, 8>, 8); else if (many) launch(layer_norm_kernel<1, 4>, 4); else launch(layer_norm_kernel<1, 1>, 1); }
     else if (C <= 1024) { if (many) launch(layer_norm_kernel<2, 4>, 4); else launch(layer_norm_kernel<2, 1>, 1); }
     else if (C <= 2048) { if (many) launch(layer_norm_kernel<4, 2>, 2); else launch(layer_norm_kernel<4, 1>, 1); }
     else launch(layer_norm_kernel<8, 1>, 1);
@@ -514,6 +515,7 @@ extern "C" int odise_hip_layer_norm(odise_hip_ctx* ctx, const void* x, void* y, 
 // tools hook (include/odise_hip_tools.h): chunk density of the GroupNorm statistics pass and whether the apply kernel finishes the statistics itself
 extern "C" int odise_hip_gn_tuning(int chunk_factor, int fold_in_apply) {
     if (chunk_factor >= 1) odise::g_gn_chunk_factor = chunk_factor;
+    if (chunk_factor < 0) odise::g_ln_rows8 = -chunk_factor;
     odise::g_gn_fold_in_apply = fold_in_apply != 0;
     return 0;
 }
