@@ -72,6 +72,8 @@ def parse():
     p.add_argument("--vae-chunk-mb", type=float, default=None, help="A/B: ODISE_OPT_VAE_CHUNK_BYTES in MiB (0 = all crops per launch; default: the library's)")
     p.add_argument("--attn-kvres", type=int, default=1, choices=[0, 1], help="A/B: 0 = the CLIP towers' attention on the tiled kernel instead of the K/V-resident one")
     p.add_argument("--attn-sa", type=int, default=1, choices=[0, 1], help="A/B: 0 = the UNet's self-attention on the tiled kernel instead of the software-pipelined one")
+    p.add_argument("--maskclip-passes", type=int, default=0, choices=[0, 1, 2, 3], help="A/B: ODISE_OPT_MASKCLIP_PASSES (0 = MaskCLIP's image tokens ride in the crops' CLIP "
+                   "tower, 1 = two passes in place, 2 = one pass over image + mask tokens, 3 = image tokens as a tower of their own behind the UNet)")
     p.add_argument("--pipeline", action="store_true", help="encoder prefetch (odise_hip_infer_prefetch): the steps alternate between two resident sets of "
                    "--images pictures, and every model call enqueues the OTHER set's input side + VAE encoder behind its own VAE lane on a low-priority "
                    "stream; the next call starts from that latent.  Outputs are bit-identical to the plain call; every step is still one synchronous call")
@@ -402,6 +404,7 @@ def main():
     from odise_amd.runtime import Context
     ctx = Context(local_rank)
     ctx.set_option(ctx.OPT_CLIP_LN_FOLD, args.clip_ln_fold)
+    ctx.set_option(ctx.OPT_MASKCLIP_PASSES, args.maskclip_passes)
     if args.gemm_flags:
         ctx.lib.odise_hip_gemm_debug(args.gemm_flags << 4)
     if args.pipeline:
@@ -700,7 +703,7 @@ def main():
                                        f"exchange stream)") if gather else f"dp{world}",
                        "rccl_ranks": rccl_ranks, "batches_in_flight": n_fly, "one_batch_alone_ms": single_ms,
                        "vae_chunk_bytes": ctx.get_option(ctx.OPT_VAE_CHUNK_BYTES), "clip_ln_fold": ctx.get_option(ctx.OPT_CLIP_LN_FOLD),
-                       "gemm_flags": args.gemm_flags,
+                       "gemm_flags": args.gemm_flags, "maskclip_passes": ctx.get_option(ctx.OPT_MASKCLIP_PASSES),
                        "pipeline": (f"encoder-prefetch (start {args.prefetch_start}, {args.prefetch_cus or 8}/8 CUs)" if args.pipeline else None)},
             "roofline": {"bound": "mfma", "achieved": achieved, "peak": MFMA_F16_PEAK / 1e12, "unit": "TFLOP/s", "frac": achieved * 1e12 / MFMA_F16_PEAK,
                          "traffic": None,

@@ -78,8 +78,20 @@ int odise_hip_device_info(odise_hip_ctx* ctx, char* name_buf, int buf_len, int* 
  *                              128-query / 64-key tiles (the SD UNet's 64^2 and 32^2 levels) the software-pipelined kernel, the tiled kernel
  *                              elsewhere; 2 = never the K / V^T-resident kernel, 4 = never the pipelined one, 6 = always the tiled kernel.  The
  *                              resident form steps the running softmax maximum per 32 instead of 64 keys (results agree to fp32 rounding);
- *                              the pipelined form is bit-identical to the tiled one. */
-enum { ODISE_OPT_CLIP_LN_FOLD = 1, ODISE_OPT_VAE_CHUNK_BYTES = 2, ODISE_OPT_ATTN_KV_RESIDENT = 3, ODISE_OPT_PREFETCH_CU_EIGHTHS = 4, ODISE_OPT_PREFETCH_START = 5 };
+ *                              the pipelined form is bit-identical to the tiled one.
+ *   ODISE_OPT_MASKCLIP_PASSES  MaskCLIP (clip.py:252-323) hides the mask tokens from every query (clip.py:314-315), so the 577 image tokens of a
+ *                              picture run the plain tower whatever the masks are and the Q mask tokens only read its keys and values.
+ *                              0 (default) = two passes: the image tokens leave q|k and V^T of every block, the mask tokens follow as B x Q
+ *                              rows; in odise_hip_infer the pictures' image tokens RIDE IN THE CROPS' CLIP TOWER of the implicit captioner (the
+ *                              same frozen ViT-L/14@336: pictures + crops are one batch of token rows on the second lane), so only the
+ *                              mask-token pass is left on the serial tail behind the mask head.  1 = two passes, both where the reference runs
+ *                              the tower (after the mask head).  2 = one pass over [577 image | Q mask] token rows (the reference's layout).
+ *                              3 = as 0 with the first pass as a tower of its own on the second lane behind the UNet.  The forms run the same
+ *                              arithmetic per row on different GEMM tiles and LayerNorm forms (CLIP_LN_FOLD counts the rows of the tower the
+ *                              tokens are in): results agree to fp16 rounding.  odise_hip_classify / odise_hip_maskclip_embed called on their
+ *                              own run 0 and 3 as 1. */
+enum { ODISE_OPT_CLIP_LN_FOLD = 1, ODISE_OPT_VAE_CHUNK_BYTES = 2, ODISE_OPT_ATTN_KV_RESIDENT = 3, ODISE_OPT_PREFETCH_CU_EIGHTHS = 4, ODISE_OPT_PREFETCH_START = 5,
+       ODISE_OPT_MASKCLIP_PASSES = 6 };
 int odise_hip_set_option(odise_hip_ctx* ctx, int option, int64_t value);
 int odise_hip_get_option(odise_hip_ctx* ctx, int option, int64_t* value);
 /* Launch probe (measurement, bench.py's `roofline`): HIP events around every launch of ONE shape - conv != 0: the implicit GEMM of a convolution

@@ -78,6 +78,7 @@ extern "C" int odise_hip_destroy(odise_hip_ctx* ctx) {
     if (ctx->ev_fork) (void)hipEventDestroy(ctx->ev_fork);
     if (ctx->ev_mid) (void)hipEventDestroy(ctx->ev_mid);
     if (ctx->ev_join) (void)hipEventDestroy(ctx->ev_join);
+    if (ctx->ev_mclip) (void)hipEventDestroy(ctx->ev_mclip);
     if (ctx->stream2) (void)hipStreamDestroy(ctx->stream2);
     if (ctx->zeros) (void)hipFree(ctx->zeros);
     if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
@@ -190,6 +191,10 @@ extern "C" int odise_hip_set_option(odise_hip_ctx* ctx, int option, int64_t valu
             ODISE_REQUIRE(value == 0 || value == 1, "set_option: PREFETCH_START takes 0 (behind the VAE lane) or 1 (behind the backbone)");
             ctx->prefetch_start = (int)value;
             return ODISE_OK;
+        case ODISE_OPT_MASKCLIP_PASSES:
+            ODISE_REQUIRE(value >= 0 && value <= 3, "set_option: MASKCLIP_PASSES takes 0 (image tokens in the crops' tower), 1 (two passes in place), 2 (one pass) or 3 (image tokens as a tower of their own on the second lane)");
+            ctx->maskclip_passes = (int)value;
+            return ODISE_OK;
         default:
             set_error("set_option: unknown option %d", option);
             return ODISE_ERR_ARG;
@@ -203,6 +208,7 @@ extern "C" int odise_hip_get_option(odise_hip_ctx* ctx, int option, int64_t* val
         case ODISE_OPT_ATTN_KV_RESIDENT: *value = ctx->attn_kv_resident; return ODISE_OK;
         case ODISE_OPT_PREFETCH_CU_EIGHTHS: *value = ctx->prefetch_cu_eighths; return ODISE_OK;
         case ODISE_OPT_PREFETCH_START: *value = ctx->prefetch_start; return ODISE_OK;
+        case ODISE_OPT_MASKCLIP_PASSES: *value = ctx->maskclip_passes; return ODISE_OK;
         default:
             set_error("get_option: unknown option %d", option);
             return ODISE_ERR_ARG;

@@ -57,13 +57,17 @@ struct ClassifyModel {
     size_t post_cap = 0;
     void* in_buf = nullptr;
     size_t in_cap = 0;
+    // postprocess_batch: image b's pixel pass writes set b % kPostSets of (S, ids); ev_set[i] = the decision chain that read set i is done
+    static constexpr int kPostSets = 4;
+    hipEvent_t ev_set[kPostSets] = {nullptr, nullptr, nullptr, nullptr};
 };
 
 static int g_sem_tile = -1;   // tools hook (odise_hip_sem_tile): force the tile of the semantic GEMM for A/B runs; -1 = the rule in postprocess_batch
 
 static int scratch_reserve(odise_hip_ctx* ctx, void** buf, size_t* cap, size_t bytes) {
     if (*cap >= bytes) return ODISE_OK;
-    ODISE_CHECK_HIP(hipStreamSynchronize(ctx->stream));
+    (void)ctx;
+    ODISE_CHECK_HIP(hipDeviceSynchronize());   // the second lane reads these buffers too (postprocess_batch)
     if (*buf) ODISE_CHECK_HIP(hipFree(*buf));
     *buf = nullptr;
     *cap = 0;
@@ -88,6 +92,8 @@ void classify_destroy(ModelStore* ms) {
         }
         if (ms->classify->post_buf) (void)hipFree(ms->classify->post_buf);
         if (ms->classify->in_buf) (void)hipFree(ms->classify->in_buf);
+        for (hipEvent_t& ev : ms->classify->ev_set)
+            if (ev) { (void)hipEventDestroy(ev); ev = nullptr; }
         free_allocs(ms->classify->owned);
     }
     delete ms->classify;
@@ -234,7 +240,31 @@ extern "C" int odise_hip_set_vocabulary(odise_hip_ctx* ctx, const float* cat_tex
 
 // image [B,3,H,W] f32 device in [0,1] (the de-normalised images of the batch, odise.py:240-242); consumes the outputs of the last
 // odise_hip_head_forward; mask_cls [B,Q,K+1] f32 device (log-probabilities, odise.py:323); clip_embed (optional) [B,Q,dim] f32.
+// MaskCLIP's tower over B pictures and their Q mask tokens (tmask: launch_maskclip_token_mask's [B][T + Q][ldm] rows), in the form
+// ODISE_OPT_MASKCLIP_PASSES names.  kv_ready: the image-token pass of THESE pictures has been enqueued already (odise_hip_infer).
+static int maskclip_tower(Exec& ex, const float* image01, int B, int H, int W, int S, int T, int Q, const uint8_t* tmask, int64_t ldm, f16* ce, bool kv_ready) {
+    odise_hip_ctx* ctx = ex.ctx;
+    if (ctx->maskclip_passes == 2) {
+        Act img;
+        ODISE_TRY(ex.alloc(img, B, S, S, 8));
+        ODISE_TRY(launch_resize_bilinear_norm(ctx, image01, img.p, B, H, W, S));
+        return clip_tower(ex, img, Q, tmask, ldm, ce);
+    }
+    ClipKV& kv = ex.ms->mclip;
+    if (kv_ready && kv.ready && kv.B == B) {
+        if (kv.on_lane2) ODISE_CHECK_HIP(hipStreamWaitEvent(ctx->stream, ctx->ev_mclip, 0));
+    } else {
+        ODISE_TRY(maskclip_image_pass(ex, image01, B, H, W));
+    }
+    kv.ready = false;   // consumed
+    return maskclip_mask_pass(ex, Q, tmask + (size_t)T * ldm, ldm, (int64_t)(T + Q) * ldm, ce);
+}
+
+static int classify_impl(odise_hip_ctx* ctx, const float* image, int B, int H, int W, float* mask_cls, float* clip_embed_out, bool kv_ready);
 extern "C" int odise_hip_classify(odise_hip_ctx* ctx, const float* image, int B, int H, int W, float* mask_cls, float* clip_embed_out) {
+    return classify_impl(ctx, image, B, H, W, mask_cls, clip_embed_out, false);
+}
+static int classify_impl(odise_hip_ctx* ctx, const float* image, int B, int H, int W, float* mask_cls, float* clip_embed_out, bool kv_ready) {
     ODISE_REQUIRE(ctx && image && mask_cls, "classify: null argument");
     ODISE_CHECK_HIP(hipSetDevice(ctx->device));   // the caller may be a new host thread, or hold another device current
     ModelStore* ms = store_of(ctx);
@@ -274,12 +304,9 @@ extern "C" int odise_hip_classify(odise_hip_ctx* ctx, const float* image, int B,
     d.C = L1; d.ldc = c->Ktot + 1; d.c_dtype = ODISE_F32; d.alpha = 1.f; d.batch = 1;
     ODISE_TRY(ex.gemm(d));
     // ---- MaskCLIP (clip.py:325-338): image and masks bilinearly resized to 336^2 -----------------------------------------
-    Act img;
-    ODISE_TRY(ex.alloc(img, B, S, S, 8));
-    ODISE_TRY(launch_resize_bilinear_norm(ctx, image, img.p, B, H, W, S));
     ODISE_TRY(launch_maskclip_token_mask(ctx, ho.pred_masks, tmask, B, Q, ho.h4, ho.w4, S, patch, T, ldm));
     stage_mark(ctx, "classify: text logits + MaskCLIP inputs");
-    ODISE_TRY(clip_tower(ex, img, Q, tmask, ldm, ce));
+    ODISE_TRY(maskclip_tower(ex, image, B, H, W, S, T, Q, tmask, ldm, ce, kv_ready));
     stage_mark(ctx, "classify: MaskCLIP tower done");
     if (clip_embed_out) ODISE_TRY(odise_hip_cast_f16_to_f32(ctx, ce, clip_embed_out, (size_t)MQ * c->dim));
     ODISE_TRY(launch_l2_normalize_f16(ctx, ce, ce_n, MQ, c->dim));
@@ -406,11 +433,8 @@ extern "C" int odise_hip_maskclip_embed(odise_hip_ctx* ctx, const float* image, 
     uint8_t* tmask = (uint8_t*)ex.alloc_bytes((size_t)B * (T + Q) * ldm);
     if (!logits16 || !ce || !tmask) return ODISE_ERR_NOMEM;
     ODISE_TRY(odise_hip_cast_f32_to_f16(ctx, pred_masks, logits16, (size_t)MQ * h * w));
-    Act img;
-    ODISE_TRY(ex.alloc(img, B, S, S, 8));
-    ODISE_TRY(launch_resize_bilinear_norm(ctx, image, img.p, B, H, W, S));
     ODISE_TRY(launch_maskclip_token_mask(ctx, logits16, tmask, B, Q, h, w, S, patch, T, ldm));
-    ODISE_TRY(clip_tower(ex, img, Q, tmask, ldm, ce));
+    ODISE_TRY(maskclip_tower(ex, image, B, H, W, S, T, Q, tmask, ldm, ce, false));
     return odise_hip_cast_f16_to_f32(ctx, ce, clip_embed, (size_t)MQ * cdim);
 }
 
@@ -450,7 +474,10 @@ extern "C" int odise_hip_postprocess_batch(odise_hip_ctx* ctx, const odise_post_
     const size_t o_counts = take((size_t)B * 3 * Q * 4), o_stats = take((size_t)B * 2 * Qpad * 4), o_stuff = take((size_t)K * 4);
     const size_t o_thing = take((size_t)K), o_probs = take(want_inst ? (size_t)B * Q * K * 4 : 0), o_semT = take((size_t)B * K * Qpad * 2);
     const size_t o_partial = take((size_t)512 * 2 * Qpad * 4);
-    const size_t o_ids = take((size_t)max_pix * 4), o_S = take((size_t)max_pix * Qpad * 2);
+    // (S, ids) of up to kPostSets images in flight: the next image's pixel pass does not wait for the decision chain that still reads this one's
+    const int nsets = std::min(B, (int)ClassifyModel::kPostSets);
+    const size_t ids_set = ((size_t)max_pix * 4 + 255) & ~(size_t)255, S_set = ((size_t)max_pix * Qpad * 2 + 255) & ~(size_t)255;
+    const size_t o_ids = take(ids_set * nsets), o_S = take(S_set * nsets);
     ODISE_TRY(scratch_reserve(ctx, &c->post_buf, &c->post_cap, off));
     char* base = (char*)c->post_buf;
     float* kscore = (float*)(base + o_kscore);
@@ -463,8 +490,6 @@ extern "C" int odise_hip_postprocess_batch(odise_hip_ctx* ctx, const odise_post_
     float* probs = want_inst ? (float*)(base + o_probs) : nullptr;
     f16* semT = (f16*)(base + o_semT);
     float* partial = (float*)(base + o_partial);
-    int* ids = (int*)(base + o_ids);
-    f16* S = (f16*)(base + o_S);
     if (d->isthing) ODISE_CHECK_HIP(hipMemcpyAsync(thing, d->isthing, (size_t)K, hipMemcpyHostToDevice, ctx->stream));
     ODISE_CHECK_HIP(hipMemsetAsync(counts, 0, (size_t)B * 3 * Q * 4, ctx->stream));
     // the panoptic records may be the source buffer of the previous batch's all-gather (still running on the exchange stream while the
@@ -479,21 +504,23 @@ extern "C" int odise_hip_postprocess_batch(odise_hip_ctx* ctx, const odise_post_
         g.Q = Q; g.Qpad = Qpad;
         return g;
     };
-    // The per-image chain after the pixel pass - mask statistics for the instance scores, the sequential segment walk, the record write - is
-    // a handful of small kernels (one of them a single thread per image).  With the second lane present they run there, beside the
-    // HBM-bound semantic GEMM of the same image on the main stream; the next image's pixel pass (which overwrites S and ids) waits for them.
+    // The per-image chain after the pixel pass - mask statistics for the instance scores, the sequential segment walk, the record write, the
+    // instance head's top-k and its binary masks - is a handful of small kernels (one of them a single thread per image) plus one write-bound
+    // one.  With the second lane present they run there, beside the NEXT image's pixel pass on the main stream: every image in flight has its
+    // own (S, ids), so the main stream is four pixel passes back to back and only the last image's chain is exposed (round 5: the next pixel
+    // pass waited for the chain, and the top-k + masks of all images followed the loop: 2.5 ms for four pictures).
 #ifdef ODISE_TOOLS
     static const bool serial_post = getenv("ODISE_POST_SERIAL") != nullptr;   // A/B: the chain on the main stream
 #else
     const bool serial_post = false;
 #endif
     const bool side = !serial_post && ctx->lanes == 2 && ctx->stream2 && ctx->ev_fork && ctx->ev_join;
+    if (side)
+        for (int i = 0; i < nsets; ++i)
+            if (!c->ev_set[i]) ODISE_CHECK_HIP(hipEventCreateWithFlags(&c->ev_set[i], hipEventDisableTiming));
     bool side_pending = false;
-    auto join_side = [&]() -> int {
-        if (side_pending) ODISE_CHECK_HIP(hipStreamWaitEvent(ctx->stream, ctx->ev_join, 0));
-        side_pending = false;
-        return ODISE_OK;
-    };
+    bool set_busy[ClassifyModel::kPostSets] = {false, false, false, false};
+    int n_img = 0;   // images processed so far (skipped ones do not take a set)
     for (int b = 0; b < B; ++b) {
         const PostGeom g = geometry(b);
         const int npix = g.oh * g.ow;
@@ -507,7 +534,11 @@ extern "C" int odise_hip_postprocess_batch(odise_hip_ctx* ctx, const odise_post_
         const bool fused_sem = sem && g_sem_tile < 0 && postprocess_pixels_fuses_semantic(g);
         const bool need_S = (sem && !fused_sem) || amax || inst;
         if (!need_S && !pan && !sem) continue;
-        ODISE_TRY(join_side());
+        const int set = n_img++ % nsets;
+        int* ids = (int*)(base + o_ids + ids_set * set);
+        f16* S = (f16*)(base + o_S + S_set * set);
+        if (set_busy[set]) ODISE_CHECK_HIP(hipStreamWaitEvent(ctx->stream, c->ev_set[set], 0));   // the chain of the image that used this set before
+        set_busy[set] = false;
         if (fused_sem) ms->macs += (double)K * npix * Qpad;
         ODISE_TRY(launch_postprocess_pixels(ctx, logits, kscore + (size_t)b * Q, need_S ? S : nullptr, pan ? ids : nullptr, counts + (size_t)b * 3 * Q, g,
                                             fused_sem ? semT + (size_t)b * K * Qpad : nullptr, fused_sem ? sem : nullptr, fused_sem ? K : 0));
@@ -518,6 +549,12 @@ extern "C" int odise_hip_postprocess_batch(odise_hip_ctx* ctx, const odise_post_
                                                  pan + npix, Q, K, d->overlap_threshold, ODISE_MAX_SEGMENTS, stuff));
                 ODISE_TRY(launch_panoptic_write(ctx, ids, map + (size_t)b * Q, pan, npix));
             }
+            if (inst) {   // the image's top-k (one block) and the selected masks
+                int* tb = d->inst_table + (size_t)b * (1 + 2 * topk);
+                ODISE_TRY(launch_instance_topk(ctx, probs + (size_t)b * Q * K, stats + (size_t)b * 2 * Qpad, thing, tb, d->inst_scores + (size_t)b * topk, 1, Q, Qpad,
+                                               K, topk, d->panoptic_on ? 1 : 0));
+                if (d->inst_masks && d->inst_masks[b]) ODISE_TRY(launch_instance_masks(ctx, logits, tb + 1, d->inst_masks[b], std::min(topk, Q * K), g, tb));
+            }
             return ODISE_OK;
         };
         if (side && (inst || pan)) {
@@ -526,8 +563,10 @@ extern "C" int odise_hip_postprocess_batch(odise_hip_ctx* ctx, const odise_post_
                 Lane2 lane(ctx, ms);
                 ODISE_CHECK_HIP(hipStreamWaitEvent(ctx->stream, ctx->ev_fork, 0));
                 ODISE_TRY(decisions());
+                ODISE_CHECK_HIP(hipEventRecord(c->ev_set[set], ctx->stream));
                 ODISE_CHECK_HIP(hipEventRecord(ctx->ev_join, ctx->stream));
             }
+            set_busy[set] = true;
             side_pending = true;
         }
         if (sem && !fused_sem) {   // sem_seg[c, p] = sum_q softmax(mask_cls)[q, c] * sigmoid(mask)[q, p]  (maskformer_model.py:280-284) as an MFMA GEMM
@@ -543,25 +582,15 @@ extern "C" int odise_hip_postprocess_batch(odise_hip_ctx* ctx, const odise_post_
             ODISE_TRY(gemm_forced(ctx, &gd, g_sem_tile >= 0 ? g_sem_tile : (K <= 64 ? -1 : 5), 0));
         }
         if (amax) ODISE_TRY(launch_semantic_argmax(ctx, S, semT + (size_t)b * K * Qpad, amax, npix, Qpad, K));
-        if (!side) ODISE_TRY(decisions());
+        if (!(side && (inst || pan))) ODISE_TRY(decisions());
     }
-    if (want_inst) {   // the top-k selection of every image in one launch (one block per image), then the selected masks
-        if (side_pending) {   // behind the last image's chain on the second lane, i.e. beside that image's semantic GEMM
-            Lane2 lane(ctx, ms);
-            ODISE_TRY(launch_instance_topk(ctx, probs, stats, thing, d->inst_table, d->inst_scores, B, Q, Qpad, K, topk, d->panoptic_on ? 1 : 0));
-            ODISE_CHECK_HIP(hipEventRecord(ctx->ev_join, ctx->stream));
-        } else {
-            ODISE_TRY(launch_instance_topk(ctx, probs, stats, thing, d->inst_table, d->inst_scores, B, Q, Qpad, K, topk, d->panoptic_on ? 1 : 0));
-        }
-        ODISE_TRY(join_side());
-        for (int b = 0; b < B && d->inst_masks; ++b) {
-            if (!d->inst_masks[b]) continue;
-            int* tb = d->inst_table + (size_t)b * (1 + 2 * topk);
-            const f16* logits = ho.pred_masks + (size_t)b * Q * ho.h4 * ho.w4;
-            ODISE_TRY(launch_instance_masks(ctx, logits, tb + 1, d->inst_masks[b], std::min(topk, Q * K), geometry(b), tb));
-        }
+    if (want_inst && n_img < B) {
+        // images that produced nothing else still owe their (empty) instance tables - cannot happen with want_inst (it makes need_S true); kept as a guard
+        set_error("postprocess_batch: an image was skipped although the instance head is on");
+        return ODISE_ERR_STATE;
     }
-    return join_side();   // everything the call produced is ordered on the context's stream
+    if (side_pending) ODISE_CHECK_HIP(hipStreamWaitEvent(ctx->stream, ctx->ev_join, 0));   // everything the call produced is ordered on the context's stream
+    return ODISE_OK;
 }
 
 extern "C" int odise_hip_infer(odise_hip_ctx* ctx, const odise_infer_desc* d) {
@@ -608,13 +637,23 @@ extern "C" int odise_hip_infer(odise_hip_ctx* ctx, const odise_infer_desc* d) {
         pf.has_ready = false;   // consumed (or dropped) by this call
     }
     {
+        // MaskCLIP's image tokens do not depend on the mask head (engine.h ClipKV): the backbone stage enqueues their pass beside its own lanes
+        ClipKV& kv = ms->mclip;
+        kv.ready = false;
+        kv.planned = ctx->maskclip_passes == 0 || ctx->maskclip_passes == 3;
+        kv.plan_image = img01; kv.plan_B = B; kv.plan_H = H; kv.plan_W = W;
         const int rc_bb = odise_hip_backbone_forward(ctx, padded, B, Hp, Wp, nullptr);
         ms->pf.use_now = false;   // on every exit path: a stored latent must never be consumed by a later, unrelated backbone call
-        if (rc_bb != ODISE_OK) return rc_bb;
+        kv.planned = false;       // (likewise: a later backbone call of another caller must not run this call's pass)
+        if (rc_bb != ODISE_OK) { kv.ready = false; return rc_bb; }
     }
     stage_mark(ctx, "backbone done (taps projected + stitched)");
-    ODISE_TRY(odise_hip_head_forward(ctx, nullptr, B, 0, Hp / 4, Wp / 4, nullptr, nullptr, nullptr, nullptr));
-    ODISE_TRY(odise_hip_classify(ctx, img01, B, H, W, mask_cls, nullptr));
+    {
+        int rc_h = odise_hip_head_forward(ctx, nullptr, B, 0, Hp / 4, Wp / 4, nullptr, nullptr, nullptr, nullptr);
+        if (rc_h == ODISE_OK) rc_h = classify_impl(ctx, img01, B, H, W, mask_cls, nullptr, true);
+        ms->mclip.ready = false;
+        if (rc_h != ODISE_OK) return rc_h;
+    }
     stage_mark(ctx, "classification done (MaskCLIP + logits)");
     if (d->mask_cls_out) ODISE_CHECK_HIP(hipMemcpyAsync(d->mask_cls_out, mask_cls, n_cls * 4, hipMemcpyDeviceToDevice, ctx->stream));
     odise_post_desc p = d->post;

@@ -47,8 +47,12 @@ __global__ void __launch_bounds__(256) resize_bilinear_norm_kernel(const float* 
 // one block per (b, token row) of the [T image | Q mask] layout; logits [B,Q,h,w] f16.
 // image rows: everything visible.  mask row q: col 0 (class token) visible, col 1+p visible iff max over the patch of the
 // bilinearly resized mask probability >= 0.5.
+// A thread owns a COLUMN of the resized S x S mask (its x taps are fixed, the y taps of a row are the same for the whole block: scalar work) and
+// walks it one patch row at a time; the column maxima of a patch row meet in LDS.  Same taps, same interpolation order per sample as one thread
+// per patch (round 5: 196 samples x 4 strided loads each, 300 us for 4 pictures on the serial tail) - a maximum does not care about the order.
 __global__ void __launch_bounds__(256) maskclip_token_mask_kernel(const f16* __restrict__ logits, uint8_t* __restrict__ out, int Q, int h,
                                                                  int w, int S, int patch, int T, int64_t ldm) {
+    extern __shared__ float colmax[];   // [S]
     const int TA = T + Q;
     const int b = blockIdx.x / TA, row = blockIdx.x % TA;
     uint8_t* orow = out + ((int64_t)b * TA + row) * ldm;
@@ -58,23 +62,29 @@ __global__ void __launch_bounds__(256) maskclip_token_mask_kernel(const f16* __r
     }
     const int q = row - T, G = S / patch;
     const f16* lr = logits + ((int64_t)b * Q + q) * h * w;
-    for (int p = threadIdx.x; p < G * G; p += blockDim.x) {
-        const int py = p / G, px = p - py * G;
-        float mx = -INFINITY;
-        for (int dy = 0; dy < patch; ++dy) {
-            int y0, y1;
-            float ty;
-            bil_setup(py * patch + dy, h, S, y0, y1, ty);
-            for (int dx = 0; dx < patch; ++dx) {
-                int x0, x1;
-                float tx;
-                bil_setup(px * patch + dx, w, S, x0, x1, tx);
+    for (int py = 0; py < G; ++py) {
+        for (int ox = threadIdx.x; ox < S; ox += blockDim.x) {
+            int x0, x1;
+            float tx;
+            bil_setup(ox, w, S, x0, x1, tx);
+            float mx = -INFINITY;
+            for (int dy = 0; dy < patch; ++dy) {
+                int y0, y1;
+                float ty;
+                bil_setup(py * patch + dy, h, S, y0, y1, ty);
                 const float v00 = (float)lr[y0 * w + x0], v01 = (float)lr[y0 * w + x1], v10 = (float)lr[y1 * w + x0], v11 = (float)lr[y1 * w + x1];
                 const float top = v00 + tx * (v01 - v00), bot = v10 + tx * (v11 - v10);
                 mx = fmaxf(mx, top + ty * (bot - top));
             }
+            colmax[ox] = mx;
         }
-        orow[1 + p] = (1.f / (1.f + expf(-mx))) < 0.5f ? 1 : 0;
+        __syncthreads();
+        for (int px = threadIdx.x; px < G; px += blockDim.x) {
+            float m = colmax[px * patch];
+            for (int dx = 1; dx < patch; ++dx) m = fmaxf(m, colmax[px * patch + dx]);
+            orow[1 + py * G + px] = (1.f / (1.f + expf(-m))) < 0.5f ? 1 : 0;
+        }
+        __syncthreads();
     }
     if (threadIdx.x == 0) orow[0] = 0;
     for (int i = T + threadIdx.x; i < ldm; i += blockDim.x) orow[i] = 1;
@@ -629,11 +639,11 @@ __global__ void __launch_bounds__(256) post_decide_kernel(const float* __restric
     const int b = blockIdx.x;
     const float* mc = mask_cls + (int64_t)b * cls_stride;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    if (semT) {   // zero the padding columns q in [Q, Qpad)
+    if (semT && blockIdx.y == 0) {   // zero the padding columns q in [Q, Qpad)
         f16* st = semT + (int64_t)b * semT_stride;
         for (int i = threadIdx.x; i < K * (Qpad - Q); i += blockDim.x) st[(int64_t)(i / (Qpad - Q)) * Qpad + Q + i % (Qpad - Q)] = (f16)0.f;
     }
-    for (int q = wave; q < Q; q += 4) {
+    for (int q = blockIdx.y * 4 + wave; q < Q; q += 4 * gridDim.y) {   // one wavefront per query (grid.y = Q / 4: a single block per image took 71 us on the serial tail)
         const float* row = mc + (int64_t)q * (K + 1);
         float m = -INFINITY;
         for (int k = lane; k <= K; k += 64) m = fmaxf(m, row[k]);
@@ -743,15 +753,36 @@ __global__ void __launch_bounds__(1024) instance_topk_kernel(const float* __rest
             if ((kx & himask) == prefix) atomicAdd(&hist[(kx >> shift) & 255u], 1u);
         }
         __syncthreads();
-        if (tid == 0) {
-            unsigned int need = s_need, acc = 0;
-            int d = 255;
-            for (; d > 0; --d) {
-                if (acc + hist[d] >= need) break;
-                acc += hist[d];
+        if (tid < 64) {
+            // the largest digit d with  sum of hist[d' > d] < need <= sum of hist[d' >= d]  (d = 0 if none: the serial walk's fall-through).
+            // Lane l owns digits 4l .. 4l+3; `above` = everything in higher lanes (inclusive suffix scan over the lanes minus its own four).
+            const unsigned int need = s_need;
+            const unsigned int h0 = hist[4 * tid], h1 = hist[4 * tid + 1], h2 = hist[4 * tid + 2], h3 = hist[4 * tid + 3];
+            const unsigned int own = h0 + h1 + h2 + h3;
+            unsigned int suf = own;
+#pragma unroll
+            for (int o = 1; o < 64; o <<= 1) {
+                const unsigned int up = __shfl_down(suf, o);
+                if (tid + o < 64) suf += up;
             }
-            s_need = need - acc;                     // how many of digit d (and the finer digits below) are still needed
-            s_prefix = prefix | ((unsigned)d << shift);
+            const unsigned int above = suf - own;
+            // within the lane, from digit 4l+3 downwards
+            int d = -1;
+            unsigned int acc = above;
+            if (acc < need) {
+                if (acc + h3 >= need) d = 4 * tid + 3;
+                else if (acc + h3 + h2 >= need) { d = 4 * tid + 2; acc += h3; }
+                else if (acc + h3 + h2 + h1 >= need) { d = 4 * tid + 1; acc += h3 + h2; }
+                else if (acc + own >= need) { d = 4 * tid; acc += h3 + h2 + h1; }
+            }
+            // exactly one lane finds its digit unless the total is short of `need` (then digit 0 with everything above it, as the serial walk)
+            const unsigned long long found = __ballot(d >= 0);
+            if (found == 0ull) {
+                if (tid == 0) { s_need = need - (suf - h0); s_prefix = prefix; }
+            } else if (d >= 0) {
+                s_need = need - acc;                     // how many of digit d (and the finer digits below) are still needed
+                s_prefix = prefix | ((unsigned)d << shift);
+            }
         }
         __syncthreads();
     }
@@ -810,22 +841,47 @@ __global__ void __launch_bounds__(1024) instance_topk_kernel(const float* __rest
     }
     for (int t = k_sel + tid; t < topk; t += nt) tb[1 + t] = -1;
     __syncthreads();
-    if (tid == 0) {
-        int n = 0;
-        for (int t = 0; t < k_sel; ++t) {
-            const int flat = tb[1 + t];
-            const int q = flat / K, c = flat - q * K;
-            if (things_only && !isthing[c]) continue;
+    // the kept entries in rank order: chunks of `nt` ranks, a block-wide exclusive count of the kept ones before each (every chunk reads its
+    // flat indices before any thread of it writes: an entry moves to a slot at or below its own rank, i.e. one already read)
+    __shared__ unsigned int wk[16];
+    __shared__ int s_n;
+    if (tid == 0) s_n = 0;
+    __syncthreads();
+    for (int base = 0; base < k_sel; base += nt) {
+        const int t = base + tid;
+        const int flat = t < k_sel ? tb[1 + t] : -1;
+        int q = 0, c = 0;
+        bool keep = false;
+        if (flat >= 0) {
+            q = flat / K;
+            c = flat - q * K;
+            keep = !(things_only && !isthing[c]);
+        }
+        const unsigned long long bk = __ballot(keep);
+        const int lane = tid & 63, w = tid >> 6;
+        if (lane == 0) wk[w] = __popcll(bk);
+        __syncthreads();
+        unsigned int before = 0, total = 0;
+        for (int j = 0; j < (nt >> 6); ++j) {
+            if (j < w) before += wk[j];
+            total += wk[j];
+        }
+        before += __popcll(bk & (lane ? (~0ull >> (64 - lane)) : 0ull));
+        const int n0 = s_n;
+        if (keep) {
             const float s = pr[flat];
             const float mask_score = st[q] / (st[Qpad + q] + 1e-6f);
-            tb[1 + n] = q;
-            tb[1 + topk + n] = c;
-            sc[n] = s * mask_score;
-            ++n;
+            tb[1 + n0 + before] = q;
+            tb[1 + topk + n0 + before] = c;
+            sc[n0 + before] = s * mask_score;
         }
-        for (int t = n; t < topk; ++t) { tb[1 + t] = 0; tb[1 + topk + t] = 0; sc[t] = 0.f; }
-        tb[0] = n;
+        __syncthreads();
+        if (tid == 0) s_n = n0 + (int)total;
+        __syncthreads();
     }
+    const int n = s_n;
+    for (int t = n + tid; t < topk; t += nt) { tb[1 + t] = 0; tb[1 + topk + t] = 0; sc[t] = 0.f; }
+    if (tid == 0) tb[0] = n;
 }
 
 
@@ -905,7 +961,8 @@ int launch_resize_bilinear_norm(odise_hip_ctx* ctx, const float* x, f16* y, int 
 }
 int launch_maskclip_token_mask(odise_hip_ctx* ctx, const f16* logits, uint8_t* out, int B, int Q, int h, int w, int S, int patch, int T,
                                int64_t ldm) {
-    hipLaunchKernelGGL(maskclip_token_mask_kernel, dim3((unsigned)(B * (T + Q))), dim3(256), 0, ctx->stream, logits, out, Q, h, w, S, patch, T, ldm);
+    ODISE_REQUIRE(S % patch == 0 && S <= 8192, "maskclip_token_mask: image %d / patch %d", S, patch);
+    hipLaunchKernelGGL(maskclip_token_mask_kernel, dim3((unsigned)(B * (T + Q))), dim3(256), (size_t)S * sizeof(float), ctx->stream, logits, out, Q, h, w, S, patch, T, ldm);
     ODISE_CHECK_HIP(hipGetLastError());
     return ODISE_OK;
 }
@@ -970,7 +1027,7 @@ int launch_column_stats(odise_hip_ctx* ctx, const f16* S, float* partial, float*
 }
 int launch_post_decide(odise_hip_ctx* ctx, const float* mask_cls, float* kscore, int* label, f16* semT, float* probs, int B, int Q, int Qpad, int K,
                        float object_mask_threshold) {
-    hipLaunchKernelGGL(post_decide_kernel, dim3((unsigned)B), dim3(256), 0, ctx->stream, mask_cls, kscore, label, semT, probs, Q, Qpad, K,
+    hipLaunchKernelGGL(post_decide_kernel, dim3((unsigned)B, (unsigned)ceil_div(Q, 4)), dim3(256), 0, ctx->stream, mask_cls, kscore, label, semT, probs, Q, Qpad, K,
                        object_mask_threshold, (int64_t)Q * (K + 1), (int64_t)Q, (int64_t)K * Qpad, (int64_t)Q * K);
     ODISE_CHECK_HIP(hipGetLastError());
     return ODISE_OK;

@@ -99,6 +99,7 @@ struct odise_hip_ctx {
     hipStream_t stream2 = nullptr;
     void* ws2 = nullptr;
     hipEvent_t ev_fork = nullptr, ev_mid = nullptr, ev_join = nullptr;
+    hipEvent_t ev_mclip = nullptr;   // the MaskCLIP image-token pass enqueued on the second lane is done (engine.h ClipKV)
     int lanes = 2;  // 1 = everything on the one stream (tools A/B: odise_hip_set_lanes)
     // encoder prefetch (engine.h Prefetch, odise_hip_infer_prefetch): a third, lowest-priority stream with its own split-K workspace; the next
     // batch's VAE encoder runs there behind ev_pf_go (recorded when the current batch's VAE lane is done) and publishes ev_pf_done
@@ -110,6 +111,7 @@ struct odise_hip_ctx {
     void* comm = nullptr;  // odise::Comm* (comm.cpp): RCCL communicator + exchange stream, created by odise_hip_comm_init
     // per-context execution options (odise_hip_set_option, include/odise_hip.h); read on the host when a stage is enqueued
     int clip_ln_fold = 0;            // ODISE_OPT_CLIP_LN_FOLD: 0 = by token count, 1 = always, 2 = never
+    int maskclip_passes = 0;         // ODISE_OPT_MASKCLIP_PASSES: 0 = image tokens ride in the crops' tower, 1 = two passes in place, 2 = one pass, 3 = own tower on the second lane
     int attn_kv_resident = 0;        // ODISE_OPT_ATTN_KV_RESIDENT: 0 = by the library's rules (attn.hip attn_kvres_ok / attn_sa_ok), bit 1 (2) = never the K/V-resident
                                      // kernel, bit 2 (4) = never the pipelined self-attention kernel
     int64_t vae_chunk_bytes = 0;     // ODISE_OPT_VAE_CHUNK_BYTES: crops per VAE launch so that one activation stays below this (0 = all crops at once, the default)

@@ -34,6 +34,7 @@ void models_destroy(odise_hip_ctx* ctx) {
     for (void* p : ms->dev_allocs) (void)hipFree(p);
     if (ms->arena.base) (void)hipFree(ms->arena.base);
     if (ms->arena2.base) (void)hipFree(ms->arena2.base);
+    if (ms->mclip.buf) (void)hipFree(ms->mclip.buf);
     for (Arena& a : ms->pf.arena)
         if (a.base) (void)hipFree(a.base);
     delete ms;
@@ -103,6 +104,7 @@ int ensure_lane2(odise_hip_ctx* ctx, ModelStore* ms, size_t arena_bytes) {
         ODISE_CHECK_HIP(hipEventCreateWithFlags(&ctx->ev_fork, hipEventDisableTiming));
         ODISE_CHECK_HIP(hipEventCreateWithFlags(&ctx->ev_mid, hipEventDisableTiming));
         ODISE_CHECK_HIP(hipEventCreateWithFlags(&ctx->ev_join, hipEventDisableTiming));
+        ODISE_CHECK_HIP(hipEventCreateWithFlags(&ctx->ev_mclip, hipEventDisableTiming));
     }
     if (ms->arena2.cap < arena_bytes) {
         ODISE_CHECK_HIP(hipStreamSynchronize(ctx->stream));

@@ -99,6 +99,30 @@ struct Prefetch {
     Arena arena[2];
 };
 
+// MaskCLIP in two passes.  The attention mask the reference builds (clip.py:307-318) hides the mask tokens from EVERY query: the 577 image tokens
+// of a picture run the plain tower whatever the masks are, and the Q mask tokens only read that stream's keys and values.  The image-token pass
+// therefore needs nothing of the mask head: odise_hip_infer lets the pictures RIDE IN THE CROPS' TOWER (the implicit captioner's CLIP, the same
+// frozen ViT-L/14@336 weights, clip.py:77-97 / 239-246: B pictures + B x K crops are one batch of token rows on the second lane, whose GEMM grids
+// have room in their last round), which leaves q|k and V^T of the pictures' rows of every block here; the mask-token pass (B x Q rows) is what
+// remains on the serial tail behind the mask head.
+// Layout: the pictures are the FIRST images of the tower's batch, and block l writes its q|k rows at qk + l * qk_stride and its V^T columns at
+// vt + l * vt_stride of a matrix with ldvt columns: the rows / columns of the other images (dead once the block's attention has run) lie where the
+// next blocks' picture rows / columns go and are overwritten by them - one buffer of layers x pictures + 1 x others instead of layers x everything.
+struct ClipKV {
+    void* buf = nullptr;     // device, grows
+    size_t cap = 0;
+    f16* qk = nullptr;       // block l, picture b, token t: qk + l * qk_stride + (b * TP + t) * 2 * width  (q | k halves)
+    f16* vt = nullptr;       // block l, channel c, picture b, token t: vt + l * vt_stride + c * ldvt + b * TP + t
+    f16* cls = nullptr;      // [width] the class-token row after ln_pre: what every mask token starts from (clip.py:268-270)
+    int B = 0, TP = 0, layers = 0, width = 0;
+    size_t qk_stride = 0, vt_stride = 0;   // elements per block
+    int64_t ldvt = 0;
+    // the pass odise_hip_infer planned for its pictures, and whether it has been enqueued
+    const float* plan_image = nullptr;
+    int plan_B = 0, plan_H = 0, plan_W = 0;
+    bool planned = false, ready = false, on_lane2 = false;   // on_lane2: a pass of its own on the second lane, published by ev_mclip
+};
+
 struct ModelStore {
     std::map<std::string, HostTensor> host;
     std::vector<void*> dev_allocs;              // weights that live as long as the context
@@ -107,6 +131,7 @@ struct ModelStore {
     Arena arena;
     Arena arena2;   // activations of the second lane (Lane2)
     Prefetch pf;    // encoder prefetch of the next batch (odise_hip_infer_prefetch)
+    ClipKV mclip;   // MaskCLIP image-token pass of the batch in progress
     UNetModel* unet = nullptr;
     struct ExtractorModel* extractor = nullptr;
     struct MaskGenModel* maskgen = nullptr;
@@ -238,7 +263,10 @@ int launch_clip_preprocess(odise_hip_ctx* ctx, const float* x, f16* y, int N, in
 int launch_softmax_rows(odise_hip_ctx* ctx, const f16* x, f16* y, int64_t rows, int cols, int64_t ld, float scale);
 int launch_clip_assemble(odise_hip_ctx* ctx, const f16* patches, const float* cls, const float* pos, f16* tok, int B, int T, int extra,
                          int TP, int Cw);
-int clip_tower(Exec& ex, const Act& img, int extra, const uint8_t* mask, int64_t ldm, f16* out);
+int clip_tower(Exec& ex, const Act& img, int extra, const uint8_t* mask, int64_t ldm, f16* out, ClipKV* kv = nullptr, int kv_images = 0);
+int maskclip_image_pass(Exec& ex, const float* image01, int B, int H, int W);   // -> ms->mclip (enqueued on the context's current stream)
+int maskclip_mask_pass(Exec& ex, int Q, const uint8_t* mask, int64_t ldm, int64_t stride_mask, f16* out);
+int maskclip_planned_pass(odise_hip_ctx* ctx, ModelStore* ms);                   // backbone stage, both lanes enqueued: ODISE_OPT_MASKCLIP_PASSES 3
 int clip_dims(ModelStore* ms, int* image, int* patch, int* tokens, int* out_dim);
 int launch_cond_inputs(odise_hip_ctx* ctx, const float* proj, const float* A1, const float* A2, float* out, int B, int T, int Cw);
 

@@ -419,7 +419,11 @@ static int run_vae_attn(Exec& ex, const VaeAttn& w, const Act& x, Act& out) {
 // Token rows: every image owns TP = round_up(577 + Q, 8) rows of the activation matrices (the tail rows are zero at the input and never read
 // as keys, values or results), so that V^T of ALL images is ONE GEMM Wv x n^T -> [width, B*TP] whose column block b*TP.. is image b's
 // 16-byte-aligned V^T (the per-image batched form ran at 309 TFLOP/s: 3 column tiles for 577 tokens, 192 tiles on 256 CUs).
-int clip_tower(Exec& ex, const Act& img, int extra, const uint8_t* mask, int64_t ldm, f16* out) {
+// kv != nullptr (extra = 0): the first kv_images images of the batch are MaskCLIP's pictures (engine.h ClipKV): q|k and V^T of EVERY block are
+// written in kv's sliding layout, the class-token row after ln_pre goes to kv->cls, and those images leave the tower with the last block's
+// projections (no output bit of MaskCLIP depends on the image tokens beyond them).  The other images (the crops of the implicit captioner) run
+// the plain tower beside them; with kv_images = img.n there is no output and the pass ends there.
+int clip_tower(Exec& ex, const Act& img, int extra, const uint8_t* mask, int64_t ldm, f16* out, ClipKV* kv, int kv_images) {
     ExtractorModel* e = ex.ms->extractor;
     const int B = img.n, S = e->clip_image, Wd = e->clip_width, T = e->clip_tokens, G = S / e->clip_patch;
     const int TA = T + extra;
@@ -428,18 +432,21 @@ int clip_tower(Exec& ex, const Act& img, int extra, const uint8_t* mask, int64_t
     Act patches;
     ODISE_TRY(ex.conv(img, e->clip_conv1, patches, e->clip_patch, 0, false, nullptr, nullptr, 0, ODISE_ACT_NONE, 0, 0, G, G));
     const int64_t M = (int64_t)B * TP;
-    const int64_t ldvt = M;
+    const int64_t ldvt = kv ? kv->ldvt : M;
+    const int Bk = kv ? kv_images : 0;   // leading images that only leave keys and values
+    ODISE_REQUIRE(!kv || (extra == 0 && Bk >= 1 && Bk <= B && kv->B == Bk && kv->TP == TP), "clip_tower: key / value store laid out for another batch");
     f16* x = (f16*)ex.alloc_bytes((size_t)M * Wd * 2);
     f16* x2 = (f16*)ex.alloc_bytes((size_t)M * Wd * 2);
     f16* n = (f16*)ex.alloc_bytes((size_t)M * Wd * 2);
-    f16* qk = (f16*)ex.alloc_bytes((size_t)M * 2 * Wd * 2);
-    f16* vt = (f16*)ex.alloc_bytes((size_t)Wd * ldvt * 2);
+    f16* qk = kv ? kv->qk : (f16*)ex.alloc_bytes((size_t)M * 2 * Wd * 2);
+    f16* vt = kv ? kv->vt : (f16*)ex.alloc_bytes((size_t)Wd * ldvt * 2);
     f16* att = (f16*)ex.alloc_bytes((size_t)M * Wd * 2);
     f16* hid = (f16*)ex.alloc_bytes((size_t)M * 4 * Wd * 2);
     if (!x || !x2 || !n || !qk || !vt || !att || !hid) return ODISE_ERR_NOMEM;
     if (TP > TA) ODISE_CHECK_HIP(hipMemsetAsync(att, 0, (size_t)M * Wd * 2, ex.ctx->stream));  // the attention never writes the tail rows: keep them finite
     ODISE_TRY(launch_clip_assemble(ex.ctx, patches.p, e->clip_cls, e->clip_pos, n, B, T, extra, TP, Wd));
     ODISE_TRY(ex.layer_norm(n, x, M, e->clip_ln_pre, 1e-5f));
+    if (kv) ODISE_TRY(launch_broadcast_rows(ex.ctx, x, kv->cls, Wd, 1));   // ln_pre(class_embedding + pos[0]): what every mask token starts from (clip.py:268-270)
     const int heads = e->clip_heads, D = Wd / heads;
     // ln_1 / ln_2 of the blocks never touch HBM as tensors: the GEMM that writes the residual stream (out-proj, c_proj) leaves per-row partial
     // sums next to it, and the GEMMs that would read LN(x) read x with the affine folded into their weights (LnEpi, gemm_epilogue_f16).  8 -> 6
@@ -470,9 +477,15 @@ int clip_tower(Exec& ex, const Act& img, int extra, const uint8_t* mask, int64_t
         return gemm_ln(ex.ctx, &d, ln);
     };
     bool first = true;
+    int layer = 0;
     for (const ClipBlock& b : e->clip_blocks) {
         const bool folded1 = fold && !first;   // statistics of x were left by the previous block's c_proj
         first = false;
+        if (kv) {
+            qk = kv->qk + (size_t)layer * kv->qk_stride;
+            vt = kv->vt + (size_t)layer * kv->vt_stride;
+            ++layer;
+        }
         odise_gemm_desc d;
         memset(&d, 0, sizeof(d));
         d.M = Wd; d.N = (int)M; d.K = Wd;  // V^T of every image side by side (only its first T columns are ever read: the image tokens)
@@ -494,12 +507,17 @@ int clip_tower(Exec& ex, const Act& img, int extra, const uint8_t* mask, int64_t
             d.A = b.v.w; d.W = n; d.bias_m = b.v_bias;
             ODISE_TRY(ex.gemm(d));
         }
+        const bool last = &b == &e->clip_blocks.back();
+        if (kv && last && Bk == B) {
+            ex.ms->arena.release(mk);
+            return ODISE_OK;
+        }
         odise_attn_desc a;
         memset(&a, 0, sizeof(a));
         // The plain tower's result is ln_post(x[:, 0]) (clip.py:196-206): of the LAST block only the class token's row is ever read, so its
         // attention has one query per image and its out-proj / MLP run on B rows instead of B x 577 (dead work of the reference is not executed:
         // no output bit depends on the other 576 rows; -0.3 ms on the step's critical lane)
-        const bool cls_only = extra == 0 && &b == &e->clip_blocks.back();
+        const bool cls_only = extra == 0 && last;
         a.B = B; a.H = heads; a.Lq = cls_only ? 1 : TA; a.Lk = T; a.D = D;
         a.Q = qk; a.ldq = 2 * Wd; a.strideQ = (int64_t)TP * 2 * Wd;
         a.K = qk + Wd; a.ldk = 2 * Wd; a.strideK = (int64_t)TP * 2 * Wd;
@@ -507,25 +525,40 @@ int clip_tower(Exec& ex, const Act& img, int extra, const uint8_t* mask, int64_t
         a.O = att; a.ldo = Wd; a.strideO = (int64_t)TP * Wd;
         if (extra > 0) { a.mask = mask; a.ldmask = ldm; a.strideMask = (int64_t)TA * ldm; }
         a.scale = 1.0f / sqrtf((float)D);
-        ODISE_TRY(ex.attention(a));
+        if (Bk > 0 && Bk < B) {
+            // pictures and crops as two launches: the crops keep the grid the K / V^T-resident kernel wants ((head, image) pairs in whole rounds
+            // of the chip, attn.hip attn_kvres_ok), the few pictures take the tiled kernel; in the last block the pictures are done
+            odise_attn_desc ac = a;
+            ac.B = B - Bk;
+            ac.Q = qk + (size_t)Bk * a.strideQ; ac.K = qk + Wd + (size_t)Bk * a.strideK; ac.Vt = vt + (size_t)Bk * a.strideVt; ac.O = att + (size_t)Bk * a.strideO;
+            ODISE_TRY(ex.attention(ac));
+            if (!last) {
+                a.B = Bk;
+                ODISE_TRY(ex.attention(a));
+            }
+        } else {
+            ODISE_TRY(ex.attention(a));
+        }
         if (cls_only) {
-            f16* x2c = (f16*)ex.alloc_bytes((size_t)B * Wd * 2);
-            f16* nc = (f16*)ex.alloc_bytes((size_t)B * Wd * 2);
-            f16* hc = (f16*)ex.alloc_bytes((size_t)B * 4 * Wd * 2);
-            f16* xc = (f16*)ex.alloc_bytes((size_t)B * Wd * 2);
+            const int Bc = B - Bk;   // the images that have an output
+            const size_t skip = (size_t)Bk * TP * Wd;
+            f16* x2c = (f16*)ex.alloc_bytes((size_t)Bc * Wd * 2);
+            f16* nc = (f16*)ex.alloc_bytes((size_t)Bc * Wd * 2);
+            f16* hc = (f16*)ex.alloc_bytes((size_t)Bc * 4 * Wd * 2);
+            f16* xc = (f16*)ex.alloc_bytes((size_t)Bc * Wd * 2);
             if (!x2c || !nc || !hc || !xc) return ODISE_ERR_NOMEM;
             memset(&d, 0, sizeof(d));   // x2[cls] = x[cls] + attn[cls] Wo^T + bo: the row stride TP*Wd picks token 0 of every image
-            d.M = B; d.N = Wd; d.K = Wd;
-            d.A = att; d.lda = (int64_t)TP * Wd; d.W = b.out.w; d.ldw = Wd;
+            d.M = Bc; d.N = Wd; d.K = Wd;
+            d.A = att + skip; d.lda = (int64_t)TP * Wd; d.W = b.out.w; d.ldw = Wd;
             d.C = x2c; d.ldc = Wd; d.c_dtype = ODISE_F16; d.bias_n = b.out.b;
-            d.residual = x; d.ldr = (int64_t)TP * Wd; d.alpha = 1.f; d.batch = 1;
+            d.residual = x + skip; d.ldr = (int64_t)TP * Wd; d.alpha = 1.f; d.batch = 1;
             ODISE_TRY(ex.gemm(d));
-            ODISE_TRY(ex.layer_norm(x2c, nc, B, b.ln2, 1e-5f));
-            ODISE_TRY(ex.linear(nc, B, b.fc, hc, ODISE_ACT_QUICKGELU));
-            ODISE_TRY(ex.linear(hc, B, b.proj, xc, ODISE_ACT_NONE, x2c));
-            ODISE_TRY(ex.layer_norm(xc, nc, B, e->clip_ln_post, 1e-5f));
+            ODISE_TRY(ex.layer_norm(x2c, nc, Bc, b.ln2, 1e-5f));
+            ODISE_TRY(ex.linear(nc, Bc, b.fc, hc, ODISE_ACT_QUICKGELU));
+            ODISE_TRY(ex.linear(hc, Bc, b.proj, xc, ODISE_ACT_NONE, x2c));
+            ODISE_TRY(ex.layer_norm(xc, nc, Bc, e->clip_ln_post, 1e-5f));
             memset(&d, 0, sizeof(d));
-            d.M = B; d.N = e->clip_out; d.K = Wd; d.A = nc; d.lda = Wd; d.W = e->clip_proj.w; d.ldw = Wd;
+            d.M = Bc; d.N = e->clip_out; d.K = Wd; d.A = nc; d.lda = Wd; d.W = e->clip_proj.w; d.ldw = Wd;
             d.C = out; d.ldc = e->clip_out; d.c_dtype = ODISE_F16; d.alpha = 1.f; d.batch = 1;
             ODISE_TRY(ex.gemm(d));
             ex.ms->arena.release(mk);
@@ -562,6 +595,98 @@ int clip_tower(Exec& ex, const Act& img, int extra, const uint8_t* mask, int64_t
     return ODISE_OK;
 }
 
+
+// ---- MaskCLIP in two passes (engine.h ClipKV; clip.py:252-323) ----------------------------------------------------------------------------
+// Reserves and lays out the key / value store for B pictures that run the tower with `others` further images behind them.
+static int maskclip_kv_layout(odise_hip_ctx* ctx, ModelStore* ms, int B, int others) {
+    const ExtractorModel* e = ms->extractor;
+    ClipKV& kv = ms->mclip;
+    kv.ready = false;
+    const int Wd = e->clip_width, L = (int)e->clip_blocks.size();
+    const int TP = (int)round_up(e->clip_tokens, 8);
+    const size_t Mp = (size_t)B * TP, Mo = (size_t)others * TP;
+    const size_t rows = Mp * L + Mo;   // block l writes rows / columns [l * Mp, l * Mp + Mp + Mo): the tail is overwritten by the blocks after it
+    const size_t need = (rows * 2 * Wd + (size_t)Wd * rows + Wd) * sizeof(f16) + 256;
+    if (kv.cap < need) {
+        // nothing enqueued may still read the old buffer (the mask-token pass of the previous call runs on the main stream, a tower on the second)
+        ODISE_CHECK_HIP(hipDeviceSynchronize());
+        if (kv.buf) ODISE_CHECK_HIP(hipFree(kv.buf));
+        kv.buf = nullptr;
+        kv.cap = 0;
+        ODISE_CHECK_HIP(hipMalloc(&kv.buf, need + need / 8));
+        kv.cap = need + need / 8;
+    }
+    kv.qk = (f16*)kv.buf;
+    kv.vt = kv.qk + rows * 2 * Wd;
+    kv.cls = kv.vt + (size_t)Wd * rows;
+    kv.B = B; kv.TP = TP; kv.layers = L; kv.width = Wd;
+    kv.qk_stride = Mp * 2 * Wd; kv.vt_stride = Mp; kv.ldvt = (int64_t)rows;
+    return ODISE_OK;
+}
+
+// Pass 1 on its own: the image tokens of B pictures [B,3,H,W] in [0,1] (bilinear to 336^2 + CLIP normalisation, clip.py:325-338) through the tower.
+int maskclip_image_pass(Exec& ex, const float* image01, int B, int H, int W) {
+    ExtractorModel* e = ex.ms->extractor;
+    ODISE_TRY(maskclip_kv_layout(ex.ctx, ex.ms, B, 0));
+    const int S = e->clip_image;
+    const size_t mk = ex.ms->arena.mark();
+    Act img;
+    int rc = ex.alloc(img, B, S, S, 8);
+    if (rc == ODISE_OK) rc = launch_resize_bilinear_norm(ex.ctx, image01, img.p, B, H, W, S);
+    if (rc == ODISE_OK) rc = clip_tower(ex, img, 0, nullptr, 0, nullptr, &ex.ms->mclip, B);
+    ex.ms->arena.release(mk);
+    return rc;
+}
+
+// Pass 2: Q mask tokens per picture (all copies of the class token after ln_pre) read the keys / values pass 1 left; mask [B][Q][ldm] u8
+// (1 = patch hidden from that mask token; column 0 = the class token, always visible), pictures `stride_mask` bytes apart.  out [B,Q,clip_out].
+int maskclip_mask_pass(Exec& ex, int Q, const uint8_t* mask, int64_t ldm, int64_t stride_mask, f16* out) {
+    ExtractorModel* e = ex.ms->extractor;
+    const ClipKV& kv = ex.ms->mclip;
+    const int B = kv.B, TP = kv.TP, Wd = e->clip_width, T = e->clip_tokens, heads = e->clip_heads, D = Wd / heads;
+    ODISE_REQUIRE(kv.buf && kv.layers == (int)e->clip_blocks.size() && kv.width == Wd, "maskclip: the image-token pass has not run for this tower");
+    const int64_t M = (int64_t)B * Q;
+    const size_t mk = ex.ms->arena.mark();
+    f16* x = (f16*)ex.alloc_bytes((size_t)M * Wd * 2);
+    f16* x2 = (f16*)ex.alloc_bytes((size_t)M * Wd * 2);
+    f16* n = (f16*)ex.alloc_bytes((size_t)M * Wd * 2);
+    f16* q = (f16*)ex.alloc_bytes((size_t)M * Wd * 2);
+    f16* att = (f16*)ex.alloc_bytes((size_t)M * Wd * 2);
+    f16* hid = (f16*)ex.alloc_bytes((size_t)M * 4 * Wd * 2);
+    if (!x || !x2 || !n || !q || !att || !hid) return ODISE_ERR_NOMEM;
+    ODISE_TRY(launch_broadcast_rows(ex.ctx, kv.cls, x, Wd, (int)M));
+    int layer = 0;
+    for (const ClipBlock& b : e->clip_blocks) {
+        ODISE_TRY(ex.layer_norm(x, n, M, b.ln1, 1e-5f));
+        LinW wq = b.qk;   // the query rows of the fused q|k projection
+        wq.out = Wd;
+        ODISE_TRY(ex.linear(n, M, wq, q));
+        odise_attn_desc a;
+        memset(&a, 0, sizeof(a));
+        a.B = B; a.H = heads; a.Lq = Q; a.Lk = T; a.D = D;
+        a.Q = q; a.ldq = Wd; a.strideQ = (int64_t)Q * Wd;
+        a.K = kv.qk + (size_t)layer * kv.qk_stride + Wd; a.ldk = 2 * Wd; a.strideK = (int64_t)TP * 2 * Wd;
+        a.Vt = kv.vt + (size_t)layer * kv.vt_stride; a.ldvt = kv.ldvt; a.strideVt = TP;
+        a.O = att; a.ldo = Wd; a.strideO = (int64_t)Q * Wd;
+        a.mask = mask; a.ldmask = ldm; a.strideMask = stride_mask;
+        a.scale = 1.0f / sqrtf((float)D);
+        ODISE_TRY(ex.attention(a));
+        ODISE_TRY(ex.linear(att, M, b.out, x2, ODISE_ACT_NONE, x));          // x2 = x + attn
+        ODISE_TRY(ex.layer_norm(x2, n, M, b.ln2, 1e-5f));
+        ODISE_TRY(ex.linear(n, M, b.fc, hid, ODISE_ACT_QUICKGELU));
+        ODISE_TRY(ex.linear(hid, M, b.proj, x, ODISE_ACT_NONE, x2));         // x = x2 + mlp
+        ++layer;
+    }
+    ODISE_TRY(ex.layer_norm(x, n, M, e->clip_ln_post, 1e-5f));
+    odise_gemm_desc d;
+    memset(&d, 0, sizeof(d));
+    d.M = (int)M; d.N = e->clip_out; d.K = Wd; d.A = n; d.lda = Wd; d.W = e->clip_proj.w; d.ldw = Wd;
+    d.C = out; d.ldc = e->clip_out; d.c_dtype = ODISE_F16; d.alpha = 1.f; d.batch = 1;
+    ODISE_TRY(ex.gemm(d));
+    ex.ms->arena.release(mk);
+    return ODISE_OK;
+}
+
 int clip_dims(ModelStore* ms, int* image, int* patch, int* tokens, int* out_dim) {
     ExtractorModel* e = ms->extractor;
     if (!e || !e->built) return ODISE_ERR_STATE;
@@ -572,12 +697,25 @@ int clip_dims(ModelStore* ms, int* image, int* patch, int* tokens, int* out_dim)
     return ODISE_OK;
 }
 
+// The implicit captioner's image embedding of the B crops (ldm.py:697-718).  When odise_hip_infer has planned MaskCLIP's image-token pass for its
+// pictures (ODISE_OPT_MASKCLIP_PASSES 0), they ride in this tower as its first images: same weights, same token rows, and the GEMM grids of
+// 16 crops have room for them in their last round (37 -> 46 row tiles of 256: 592 -> 736 tiles on 256 CUs, three rounds either way).
 static int run_clip(Exec& ex, ExtractorModel* e, const float* image, int B, int H, int W, f16* prefix16 /*[B, clip_out]*/) {
+    ClipKV& kv = ex.ms->mclip;
+    const bool ride = kv.planned && !kv.ready && ex.ctx->maskclip_passes == 0;
+    const int Bp = ride ? kv.plan_B : 0;
+    if (ride) ODISE_TRY(maskclip_kv_layout(ex.ctx, ex.ms, Bp, B));
     const size_t mk = ex.ms->arena.mark();
+    const int S = e->clip_image;
     Act img;
-    ODISE_TRY(ex.alloc(img, B, e->clip_image, e->clip_image, 8));
-    ODISE_TRY(launch_clip_preprocess(ex.ctx, image, img.p, B, H, W, e->clip_image));
-    ODISE_TRY(clip_tower(ex, img, 0, nullptr, 0, prefix16));
+    ODISE_TRY(ex.alloc(img, Bp + B, S, S, 8));
+    if (ride) ODISE_TRY(launch_resize_bilinear_norm(ex.ctx, kv.plan_image, img.p, Bp, kv.plan_H, kv.plan_W, S));
+    ODISE_TRY(launch_clip_preprocess(ex.ctx, image, img.p + (size_t)Bp * S * S * 8, B, H, W, S));
+    ODISE_TRY(clip_tower(ex, img, 0, nullptr, 0, prefix16, ride ? &kv : nullptr, Bp));
+    if (ride) {
+        kv.on_lane2 = false;   // ordered by the lane's join like everything else of this tower
+        kv.ready = true;
+    }
     ex.ms->arena.release(mk);
     return ODISE_OK;
 }
@@ -691,6 +829,28 @@ int extractor_encoder_only(odise_hip_ctx* ctx, ModelStore* ms, const float* imag
 // this before it touches a UNet tap (stream-side wait, the host never blocks)
 int extractor_join(odise_hip_ctx* ctx) {
     if (ctx->lanes == 2 && !standalone_graph_capture(ctx)) ODISE_CHECK_HIP(hipStreamWaitEvent(ctx->stream, ctx->ev_join, 0));
+    return ODISE_OK;
+}
+
+// ODISE_OPT_MASKCLIP_PASSES 3: the image-token pass odise_hip_infer planned for its pictures as a tower of its own, enqueued by the backbone stage
+// once both lanes of the extractor are: on the second lane behind the UNet, i.e. beside the projections, the pixel decoder and the masked decoder
+// of the main stream, which waits for ev_mclip before the mask-token pass.  A pass that cannot be placed (one lane, no room in the lane's
+// arena) is left to the classification stage, which then runs it in place.
+int maskclip_planned_pass(odise_hip_ctx* ctx, ModelStore* ms) {
+    ClipKV& kv = ms->mclip;
+    if (!kv.planned || kv.ready || ctx->maskclip_passes != 3) return ODISE_OK;
+    if (!(ctx->lanes == 2 && !standalone_graph_capture(ctx))) return ODISE_OK;
+    const ExtractorModel* e = ms->extractor;
+    const size_t rows = (size_t)kv.plan_B * round_up(e->clip_tokens, 8);
+    const size_t need = rows * e->clip_width * 2 * 9 + (size_t)kv.plan_B * e->clip_image * e->clip_image * 16 * 2 + ((size_t)16 << 20);
+    if (ms->arena2.cap - ms->arena2.off < need) return ODISE_OK;
+    Lane2 lane(ctx, ms);
+    Exec ex{ctx, ms};
+    ODISE_TRY(maskclip_image_pass(ex, kv.plan_image, kv.plan_B, kv.plan_H, kv.plan_W));
+    stage_mark(ctx, "lane 2: MaskCLIP image tokens done");
+    ODISE_CHECK_HIP(hipEventRecord(ctx->ev_mclip, ctx->stream));
+    kv.on_lane2 = true;
+    kv.ready = true;
     return ODISE_OK;
 }
 

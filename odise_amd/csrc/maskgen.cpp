@@ -492,6 +492,7 @@ static int backbone_forward(odise_hip_ctx* ctx, const float* image, int B, int H
     stage_mark(ctx, "backbone: crops extracted");
     ODISE_TRY(extractor_launch(ctx, ms, crops, B * K, S, S, false, /*join=*/!defer_join));
     stage_mark(ctx, "extractor: VAE lane done (main stream; the CLIP -> UNet lane is joined later)");
+    ODISE_TRY(maskclip_planned_pass(ctx, ms));   // ODISE_OPT_MASKCLIP_PASSES 3: MaskCLIP's image tokens behind the UNet on the second lane (engine.h ClipKV)
     ms->pf.use_now = false;
     if (ms->pf.has_pending && ctx->prefetch_start == 0) prefetch_try(ctx, ms, g);   // the NEXT batch's encoder behind this batch's VAE lane
     const Act* taps = extractor_taps(ms);

@@ -114,7 +114,7 @@ class Context:
         check(self.lib.odise_hip_sync(self.h), "sync")
 
     # ---- per-context execution options (include/odise_hip.h ODISE_OPT_*) ---------------------
-    OPT_CLIP_LN_FOLD, OPT_VAE_CHUNK_BYTES, OPT_ATTN_KV_RESIDENT, OPT_PREFETCH_CU_EIGHTHS, OPT_PREFETCH_START = 1, 2, 3, 4, 5
+    OPT_CLIP_LN_FOLD, OPT_VAE_CHUNK_BYTES, OPT_ATTN_KV_RESIDENT, OPT_PREFETCH_CU_EIGHTHS, OPT_PREFETCH_START, OPT_MASKCLIP_PASSES = 1, 2, 3, 4, 5, 6
 
     def set_option(self, option: int, value: int) -> None:
         check(self.lib.odise_hip_set_option(self.h, option, value), "set_option")

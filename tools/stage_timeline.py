@@ -21,11 +21,13 @@ def main():
     ap.add_argument("--pipeline", action="store_true", help="encoder prefetch: the calls alternate between two sets of pictures, each preparing the other")
     ap.add_argument("--prefetch-start", type=int, default=1)
     ap.add_argument("--prefetch-cus", type=int, default=0)
+    ap.add_argument("--maskclip-passes", type=int, default=0, help="ODISE_OPT_MASKCLIP_PASSES")
     args = ap.parse_args()
     from odise_amd.runtime import Context
     ctx = Context(0)
     if args.lanes == 1:
         ctx.lib.odise_hip_set_lanes(ctx.h, 1)
+    ctx.set_option(ctx.OPT_MASKCLIP_PASSES, args.maskclip_passes)
     S, B = 1024, args.images
     u8 = [bench.image_u8(S, b) for b in range(B)]
     hip, _ = bench.calibrated_model(ctx, u8[0], S, 133, 254, set(range(80)), None)
