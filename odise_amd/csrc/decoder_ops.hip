@@ -229,7 +229,7 @@ __device__ __forceinline__ void bilinear_setup(int o, int in, int out, int& i0, 
     t = s - (float)i0;
 }
 
-// y [N,OH,OW,C] = a [N,OH,OW,C] + bilinear(b [N,H,W,C] -> OH x OW)
+// y [N,OH,OW,C] = a [N,OH,OW,C] + bilinear(b [N,H,W,C] -> OH x OW); a = nullptr: the resized map alone
 __global__ void __launch_bounds__(256) bilinear_add_kernel(const f16* __restrict__ a, const f16* __restrict__ b, f16* __restrict__ y, int H,
                                                           int W, int OH, int OW, int C8, int64_t total) {
     for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * blockDim.x) {
@@ -247,7 +247,8 @@ __global__ void __launch_bounds__(256) bilinear_add_kernel(const f16* __restrict
         const f16x8 v01 = *reinterpret_cast<const f16x8*>(bb + ((int64_t)y0 * W + x1) * C8 * 8);
         const f16x8 v10 = *reinterpret_cast<const f16x8*>(bb + ((int64_t)y1 * W + x0) * C8 * 8);
         const f16x8 v11 = *reinterpret_cast<const f16x8*>(bb + ((int64_t)y1 * W + x1) * C8 * 8);
-        const f16x8 va = *reinterpret_cast<const f16x8*>(a + idx * 8);
+        f16x8 va = {0, 0, 0, 0, 0, 0, 0, 0};
+        if (a) va = *reinterpret_cast<const f16x8*>(a + idx * 8);
         f16x8 o;
 #pragma unroll
         for (int i = 0; i < 8; ++i) {

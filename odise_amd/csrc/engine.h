@@ -278,10 +278,12 @@ int launch_upsample_nearest(odise_hip_ctx* ctx, const f16* x, f16* y, int N, int
 int launch_stitch(odise_hip_ctx* ctx, const f16* feat, f16* out, float* out_nchw, int B, int K, const int* boxes_dev, int ch, int cw, int OH,
                   int OW, int C);
 int launch_broadcast_rows(odise_hip_ctx* ctx, const f16* x, f16* y, int64_t n, int B);
+int layer_norm_add_table(odise_hip_ctx* ctx, const void* x, void* y, const float* gamma, const float* beta, int rows, int C, float eps, f16* y2,
+                         const float* table, int P);   // y = LayerNorm(x), y2 (optional; C <= 256) = y + table[row % P]
 int launch_add_vec_table(odise_hip_ctx* ctx, const f16* x, const float* vec, const float* table, f16* y, int64_t N, int P, int C);
 bool msda_fused_ok(int M, int D, int L, int P);
 int launch_msda_fused(odise_hip_ctx* ctx, const f16* value, const float* off, const float* aw, f16* out, const int* Hs, const int* Ws, const int* starts, int B,
-                      int S, int M, int Lq);   // msda.hip: softmax + sampling locations + gather in one kernel (L = 3, P = 4, D = 32)
+                      int S, int M, int Lq, int ld_off = 0, int ld_aw = 0);   // msda.hip: softmax + sampling locations + gather in one kernel (L = 3, P = 4, D = 32)
 int launch_msda_prepare(odise_hip_ctx* ctx, const float* off, const float* aw, float* loc, float* w, int B, int Lq, int M, int L, int P,
                         const int* Hs, const int* Ws, const int* starts);
 int launch_bilinear_add(odise_hip_ctx* ctx, const f16* a, const f16* b, f16* y, int N, int H, int W, int OH, int OW, int C);

@@ -24,6 +24,7 @@ struct BottleneckW {
 };
 struct MsdaLayerW {
     LinW off, aw, value, out, lin1, lin2;
+    LinW offaw;   // sampling_offsets | attention_weights stacked: both read the same query, one GEMM writes [rows, 2 MLP + MLP] (ms_deform_attn.py:98-107)
     NormW norm1, norm2;
 };
 struct MhaW {
@@ -216,6 +217,20 @@ static int build_head_weights(odise_hip_ctx* ctx, ModelStore* ms, HeadW* g, std:
         ODISE_TRY(pk.linear(k + ".linear1", L.lin1));
         ODISE_TRY(pk.linear(k + ".linear2", L.lin2));
         ODISE_TRY(pk.norm(k + ".norm2", L.norm2));
+        if (L.off.in == L.aw.in && L.off.b && L.aw.b) {
+            const size_t wo = (size_t)L.off.out * L.off.in * sizeof(f16), wa = (size_t)L.aw.out * L.aw.in * sizeof(f16);
+            char* w = nullptr;
+            char* bb = nullptr;
+            ODISE_CHECK_HIP(hipMalloc((void**)&w, wo + wa));
+            ms->track(w);
+            ODISE_CHECK_HIP(hipMalloc((void**)&bb, (size_t)(L.off.out + L.aw.out) * sizeof(float)));
+            ms->track(bb);
+            ODISE_CHECK_HIP(hipMemcpy(w, L.off.w, wo, hipMemcpyDeviceToDevice));
+            ODISE_CHECK_HIP(hipMemcpy(w + wo, L.aw.w, wa, hipMemcpyDeviceToDevice));
+            ODISE_CHECK_HIP(hipMemcpy(bb, L.off.b, (size_t)L.off.out * sizeof(float), hipMemcpyDeviceToDevice));
+            ODISE_CHECK_HIP(hipMemcpy(bb + (size_t)L.off.out * sizeof(float), L.aw.b, (size_t)L.aw.out * sizeof(float), hipMemcpyDeviceToDevice));
+            L.offaw.w = (f16*)w; L.offaw.b = (float*)bb; L.offaw.in = L.off.in; L.offaw.out = L.off.out + L.aw.out;
+        }
         g->enc_layers.push_back(L);
     }
     if (g->enc_layers.empty()) {
@@ -572,7 +587,70 @@ struct PixDec {
     Act mf;           // mask_features, pixel-major [B, HW4, C]  (W operand of the mask-logit GEMM)
     f16* mfT = nullptr;  // mask_features, channel-major [B, C, HW4] (W operand of the pooling GEMM)
     int h4 = 0, w4 = 0;
+    // what the masked decoder reads of the encoder output alone (decoder_memory_projections): K and V^T of every layer's cross-attention
+    static constexpr int kMaxDecLayers = 16;
+    f16* kproj[kMaxDecLayers] = {};
+    f16* vtproj[kMaxDecLayers] = {};
+    bool kv_done = false, kv_on_lane2 = false;
 };
+
+static int ensure_pe_tables(odise_hip_ctx* ctx, ModelStore* ms, MaskGenModel* g, const int hs[3], const int ws[3]);
+
+// The cross-attention keys and values of ALL decoder layers (odise.py:676-690: src + level_embed, pos; mask2former_transformer_decoder.py:95-118)
+// depend on the encoder output only: 2 x layers GEMMs that sat inside the layers' dependent chains (20-52 us of each) run here, once - on the
+// second lane beside the FPN half of the pixel decoder when the caller says so (side = true; the predictor waits for ev_join before its first
+// attention).
+static int decoder_memory_projections(odise_hip_ctx* ctx, MaskGenModel* g, PixDec& pd, bool side) {
+    ModelStore* ms = store_of(ctx);
+    Exec ex{ctx, ms};
+    const int C = g->C, B = pd.ms_feat[0].n, nl = (int)g->dec_layers.size();
+    ODISE_REQUIRE(nl <= PixDec::kMaxDecLayers, "masked decoder: %d layers", nl);
+    int hs[3], ws[3];
+    for (int l = 0; l < 3; ++l) { hs[l] = pd.ms_feat[l].h; ws[l] = pd.ms_feat[l].w; }
+    ODISE_TRY(ensure_pe_tables(ctx, ms, g, hs, ws));
+    f16* valin[3]; f16* keyin[3];
+    for (int l = 0; l < 3; ++l) {
+        const int64_t P = (int64_t)hs[l] * ws[l];
+        valin[l] = (f16*)ex.alloc_bytes((size_t)B * P * C * 2);
+        keyin[l] = (f16*)ex.alloc_bytes((size_t)B * P * C * 2);
+        if (!valin[l] || !keyin[l]) return ODISE_ERR_NOMEM;
+    }
+    for (int i = 0; i < nl; ++i) {
+        const int l = i % 3;
+        const int64_t P = (int64_t)hs[l] * ws[l];
+        pd.kproj[i] = (f16*)ex.alloc_bytes((size_t)B * P * C * 2);
+        pd.vtproj[i] = (f16*)ex.alloc_bytes((size_t)B * C * round_up(P, 8) * 2);
+        if (!pd.kproj[i] || !pd.vtproj[i]) return ODISE_ERR_NOMEM;
+    }
+    auto run = [&]() -> int {
+        for (int l = 0; l < 3; ++l) {
+            const int64_t P = (int64_t)hs[l] * ws[l];
+            ODISE_TRY(launch_add_vec_table(ctx, pd.ms_feat[l].p, g->dec_level_embed + (size_t)l * C, nullptr, valin[l], B, (int)P, C));
+            ODISE_TRY(launch_add_vec_table(ctx, valin[l], nullptr, g->pe[l], keyin[l], B, (int)P, C));
+        }
+        for (int i = 0; i < nl; ++i) {
+            const DecLayerW& L = g->dec_layers[i];
+            const int l = i % 3;
+            const int64_t P = (int64_t)hs[l] * ws[l];
+            ODISE_TRY(ex.linear(keyin[l], B * P, L.cross.k, pd.kproj[i]));
+            ODISE_TRY(gemm_vt(ex, L.cross.v, L.cross.v_bias, valin[l], B, P, round_up(P, 8), pd.vtproj[i]));
+        }
+        return ODISE_OK;
+    };
+    const bool lane2 = side && ctx->lanes == 2 && ctx->stream2 && ctx->ev_fork && ctx->ev_join;
+    if (lane2) {
+        ODISE_CHECK_HIP(hipEventRecord(ctx->ev_fork, ctx->stream));
+        Lane2 lane(ctx, ms);
+        ODISE_CHECK_HIP(hipStreamWaitEvent(ctx->stream, ctx->ev_fork, 0));
+        ODISE_TRY(run());
+        ODISE_CHECK_HIP(hipEventRecord(ctx->ev_join, ctx->stream));
+    } else {
+        ODISE_TRY(run());
+    }
+    pd.kv_done = true;
+    pd.kv_on_lane2 = lane2;
+    return ODISE_OK;
+}
 
 // sine positional tables of the three transformer levels (shared by the pixel decoder's encoder and the predictor)
 static int ensure_pe_tables(odise_hip_ctx* ctx, ModelStore* ms, MaskGenModel* g, const int hs[3], const int ws[3]) {
@@ -626,7 +704,7 @@ static int ensure_pe_tables(odise_hip_ctx* ctx, ModelStore* ms, MaskGenModel* g,
 static int g_msda_unfused = 0;   // tools hook (odise_hip_msda_unfused): 1 = prepare kernel + the native-op kernel, for bit-compare and A/B runs
 
 // MSDeformAttnPixelDecoder.forward_features (msdeformattn.py:314-358)
-static int pixel_decoder_forward(odise_hip_ctx* ctx, const Act feats[4], PixDec& pd) {
+static int pixel_decoder_forward(odise_hip_ctx* ctx, const Act feats[4], PixDec& pd, bool decoder_follows = false) {
     ModelStore* ms = store_of(ctx);
     MaskGenModel* g = ms->maskgen;
     Exec ex{ctx, ms};
@@ -644,8 +722,9 @@ static int pixel_decoder_forward(odise_hip_ctx* ctx, const Act feats[4], PixDec&
     f16* samp = (f16*)ex.alloc_bytes((size_t)MT * C * 2);
     f16* hid = (f16*)ex.alloc_bytes((size_t)MT * g->enc_layers[0].lin1.out * 2);
     const int M8 = g->enc_heads, LP = 3 * g->enc_points;
-    float* off = (float*)ex.alloc_bytes((size_t)MT * M8 * LP * 2 * 4);
-    float* aw = (float*)ex.alloc_bytes((size_t)MT * M8 * LP * 4);
+    float* offaw = (float*)ex.alloc_bytes((size_t)MT * M8 * LP * 3 * 4);   // [MT, 2 MLP | MLP] of the stacked projection; the separate forms use its two parts
+    float* off = offaw;
+    float* aw = offaw ? offaw + (size_t)MT * M8 * LP * 2 : nullptr;
     float* loc = (float*)ex.alloc_bytes((size_t)MT * M8 * LP * 2 * 4);
     float* wts = (float*)ex.alloc_bytes((size_t)MT * M8 * LP * 4);
     if (!src || !qin || !x1 || !val || !samp || !hid || !off || !aw || !loc || !wts) return ODISE_ERR_NOMEM;
@@ -661,23 +740,34 @@ static int pixel_decoder_forward(odise_hip_ctx* ctx, const Act feats[4], PixDec&
     }
     int64_t ss[6], ls[3];
     for (int l = 0; l < 3; ++l) { ss[2 * l] = hs[l]; ss[2 * l + 1] = ws[l]; ls[l] = starts[l]; }
-    for (const MsdaLayerW& L : g->enc_layers) {
-        ODISE_TRY(launch_add_vec_table(ctx, src, nullptr, g->enc_pos_all, qin, B, Lq, C));       // query = src + pos
+    // query = src + pos (msdeformattn.py:108-110): for the first layer a pass of its own, afterwards the second output of the LayerNorm that
+    // writes src (the same bits); sampling_offsets | attention_weights of a layer are ONE GEMM over that query
+    ODISE_TRY(launch_add_vec_table(ctx, src, nullptr, g->enc_pos_all, qin, B, Lq, C));
+    const bool fused_msda = msda_fused_ok(M8, C / M8, 3, g->enc_points) && !g_msda_unfused;
+    for (size_t li = 0; li < g->enc_layers.size(); ++li) {
+        const MsdaLayerW& L = g->enc_layers[li];
+        const bool last = li + 1 == g->enc_layers.size();
         ODISE_TRY(ex.linear(src, MT, L.value, val));
-        ODISE_TRY(gemm_f32out(ex, qin, MT, L.off, off));
-        ODISE_TRY(gemm_f32out(ex, qin, MT, L.aw, aw));
-        if (msda_fused_ok(M8, C / M8, 3, g->enc_points) && !g_msda_unfused) {
-            ODISE_TRY(launch_msda_fused(ctx, val, off, aw, samp, hs, ws, starts, B, Lq, M8, Lq));
+        if (fused_msda && L.offaw.w) {
+            const int nof = L.off.out, ld = L.offaw.out;
+            ODISE_TRY(gemm_f32out(ex, qin, MT, L.offaw, offaw));
+            ODISE_TRY(launch_msda_fused(ctx, val, offaw, offaw + nof, samp, hs, ws, starts, B, Lq, M8, Lq, ld, ld));
         } else {
-            ODISE_TRY(launch_msda_prepare(ctx, off, aw, loc, wts, B, Lq, M8, 3, g->enc_points, hs, ws, starts));
-            ODISE_TRY(odise_hip_ms_deform_attn_forward(ctx, val, ss, ls, loc, wts, B, Lq, M8, C / M8, Lq, 3, g->enc_points, 128, ODISE_F16, samp));
+            ODISE_TRY(gemm_f32out(ex, qin, MT, L.off, off));
+            ODISE_TRY(gemm_f32out(ex, qin, MT, L.aw, aw));
+            if (fused_msda) {
+                ODISE_TRY(launch_msda_fused(ctx, val, off, aw, samp, hs, ws, starts, B, Lq, M8, Lq));
+            } else {
+                ODISE_TRY(launch_msda_prepare(ctx, off, aw, loc, wts, B, Lq, M8, 3, g->enc_points, hs, ws, starts));
+                ODISE_TRY(odise_hip_ms_deform_attn_forward(ctx, val, ss, ls, loc, wts, B, Lq, M8, C / M8, Lq, 3, g->enc_points, 128, ODISE_F16, samp));
+            }
         }
         ms->macs += (double)MT * M8 * LP * 4 * (C / M8);                                           // bilinear taps
         ODISE_TRY(ex.linear(samp, MT, L.out, x1, ODISE_ACT_NONE, src));
         ODISE_TRY(ex.layer_norm(x1, src, MT, L.norm1, 1e-5f));
         ODISE_TRY(ex.linear(src, MT, L.lin1, hid, ODISE_ACT_RELU));
         ODISE_TRY(ex.linear(hid, MT, L.lin2, x1, ODISE_ACT_NONE, src));
-        ODISE_TRY(ex.layer_norm(x1, src, MT, L.norm2, 1e-5f));
+        ODISE_TRY(layer_norm_add_table(ctx, x1, src, L.norm2.g, L.norm2.b, (int)MT, L.norm2.c, 1e-5f, last ? nullptr : qin, g->enc_pos_all, Lq));
     }
     // multi-scale features (contiguous per level) = split of the encoder output
     Act (&ms_feat)[3] = pd.ms_feat;
@@ -686,6 +776,7 @@ static int pixel_decoder_forward(odise_hip_ctx* ctx, const Act feats[4], PixDec&
         const size_t rowb = (size_t)hs[l] * ws[l] * C * 2;
         ODISE_TRY(copy_rows_2d(ctx, ms_feat[l].p, rowb, src + (size_t)starts[l] * C, (size_t)Lq * C * 2, rowb, B));
     }
+    if (decoder_follows) ODISE_TRY(decoder_memory_projections(ctx, g, pd, true));   // beside the FPN half below
     // FPN level on s2 + mask features (both layouts)
     const Act& s2 = feats[0];
     const int64_t HW4 = (int64_t)s2.h * s2.w;
@@ -710,7 +801,7 @@ static int pixel_decoder_forward(odise_hip_ctx* ctx, const Act feats[4], PixDec&
 }
 
 // ODISEMultiScaleMaskedTransformerDecoder.forward (odise.py:642-727) + PooledMaskEmbed of the final prediction (odise.py:984-1015)
-static int predictor_forward(odise_hip_ctx* ctx, const PixDec& pd) {
+static int predictor_forward(odise_hip_ctx* ctx, PixDec& pd) {
     ModelStore* ms = store_of(ctx);
     MaskGenModel* g = ms->maskgen;
     Exec ex{ctx, ms};
@@ -724,27 +815,31 @@ static int predictor_forward(odise_hip_ctx* ctx, const PixDec& pd) {
     const int64_t HW4 = (int64_t)s2.h * s2.w;
     // ---- masked transformer decoder ----------------------------------------------------------------------------------------
     const int64_t MQ = (int64_t)B * Q;
-    f16* valin[3]; f16* keyin[3];
+    if (!pd.kv_done) ODISE_TRY(decoder_memory_projections(ctx, g, pd, false));   // (the stand-alone predictor: nothing ran ahead)
+    // The attention mask of layer i+1 is the prediction resized to that layer's level and thresholded (odise.py:756-765: F.interpolate(...,
+    // mode="bilinear") of the [Q, H/4, W/4] logits, then sigmoid < 0.5).  A mask logit is linear in the mask features, and bilinear resizing is
+    // linear too: resize(me . mf) = me . resize(mf).  The three resized copies of mask_features are made once (mfl), and the NINE intermediate
+    // predictions are Q x P_l products (P_l = 1/4 .. 1/64 of the pixels) instead of the full Q x HW4 mask tensor each (50 us + the resize
+    // kernel per layer on the serial tail); only the final prediction is computed at H/4 x W/4.
+    f16* mfl[3];
     for (int l = 0; l < 3; ++l) {
-        const int64_t P = (int64_t)hs[l] * ws[l];
-        valin[l] = (f16*)ex.alloc_bytes((size_t)B * P * C * 2);
-        keyin[l] = (f16*)ex.alloc_bytes((size_t)B * P * C * 2);
-        if (!valin[l] || !keyin[l]) return ODISE_ERR_NOMEM;
-        ODISE_TRY(launch_add_vec_table(ctx, ms_feat[l].p, g->dec_level_embed + (size_t)l * C, nullptr, valin[l], B, (int)P, C));
-        ODISE_TRY(launch_add_vec_table(ctx, valin[l], nullptr, g->pe[l], keyin[l], B, (int)P, C));
+        mfl[l] = (f16*)ex.alloc_bytes((size_t)B * hs[l] * ws[l] * C * 2);
+        if (!mfl[l]) return ODISE_ERR_NOMEM;
+        ODISE_TRY(launch_bilinear_add(ctx, nullptr, mf.p, mfl[l], B, s2.h, s2.w, hs[l], ws[l], C));
     }
     const int64_t maxP = (int64_t)hs[2] * ws[2];
     const int64_t ldm = round_up(maxP, 8);
     f16* out = (f16*)ex.alloc_bytes((size_t)MQ * C * 2);
     f16* tq = (f16*)ex.alloc_bytes((size_t)MQ * C * 2);
+    f16* tqe = (f16*)ex.alloc_bytes((size_t)MQ * C * 2);
     f16* t1 = (f16*)ex.alloc_bytes((size_t)MQ * 2048 * 2);
     f16* t2 = (f16*)ex.alloc_bytes((size_t)MQ * 2 * C * 2);
     f16* dn = (f16*)ex.alloc_bytes((size_t)MQ * C * 2);
     f16* me = (f16*)ex.alloc_bytes((size_t)MQ * C * 2);
     f16* att = (f16*)ex.alloc_bytes((size_t)MQ * C * 2);
     f16* qb = (f16*)ex.alloc_bytes((size_t)MQ * 2 * C * 2);
-    f16* kbuf = (f16*)ex.alloc_bytes((size_t)B * maxP * C * 2);
-    f16* vtb = (f16*)ex.alloc_bytes((size_t)B * C * ldm * 2);
+    f16* vtb = (f16*)ex.alloc_bytes((size_t)B * C * round_up(Q, 8) * 2);   // V^T of the queries' self-attention
+    f16* lgl = (f16*)ex.alloc_bytes((size_t)MQ * maxP * 2);                  // prediction at the next layer's level
     f16* masks = (f16*)ex.alloc_bytes((size_t)MQ * HW4 * 2);
     uint8_t* amask = (uint8_t*)ex.alloc_bytes((size_t)MQ * ldm);
     f16* m01 = (f16*)ex.alloc_bytes((size_t)MQ * HW4 * 2);
@@ -752,7 +847,7 @@ static int predictor_forward(odise_hip_ctx* ctx, const PixDec& pd) {
     f16* pooled = (f16*)ex.alloc_bytes((size_t)MQ * C * 2);
     f16* pooled_x = (f16*)ex.alloc_bytes((size_t)MQ * C * 2);
     f16* mask_embed = (f16*)ex.alloc_bytes((size_t)MQ * C * 2);
-    if (!out || !tq || !t1 || !t2 || !dn || !me || !att || !qb || !kbuf || !vtb || !masks || !amask || !m01 || !inv || !pooled || !pooled_x ||
+    if (!out || !tq || !tqe || !t1 || !t2 || !dn || !me || !att || !qb || !lgl || !vtb || !masks || !amask || !m01 || !inv || !pooled || !pooled_x ||
         !mask_embed)
         return ODISE_ERR_NOMEM;
     // output = query_feat broadcast over the batch
@@ -763,13 +858,20 @@ static int predictor_forward(odise_hip_ctx* ctx, const PixDec& pd) {
         ODISE_TRY(mlp3(ex, g->mask_mlp, dn, MQ, t1, t2, me));
         odise_gemm_desc d;
         memset(&d, 0, sizeof(d));  // outputs_mask[b] = mask_embed[b] (Q x C) . mask_features[b]^T (HW4 x C)
-        d.M = Q; d.N = (int)HW4; d.K = C;
+        d.M = Q; d.K = C;
         d.A = me; d.lda = C; d.strideA = (int64_t)Q * C;
-        d.W = mf.p; d.ldw = C; d.strideW = HW4 * C;
-        d.C = masks; d.ldc = HW4; d.strideC = (int64_t)Q * HW4; d.c_dtype = ODISE_F16; d.alpha = 1.f; d.batch = B;
-        ODISE_TRY(ex.gemm(d));
-        if (target_level >= 0)
-            ODISE_TRY(launch_attn_mask(ctx, masks, amask, MQ, s2.h, s2.w, hs[target_level], ws[target_level], ldm));
+        d.ldw = C; d.c_dtype = ODISE_F16; d.alpha = 1.f; d.batch = B;
+        if (target_level >= 0) {   // ... at the level the next layer attends to
+            const int64_t P = (int64_t)hs[target_level] * ws[target_level];
+            d.N = (int)P; d.W = mfl[target_level]; d.strideW = P * C;
+            d.C = lgl; d.ldc = P; d.strideC = (int64_t)Q * P;
+            ODISE_TRY(ex.gemm(d));
+            ODISE_TRY(launch_attn_mask(ctx, lgl, amask, MQ, hs[target_level], ws[target_level], hs[target_level], ws[target_level], ldm));
+        } else {                   // the final prediction
+            d.N = (int)HW4; d.W = mf.p; d.strideW = HW4 * C;
+            d.C = masks; d.ldc = HW4; d.strideC = (int64_t)Q * HW4;
+            ODISE_TRY(ex.gemm(d));
+        }
         return ODISE_OK;
     };
     ODISE_TRY(prediction_heads(0));
@@ -780,26 +882,24 @@ static int predictor_forward(odise_hip_ctx* ctx, const PixDec& pd) {
         const int l = i % 3;
         const int64_t P = (int64_t)hs[l] * ws[l];
         const int64_t ldv = round_up(P, 8);
-        // masked cross-attention (keys = level l)
-        ODISE_TRY(launch_add_vec_table(ctx, out, nullptr, g->query_embed, tq, B, Q, C));
-        ODISE_TRY(ex.linear(tq, MQ, L.cross.q, qb));
-        ODISE_TRY(ex.linear(keyin[l], B * P, L.cross.k, kbuf));
-        ODISE_TRY(gemm_vt(ex, L.cross.v, L.cross.v_bias, valin[l], B, P, ldv, vtb));
+        // masked cross-attention (keys = level l); query + query_embed left the LayerNorm that wrote `out` as its second output (tqe)
+        if (i == 0) ODISE_TRY(launch_add_vec_table(ctx, out, nullptr, g->query_embed, tqe, B, Q, C));
+        ODISE_TRY(ex.linear(tqe, MQ, L.cross.q, qb));
+        if (i == 0 && pd.kv_on_lane2) ODISE_CHECK_HIP(hipStreamWaitEvent(ctx->stream, ctx->ev_join, 0));   // the keys / values of every layer (decoder_memory_projections)
         odise_attn_desc a;
         memset(&a, 0, sizeof(a));
         a.B = B; a.H = heads; a.Lq = Q; a.Lk = (int)P; a.D = D;
         a.Q = qb; a.ldq = C; a.strideQ = (int64_t)Q * C;
-        a.K = kbuf; a.ldk = C; a.strideK = P * C;
-        a.Vt = vtb; a.ldvt = ldv; a.strideVt = (int64_t)C * ldv;
+        a.K = pd.kproj[i]; a.ldk = C; a.strideK = P * C;
+        a.Vt = pd.vtproj[i]; a.ldvt = ldv; a.strideVt = (int64_t)C * ldv;
         a.O = att; a.ldo = C; a.strideO = (int64_t)Q * C;
         a.mask = amask; a.ldmask = ldm; a.strideMask = (int64_t)Q * ldm;
         a.scale = 1.0f / sqrtf((float)D);
         ODISE_TRY(ex.attention(a));
         ODISE_TRY(ex.linear(att, MQ, L.cross.out, tq, ODISE_ACT_NONE, out));
-        ODISE_TRY(ex.layer_norm(tq, out, MQ, L.cross.norm, 1e-5f));
+        ODISE_TRY(layer_norm_add_table(ctx, tq, out, L.cross.norm.g, L.cross.norm.b, (int)MQ, C, 1e-5f, tqe, g->query_embed, Q));
         // self-attention over the queries
-        ODISE_TRY(launch_add_vec_table(ctx, out, nullptr, g->query_embed, tq, B, Q, C));
-        ODISE_TRY(ex.linear(tq, MQ, L.self.qk, qb));
+        ODISE_TRY(ex.linear(tqe, MQ, L.self.qk, qb));
         const int64_t ldq = round_up(Q, 8);
         ODISE_TRY(gemm_vt(ex, L.self.v, L.self.v_bias, out, B, Q, ldq, vtb));
         memset(&a, 0, sizeof(a));
@@ -815,7 +915,7 @@ static int predictor_forward(odise_hip_ctx* ctx, const PixDec& pd) {
         // FFN
         ODISE_TRY(ex.linear(out, MQ, L.lin1, t1, ODISE_ACT_RELU));
         ODISE_TRY(ex.linear(t1, MQ, L.lin2, tq, ODISE_ACT_NONE, out));
-        ODISE_TRY(ex.layer_norm(tq, out, MQ, L.ffn_norm, 1e-5f));
+        ODISE_TRY(layer_norm_add_table(ctx, tq, out, L.ffn_norm.g, L.ffn_norm.b, (int)MQ, C, 1e-5f, i + 1 < nl ? tqe : nullptr, g->query_embed, Q));
         ODISE_TRY(prediction_heads(i + 1 < nl ? (i + 1) % 3 : -1));
     }
     // ---- learned (object, no-object) logits of the final prediction head: outputs_class = class_embed(decoder_output), odise.py:734
@@ -855,7 +955,7 @@ static int predictor_forward(odise_hip_ctx* ctx, const PixDec& pd) {
 
 static int head_forward(odise_hip_ctx* ctx, const Act feats[4]) {
     PixDec pd;
-    ODISE_TRY(pixel_decoder_forward(ctx, feats, pd));
+    ODISE_TRY(pixel_decoder_forward(ctx, feats, pd, true));
     stage_mark(ctx, "head: pixel decoder done");
     const int rc = predictor_forward(ctx, pd);
     stage_mark(ctx, "head: masked decoder done");

@@ -126,7 +126,7 @@ __global__ void __launch_bounds__(256) msda_forward_kernel(const T* __restrict__
 // every XCD's L2 pulled all of it, because neighbouring queries (which sample neighbouring pixels) sat on eight different L2s.
 template <int L, int P, int VEC>
 __global__ void __launch_bounds__(256) msda_fused_kernel(const f16* __restrict__ value, const float* __restrict__ off, const float* __restrict__ aw,
-                                                        f16* __restrict__ out, MsdaLevels lv, int64_t total, int S, int M, int Lq) {
+                                                        f16* __restrict__ out, MsdaLevels lv, int64_t total, int S, int M, int Lq, int ld_off, int ld_aw) {
     constexpr int D = 32, dchunks = D / VEC, LP = L * P;
     typedef _Float16 fvec __attribute__((ext_vector_type(VEC)));
     // XCD-aware block order (bijective for any grid size, as in gemm.hip)
@@ -150,8 +150,8 @@ __global__ void __launch_bounds__(256) msda_fused_kernel(const f16* __restrict__
     const float ref_x = ((float)(local % lv.W[lvl]) + 0.5f) / (float)lv.W[lvl];
     float e[LP], ov[2 * LP];
     {
-        const float* a = aw + qm * LP;
-        const float* o = off + qm * LP * 2;
+        const float* a = aw + bq * ld_aw + m * LP;          // (ld: floats per query row - the two projections may be column blocks of one GEMM's output)
+        const float* o = off + bq * ld_off + m * LP * 2;
 #pragma unroll
         for (int i = 0; i < LP; i += 4) {
             const float4 t = *reinterpret_cast<const float4*>(a + i);
@@ -231,14 +231,17 @@ bool msda_fused_ok(int M, int D, int L, int P) { return D == 32 && L == 3 && P =
 // occupancy (178 VGPRs: two waves per SIMD; forcing three by a launch bound changed nothing).
 static int g_msda_vec = 8;   // tools: odise_hip_msda_fused_forward fused = 1 measures the 8-lane form
 int launch_msda_fused(odise_hip_ctx* ctx, const f16* value, const float* off, const float* aw, f16* out, const int* Hs, const int* Ws, const int* starts, int B,
-                      int S, int M, int Lq) {
+                      int S, int M, int Lq, int ld_off, int ld_aw) {
+    if (ld_off <= 0) ld_off = M * 3 * 4 * 2;
+    if (ld_aw <= 0) ld_aw = M * 3 * 4;
+    ODISE_REQUIRE(ld_off % 4 == 0 && ld_aw % 4 == 0 && ((uintptr_t)off & 15) == 0 && ((uintptr_t)aw & 15) == 0, "msda: offsets / logits must keep 16-byte rows");
     MsdaLevels lv;
     for (int l = 0; l < 3; ++l) { lv.H[l] = Hs[l]; lv.W[l] = Ws[l]; lv.start[l] = starts[l]; }
     const int64_t total = (int64_t)B * Lq * M * (32 / g_msda_vec);
     if (total == 0) return ODISE_OK;
     ODISE_REQUIRE(ceil_div(total, 256) < (1ll << 31), "msda: too many queries for one launch");
-    if (g_msda_vec == 8) hipLaunchKernelGGL((msda_fused_kernel<3, 4, 8>), dim3((unsigned)ceil_div(total, 256)), dim3(256), 0, ctx->stream, value, off, aw, out, lv, total, S, M, Lq);
-    else hipLaunchKernelGGL((msda_fused_kernel<3, 4, 4>), dim3((unsigned)ceil_div(total, 256)), dim3(256), 0, ctx->stream, value, off, aw, out, lv, total, S, M, Lq);
+    if (g_msda_vec == 8) hipLaunchKernelGGL((msda_fused_kernel<3, 4, 8>), dim3((unsigned)ceil_div(total, 256)), dim3(256), 0, ctx->stream, value, off, aw, out, lv, total, S, M, Lq, ld_off, ld_aw);
+    else hipLaunchKernelGGL((msda_fused_kernel<3, 4, 4>), dim3((unsigned)ceil_div(total, 256)), dim3(256), 0, ctx->stream, value, off, aw, out, lv, total, S, M, Lq, ld_off, ld_aw);
     ODISE_CHECK_HIP(hipGetLastError());
     return ODISE_OK;
 }

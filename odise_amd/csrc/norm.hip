@@ -352,9 +352,12 @@ __global__ void __launch_bounds__(256) layer_norm_kernel(const f16* __restrict__
 // leaves half of every wavefront idle (2.2 TB/s measured).  Here each HALF-wave owns R rows: twice the rows and bytes in flight per wave.  The
 // reductions are the same butterflies over 32 lanes in the same order (the full-wave form adds the idle half's zeros first): results are
 // bit-identical.
+// y2 (optional) = y + table[row % P] from the ROUNDED y: the next layer's query = LayerNorm output + positional table (msdeformattn.py:108-110,
+// odise.py:700-716) leaves with it instead of re-reading it in a kernel of its own (the bits add_vec_table_kernel would write).
 template <int R>
 __global__ void __launch_bounds__(256) layer_norm_half_kernel(const f16* __restrict__ x, f16* __restrict__ y, const float* __restrict__ gamma,
-                                                             const float* __restrict__ beta, int rows, int C, float eps) {
+                                                             const float* __restrict__ beta, int rows, int C, float eps, f16* __restrict__ y2,
+                                                             const float* __restrict__ table, int P) {
     const int lane = threadIdx.x & 63, l31 = lane & 31, half = lane >> 5;
     const int row0 = ((blockIdx.x * 4 + (threadIdx.x >> 6)) * 2 + half) * R;
     const int c = l31 * 8;
@@ -412,6 +415,13 @@ __global__ void __launch_bounds__(256) layer_norm_half_kernel(const f16* __restr
 #pragma unroll
             for (int i = 0; i < 8; ++i) o[i] = (f16)(((float)v[r][i] - mu[r]) * rs * gm[i] + bt[i]);
             *reinterpret_cast<f16x8*>(y + (int64_t)(row0 + r) * C + c) = o;
+            if (y2) {
+                const float* tr = table + (int64_t)((row0 + r) % P) * C + c;
+                f16x8 o2;
+#pragma unroll
+                for (int i = 0; i < 8; ++i) o2[i] = (f16)((float)o[i] + tr[i]);
+                *reinterpret_cast<f16x8*>(y2 + (int64_t)(row0 + r) * C + c) = o2;
+            }
         }
     }
 }
@@ -486,10 +496,12 @@ int group_norm_from_colpart(odise_hip_ctx* ctx, const void* x, void* y, const fl
 }
 }  // namespace odise
 
-extern "C" int odise_hip_layer_norm(odise_hip_ctx* ctx, const void* x, void* y, const float* gamma, const float* beta,
-                                    int rows, int C, float eps) {
-    using namespace odise;
+namespace odise {
+// y = LayerNorm(x); y2 (optional, C <= 256 only) = y + table[row % P]
+int layer_norm_add_table(odise_hip_ctx* ctx, const void* x, void* y, const float* gamma, const float* beta, int rows, int C, float eps, f16* y2,
+                         const float* table, int P) {
     ODISE_REQUIRE(ctx && x && y, "layer_norm: null argument");
+    ODISE_REQUIRE(!y2 || (C <= 256 && table && P >= 1), "layer_norm: the second output needs C <= 256 and a table");
     ODISE_REQUIRE(rows >= 0 && C > 0 && C % 8 == 0 && C <= 4096, "layer_norm: C=%d must be a positive multiple of 8, <= 4096", C);
     if (rows == 0) return ODISE_OK;
     auto launch = [&](auto kern, int R) {
@@ -502,14 +514,20 @@ extern "C" int odise_hip_layer_norm(odise_hip_ctx* ctx, const void* x, void* y, 
 #endif
     const bool many = rows >= many_rows;
     if (C <= 256) {   // a row fits half a wavefront: two rows per wave pass (layer_norm_half_kernel)
-        if (many) hipLaunchKernelGGL(layer_norm_half_kernel<4>, dim3((unsigned)ceil_div(rows, 4 * 2 * 4)), dim3(256), 0, ctx->stream, (const f16*)x, (f16*)y, gamma, beta, rows, C, eps);
-        else hipLaunchKernelGGL(layer_norm_half_kernel<1>, dim3((unsigned)ceil_div(rows, 4 * 2)), dim3(256), 0, ctx->stream, (const f16*)x, (f16*)y, gamma, beta, rows, C, eps);
+        if (many) hipLaunchKernelGGL(layer_norm_half_kernel<4>, dim3((unsigned)ceil_div(rows, 4 * 2 * 4)), dim3(256), 0, ctx->stream, (const f16*)x, (f16*)y, gamma, beta, rows, C, eps, y2, table, P);
+        else hipLaunchKernelGGL(layer_norm_half_kernel<1>, dim3((unsigned)ceil_div(rows, 4 * 2)), dim3(256), 0, ctx->stream, (const f16*)x, (f16*)y, gamma, beta, rows, C, eps, y2, table, P);
     } else if (C <= 512) { if (rows >= g_ln_rows8) launch(layer_norm_kernel<1, 8>, 8); else if (many) launch(layer_norm_kernel<1, 4>, 4); else launch(layer_norm_kernel<1, 1>, 1); }
     else if (C <= 1024) { if (many) launch(layer_norm_kernel<2, 4>, 4); else launch(layer_norm_kernel<2, 1>, 1); }
     else if (C <= 2048) { if (many) launch(layer_norm_kernel<4, 2>, 2); else launch(layer_norm_kernel<4, 1>, 1); }
     else launch(layer_norm_kernel<8, 1>, 1);
     ODISE_CHECK_HIP(hipGetLastError());
     return ODISE_OK;
+}
+}  // namespace odise
+
+extern "C" int odise_hip_layer_norm(odise_hip_ctx* ctx, const void* x, void* y, const float* gamma, const float* beta,
+                                    int rows, int C, float eps) {
+    return odise::layer_norm_add_table(ctx, x, y, gamma, beta, rows, C, eps, nullptr, nullptr, 1);
 }
 
 // tools hook (include/odise_hip_tools.h): chunk density of the GroupNorm statistics pass and whether the apply kernel finishes the statistics itself

@@ -15,7 +15,8 @@ def main():
     rng = np.random.default_rng(0)
     for name, B, Lq, Lk, masked in (("crops' tower, 16 crops", 16, 577, 577, False), ("crops' tower, 32 crops", 32, 577, 577, False),
                                     ("crops' tower, 18 crops (2 x 1280^2)", 18, 577, 577, False), ("MaskCLIP, 4 pictures", 4, 677, 577, True),
-                                    ("MaskCLIP, 8 pictures", 8, 677, 577, True)):
+                                    ("MaskCLIP, 8 pictures", 8, 677, 577, True),
+                                    ("MaskCLIP mask tokens, 4 pictures", 4, 100, 577, True), ("MaskCLIP mask tokens, 8 pictures", 8, 100, 577, True)):
         H, D = 16, 64
         HD = H * D
         q = ctx.to_device(rng.standard_normal((B, Lq, HD), dtype=np.float32).astype(np.float16))
@@ -24,7 +25,10 @@ def main():
         m = None
         if masked:
             m8 = np.zeros((B, Lq, 580), np.uint8)
-            m8[:, 577:, :577] = rng.random((B, Lq - 577, 577)) < 0.7
+            if Lq > 577:
+                m8[:, 577:, :577] = rng.random((B, Lq - 577, 577)) < 0.7
+            else:
+                m8[:, :, 1:577] = rng.random((B, Lq, 576)) < 0.7
             m = ctx.to_device(m8)
         o = ctx.empty((B, Lq, HD), np.float16)
         flops = 4.0 * B * H * Lq * Lk * D
