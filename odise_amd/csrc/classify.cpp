@@ -380,7 +380,7 @@ extern "C" int odise_hip_postprocess_pixels(odise_hip_ctx* ctx, int b, const flo
         ODISE_TRY(ex.gemm(d));
     }
     if (inst_stats) {
-        float* partial = (float*)ex.alloc_bytes((size_t)512 * 2 * g.Qpad * 4);
+        unsigned int* partial = (unsigned int*)ex.alloc_bytes((size_t)512 * 2 * g.Qpad * 4);
         if (!partial) return ODISE_ERR_NOMEM;
         ODISE_TRY(launch_column_stats(ctx, S, partial, inst_stats, npix, g.Qpad));
     }
@@ -473,11 +473,19 @@ extern "C" int odise_hip_postprocess_batch(odise_hip_ctx* ctx, const odise_post_
     const size_t o_kscore = take((size_t)B * Q * 4), o_label = take((size_t)B * Q * 4), o_map = take((size_t)B * Q * 4);
     const size_t o_counts = take((size_t)B * 3 * Q * 4), o_stats = take((size_t)B * 2 * Qpad * 4), o_stuff = take((size_t)K * 4);
     const size_t o_thing = take((size_t)K), o_probs = take(want_inst ? (size_t)B * Q * K * 4 : 0), o_semT = take((size_t)B * K * Qpad * 2);
-    const size_t o_partial = take((size_t)512 * 2 * Qpad * 4);
+    int max_stat_blocks = 512;   // block partials of the instance statistics: column_stats_kernel's 512, or one per tile of the tiled pixel pass
+    for (int b = 0; b < B; ++b) {
+        PostGeom gb;
+        gb.h4 = ho.h4; gb.w4 = ho.w4; gb.ph = d->pad_h; gb.pw = d->pad_w; gb.ih = d->img_hw[2 * b]; gb.iw = d->img_hw[2 * b + 1];
+        gb.oh = d->out_hw ? d->out_hw[2 * b] : gb.ih; gb.ow = d->out_hw ? d->out_hw[2 * b + 1] : gb.iw;
+        gb.Q = Q; gb.Qpad = Qpad;
+        if (postprocess_pixels_tiled(gb)) max_stat_blocks = std::max(max_stat_blocks, postprocess_pixels_stat_blocks(gb));
+    }
+    const size_t partial_set = ((size_t)max_stat_blocks * 2 * Qpad * 4 + 255) & ~(size_t)255;
     // (S, ids) of up to kPostSets images in flight: the next image's pixel pass does not wait for the decision chain that still reads this one's
     const int nsets = std::min(B, (int)ClassifyModel::kPostSets);
     const size_t ids_set = ((size_t)max_pix * 4 + 255) & ~(size_t)255, S_set = ((size_t)max_pix * Qpad * 2 + 255) & ~(size_t)255;
-    const size_t o_ids = take(ids_set * nsets), o_S = take(S_set * nsets);
+    const size_t o_ids = take(ids_set * nsets), o_S = take(S_set * nsets), o_partial = take(partial_set * nsets);
     ODISE_TRY(scratch_reserve(ctx, &c->post_buf, &c->post_cap, off));
     char* base = (char*)c->post_buf;
     float* kscore = (float*)(base + o_kscore);
@@ -489,7 +497,6 @@ extern "C" int odise_hip_postprocess_batch(odise_hip_ctx* ctx, const odise_post_
     uint8_t* thing = (uint8_t*)(base + o_thing);
     float* probs = want_inst ? (float*)(base + o_probs) : nullptr;
     f16* semT = (f16*)(base + o_semT);
-    float* partial = (float*)(base + o_partial);
     if (d->isthing) ODISE_CHECK_HIP(hipMemcpyAsync(thing, d->isthing, (size_t)K, hipMemcpyHostToDevice, ctx->stream));
     ODISE_CHECK_HIP(hipMemsetAsync(counts, 0, (size_t)B * 3 * Q * 4, ctx->stream));
     // the panoptic records may be the source buffer of the previous batch's all-gather (still running on the exchange stream while the
@@ -532,18 +539,23 @@ extern "C" int odise_hip_postprocess_batch(odise_hip_ctx* ctx, const odise_post_
         // the semantic scores come out of the pixel pass itself where its tiled form applies (an exact 4x upsampling, <= 112 queries): no
         // pixel-major matrix S is written for them; S is still produced for the instance statistics, the fused arg-max and the GEMM fallback
         const bool fused_sem = sem && g_sem_tile < 0 && postprocess_pixels_fuses_semantic(g);
-        const bool need_S = (sem && !fused_sem) || amax || inst;
-        if (!need_S && !pan && !sem) continue;
+        // ... and the tiled form leaves the instance statistics as block partials, so the instance head alone does not need S either
+        const bool fused_stats = inst && g_sem_tile < 0 && postprocess_pixels_tiled(g);
+        const bool need_S = (sem && !fused_sem) || amax || (inst && !fused_stats);
+        if (!need_S && !pan && !sem && !inst) continue;
         const int set = n_img++ % nsets;
         int* ids = (int*)(base + o_ids + ids_set * set);
         f16* S = (f16*)(base + o_S + S_set * set);
+        unsigned int* partial = (unsigned int*)(base + o_partial + partial_set * set);
         if (set_busy[set]) ODISE_CHECK_HIP(hipStreamWaitEvent(ctx->stream, c->ev_set[set], 0));   // the chain of the image that used this set before
         set_busy[set] = false;
         if (fused_sem) ms->macs += (double)K * npix * Qpad;
         ODISE_TRY(launch_postprocess_pixels(ctx, logits, kscore + (size_t)b * Q, need_S ? S : nullptr, pan ? ids : nullptr, counts + (size_t)b * 3 * Q, g,
-                                            fused_sem ? semT + (size_t)b * K * Qpad : nullptr, fused_sem ? sem : nullptr, fused_sem ? K : 0));
+                                            fused_sem ? semT + (size_t)b * K * Qpad : nullptr, fused_sem ? sem : nullptr, fused_sem ? K : 0,
+                                            fused_stats ? partial : nullptr));
         auto decisions = [&]() -> int {
-            if (inst) ODISE_TRY(launch_column_stats(ctx, S, partial, stats + (size_t)b * 2 * Qpad, npix, Qpad));
+            if (inst && fused_stats) ODISE_TRY(launch_column_fold(ctx, partial, stats + (size_t)b * 2 * Qpad, postprocess_pixels_stat_blocks(g), Qpad));
+            else if (inst) ODISE_TRY(launch_column_stats(ctx, S, partial, stats + (size_t)b * 2 * Qpad, npix, Qpad));
             if (pan) {
                 ODISE_TRY(launch_panoptic_decide(ctx, counts + (size_t)b * 3 * Q, kscore + (size_t)b * Q, label + (size_t)b * Q, thing, map + (size_t)b * Q,
                                                  pan + npix, Q, K, d->overlap_threshold, ODISE_MAX_SEGMENTS, stuff));

@@ -354,6 +354,7 @@ __global__ void __launch_bounds__(256) postprocess_pixels_x4_kernel(const f16* _
 // puts the fp16 sigmoids into an LDS image of the tile's S rows; the tile is then written out as ONE contiguous 53 KB run of the matrix
 // (256 pixels x 208 bytes are adjacent in memory), 16 bytes per lane, whole 128-byte lines.  The panoptic arg-max is finished across the
 // four query slices through LDS (ties to the lowest query, like the sequential walk), the area counters as before.
+constexpr float kStatUnit = 2048.0f;  // instance statistics: fp16 values above 0.5 are whole multiples of 2^-11 (column_stats_kernel)
 constexpr int PT_PIX = 256;          // pixels of a tile
 constexpr int PT_CELLS = 64;         // cell columns of a tile (one per lane)
 // Round 6: the semantic head rides in the same kernel (`sem` != nullptr).  sem_seg[c, p] = sum_q P[q, c] sigmoid(mask)[q, p]
@@ -366,7 +367,7 @@ template <int KS>   // k-steps of 16 of the fused semantic product: Qpad <= 16 *
 __global__ void __launch_bounds__(256) postprocess_pixels_x4_tiled_kernel(const f16* __restrict__ logits, const float* __restrict__ kscore,
                                                                          f16* __restrict__ S, int* __restrict__ ids, int* __restrict__ counts,
                                                                          PostGeom g, int tiles_per_row, const f16* __restrict__ PT,
-                                                                         float* __restrict__ sem, int K) {
+                                                                         float* __restrict__ sem, int K, unsigned int* __restrict__ stats_partial) {
     extern __shared__ __attribute__((aligned(16))) char psm[];
     const int Q = g.Q, Qpad = g.Qpad;
     const int pitch = Qpad * 2 + 8;                      // bytes per pixel row of the LDS image: 8-byte aligned, rows 4 pixels apart fall 2-way on the banks
@@ -374,8 +375,9 @@ __global__ void __launch_bounds__(256) postprocess_pixels_x4_tiled_kernel(const 
     float* red_v = reinterpret_cast<float*>(psm + (size_t)PT_PIX * pitch);   // [4][PT_PIX] best score of each query slice
     int* red_q = reinterpret_cast<int*>(red_v + 4 * PT_PIX);                // [4][PT_PIX] its query | pos << 16, -1 = none
     int* hist = red_q + 4 * PT_PIX;                                         // [3][Q]
+    unsigned int* st = reinterpret_cast<unsigned int*>(hist + 3 * Q);       // [2][Qpad] instance statistics of the tile (stats_partial)
     const int tid = threadIdx.x, lane = tid & 63, slice = tid >> 6;
-    for (int i = tid; i < 3 * Q; i += 256) hist[i] = 0;
+    for (int i = tid; i < 3 * Q + 2 * Qpad; i += 256) hist[i] = 0;
     const int oy = blockIdx.x / tiles_per_row, cx0 = (blockIdx.x - oy * tiles_per_row) * PT_CELLS;
     const int cw = (g.ow + 3) >> 2;
     const int cx = cx0 + lane;
@@ -428,7 +430,7 @@ __global__ void __launch_bounds__(256) postprocess_pixels_x4_tiled_kernel(const 
                 if (ks >= 0.f && lane == 0 && npos) atomicAdd(&hist[Q + q], npos);
             }
         }
-        if (S || (KS > 0 && sem)) {
+        if (S || (KS > 0 && sem) || stats_partial) {
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
                 typedef _Float16 f16x4v __attribute__((ext_vector_type(4)));
@@ -462,6 +464,33 @@ __global__ void __launch_bounds__(256) postprocess_pixels_x4_tiled_kernel(const 
                 atomicAdd(&hist[bq & 0xffff], 1);
                 if (bq & (1 << 16)) atomicAdd(&hist[2 * Q + (bq & 0xffff)], 1);
             }
+        }
+    }
+    // ---- instance statistics of the tile (column_stats_kernel's sums, taken from the LDS image instead of a second pass over S in HBM)
+    if (stats_partial) {
+        const int V = Qpad >> 3, PL = 256 / V;
+        const int v = tid % V, pl = tid / V;
+        const int npx = min(PT_PIX, g.ow - 4 * cx0);
+        if (pl < PL) {
+            unsigned int s[8], c[8];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) s[i] = c[i] = 0u;
+            for (int p = pl; p < npx; p += PL) {
+                typedef _Float16 f16x4v __attribute__((ext_vector_type(4)));
+                const char* src = tile + (size_t)p * pitch + v * 16;
+                const f16x4v lo = *reinterpret_cast<const f16x4v*>(src), hi = *reinterpret_cast<const f16x4v*>(src + 8);
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+                    const float a = (float)(i < 4 ? lo[i & 3] : hi[i & 3]);
+                    if (a > 0.5f) { s[i] += (unsigned int)(a * kStatUnit); c[i] += 1u; }
+                }
+            }
+#pragma unroll
+            for (int i = 0; i < 8; ++i)
+                if (c[i]) {
+                    atomicAdd(&st[v * 8 + i], s[i]);
+                    atomicAdd(&st[Qpad + v * 8 + i], c[i]);
+                }
         }
     }
     // ---- the tile's S rows: one contiguous run of the matrix
@@ -524,51 +553,57 @@ __global__ void __launch_bounds__(256) postprocess_pixels_x4_tiled_kernel(const 
     __syncthreads();
     for (int i = tid; i < 3 * Q; i += 256)
         if (hist[i]) atomicAdd(&counts[i], hist[i]);
+    if (stats_partial)
+        for (int i = tid; i < 2 * Qpad; i += 256) stats_partial[(int64_t)blockIdx.x * 2 * Qpad + i] = st[i];
 }
 
 // per-query sum over pixels of sigmoid * [sigmoid > 0.5] and count of [sigmoid > 0.5] from S (instance mask scores,
-// maskformer_model.py:376-377): block partials [nblocks][2][Qpad], folded in fixed order by column_fold_kernel
-__global__ void __launch_bounds__(256) column_stats_kernel(const f16* __restrict__ S, float* __restrict__ partial, int npix, int Qpad,
+// maskformer_model.py:376-377).  The fp16 values above 0.5 are whole multiples of 2^-11, so the sums are taken as INTEGERS in that unit: exact,
+// whatever the order - every form of the pixel pass (this kernel over S, or the tiled pass's own statistics epilogue) gives the same bits.
+// Block partials [nblocks][2][Qpad] u32 (a block covers < 2^20 pixels), folded by column_fold_kernel.
+__global__ void __launch_bounds__(256) column_stats_kernel(const f16* __restrict__ S, unsigned int* __restrict__ partial, int npix, int Qpad,
                                                           int pix_per_block) {
-    extern __shared__ float cs[];  // [PL][2][Qpad]
+    extern __shared__ unsigned int cs[];  // [2][Qpad]
     const int V = Qpad >> 3, PL = 256 / V;
     const int v = threadIdx.x % V, pl = threadIdx.x / V;
     const int p0 = blockIdx.x * pix_per_block, p1 = min(npix, p0 + pix_per_block);
-    float s[8], c[8];
+    for (int i = threadIdx.x; i < 2 * Qpad; i += blockDim.x) cs[i] = 0u;
+    __syncthreads();
+    unsigned int s[8], c[8];
 #pragma unroll
-    for (int i = 0; i < 8; ++i) s[i] = c[i] = 0.f;
+    for (int i = 0; i < 8; ++i) s[i] = c[i] = 0u;
     if (pl < PL) {
         for (int p = p0 + pl; p < p1; p += PL) {
             const f16x8 t = *reinterpret_cast<const f16x8*>(S + (int64_t)p * Qpad + v * 8);
 #pragma unroll
             for (int i = 0; i < 8; ++i) {
                 const float a = (float)t[i];
-                if (a > 0.5f) { s[i] += a; c[i] += 1.f; }
+                if (a > 0.5f) { s[i] += (unsigned int)(a * kStatUnit); c[i] += 1u; }
             }
         }
 #pragma unroll
-        for (int i = 0; i < 8; ++i) {
-            cs[(pl * 2 + 0) * Qpad + v * 8 + i] = s[i];
-            cs[(pl * 2 + 1) * Qpad + v * 8 + i] = c[i];
-        }
+        for (int i = 0; i < 8; ++i)
+            if (c[i]) {
+                atomicAdd(&cs[v * 8 + i], s[i]);
+                atomicAdd(&cs[Qpad + v * 8 + i], c[i]);
+            }
     }
     __syncthreads();
-    for (int i = threadIdx.x; i < 2 * Qpad; i += blockDim.x) {
-        float a = 0.f;
-        for (int t = 0; t < PL; ++t) a += cs[(t * 2 + i / Qpad) * Qpad + (i % Qpad)];
-        partial[(int64_t)blockIdx.x * 2 * Qpad + i] = a;
-    }
+    for (int i = threadIdx.x; i < 2 * Qpad; i += blockDim.x) partial[(int64_t)blockIdx.x * 2 * Qpad + i] = cs[i];
 }
-// one wavefront per output column: lanes stride over the block partials, then a fixed-order butterfly (deterministic)
-__global__ void __launch_bounds__(256) column_fold_kernel(const float* __restrict__ partial, float* __restrict__ out, int nblocks, int n) {
+// one wavefront per output column: lanes stride over the block partials (64-bit integer sums: exact); out [2][Qpad] f32 = (sum, count)
+__global__ void __launch_bounds__(256) column_fold_kernel(const unsigned int* __restrict__ partial, float* __restrict__ out, int nblocks, int n) {
     const int i = blockIdx.x * 4 + (threadIdx.x >> 6);
     const int lane = threadIdx.x & 63;
     if (i >= n) return;
-    double a = 0.0;
-    for (int b = lane; b < nblocks; b += 64) a += (double)partial[(int64_t)b * n + i];
+    unsigned long long a = 0ull;
+    for (int b = lane; b < nblocks; b += 64) a += partial[(int64_t)b * n + i];
 #pragma unroll
-    for (int o = 32; o > 0; o >>= 1) a += __shfl_xor(a, o);
-    if (lane == 0) out[i] = (float)a;
+    for (int o = 32; o > 0; o >>= 1) {
+        const unsigned int lo = __shfl_xor((unsigned int)a, o), hi = __shfl_xor((unsigned int)(a >> 32), o);
+        a += ((unsigned long long)hi << 32) | lo;
+    }
+    if (lane == 0) out[i] = i < n / 2 ? (float)((double)a * (1.0 / (double)kStatUnit)) : (float)a;
 }
 
 // seg[p] = map[q] where ids[p] = q | flag and the pixel is inside mask q (flag) ; 0 otherwise  (maskformer_model.py:321-333)
@@ -983,24 +1018,30 @@ int launch_classify_rows(odise_hip_ctx* ctx, const float* L1, const float* L2, c
     ODISE_CHECK_HIP(hipGetLastError());
     return ODISE_OK;
 }
-// true when the pixel pass of this geometry can also produce the semantic scores (the tiled x4 form with Qpad <= 112): the caller then passes
-// PT / sem to launch_postprocess_pixels and skips the semantic GEMM
-bool postprocess_pixels_fuses_semantic(const PostGeom& g) {
-    const size_t lds = (size_t)PT_PIX * (g.Qpad * 2 + 8) + 8 * (size_t)PT_PIX * 4 + 3 * (size_t)g.Q * sizeof(int);
-    return g.oh == g.ih && g.ow == g.iw && g.ph == 4 * g.h4 && g.pw == 4 * g.w4 && g_post_generic == 0 && lds <= 64 * 1024 && g.Qpad <= 112 && g.ow % 32 == 0;
+static size_t tiled_lds(const PostGeom& g) {
+    return (size_t)PT_PIX * (g.Qpad * 2 + 8) + 8 * (size_t)PT_PIX * 4 + 3 * (size_t)g.Q * sizeof(int) + 2 * (size_t)g.Qpad * sizeof(unsigned int);
 }
+// true when the pixel pass of this geometry runs its tiled form (an exact 4x upsampling whose tile fits 64 KB of LDS): that form can leave the
+// instance statistics itself (stats_partial: `postprocess_pixels_stat_blocks` block partials for column_fold), so S need not exist for them
+bool postprocess_pixels_tiled(const PostGeom& g) {
+    return g.oh == g.ih && g.ow == g.iw && g.ph == 4 * g.h4 && g.pw == 4 * g.w4 && g_post_generic == 0 && tiled_lds(g) <= 64 * 1024;
+}
+int postprocess_pixels_stat_blocks(const PostGeom& g) { return g.oh * (int)ceil_div((g.ow + 3) / 4, PT_CELLS); }
+// ... and the semantic scores too (Qpad <= 112): the caller then passes PT / sem to launch_postprocess_pixels and skips the semantic GEMM
+bool postprocess_pixels_fuses_semantic(const PostGeom& g) { return postprocess_pixels_tiled(g) && g.Qpad <= 112 && g.ow % 32 == 0; }
 int launch_postprocess_pixels(odise_hip_ctx* ctx, const f16* logits, const float* kscore, f16* S, int* ids, int* counts, const PostGeom& g, const f16* PT,
-                              float* sem, int K) {
+                              float* sem, int K, unsigned int* stats_partial) {
     const int npix = g.oh * g.ow;
     ODISE_REQUIRE(!sem || (PT && K > 0 && postprocess_pixels_fuses_semantic(g)), "postprocess_pixels: this geometry cannot fuse the semantic head");
+    ODISE_REQUIRE(!stats_partial || postprocess_pixels_tiled(g), "postprocess_pixels: this geometry cannot leave the instance statistics");
     if (g.oh == g.ih && g.ow == g.iw && g.ph == 4 * g.h4 && g.pw == 4 * g.w4 && g_post_generic != 1) {
-        const size_t lds = (size_t)PT_PIX * (g.Qpad * 2 + 8) + 8 * (size_t)PT_PIX * 4 + 3 * (size_t)g.Q * sizeof(int);
+        const size_t lds = tiled_lds(g);
         if (g_post_generic != 2 && lds <= 64 * 1024) {   // tiled form (two blocks per CU); odise_hip_post_generic(2) keeps the thread-per-cell-column form
             const int tiles_per_row = (int)ceil_div((g.ow + 3) / 4, PT_CELLS);
             if (sem) hipLaunchKernelGGL(postprocess_pixels_x4_tiled_kernel<7>, dim3((unsigned)(g.oh * tiles_per_row)), dim3(256), lds, ctx->stream, logits, kscore, S,
-                                        ids, counts, g, tiles_per_row, PT, sem, K);
+                                        ids, counts, g, tiles_per_row, PT, sem, K, stats_partial);
             else hipLaunchKernelGGL(postprocess_pixels_x4_tiled_kernel<0>, dim3((unsigned)(g.oh * tiles_per_row)), dim3(256), lds, ctx->stream, logits, kscore, S, ids,
-                                    counts, g, tiles_per_row, nullptr, nullptr, 0);
+                                    counts, g, tiles_per_row, nullptr, nullptr, 0, stats_partial);
             ODISE_CHECK_HIP(hipGetLastError());
             return ODISE_OK;
         }
@@ -1015,12 +1056,16 @@ int launch_postprocess_pixels(odise_hip_ctx* ctx, const f16* logits, const float
     ODISE_CHECK_HIP(hipGetLastError());
     return ODISE_OK;
 }
-int launch_column_stats(odise_hip_ctx* ctx, const f16* S, float* partial, float* out2, int npix, int Qpad) {
-    const int V = Qpad / 8, PL = 256 / V;
+int launch_column_stats(odise_hip_ctx* ctx, const f16* S, unsigned int* partial, float* out2, int npix, int Qpad) {
     const int nblocks = 512, ppb = (int)ceil_div(npix, nblocks);
     const int nb = (int)ceil_div(npix, ppb);
-    hipLaunchKernelGGL(column_stats_kernel, dim3(nb), dim3(256), (size_t)PL * 2 * Qpad * sizeof(float), ctx->stream, S, partial, npix, Qpad, ppb);
+    hipLaunchKernelGGL(column_stats_kernel, dim3(nb), dim3(256), (size_t)2 * Qpad * sizeof(unsigned int), ctx->stream, S, partial, npix, Qpad, ppb);
     ODISE_CHECK_HIP(hipGetLastError());
+    return launch_column_fold(ctx, partial, out2, nb, Qpad);
+}
+// out2 [2][Qpad] f32 = (sum of sigmoid over the mask's pixels, their count) from nb block partials [nb][2][Qpad] u32 (column_stats_kernel, or the
+// tiled pixel pass's statistics epilogue)
+int launch_column_fold(odise_hip_ctx* ctx, const unsigned int* partial, float* out2, int nb, int Qpad) {
     hipLaunchKernelGGL(column_fold_kernel, dim3((unsigned)ceil_div(2 * Qpad, 4)), dim3(256), 0, ctx->stream, partial, out2, nb, 2 * Qpad);
     ODISE_CHECK_HIP(hipGetLastError());
     return ODISE_OK;

@@ -307,9 +307,12 @@ int launch_l2_normalize_f32(odise_hip_ctx* ctx, const float* x, f16* y, int64_t 
 int launch_classify_rows(odise_hip_ctx* ctx, const float* L1, const float* L2, const int* seg, const int* ovl, const float* binary, float* out, int64_t rows, int K,
                          int Ktot, float ls1, float ls2, float alpha, float beta);
 int launch_postprocess_pixels(odise_hip_ctx* ctx, const f16* logits, const float* kscore, f16* S, int* ids, int* counts, const PostGeom& g, const f16* PT = nullptr,
-                              float* sem = nullptr, int K = 0);   // PT / sem: the semantic scores from the same pass (postprocess_pixels_fuses_semantic)
+                              float* sem = nullptr, int K = 0, unsigned int* stats_partial = nullptr);
+bool postprocess_pixels_tiled(const PostGeom& g);
+int postprocess_pixels_stat_blocks(const PostGeom& g);
+int launch_column_fold(odise_hip_ctx* ctx, const unsigned int* partial, float* out2, int nb, int Qpad);   // PT / sem: the semantic scores from the same pass (postprocess_pixels_fuses_semantic)
 bool postprocess_pixels_fuses_semantic(const PostGeom& g);
-int launch_column_stats(odise_hip_ctx* ctx, const f16* S, float* partial, float* out2, int npix, int Qpad);
+int launch_column_stats(odise_hip_ctx* ctx, const f16* S, unsigned int* partial, float* out2, int npix, int Qpad);
 int launch_panoptic_write(odise_hip_ctx* ctx, const int* ids, const int* map, int* seg, int npix);
 int launch_instance_masks(odise_hip_ctx* ctx, const f16* logits, const int* idx, float* out, int n, const PostGeom& g, const int* n_dev = nullptr);
 int launch_post_decide(odise_hip_ctx* ctx, const float* mask_cls, float* kscore, int* label, f16* semT, float* probs, int B, int Q, int Qpad, int K,
