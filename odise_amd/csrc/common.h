@@ -169,6 +169,8 @@ struct LnEpi {
     const float* rowsum = nullptr; // [M]
     float* stats_out = nullptr;    // [M][N / kLnPartCols][2]
 };
+bool conv3_c8_ok(const odise_conv_desc* d);                                                                     // conv_c8.hip
+int launch_conv3_c8(odise_hip_ctx* ctx, const odise_conv_desc* d, float* gn_stats, int* stats_blocks);
 int gemm_forced(odise_hip_ctx* ctx, const odise_gemm_desc* d, int force_tile, int force_split, const LnEpi* ln = nullptr);   // force_tile < 0: the cost model's choice
 int gemm_ln(odise_hip_ctx* ctx, const odise_gemm_desc* d, const LnEpi& ln);   // 256x256 ping-pong tile, math-first epilogue
 void jpeg_release(odise_hip_ctx* ctx);

@@ -3373,6 +3373,8 @@ int conv_forced(odise_hip_ctx* ctx, const odise_conv_desc* d, int force_tile, in
     ODISE_REQUIRE(d->X && d->Wt && d->Y, "conv2d: null device pointer");
     ODISE_REQUIRE(((uintptr_t)d->X & 15) == 0 && ((uintptr_t)d->Wt & 15) == 0, "conv2d: X/Wt must be 16-byte aligned");
     if (d->N == 0) return ODISE_OK;
+    // the 8-channel 3x3 convolution (AutoencoderKL's conv_in) has a kernel of its own (conv_c8.hip); a forced tile / split keeps the implicit GEMM
+    if (force_tile < 0 && force_split <= 0 && conv3_c8_ok(d)) return launch_conv3_c8(ctx, d, gn_stats, stats_blocks);
     GemmArgs g;
     g.M = d->N * d->OH * d->OW;
     g.N = d->Cout;

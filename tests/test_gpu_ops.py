@@ -450,6 +450,34 @@ def test_conv_fused_groupnorm_statistics(ctx, N, H, W, Cin, Cout, tile):
     close(yn.numpy(), refn.numpy(), rtol=3e-3, what=f"group_norm from fused statistics (tile {tile}, {blocks} row blocks)")
 
 
+@pytest.mark.parametrize("N,H,W", [(2, 64, 64), (1, 16, 48), (3, 32, 8), (1, 512, 512)])
+def test_conv_in_kernel_for_8_channel_images(ctx, N, H, W):
+    """AutoencoderKL's encoder.conv_in (3 -> 128 channels, input padded to 8; ldm.py:556-560) runs `conv3_c8_kernel` (csrc/conv_c8.hip): MFMA
+    operands loaded straight from the NHWC image, GroupNorm statistics reduced in the epilogue.  Against torch, against the implicit GEMM of the
+    same library (forced tile: sums of 27 products in another order - fp32 rounding before the fp16 store), and the GroupNorm that reads the
+    statistics against torch's on the tensor the kernel wrote.  Borders (zero padding), several row blocks, a one-block image."""
+    g = torch.Generator().manual_seed(N + H + W)
+    x = torch.zeros(N, H, W, 8)
+    x[..., :3] = h(torch.randn(N, H, W, 3, generator=g))
+    w = torch.zeros(128, 3, 3, 8)
+    w[..., :3] = h(torch.randn(128, 3, 3, 3, generator=g) / 27 ** 0.5 * 2.0)
+    b = torch.randn(128, generator=g)
+    gamma, beta = torch.randn(128, generator=g), torch.randn(128, generator=g)
+    dx, dw, db = ctx.to_device(x.half().numpy()), ctx.to_device(w.half().numpy()), ctx.to_device(b)
+    ref = _conv_ref(x, w, 1, 1, b)
+    out = ctx.conv2d(dx, dw, bias=db).numpy()
+    close(out, ref.numpy(), what=f"conv_in kernel {N}x{H}x{W}")
+    gen = ctx.conv2d(dx, dw, bias=db, force_tile=1).numpy().astype(np.float32)
+    ulp = np.abs(out.astype(np.float32) - gen) / np.maximum(np.abs(gen), 1e-3)
+    assert ulp.max() < 2e-3, f"conv_in kernel vs the implicit GEMM: {ulp.max():.2e} (more than an fp16 rounding step apart)"
+    y, yn, blocks = ctx.conv2d_gn(dx, dw, ctx.to_device(gamma), ctx.to_device(beta), bias=db, eps=1e-6, act=1)
+    assert blocks == H * W // 256, "the conv_in kernel did not leave its statistics"
+    assert np.array_equal(y.numpy(), out), "the statistics epilogue changed the convolution's output"
+    y16 = torch.from_numpy(y.numpy().astype(np.float32))
+    refn = F.silu(F.group_norm(y16.permute(0, 3, 1, 2), 32, gamma, beta, eps=1e-6)).permute(0, 2, 3, 1)
+    close(yn.numpy(), refn.numpy(), rtol=3e-3, what=f"group_norm from the conv_in kernel's statistics ({blocks} row blocks)")
+
+
 def test_conv_stride2_variants(ctx):
     g = torch.Generator().manual_seed(3)
     x = h(torch.randn(2, 16, 16, 64, generator=g))
