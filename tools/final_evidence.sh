@@ -25,6 +25,9 @@ for R in 1 2 3 4 5 6 7; do python bench.py --picture-rank $R --steps 2 --warmup 
 echo "bench lines done" >> $O/rc.txt
 python tools/stage_timeline.py --lanes 2 > $O/stage_timeline_2lanes.txt 2>&1
 python tools/stage_timeline.py --lanes 1 > $O/stage_timeline_1lane.txt 2>&1
+python tools/stage_timeline.py --lanes 2 --maskclip-passes 2 > $O/stage_timeline_2lanes_maskclip_one_pass.txt 2>&1
+python tools/maskclip_bench.py > $O/maskclip_passes.txt 2>&1
+python tools/conv_in_bench.py 2>&1 | head -1 > $O/conv_in_kernel.txt
 python tools/msda_bench.py 20 4 > $O/msda_variants.txt 2>&1
 python tools/clip_gemm_bench.py 5 > $O/clip_gemm_epilogues.txt 2>&1
 python tools/attn_unet_bench.py 20 > $O/attention_pipelined.txt 2>&1
