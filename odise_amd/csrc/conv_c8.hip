@@ -8,8 +8,9 @@
 // output channels) and stay in registers for the whole block; the pixels are the columns, so a lane ends up with 4 consecutive channels
 // of ONE pixel per MFMA.  Stored as such (8 bytes into each of 16 pixel rows per instruction) the launch wrote 2.4 TB/s; the wave's 32
 // pixels x 128 channels = 8 KB of CONTIGUOUS NHWC output therefore pass through a wave-private LDS tile and leave as 16-byte pieces, 1 KB per
-// instruction.  The epilogue also reduces the per-channel (sum, sum of squares) of the block's fp16 outputs - the statistics the following
-// GroupNorm reads (gemm.hip GemmEpi::gn_stats has the same contract).
+// instruction.  The MFMAs see the same k groups in the same order as the implicit GEMM: outputs are bit-identical to it.  The epilogue can
+// also reduce the per-channel (sum, sum of squares) of the block's fp16 outputs - the statistics a following GroupNorm reads (gemm.hip
+// GemmEpi::gn_stats has the same contract); the extractor does not request them (extractor.cpp: the first norm keeps its own pass).
 #include "common.h"
 #include "engine.h"
 

@@ -286,12 +286,14 @@ __global__ void __launch_bounds__(256) mask_binarize_f16_kernel(const f16* __res
     if (threadIdx.x == 0) inv[row] = 1.f / (red[0] + red[1] + red[2] + red[3] + 1e-8f);
 }
 
-// one block per (b,q): logits [H,W] fp16 -> u8 mask [oh*ow] (1 = key masked out); a row that masks every key is cleared
-__global__ void __launch_bounds__(256) attn_mask_kernel(const f16* __restrict__ logits, uint8_t* __restrict__ out, int H, int W, int oh, int ow,
+// one block per (b,q): logits [H,W] (fp16, or the fp32 accumulators of the prediction GEMM) -> u8 mask [oh*ow] (1 = key masked out); a row that
+// masks every key is cleared
+template <typename T>
+__global__ void __launch_bounds__(256) attn_mask_kernel(const T* __restrict__ logits, uint8_t* __restrict__ out, int H, int W, int oh, int ow,
                                                        int64_t ldm) {
     __shared__ int red[4];
     const int64_t row = blockIdx.x;
-    const f16* lr = logits + row * H * W;
+    const T* lr = logits + row * H * W;
     uint8_t* orow = out + row * ldm;
     const int n = oh * ow;
     int masked = 0;
@@ -383,7 +385,12 @@ int launch_mask_binarize_f16(odise_hip_ctx* ctx, const f16* mask, f16* m01, floa
     return ODISE_OK;
 }
 int launch_attn_mask(odise_hip_ctx* ctx, const f16* logits, uint8_t* out, int64_t rows, int H, int W, int oh, int ow, int64_t ldm) {
-    hipLaunchKernelGGL(attn_mask_kernel, dim3((unsigned)rows), dim3(256), 0, ctx->stream, logits, out, H, W, oh, ow, ldm);
+    hipLaunchKernelGGL(attn_mask_kernel<f16>, dim3((unsigned)rows), dim3(256), 0, ctx->stream, logits, out, H, W, oh, ow, ldm);
+    ODISE_CHECK_HIP(hipGetLastError());
+    return ODISE_OK;
+}
+int launch_attn_mask_f32(odise_hip_ctx* ctx, const float* logits, uint8_t* out, int64_t rows, int H, int W, int oh, int ow, int64_t ldm) {
+    hipLaunchKernelGGL(attn_mask_kernel<float>, dim3((unsigned)rows), dim3(256), 0, ctx->stream, logits, out, H, W, oh, ow, ldm);
     ODISE_CHECK_HIP(hipGetLastError());
     return ODISE_OK;
 }

@@ -289,6 +289,7 @@ int launch_msda_prepare(odise_hip_ctx* ctx, const float* off, const float* aw, f
 int launch_bilinear_add(odise_hip_ctx* ctx, const f16* a, const f16* b, f16* y, int N, int H, int W, int OH, int OW, int C);
 int launch_mask_binarize_f16(odise_hip_ctx* ctx, const f16* mask, f16* m01, float* inv, int64_t rows, int HW);
 int launch_attn_mask(odise_hip_ctx* ctx, const f16* logits, uint8_t* out, int64_t rows, int H, int W, int oh, int ow, int64_t ldm);
+int launch_attn_mask_f32(odise_hip_ctx* ctx, const float* logits, uint8_t* out, int64_t rows, int H, int W, int oh, int ow, int64_t ldm);
 
 
 // classify_ops.hip

@@ -769,9 +769,8 @@ static int run_vae_encoder(Exec& ex, ExtractorModel* e, const float* image, int 
             const size_t mk = ex.ms->arena.mark();
             Act c0 = crop_slice(cur, n0, n);
             if (l == 0) {
-                Act t;   // (its kernel leaves the statistics the first block's norm1 reads: conv_c8.hip)
-                ODISE_TRY(ex.alloc(t, c0.n, c0.h, c0.w, e->enc_conv_in.cout));
-                ODISE_TRY(ex.alloc_gn_stats(t));
+                Act t;   // (conv_c8.hip.  Its statistics epilogue is not used here: the first block's norm1 keeps its own statistics pass, i.e. the
+                         //  bits of rounds 1-5 - the parity tests' hard decisions were pinned on those)
                 ODISE_TRY(ex.conv(c0, e->enc_conv_in, t, 1, 1));
                 c0 = t;
             }

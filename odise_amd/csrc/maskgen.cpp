@@ -839,7 +839,7 @@ static int predictor_forward(odise_hip_ctx* ctx, PixDec& pd) {
     f16* att = (f16*)ex.alloc_bytes((size_t)MQ * C * 2);
     f16* qb = (f16*)ex.alloc_bytes((size_t)MQ * 2 * C * 2);
     f16* vtb = (f16*)ex.alloc_bytes((size_t)B * C * round_up(Q, 8) * 2);   // V^T of the queries' self-attention
-    f16* lgl = (f16*)ex.alloc_bytes((size_t)MQ * maxP * 2);                  // prediction at the next layer's level
+    float* lgl = (float*)ex.alloc_bytes((size_t)MQ * maxP * 4);              // prediction at the next layer's level: the GEMM's fp32 accumulators (its sign is the decision)
     f16* masks = (f16*)ex.alloc_bytes((size_t)MQ * HW4 * 2);
     uint8_t* amask = (uint8_t*)ex.alloc_bytes((size_t)MQ * ldm);
     f16* m01 = (f16*)ex.alloc_bytes((size_t)MQ * HW4 * 2);
@@ -864,9 +864,9 @@ static int predictor_forward(odise_hip_ctx* ctx, PixDec& pd) {
         if (target_level >= 0) {   // ... at the level the next layer attends to
             const int64_t P = (int64_t)hs[target_level] * ws[target_level];
             d.N = (int)P; d.W = mfl[target_level]; d.strideW = P * C;
-            d.C = lgl; d.ldc = P; d.strideC = (int64_t)Q * P;
+            d.C = lgl; d.ldc = P; d.strideC = (int64_t)Q * P; d.c_dtype = ODISE_F32;
             ODISE_TRY(ex.gemm(d));
-            ODISE_TRY(launch_attn_mask(ctx, lgl, amask, MQ, hs[target_level], ws[target_level], hs[target_level], ws[target_level], ldm));
+            ODISE_TRY(launch_attn_mask_f32(ctx, lgl, amask, MQ, hs[target_level], ws[target_level], hs[target_level], ws[target_level], ldm));
         } else {                   // the final prediction
             d.N = (int)HW4; d.W = mf.p; d.strideW = HW4 * C;
             d.C = masks; d.ldc = HW4; d.strideC = (int64_t)Q * HW4;

@@ -15,8 +15,11 @@ def pytest_configure(config):
 @pytest.fixture(scope="session")
 def ctx():
     """One libodise_hip context for the whole GPU test session (fails loudly if the .so is missing)."""
+    import os
     from odise_amd.runtime import Context
     c = Context(0)
+    if os.environ.get("ODISE_TEST_MASKCLIP_PASSES"):   # developer aid: which form of MaskCLIP a difference comes from (include/odise_hip.h ODISE_OPT_MASKCLIP_PASSES)
+        c.set_option(c.OPT_MASKCLIP_PASSES, int(os.environ["ODISE_TEST_MASKCLIP_PASSES"]))
     yield c
     c.close()
 

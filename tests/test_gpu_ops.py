@@ -467,9 +467,10 @@ def test_conv_in_kernel_for_8_channel_images(ctx, N, H, W):
     ref = _conv_ref(x, w, 1, 1, b)
     out = ctx.conv2d(dx, dw, bias=db).numpy()
     close(out, ref.numpy(), what=f"conv_in kernel {N}x{H}x{W}")
-    gen = ctx.conv2d(dx, dw, bias=db, force_tile=1).numpy().astype(np.float32)
-    ulp = np.abs(out.astype(np.float32) - gen) / np.maximum(np.abs(gen), 1e-3)
-    assert ulp.max() < 2e-3, f"conv_in kernel vs the implicit GEMM: {ulp.max():.2e} (more than an fp16 rounding step apart)"
+    gen = ctx.conv2d(dx, dw, bias=db, force_tile=1).numpy()
+    ndiff = int((out != gen).sum())
+    print(f"conv_in kernel vs the implicit GEMM (64 x 128 tile): {ndiff} of {out.size} outputs differ")
+    assert ndiff == 0, "the conv_in kernel feeds the MFMAs the same k groups in the same order as the implicit GEMM: the outputs must agree to the bit"
     y, yn, blocks = ctx.conv2d_gn(dx, dw, ctx.to_device(gamma), ctx.to_device(beta), bias=db, eps=1e-6, act=1)
     assert blocks == H * W // 256, "the conv_in kernel did not leave its statistics"
     assert np.array_equal(y.numpy(), out), "the statistics epilogue changed the convolution's output"
