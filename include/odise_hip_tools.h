@@ -83,6 +83,11 @@ int odise_hip_backbone_maps(odise_hip_ctx* ctx, float** out4, int* shape_bchw4x4
  * in the measurement build of the library. */
 int odise_hip_mfma_probe(odise_hip_ctx* ctx, float* host_out);
 
+/* MaskCLIP's visibility rows (clip.py:288-318: bilinear resize of the mask probabilities to the CLIP input, max over each patch, >= 0.5):
+ * out [B][T + Q][ldm] u8 (1 = hidden; rows < T are the image tokens' all-visible rows) from logits [B,Q,h,w] f16; T = (S / patch)^2 + 1.
+ * plain = 1 runs the form that interpolates both source rows of every sample row anew (the two forms must agree to the bit). */
+int odise_hip_maskclip_token_mask(odise_hip_ctx* ctx, const void* logits_f16, void* out_u8, int B, int Q, int h, int w, int S, int patch, int T,
+                                  int64_t ldm, int plain);
 #ifdef __cplusplus
 }
 #endif

@@ -51,7 +51,7 @@ __global__ void __launch_bounds__(256) resize_bilinear_norm_kernel(const float* 
 // walks it one patch row at a time; the column maxima of a patch row meet in LDS.  Same taps, same interpolation order per sample as one thread
 // per patch (round 5: 196 samples x 4 strided loads each, 300 us for 4 pictures on the serial tail) - a maximum does not care about the order.
 __global__ void __launch_bounds__(256) maskclip_token_mask_kernel(const f16* __restrict__ logits, uint8_t* __restrict__ out, int Q, int h,
-                                                                 int w, int S, int patch, int T, int64_t ldm) {
+                                                                 int w, int S, int patch, int T, int64_t ldm, int plain) {
     extern __shared__ float colmax[];   // [S]
     const int TA = T + Q;
     const int b = blockIdx.x / TA, row = blockIdx.x % TA;
@@ -62,6 +62,63 @@ __global__ void __launch_bounds__(256) maskclip_token_mask_kernel(const f16* __r
     }
     const int q = row - T, G = S / patch;
     const f16* lr = logits + ((int64_t)b * Q + q) * h * w;
+    if (S <= 2 * 256 && !plain) {
+        // (the CLIP input: 336 columns.)  A column's horizontal interpolant of source row y, H(y) = v[y][x0] + tx (v[y][x1] - v[y][x0]), is the
+        // `top` of one sample row and the `bot` of the one before (consecutive sample rows share source rows: 336 samples over 256 rows), so the
+        // two held rows are reused whenever the next sample row names them again - the same expression, evaluated once: the same bits.
+        int x0[2], x1[2];
+        float tx[2], h0[2], h1[2];
+        bool cok[2];
+#pragma unroll
+        for (int c = 0; c < 2; ++c) {
+            const int ox = threadIdx.x + 256 * c;
+            cok[c] = ox < S;
+            bil_setup(cok[c] ? ox : S - 1, w, S, x0[c], x1[c], tx[c]);
+            h0[c] = h1[c] = 0.f;
+        }
+        int hy0 = -1, hy1 = -1;   // the source rows h0 / h1 hold (block-uniform)
+        for (int py = 0; py < G; ++py) {
+            float mx[2] = {-INFINITY, -INFINITY};
+            for (int dy = 0; dy < patch; ++dy) {
+                int y0, y1;
+                float ty;
+                bil_setup(py * patch + dy, h, S, y0, y1, ty);
+#pragma unroll
+                for (int c = 0; c < 2; ++c) {
+                    if (!cok[c]) continue;
+                    float n0, n1;
+                    if (y0 == hy0) n0 = h0[c];
+                    else if (y0 == hy1) n0 = h1[c];
+                    else {
+                        const float a = (float)lr[y0 * w + x0[c]], bb = (float)lr[y0 * w + x1[c]];
+                        n0 = a + tx[c] * (bb - a);
+                    }
+                    if (y1 == y0) n1 = n0;
+                    else if (y1 == hy1) n1 = h1[c];
+                    else if (y1 == hy0) n1 = h0[c];
+                    else {
+                        const float a = (float)lr[y1 * w + x0[c]], bb = (float)lr[y1 * w + x1[c]];
+                        n1 = a + tx[c] * (bb - a);
+                    }
+                    h0[c] = n0;
+                    h1[c] = n1;
+                    mx[c] = fmaxf(mx[c], n0 + ty * (n1 - n0));
+                }
+                hy0 = y0;
+                hy1 = y1;
+            }
+#pragma unroll
+            for (int c = 0; c < 2; ++c)
+                if (cok[c]) colmax[threadIdx.x + 256 * c] = mx[c];
+            __syncthreads();
+            for (int px = threadIdx.x; px < G; px += blockDim.x) {
+                float m = colmax[px * patch];
+                for (int dx = 1; dx < patch; ++dx) m = fmaxf(m, colmax[px * patch + dx]);
+                orow[1 + py * G + px] = (1.f / (1.f + expf(-m))) < 0.5f ? 1 : 0;
+            }
+            __syncthreads();
+        }
+    } else
     for (int py = 0; py < G; ++py) {
         for (int ox = threadIdx.x; ox < S; ox += blockDim.x) {
             int x0, x1;
@@ -994,10 +1051,12 @@ int launch_resize_bilinear_norm(odise_hip_ctx* ctx, const float* x, f16* y, int 
     ODISE_CHECK_HIP(hipGetLastError());
     return ODISE_OK;
 }
+static int g_token_mask_plain = 0;   // tools hook (odise_hip_maskclip_token_mask): 1 = every sample row interpolates its two source rows anew (bit-compare)
 int launch_maskclip_token_mask(odise_hip_ctx* ctx, const f16* logits, uint8_t* out, int B, int Q, int h, int w, int S, int patch, int T,
                                int64_t ldm) {
     ODISE_REQUIRE(S % patch == 0 && S <= 8192, "maskclip_token_mask: image %d / patch %d", S, patch);
-    hipLaunchKernelGGL(maskclip_token_mask_kernel, dim3((unsigned)(B * (T + Q))), dim3(256), (size_t)S * sizeof(float), ctx->stream, logits, out, Q, h, w, S, patch, T, ldm);
+    hipLaunchKernelGGL(maskclip_token_mask_kernel, dim3((unsigned)(B * (T + Q))), dim3(256), (size_t)S * sizeof(float), ctx->stream, logits, out, Q, h, w, S, patch, T, ldm,
+                       g_token_mask_plain);
     ODISE_CHECK_HIP(hipGetLastError());
     return ODISE_OK;
 }
@@ -1131,3 +1190,14 @@ int launch_instance_masks(odise_hip_ctx* ctx, const f16* logits, const int* idx,
 }  // namespace odise
 
 extern "C" int odise_hip_post_generic(int on) { odise::g_post_generic = on; return 0; }
+// test hook (include/odise_hip_tools.h): MaskCLIP's visibility rows [B][T + Q][ldm] u8 from mask logits [B,Q,h,w] f16; plain = 1: the form without
+// the reuse of interpolated source rows
+extern "C" int odise_hip_maskclip_token_mask(odise_hip_ctx* ctx, const void* logits_f16, void* out_u8, int B, int Q, int h, int w, int S, int patch, int T,
+                                             int64_t ldm, int plain) {
+    ODISE_REQUIRE(ctx && logits_f16 && out_u8 && B >= 1 && Q >= 1 && h >= 1 && w >= 1 && patch >= 1 && T == (S / patch) * (S / patch) + 1 && ldm >= T,
+                  "maskclip_token_mask: bad argument");
+    odise::g_token_mask_plain = plain ? 1 : 0;
+    const int rc = odise::launch_maskclip_token_mask(ctx, (const odise::f16*)logits_f16, (uint8_t*)out_u8, B, Q, h, w, S, patch, T, ldm);
+    odise::g_token_mask_plain = 0;
+    return rc;
+}

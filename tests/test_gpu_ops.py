@@ -72,6 +72,35 @@ def test_msda_linearity_and_empty(ctx):
     assert e.shape == (2, 0, 256)
 
 
+def test_maskclip_visibility_rows_two_forms_and_torch(ctx):
+    """MaskCLIP's attention-mask rows (clip.py:288-318): mask logits resized bilinearly to the 336^2 CLIP input, max-pooled over the 14 x 14
+    patches, visible iff sigmoid >= 0.5.  `maskclip_token_mask_kernel` walks columns and reuses a source row's horizontal interpolant for the
+    sample rows that share it; `plain` interpolates anew for every sample row: the same expression evaluated once or twice - the rows must agree
+    to the bit.  Against torch's interpolate + max_pool2d: every entry whose pooled logit is not within rounding of zero."""
+    g = torch.Generator().manual_seed(5)
+    B, Q, hh, ww, S, patch = 2, 7, 64, 48, 336, 14
+    T = (S // patch) ** 2 + 1
+    ldm = (T + 7) // 8 * 8
+    coarse = torch.randn(B, Q, 8, 6, generator=g) * 3.0
+    logits = h(F.interpolate(coarse, size=(hh, ww), mode="bicubic", align_corners=False) + 0.3 * torch.randn(B, Q, hh, ww, generator=g))
+    dl = ctx.to_device(logits.half().numpy())
+    rows = {}
+    for plain in (0, 1):
+        out = ctx.empty((B, T + Q, ldm), np.uint8)
+        _lib.check(ctx.lib.odise_hip_maskclip_token_mask(ctx.h, dl, out, B, Q, hh, ww, S, patch, T, ldm, plain), "maskclip_token_mask")
+        rows[plain] = out.numpy()
+    assert np.array_equal(rows[0], rows[1]), "reusing a source row's interpolant changed a visibility bit"
+    got = rows[0]
+    assert (got[:, :T, :T] == 0).all() and (got[:, :, T:] == 1).all() and (got[:, T:, 0] == 0).all()
+    up = F.interpolate(logits.float(), size=(S, S), mode="bilinear", align_corners=False)
+    pooled = F.max_pool2d(up, patch, patch).reshape(B, Q, -1)
+    ref = (torch.sigmoid(pooled) < 0.5).numpy().astype(np.uint8)
+    sure = (pooled.abs() > 1e-3).numpy()
+    mism = (got[:, T:, 1:T] != ref) & sure
+    print(f"visibility rows: {int(ref.sum())} of {ref.size} patches hidden; mismatches outside |logit| < 1e-3: {int(mism.sum())}")
+    assert mism.sum() == 0 and 0.05 < ref.mean() < 0.95
+
+
 def test_msda_fused_gather_against_prepare_plus_native_op(ctx):
     """msda_fused_kernel (round 6: softmax + sampling locations + branch-free gather, XCD-aware block order) against msda_prepare_kernel + the
     native-op kernel on the same raw projections, offsets large enough that a fifth of the points leave the maps (zero padding outside
