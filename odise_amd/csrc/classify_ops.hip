@@ -457,14 +457,26 @@ __global__ void __launch_bounds__(256) postprocess_pixels_x4_tiled_kernel(const 
         f16x8 sv[4];
 #pragma unroll
         for (int k = 0; k < 4; ++k) sv[k] = f16x8{0, 0, 0, 0, 0, 0, 0, 0};
+        // the six taps and the score of ALL eight queries of the group first (clamped query index: always in range, wave-uniform): 56 loads in
+        // flight per lane.  Issued one query at a time - load, wait, sigmoid, next - the pass was a chain of ~26 memory latencies per wave with
+        // two waves per SIMD to hide them (LDS bounds the occupancy): 300 us of a pass whose VALU work is ~80.
+        f16 tap[8][6];
+        float ksv[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int qc = min(q0 + j, Q - 1);
+            const f16* lr = logits + (int64_t)qc * plane;
+            tap[j][0] = lr[oa + cl]; tap[j][1] = lr[oa + cxc]; tap[j][2] = lr[oa + cr];
+            tap[j][3] = lr[ob + cl]; tap[j][4] = lr[ob + cxc]; tap[j][5] = lr[ob + cr];
+            ksv[j] = kscore[qc];
+        }
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
             const int q = q0 + j;
             if (q < Q) {  // uniform branch
-                const f16* lr = logits + (int64_t)q * plane;
-                const float al = (float)lr[oa + cl], ac = (float)lr[oa + cxc], ar = (float)lr[oa + cr];
-                const float bl = (float)lr[ob + cl], bc = (float)lr[ob + cxc], br = (float)lr[ob + cr];
-                const float ks = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(kscore[q])));   // wave-uniform by construction: keep the test scalar
+                const float al = (float)tap[j][0], ac = (float)tap[j][1], ar = (float)tap[j][2];
+                const float bl = (float)tap[j][3], bc = (float)tap[j][4], br = (float)tap[j][5];
+                const float ks = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(ksv[j])));   // wave-uniform by construction: keep the test scalar
                 int npos = 0;
 #pragma unroll
                 for (int k = 0; k < 4; ++k) {
