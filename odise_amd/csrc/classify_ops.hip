@@ -843,6 +843,16 @@ __global__ void __launch_bounds__(1024) instance_topk_kernel(const float* __rest
     const int N = Q * K;
     const int k_sel = topk < N ? topk : N;
     const int tid = threadIdx.x, nt = blockDim.x;
+    // the keys this thread looks at, once (Q * K <= 16 x the block: the released vocabularies): the four digit passes and the compaction below read
+    // them again and again, and each pass was a chain of load - wait - atomic per key (13 memory latencies per pass: most of the kernel's 66 us)
+    constexpr int KREG = 16;
+    const bool small = N <= KREG * nt;
+    unsigned int kreg[KREG];
+#pragma unroll
+    for (int r = 0; r < KREG; ++r) {
+        const int i = tid + r * nt;
+        kreg[r] = (small && i < N) ? keys[i] : 0u;
+    }
     // ---- radix select: the k_sel-th largest key
     if (tid == 0) { s_prefix = 0; s_need = (unsigned)k_sel; }
     __syncthreads();
@@ -852,9 +862,17 @@ __global__ void __launch_bounds__(1024) instance_topk_kernel(const float* __rest
         __syncthreads();
         const unsigned int prefix = s_prefix;
         const unsigned int himask = pass == 0 ? 0u : (0xffffffffu << (shift + 8));
-        for (int i = tid; i < N; i += nt) {
-            const unsigned int kx = keys[i];
-            if ((kx & himask) == prefix) atomicAdd(&hist[(kx >> shift) & 255u], 1u);
+        if (small) {
+#pragma unroll
+            for (int r = 0; r < KREG; ++r) {
+                const unsigned int kx = kreg[r];
+                if (tid + r * nt < N && (kx & himask) == prefix) atomicAdd(&hist[(kx >> shift) & 255u], 1u);
+            }
+        } else {
+            for (int i = tid; i < N; i += nt) {
+                const unsigned int kx = keys[i];
+                if ((kx & himask) == prefix) atomicAdd(&hist[(kx >> shift) & 255u], 1u);
+            }
         }
         __syncthreads();
         if (tid < 64) {
@@ -896,9 +914,15 @@ __global__ void __launch_bounds__(1024) instance_topk_kernel(const float* __rest
     const unsigned int c_gt = (unsigned)k_sel - need_eq;
     if (tid == 0) { s_count = 0; s_base = 0; }
     __syncthreads();
-    for (int base = 0; base < N; base += nt) {
+    for (int base = 0, rr = 0; base < N; base += nt, ++rr) {
         const int i = base + tid;
-        const unsigned int kx = i < N ? keys[i] : 0u;
+        unsigned int kx = 0u;
+        if (small) {   // kreg[rr] without a dynamic register index: rr is block-uniform
+#pragma unroll
+            for (int r = 0; r < KREG; ++r) kx = r == rr ? kreg[r] : kx;
+        } else if (i < N) {
+            kx = keys[i];
+        }
         const bool gt = i < N && kx > T, eq = i < N && kx == T;
         const unsigned long long bg = __ballot(gt), be = __ballot(eq);
         const int lane = tid & 63, w = tid >> 6;
