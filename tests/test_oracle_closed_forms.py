@@ -78,3 +78,26 @@ def test_panoptic_inference_on_handmade_masks():
     assert (seg[:, :2] == 1).all() and (seg[:, 2:] == 2).all() and seg.dtype == torch.int32
     sem = om.semantic_inference(mask_cls, mask_pred)
     assert sem.shape == (K, 4, 4) and sem.argmax(0)[0, 0] == 0 and sem.argmax(0)[0, 3] == 2
+
+
+def test_attention_mask_of_a_layer_from_resized_mask_features():
+    """forward_prediction_heads (odise.py:756-765) resizes the prediction [Q, H/4, W/4] = mask_embed . mask_features to the next layer's level
+    and thresholds it.  Both steps before the threshold are linear: resize(me . mf) = me . resize(mf) - what the library uses to compute the
+    nine intermediate predictions at 1/4 .. 1/64 of the pixels (csrc/maskgen.cpp predictor_forward).  In fp64 the two orders agree to rounding,
+    and so do the thresholded masks wherever the logit is not within rounding of zero; for exact 2x / 4x / 8x reductions the bilinear resize is
+    the mean of the four centre pixels of each cell."""
+    g = torch.Generator().manual_seed(7)
+    me = torch.randn(2, 9, 16, generator=g, dtype=torch.float64)
+    mf = torch.randn(2, 16, 32, 48, generator=g, dtype=torch.float64)
+    full = torch.einsum("bqc,bchw->bqhw", me, mf)
+    for f in (2, 4, 8):
+        size = (32 // f, 48 // f)
+        a = torch.nn.functional.interpolate(full, size=size, mode="bilinear", align_corners=False)
+        mfl = torch.nn.functional.interpolate(mf, size=size, mode="bilinear", align_corners=False)
+        b = torch.einsum("bqc,bchw->bqhw", me, mfl)
+        assert (a - b).abs().max().item() < 1e-12 * full.abs().max().item()
+        sure = a.abs() > 1e-9
+        assert torch.equal((a.sigmoid() < 0.5)[sure], (b.sigmoid() < 0.5)[sure])
+        c = f // 2 - 1   # the four centre pixels of an f x f cell
+        mean4 = (mf[..., c::f, c::f] + mf[..., c + 1::f, c::f] + mf[..., c::f, c + 1::f] + mf[..., c + 1::f, c + 1::f]) / 4
+        assert (mean4 - mfl).abs().max().item() < 1e-12
