@@ -244,7 +244,9 @@ extern "C" int odise_hip_set_vocabulary(odise_hip_ctx* ctx, const float* cat_tex
 // ODISE_OPT_MASKCLIP_PASSES names.  kv_ready: the image-token pass of THESE pictures has been enqueued already (odise_hip_infer).
 static int maskclip_tower(Exec& ex, const float* image01, int B, int H, int W, int S, int T, int Q, const uint8_t* tmask, int64_t ldm, f16* ce, bool kv_ready) {
     odise_hip_ctx* ctx = ex.ctx;
-    if (ctx->maskclip_passes == 2) {
+    const bool have_pass1 = kv_ready && ex.ms->mclip.ready && ex.ms->mclip.B == B;
+    // (the two-pass forms need their key / value store, ~0.3 GB per picture: when it cannot be reserved the reference's one-pass layout runs instead)
+    if (ctx->maskclip_passes == 2 || (!have_pass1 && !maskclip_kv_available(ctx, ex.ms, B))) {
         Act img;
         ODISE_TRY(ex.alloc(img, B, S, S, 8));
         ODISE_TRY(launch_resize_bilinear_norm(ctx, image01, img.p, B, H, W, S));

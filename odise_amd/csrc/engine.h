@@ -264,6 +264,7 @@ int launch_softmax_rows(odise_hip_ctx* ctx, const f16* x, f16* y, int64_t rows, 
 int launch_clip_assemble(odise_hip_ctx* ctx, const f16* patches, const float* cls, const float* pos, f16* tok, int B, int T, int extra,
                          int TP, int Cw);
 int clip_tower(Exec& ex, const Act& img, int extra, const uint8_t* mask, int64_t ldm, f16* out, ClipKV* kv = nullptr, int kv_images = 0);
+bool maskclip_kv_available(odise_hip_ctx* ctx, ModelStore* ms, int B);            // the store of pass 1 on its own can be reserved (else: run the one-pass form)
 int maskclip_image_pass(Exec& ex, const float* image01, int B, int H, int W);   // -> ms->mclip (enqueued on the context's current stream)
 int maskclip_mask_pass(Exec& ex, int Q, const uint8_t* mask, int64_t ldm, int64_t stride_mask, f16* out);
 int maskclip_planned_pass(odise_hip_ctx* ctx, ModelStore* ms);                   // backbone stage, both lanes enqueued: ODISE_OPT_MASKCLIP_PASSES 3

@@ -624,6 +624,13 @@ static int maskclip_kv_layout(odise_hip_ctx* ctx, ModelStore* ms, int B, int oth
     return ODISE_OK;
 }
 
+// true when the key / value store for B pictures on their own is (or can be) reserved; false leaves no error behind: the caller runs the one-pass form
+bool maskclip_kv_available(odise_hip_ctx* ctx, ModelStore* ms, int B) {
+    if (maskclip_kv_layout(ctx, ms, B, 0) == ODISE_OK) return true;
+    (void)hipGetLastError();
+    return false;
+}
+
 // Pass 1 on its own: the image tokens of B pictures [B,3,H,W] in [0,1] (bilinear to 336^2 + CLIP normalisation, clip.py:325-338) through the tower.
 int maskclip_image_pass(Exec& ex, const float* image01, int B, int H, int W) {
     ExtractorModel* e = ex.ms->extractor;
@@ -702,9 +709,13 @@ int clip_dims(ModelStore* ms, int* image, int* patch, int* tokens, int* out_dim)
 // 16 crops have room for them in their last round (37 -> 46 row tiles of 256: 592 -> 736 tiles on 256 CUs, three rounds either way).
 static int run_clip(Exec& ex, ExtractorModel* e, const float* image, int B, int H, int W, f16* prefix16 /*[B, clip_out]*/) {
     ClipKV& kv = ex.ms->mclip;
-    const bool ride = kv.planned && !kv.ready && ex.ctx->maskclip_passes == 0;
+    bool ride = kv.planned && !kv.ready && ex.ctx->maskclip_passes == 0;
+    if (ride && maskclip_kv_layout(ex.ctx, ex.ms, kv.plan_B, B) != ODISE_OK) {
+        // the key / value store could not be reserved: the pictures do not ride; the classification stage falls back (classify.cpp maskclip_tower)
+        (void)hipGetLastError();
+        ride = false;
+    }
     const int Bp = ride ? kv.plan_B : 0;
-    if (ride) ODISE_TRY(maskclip_kv_layout(ex.ctx, ex.ms, Bp, B));
     const size_t mk = ex.ms->arena.mark();
     const int S = e->clip_image;
     Act img;
