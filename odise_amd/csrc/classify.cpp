@@ -245,7 +245,7 @@ extern "C" int odise_hip_set_vocabulary(odise_hip_ctx* ctx, const float* cat_tex
 static int maskclip_tower(Exec& ex, const float* image01, int B, int H, int W, int S, int T, int Q, const uint8_t* tmask, int64_t ldm, f16* ce, bool kv_ready) {
     odise_hip_ctx* ctx = ex.ctx;
     const bool have_pass1 = kv_ready && ex.ms->mclip.ready && ex.ms->mclip.B == B;
-    // (the two-pass forms need their key / value store, ~0.3 GB per picture: when it cannot be reserved the reference's one-pass layout runs instead)
+    // (the two-pass forms need their key / value store, ~0.1 GB per picture: when it cannot be reserved the reference's one-pass layout runs instead)
     if (ctx->maskclip_passes == 2 || (!have_pass1 && !maskclip_kv_available(ctx, ex.ms, B))) {
         Act img;
         ODISE_TRY(ex.alloc(img, B, S, S, 8));
